@@ -1,0 +1,47 @@
+# Builds the MI355X (gfx950) engine in-tree:
+#   whisper.tflite_amd/lib/libwhisper-tflite.so   C ABI (include/wt_capi.h) + C++ surface
+#   whisper.tflite_amd/bin/encdec                 the reference's CLI, same flags
+#   whisper.tflite_amd/bin/wt-make-assets         synthetic weights / vocab writer
+#   oracle/libwt_oracle.so (+ oracle/_ref/)       test infrastructure (see oracle/)
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH  ?= gfx950
+PKG   := whisper.tflite_amd
+SRC   := $(PKG)/csrc
+OBJ   := $(PKG)/build
+CXXFLAGS := -std=c++17 -O3 -fPIC -Iinclude -I$(SRC) -Wall -Wno-unused-result
+HIPFLAGS := $(CXXFLAGS) --offload-arch=$(ARCH) -ffp-contract=fast
+
+KERNELS := k_gemm k_misc k_attention
+HOSTSRC := engine capi host_util weights_gen whisper_api
+OBJS := $(addprefix $(OBJ)/,$(addsuffix .o,$(KERNELS) $(HOSTSRC)))
+
+all: lib apps oracle
+lib: $(PKG)/lib/libwhisper-tflite.so
+apps: $(PKG)/bin/encdec $(PKG)/bin/wt-make-assets
+oracle:
+	$(MAKE) -C oracle
+
+$(OBJ)/%.o: $(SRC)/%.hip $(SRC)/kernels.h
+	@mkdir -p $(OBJ)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(OBJ)/%.o: $(SRC)/%.cpp $(wildcard $(SRC)/*.h) $(wildcard include/*.h)
+	@mkdir -p $(OBJ)
+	$(HIPCC) $(CXXFLAGS) -c $< -o $@
+
+$(PKG)/lib/libwhisper-tflite.so: $(OBJS)
+	@mkdir -p $(PKG)/lib
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(OBJS)
+
+$(PKG)/bin/encdec: $(PKG)/app/encdec.cpp $(PKG)/lib/libwhisper-tflite.so
+	@mkdir -p $(PKG)/bin
+	$(HIPCC) $(CXXFLAGS) -o $@ $< -L$(PKG)/lib -lwhisper-tflite -Wl,-rpath,'$$ORIGIN/../lib'
+
+$(PKG)/bin/wt-make-assets: $(PKG)/app/make_assets.cpp $(PKG)/lib/libwhisper-tflite.so
+	@mkdir -p $(PKG)/bin
+	$(HIPCC) $(CXXFLAGS) -o $@ $< -L$(PKG)/lib -lwhisper-tflite -Wl,-rpath,'$$ORIGIN/../lib'
+
+clean:
+	rm -rf $(OBJ) $(PKG)/lib $(PKG)/bin
+	$(MAKE) -C oracle clean
+.PHONY: all lib apps oracle clean

@@ -1,0 +1,137 @@
+/* wt_capi.h — C ABI of the MI355X (gfx950) Whisper EncDec engine.
+ *
+ * Drop-in boundary for the reference's engine surface (jerinphilip/whisper.tflite @ v2):
+ * every entry point below is what a binding for that path would call instead of the
+ * TFLite-interpreter-backed implementation.  Plain pointers and sizes only; nothing here
+ * throws or exits; errors are int status codes plus wt_last_error().
+ *
+ * Threading contract = the reference's (an engine is NOT re-entrant; callers serialise,
+ * cf. io/github/jerinphilip/whisper/Whisper.java:109-113): one in-flight call per handle,
+ * one handle per GPU (device_id at create), one HIP stream per handle.
+ */
+#ifndef WT_CAPI_H_
+#define WT_CAPI_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct wt_engine wt_engine;
+
+enum wt_status {
+  WT_OK = 0,
+  WT_ERR_INVALID_ARG = 1,
+  WT_ERR_IO = 2,          /* file missing / unreadable (reference: MmapFile throws, mmap_file.cpp:16-29) */
+  WT_ERR_FORMAT = 3,      /* malformed weight or vocab file */
+  WT_ERR_UNSUPPORTED = 4, /* e.g. EngineType Monolith (out of scope) */
+  WT_ERR_DEVICE = 5,      /* no usable gfx950 device / HIP failure: the product has NO CPU fallback */
+  WT_ERR_BUFFER = 6       /* caller buffer too small; *len still reports the needed size */
+};
+
+/* reference whisper.h:199-204 enum class EngineType */
+enum wt_engine_type { WT_ENGINE_MONOLITH = 0, WT_ENGINE_ENCDEC = 1 };
+
+/* Fixed audio geometry of the path (reference whisper.h:34-39). */
+#define WT_SAMPLE_RATE 16000
+#define WT_N_FFT 400
+#define WT_HOP 160
+#define WT_CHUNK_SAMPLES 480000 /* kSampleRate * kChunkSize */
+#define WT_MAX_IDS 32           /* ids per clip: 4 prompt + <=27 generated (whisper.cpp:364-367), padded */
+
+typedef struct wt_dims {
+  int32_t n_mels, n_audio_ctx, n_audio_state, n_audio_head, n_audio_layer;
+  int32_t n_vocab, n_text_ctx, n_text_state, n_text_head, n_text_layer;
+} wt_dims;
+
+/* Per-stage device time of the last batch call, from HIP events on the engine's stream. */
+typedef struct wt_timings {
+  float logmel_ms, encoder_ms, cross_kv_ms, decoder_ms, total_ms;
+  int32_t batch, decoder_steps;
+} wt_timings;
+
+/* ---- lifecycle -------------------------------------------------------------------------
+ * Replaces whisper::create_engine (whisper.h:259-260, whisper.cpp:778-790) and
+ * EncDec::EncDec (whisper.cpp:740-750).  `model_prefix` resolves to "<prefix>.wtw" (this
+ * build's weight file, standing in for "<prefix>.encoder.tflite"/"<prefix>.decoder.tflite",
+ * whisper.cpp:743-744); `vocab_path` is the reference's filters+vocab .bin, byte-compatible.
+ * On failure *out is NULL and wt_last_error(NULL) describes why. */
+int wt_engine_create(int engine_type, const char* model_prefix, const char* vocab_path,
+                     int multilingual, int device_id, wt_engine** out);
+/* Replaces `delete engine` (bindings/java/whisper.tflite.cpp:36-42). NULL is a no-op. */
+void wt_engine_destroy(wt_engine* h);
+/* Message of the last failing call on `h` (or of the last failing create when h == NULL). */
+const char* wt_last_error(const wt_engine* h);
+int wt_engine_dims(const wt_engine* h, wt_dims* out);
+
+/* Options (reference hard-codes them): "language" (prompt language id, whisper.cpp:327,
+ * default language_id("de") = 2), "max_tokens" (max decoder positions, whisper.cpp:364,
+ * default 30), "stop_at_eot" (whisper.cpp:397-399, default 1), "verbose" (default 0),
+ * "cross_chunks" (key chunks per (clip, head) in the decoder cross attention). */
+int wt_engine_set_option(wt_engine* h, const char* key, long value);
+int wt_engine_get_option(const wt_engine* h, const char* key, long* value);
+
+/* ---- single-clip entry points (the reference's two virtuals) ----------------------------
+ * Replace Engine::transcribe(std::vector<float>&) (whisper.h:160, whisper.cpp:752-769; JNI
+ * transcribeBuffer, bindings/java/whisper.tflite.cpp:45-58) and
+ * Engine::transcribe(const char*) (whisper.h:161, whisper.cpp:771-776; JNI transcribeFile
+ * :61-71).  pcm is padded with zeros / truncated to 480000 samples like the reference
+ * (whisper.cpp:753) but the caller's buffer is not modified.  Text is written without a
+ * terminating NUL guarantee beyond min(len, cap-1); *len gets the full byte length. */
+int wt_transcribe_pcm(wt_engine* h, const float* pcm, size_t n_samples, char* out, size_t cap,
+                      size_t* len);
+int wt_transcribe_file(wt_engine* h, const char* wav_path, char* out, size_t cap, size_t* len);
+
+/* ---- batch entry points (the reference is batch 1; clips are independent) ---------------
+ * Host-pointer forms copy over PCIe; *_dev forms take device pointers already in HBM (the
+ * form bench.py times).  All are synchronous on return.
+ *   pcm  [B][480000] fp32           mel [B][n_mels][2*n_audio_ctx] fp32 (reference Mel
+ *   layout, whisper.cpp:184: [mel][frame])     ids [B][WT_MAX_IDS] int64, n_ids [B] int32.
+ * ids rows hold prompt + generated ids exactly as Decoder::forward returns them
+ * (whisper.cpp:402), zero-padded. */
+int wt_logmel_batch(wt_engine* h, const float* pcm, int batch, float* mel);
+int wt_logmel_batch_dev(wt_engine* h, const float* d_pcm, int batch, float* d_mel);
+int wt_encdec_tokens_batch(wt_engine* h, const float* mel, int batch, int64_t* ids, int32_t* n_ids);
+int wt_encdec_tokens_batch_dev(wt_engine* h, const float* d_mel, int batch, int64_t* ids,
+                               int32_t* n_ids);
+/* PCM -> ids in one call (front end + encoder + decoder), device-resident input. */
+int wt_transcribe_tokens_batch_dev(wt_engine* h, const float* d_pcm, int batch, int64_t* ids,
+                                   int32_t* n_ids);
+
+/* Stage taps for parity tests: encoder output [B][n_audio_ctx][n_audio_state] and the
+ * last-position logits of every argmax step [B][steps][n_vocab] (either may be NULL). */
+int wt_encdec_debug_batch(wt_engine* h, const float* mel, int batch, int64_t* ids, int32_t* n_ids,
+                          float* enc_out, float* logits, int logits_steps_cap);
+
+int wt_last_timings(const wt_engine* h, wt_timings* out);
+
+/* ---- host-side helpers of the path ------------------------------------------------------ */
+/* whisper.cpp:634-665 decode() over the engine's vocab. */
+int wt_decode_text(wt_engine* h, const int64_t* ids, int n, int omit_special_tokens, char* out,
+                   size_t cap, size_t* len);
+/* whisper.cpp:510-515 / :517 language table (returns the table size, 100, when absent). */
+int wt_language_id(const char* code);
+const char* wt_lang_code(int id);
+/* wav_util.cpp:18-87 wav_read_legacy: *n gets the sample count (WT_ERR_IO when the reference
+ * would return an empty vector); at most cap samples are written. */
+int wt_wav_read_legacy(const char* path, float* out, size_t cap, size_t* n);
+/* token ids the engine uses: out[0..8] = n_vocab, eot, sot, translate, transcribe, prev,
+ * solm, not, beg (whisper.h:69-91 after whisper.cpp:218-226). */
+int wt_vocab_info(const wt_engine* h, int32_t out[9]);
+/* mel filter bank as loaded from the vocab file: [n_mel][n_fft]; returns element count. */
+int wt_filters(const wt_engine* h, float* out, size_t cap, int32_t* n_mel, int32_t* n_fft);
+
+/* ---- asset tooling (stand-ins for the reference's offline export) ---------- */
+/* Deterministic random-init weights of a named architecture ("tiny", "tiny.en", "base",
+ * "micro") -> "<path>" in .wtw format. */
+int wt_write_synthetic_weights(const char* path, const char* arch, uint64_t seed);
+/* filters+vocab .bin in the reference layout with a Slaney 80x201 bank and n_tokens
+ * synthetic tokens. */
+int wt_write_synthetic_vocab(const char* path, int n_tokens);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WT_CAPI_H_ */

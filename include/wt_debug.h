@@ -1,0 +1,29 @@
+/* wt_debug.h — kernel-level taps for parity tests (host in / host out, synchronous).
+ * NOT part of the drop-in boundary (wt_capi.h); they exist so that a parity failure of
+ * the whole path can be localised to one gfx950 kernel.  epi bits: 1 bias, 2 GELU(erf),
+ * 4 residual (R, same shape as the output), 8 positional add. */
+#ifndef WT_DEBUG_H_
+#define WT_DEBUG_H_
+#include "wt_capi.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* C[M][N] = epi(A[M][K] . W[N][K]^T); needs N % 128 == 0, K % 32 == 0 */
+int wt_dbg_gemm(wt_engine* h, int M, int N, int K, const float* A, const float* W, const float* bias,
+                const float* R, const float* pos, int pos_period, int epi, float* C);
+/* Y[B][N] = epi(X[B][K] . W[N][K]^T), B <= 64; argmax_out[B] (optional) = last maximal column */
+int wt_dbg_skinny(wt_engine* h, int B, int N, int K, const float* X, const float* W, const float* bias,
+                  const float* R, int epi, float* Y, int64_t* argmax_out);
+int wt_dbg_layernorm(wt_engine* h, int M, int d, const float* x, const float* g, const float* b, float* y);
+/* qkv [B*T][3*heads*64] -> out [B*T][heads*64] */
+int wt_dbg_encoder_attention(wt_engine* h, int batch, int T, int heads, const float* qkv, float* out);
+/* q [B][heads*64], kc/vc [B][heads][T][64] -> out [B][heads*64] */
+int wt_dbg_cross_attention(wt_engine* h, int batch, int heads, int T, int chunks, const float* q,
+                           const float* kc, const float* vc, float* out);
+/* qkv [B][3d]; caches [B][cap][d] updated in place at row pos; out [B][d] */
+int wt_dbg_self_attention(wt_engine* h, int batch, int heads, int cap, int pos, const float* qkv,
+                          float* kcache, float* vcache, float* out);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,85 @@
+"""CPU: the oracle's encoder/decoder restatement against golden vectors from an independent
+implementation (HuggingFace transformers Whisper, tools/gen_golden.py).  The reference's own
+model arithmetic lives in the absent TFLite runtime: parity vs TFLite itself is UNPINNED."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLD
+
+# fp32 end to end on both sides, different summation orders: logits agree to ~1e-5
+LOGIT_TOL = 1e-4
+ENC_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def micro(orc, assets):
+    g = np.load(os.path.join(GOLD, "model_micro.npz"), allow_pickle=False)
+    prefix, _ = assets("micro", int(g["seed"]))
+    m = orc.Model(prefix + ".wtw")
+    yield m, g
+    m.close()
+
+
+def test_micro_encoder_vs_hf(micro):
+    m, g = micro
+    for b in range(g["mel"].shape[0]):
+        enc = m.encode(g["mel"][b], n_threads=4)
+        assert np.abs(enc - g["enc_out"][b]).max() < ENC_TOL
+
+
+def test_micro_greedy_ids_and_logits_vs_hf(micro):
+    m, g = micro
+    for b in range(g["mel"].shape[0]):
+        ids, logits = m.decode_greedy(g["enc_out"][b], g["prompt"], 30, eot=-1, stop_at_eot=False,
+                                      use_cache=True, n_threads=4, want_logits=True)
+        assert logits.shape == (27, m.dims["n_vocab"])
+        assert np.abs(logits - g["logits"][b]).max() < LOGIT_TOL
+        margin = g["top2"][b, :, 2] - g["top2"][b, :, 3]
+        assert margin.min() > 20 * LOGIT_TOL  # the fixture is only decisive with a clear winner
+        assert list(ids) == list(g["ids"][b])
+
+
+def test_cache_and_no_cache_agree(micro):
+    """use_cache=0 re-runs the whole prefix and the cross K/V every step, the structure of the
+    reference loop (whisper.cpp:367-375); it must emit the same ids as the cached form."""
+    m, g = micro
+    a, la = m.decode_greedy(g["enc_out"][0], g["prompt"], 30, -1, False, True, 2, True)
+    b, lb = m.decode_greedy(g["enc_out"][0], g["prompt"], 30, -1, False, False, 2, True)
+    assert list(a) == list(b)
+    assert np.abs(la - lb).max() < 1e-5
+
+
+def test_eot_stops_the_loop(micro):
+    m, g = micro
+    first = int(g["ids"][0][4])  # declare the first generated token to be EOT
+    ids, _ = m.decode_greedy(g["enc_out"][0], g["prompt"], 30, eot=first, stop_at_eot=True)
+    assert list(ids) == list(g["prompt"]) + [first]
+    ids, _ = m.decode_greedy(g["enc_out"][0], g["prompt"], 30, eot=first, stop_at_eot=False)
+    assert len(ids) == 31  # 4 prompt + 27 generated (whisper.cpp:364-367)
+
+
+def test_batch_entry_matches_single(micro):
+    m, g = micro
+    ids, n = m.encdec_batch(g["mel"], g["prompt"], 30, -1, False, True, n_threads=3)
+    assert list(n) == [31] * g["mel"].shape[0]
+    assert np.array_equal(ids, g["ids"])
+
+
+def test_tiny_vs_hf(orc, assets):
+    """Full whisper-tiny dims (1500 positions, 51865 vocab), one clip."""
+    g = np.load(os.path.join(GOLD, "model_tiny.npz"), allow_pickle=False)
+    prefix, _ = assets("tiny", int(g["seed"]))
+    m = orc.Model(prefix + ".wtw")
+    rng = np.random.default_rng(int(g["mel_seed"]))
+    mel = rng.uniform(-1.0, 1.5, size=(2, 80, 3000)).astype(np.float32)
+    enc = m.encode(mel[0], n_threads=8)
+    assert np.abs(enc[0:4, 0:8] - g["enc_head"][0]).max() < ENC_TOL
+    assert np.abs(enc[-4:, -8:] - g["enc_tail"][0]).max() < ENC_TOL
+    assert np.abs(enc[::250] - g["enc_rows"][0]).max() < ENC_TOL
+    assert abs(np.sqrt((enc.astype(np.float64) ** 2).sum()) - g["enc_l2"][0]) < 1e-2
+    ids, logits = m.decode_greedy(enc, g["prompt"], 30, eot=-1, stop_at_eot=False, n_threads=8, want_logits=True)
+    assert np.abs(logits[:, ::997] - g["logits_cols"][0]).max() < LOGIT_TOL
+    assert list(ids) == list(g["ids"][0])
+    m.close()

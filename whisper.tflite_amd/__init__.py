@@ -1,0 +1,364 @@
+"""whisper.tflite_amd — Python host mirror of the reference engine interface over the C ABI.
+
+The product is the native library ``lib/libwhisper-tflite.so`` (hand-written gfx950
+kernels behind ``include/wt_capi.h``).  This module only binds it with ctypes so that
+tests, ``bench.py`` and ``__graft_entry__.py`` can drive it; it contains no compute and no
+fallback: if the library is missing or no MI355X is present, calls fail loudly.
+
+Interface mirrored (reference jerinphilip/whisper.tflite @ v2):
+  * ``Engine.transcribe(samples)`` / ``Engine.transcribe(path)``  — whisper.h:159-163
+  * ``create_engine(EngineType, model_prefix, vocab_path, multilingual)`` — whisper.h:259-260
+  * ``EngineType`` — whisper.h:199-204
+
+The directory is named like the reference's ``whisper.tflite/`` source directory, so it is
+not importable with a plain ``import`` statement; load it with
+``__graft_entry__.load_package()`` (importlib by path).
+"""
+from __future__ import annotations
+
+import ctypes
+import enum
+import os
+from ctypes import (POINTER, byref, c_char_p, c_float, c_int, c_int32, c_int64, c_long, c_size_t,
+                    c_uint64, c_void_p)
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libwhisper-tflite.so")
+
+WT_OK = 0
+WT_MAX_IDS = 32
+CHUNK_SAMPLES = 480000
+STATUS_NAMES = {0: "WT_OK", 1: "WT_ERR_INVALID_ARG", 2: "WT_ERR_IO", 3: "WT_ERR_FORMAT",
+                4: "WT_ERR_UNSUPPORTED", 5: "WT_ERR_DEVICE", 6: "WT_ERR_BUFFER"}
+
+# Every symbol include/wt_capi.h and include/wt_debug.h declare.
+CAPI_SYMBOLS = [
+    "wt_engine_create", "wt_engine_destroy", "wt_last_error", "wt_engine_dims",
+    "wt_engine_set_option", "wt_engine_get_option", "wt_transcribe_pcm", "wt_transcribe_file",
+    "wt_logmel_batch", "wt_logmel_batch_dev", "wt_encdec_tokens_batch",
+    "wt_encdec_tokens_batch_dev", "wt_transcribe_tokens_batch_dev", "wt_encdec_debug_batch",
+    "wt_last_timings", "wt_decode_text", "wt_language_id", "wt_lang_code", "wt_wav_read_legacy",
+    "wt_vocab_info", "wt_filters", "wt_write_synthetic_weights", "wt_write_synthetic_vocab",
+]
+DEBUG_SYMBOLS = [
+    "wt_dbg_gemm", "wt_dbg_skinny", "wt_dbg_layernorm", "wt_dbg_encoder_attention",
+    "wt_dbg_cross_attention", "wt_dbg_self_attention",
+]
+
+
+class WtError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"{STATUS_NAMES.get(code, code)}: {message}")
+        self.code = code
+
+
+class EngineType(enum.IntEnum):
+    Monolith = 0
+    EncDec = 1
+
+
+class Dims(ctypes.Structure):
+    _fields_ = [(n, c_int32) for n in (
+        "n_mels", "n_audio_ctx", "n_audio_state", "n_audio_head", "n_audio_layer",
+        "n_vocab", "n_text_ctx", "n_text_state", "n_text_head", "n_text_layer")]
+
+
+class Timings(ctypes.Structure):
+    _fields_ = [("logmel_ms", c_float), ("encoder_ms", c_float), ("cross_kv_ms", c_float),
+                ("decoder_ms", c_float), ("total_ms", c_float), ("batch", c_int32),
+                ("decoder_steps", c_int32)]
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """Loads the native library; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `make lib` (or __graft_entry__.build()); "
+                "there is no Python/CPU fallback for the engine")
+        L = ctypes.CDLL(LIB_PATH)
+        fp, ip64, ip32 = POINTER(c_float), POINTER(c_int64), POINTER(c_int32)
+        L.wt_engine_create.argtypes = [c_int, c_char_p, c_char_p, c_int, c_int, POINTER(c_void_p)]
+        L.wt_engine_destroy.argtypes = [c_void_p]
+        L.wt_engine_destroy.restype = None
+        L.wt_last_error.argtypes = [c_void_p]
+        L.wt_last_error.restype = c_char_p
+        L.wt_engine_dims.argtypes = [c_void_p, POINTER(Dims)]
+        L.wt_engine_set_option.argtypes = [c_void_p, c_char_p, c_long]
+        L.wt_engine_get_option.argtypes = [c_void_p, c_char_p, POINTER(c_long)]
+        L.wt_transcribe_pcm.argtypes = [c_void_p, fp, c_size_t, c_char_p, c_size_t, POINTER(c_size_t)]
+        L.wt_transcribe_file.argtypes = [c_void_p, c_char_p, c_char_p, c_size_t, POINTER(c_size_t)]
+        L.wt_logmel_batch.argtypes = [c_void_p, fp, c_int, fp]
+        L.wt_logmel_batch_dev.argtypes = [c_void_p, c_void_p, c_int, c_void_p]
+        L.wt_encdec_tokens_batch.argtypes = [c_void_p, fp, c_int, ip64, ip32]
+        L.wt_encdec_tokens_batch_dev.argtypes = [c_void_p, c_void_p, c_int, ip64, ip32]
+        L.wt_transcribe_tokens_batch_dev.argtypes = [c_void_p, c_void_p, c_int, ip64, ip32]
+        L.wt_encdec_debug_batch.argtypes = [c_void_p, fp, c_int, ip64, ip32, fp, fp, c_int]
+        L.wt_last_timings.argtypes = [c_void_p, POINTER(Timings)]
+        L.wt_decode_text.argtypes = [c_void_p, ip64, c_int, c_int, c_char_p, c_size_t, POINTER(c_size_t)]
+        L.wt_language_id.argtypes = [c_char_p]
+        L.wt_lang_code.argtypes = [c_int]
+        L.wt_lang_code.restype = c_char_p
+        L.wt_wav_read_legacy.argtypes = [c_char_p, fp, c_size_t, POINTER(c_size_t)]
+        L.wt_vocab_info.argtypes = [c_void_p, ip32]
+        L.wt_filters.argtypes = [c_void_p, fp, c_size_t, ip32, ip32]
+        L.wt_write_synthetic_weights.argtypes = [c_char_p, c_char_p, c_uint64]
+        L.wt_write_synthetic_vocab.argtypes = [c_char_p, c_int]
+        L.wt_dbg_gemm.argtypes = [c_void_p, c_int, c_int, c_int, fp, fp, fp, fp, fp, c_int, c_int, fp]
+        L.wt_dbg_skinny.argtypes = [c_void_p, c_int, c_int, c_int, fp, fp, fp, fp, c_int, fp, ip64]
+        L.wt_dbg_layernorm.argtypes = [c_void_p, c_int, c_int, fp, fp, fp, fp]
+        L.wt_dbg_encoder_attention.argtypes = [c_void_p, c_int, c_int, c_int, fp, fp]
+        L.wt_dbg_cross_attention.argtypes = [c_void_p, c_int, c_int, c_int, c_int, fp, fp, fp, fp]
+        L.wt_dbg_self_attention.argtypes = [c_void_p, c_int, c_int, c_int, c_int, fp, fp, fp, fp]
+        _lib = L
+    return _lib
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _fp(a: np.ndarray):
+    return a.ctypes.data_as(POINTER(c_float)) if a is not None else None
+
+
+def write_synthetic_weights(path: str, arch: str = "tiny", seed: int = 0) -> None:
+    rc = lib().wt_write_synthetic_weights(path.encode(), arch.encode(), seed)
+    if rc != WT_OK:
+        raise WtError(rc, lib().wt_last_error(None).decode())
+
+
+def write_synthetic_vocab(path: str, n_tokens: int = 50257) -> None:
+    rc = lib().wt_write_synthetic_vocab(path.encode(), n_tokens)
+    if rc != WT_OK:
+        raise WtError(rc, lib().wt_last_error(None).decode())
+
+
+def language_id(code: str) -> int:
+    return lib().wt_language_id(code.encode())
+
+
+def lang_code(idx: int) -> str:
+    return lib().wt_lang_code(idx).decode()
+
+
+def wav_read_legacy(path: str) -> np.ndarray:
+    n = c_size_t(0)
+    rc = lib().wt_wav_read_legacy(path.encode(), None, 0, byref(n))
+    if rc != WT_OK:
+        return np.zeros(0, np.float32)  # the reference returns an empty vector
+    out = np.zeros(n.value, np.float32)
+    lib().wt_wav_read_legacy(path.encode(), _fp(out), out.size, byref(n))
+    return out
+
+
+class Engine:
+    """Mirror of ``whisper::Engine`` / ``whisper::EncDec`` (reference whisper.h:159-197)."""
+
+    def __init__(self, model_prefix: str, vocab_path: str, multilingual: bool = True,
+                 engine_type: EngineType = EngineType.EncDec, device_id: int = 0):
+        self._h = c_void_p()
+        rc = lib().wt_engine_create(int(engine_type), model_prefix.encode(), vocab_path.encode(),
+                                    int(bool(multilingual)), device_id, byref(self._h))
+        if rc != WT_OK:
+            self._h = c_void_p()
+            raise WtError(rc, lib().wt_last_error(None).decode())
+        d = Dims()
+        lib().wt_engine_dims(self._h, byref(d))
+        self.dims = d
+
+    # -- lifecycle -------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None) and self._h.value:
+            lib().wt_engine_destroy(self._h)
+            self._h = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int) -> None:
+        if rc != WT_OK:
+            raise WtError(rc, lib().wt_last_error(self._h).decode())
+
+    @property
+    def handle(self) -> c_void_p:
+        return self._h
+
+    def set_option(self, key: str, value: int) -> None:
+        self._check(lib().wt_engine_set_option(self._h, key.encode(), int(value)))
+
+    def get_option(self, key: str) -> int:
+        v = c_long(0)
+        self._check(lib().wt_engine_get_option(self._h, key.encode(), byref(v)))
+        return v.value
+
+    # -- shapes ----------------------------------------------------------------------
+    @property
+    def mel_shape(self):
+        return (self.dims.n_mels, 2 * self.dims.n_audio_ctx)
+
+    @property
+    def pcm_len(self) -> int:
+        return 2 * self.dims.n_audio_ctx * 160
+
+    # -- the reference's two virtuals ------------------------------------------------
+    def transcribe(self, samples_or_path) -> str:
+        buf = ctypes.create_string_buffer(16384)
+        n = c_size_t(0)
+        if isinstance(samples_or_path, (str, bytes, os.PathLike)):
+            path = os.fsencode(samples_or_path)
+            self._check(lib().wt_transcribe_file(self._h, path, buf, len(buf), byref(n)))
+        else:
+            pcm = _f32(samples_or_path).reshape(-1)
+            self._check(lib().wt_transcribe_pcm(self._h, _fp(pcm), pcm.size, buf, len(buf), byref(n)))
+        return buf.raw[: n.value].decode("utf-8", errors="replace")
+
+    # -- batch entry points ----------------------------------------------------------
+    def logmel_batch(self, pcm) -> np.ndarray:
+        pcm = _f32(pcm).reshape(-1, self.pcm_len)
+        mel = np.empty((pcm.shape[0],) + self.mel_shape, np.float32)
+        self._check(lib().wt_logmel_batch(self._h, _fp(pcm), pcm.shape[0], _fp(mel)))
+        return mel
+
+    def encdec_tokens_batch(self, mel):
+        mel = _f32(mel).reshape((-1,) + self.mel_shape)
+        B = mel.shape[0]
+        ids = np.zeros((B, WT_MAX_IDS), np.int64)
+        n = np.zeros(B, np.int32)
+        self._check(lib().wt_encdec_tokens_batch(
+            self._h, _fp(mel), B, ids.ctypes.data_as(POINTER(c_int64)), n.ctypes.data_as(POINTER(c_int32))))
+        return ids, n
+
+    def encdec_tokens_batch_dev(self, d_mel_ptr: int, batch: int):
+        ids = np.zeros((batch, WT_MAX_IDS), np.int64)
+        n = np.zeros(batch, np.int32)
+        self._check(lib().wt_encdec_tokens_batch_dev(
+            self._h, c_void_p(d_mel_ptr), batch, ids.ctypes.data_as(POINTER(c_int64)),
+            n.ctypes.data_as(POINTER(c_int32))))
+        return ids, n
+
+    def transcribe_tokens_batch_dev(self, d_pcm_ptr: int, batch: int):
+        ids = np.zeros((batch, WT_MAX_IDS), np.int64)
+        n = np.zeros(batch, np.int32)
+        self._check(lib().wt_transcribe_tokens_batch_dev(
+            self._h, c_void_p(d_pcm_ptr), batch, ids.ctypes.data_as(POINTER(c_int64)),
+            n.ctypes.data_as(POINTER(c_int32))))
+        return ids, n
+
+    def logmel_batch_dev(self, d_pcm_ptr: int, batch: int, d_mel_ptr: int) -> None:
+        self._check(lib().wt_logmel_batch_dev(self._h, c_void_p(d_pcm_ptr), batch, c_void_p(d_mel_ptr)))
+
+    def encdec_debug_batch(self, mel, want_enc_out=True, want_logits=True, steps_cap=27):
+        mel = _f32(mel).reshape((-1,) + self.mel_shape)
+        B = mel.shape[0]
+        ids = np.zeros((B, WT_MAX_IDS), np.int64)
+        n = np.zeros(B, np.int32)
+        enc = np.zeros((B, self.dims.n_audio_ctx, self.dims.n_audio_state), np.float32) if want_enc_out else None
+        logits = np.zeros((B, steps_cap, self.dims.n_vocab), np.float32) if want_logits else None
+        self._check(lib().wt_encdec_debug_batch(
+            self._h, _fp(mel), B, ids.ctypes.data_as(POINTER(c_int64)), n.ctypes.data_as(POINTER(c_int32)),
+            _fp(enc) if enc is not None else None, _fp(logits) if logits is not None else None, steps_cap))
+        return ids, n, enc, logits
+
+    def timings(self) -> Timings:
+        t = Timings()
+        self._check(lib().wt_last_timings(self._h, byref(t)))
+        return t
+
+    # -- host helpers ----------------------------------------------------------------
+    def decode_text(self, ids, omit_special_tokens: bool = False) -> str:
+        ids = np.ascontiguousarray(ids, dtype=np.int64).reshape(-1)
+        buf = ctypes.create_string_buffer(16384)
+        n = c_size_t(0)
+        self._check(lib().wt_decode_text(self._h, ids.ctypes.data_as(POINTER(c_int64)), ids.size,
+                                         int(omit_special_tokens), buf, len(buf), byref(n)))
+        return buf.raw[: n.value].decode("utf-8", errors="replace")
+
+    def vocab_info(self) -> dict:
+        out = (c_int32 * 9)()
+        self._check(lib().wt_vocab_info(self._h, out))
+        keys = ("n_vocab", "eot", "sot", "translate", "transcribe", "prev", "solm", "not", "beg")
+        return dict(zip(keys, list(out)))
+
+    def filters(self) -> np.ndarray:
+        nm, nf = c_int32(0), c_int32(0)
+        total = lib().wt_filters(self._h, None, 0, byref(nm), byref(nf))
+        out = np.zeros(total, np.float32)
+        lib().wt_filters(self._h, _fp(out), out.size, byref(nm), byref(nf))
+        return out.reshape(nm.value, nf.value)
+
+    # -- kernel-level taps (include/wt_debug.h) --------------------------------------
+    def dbg_gemm(self, A, W, bias=None, R=None, pos=None, epi=0):
+        A, W = _f32(A), _f32(W)
+        M, K = A.shape
+        N = W.shape[0]
+        C = np.zeros((M, N), np.float32)
+        bias = _f32(bias) if bias is not None else None
+        R = _f32(R) if R is not None else None
+        pos = _f32(pos) if pos is not None else None
+        self._check(lib().wt_dbg_gemm(self._h, M, N, K, _fp(A), _fp(W), _fp(bias), _fp(R), _fp(pos),
+                                      pos.shape[0] if pos is not None else 0, epi, _fp(C)))
+        return C
+
+    def dbg_skinny(self, X, W, bias=None, R=None, epi=0, want_argmax=False):
+        X, W = _f32(X), _f32(W)
+        B, K = X.shape
+        N = W.shape[0]
+        Y = np.zeros((B, N), np.float32)
+        bias = _f32(bias) if bias is not None else None
+        R = _f32(R) if R is not None else None
+        am = np.zeros(B, np.int64) if want_argmax else None
+        self._check(lib().wt_dbg_skinny(self._h, B, N, K, _fp(X), _fp(W), _fp(bias), _fp(R), epi, _fp(Y),
+                                        am.ctypes.data_as(POINTER(c_int64)) if am is not None else None))
+        return (Y, am) if want_argmax else Y
+
+    def dbg_layernorm(self, x, g, b):
+        x, g, b = _f32(x), _f32(g), _f32(b)
+        y = np.zeros_like(x)
+        self._check(lib().wt_dbg_layernorm(self._h, x.shape[0], x.shape[1], _fp(x), _fp(g), _fp(b), _fp(y)))
+        return y
+
+    def dbg_encoder_attention(self, qkv, batch, T, heads):
+        qkv = _f32(qkv)
+        out = np.zeros((batch * T, heads * 64), np.float32)
+        self._check(lib().wt_dbg_encoder_attention(self._h, batch, T, heads, _fp(qkv), _fp(out)))
+        return out
+
+    def dbg_cross_attention(self, q, kc, vc, chunks=4):
+        q, kc, vc = _f32(q), _f32(kc), _f32(vc)
+        B, H, T, _ = kc.shape
+        out = np.zeros((B, H * 64), np.float32)
+        self._check(lib().wt_dbg_cross_attention(self._h, B, H, T, chunks, _fp(q), _fp(kc), _fp(vc), _fp(out)))
+        return out
+
+    def dbg_self_attention(self, qkv, kcache, vcache, pos):
+        qkv, kcache, vcache = _f32(qkv), _f32(kcache).copy(), _f32(vcache).copy()
+        B, cap, d = kcache.shape
+        out = np.zeros((B, d), np.float32)
+        self._check(lib().wt_dbg_self_attention(self._h, B, d // 64, cap, pos, _fp(qkv), _fp(kcache),
+                                                _fp(vcache), _fp(out)))
+        return out, kcache, vcache
+
+
+def create_engine(engine_type, model_prefix: str, vocab_path: str, multilingual: bool):
+    """Mirror of ``whisper::create_engine`` (reference whisper.cpp:778-790): returns None
+    (after a message on stderr) for an unknown or unsupported engine type."""
+    import sys
+    try:
+        et = EngineType(int(engine_type))
+    except ValueError:
+        print("Unknown engine-type", file=sys.stderr)
+        return None
+    if et == EngineType.Monolith:
+        print("EngineType::Monolith is not provided by the MI355X build", file=sys.stderr)
+        return None
+    return Engine(model_prefix, vocab_path, multilingual, et)

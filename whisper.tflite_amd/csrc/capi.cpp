@@ -1,0 +1,425 @@
+// extern "C" boundary (include/wt_capi.h): exception-free wrappers over wt::Engine.
+#include "wt_capi.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "engine.h"
+#include "weights_gen.h"
+#include "wt_debug.h"
+#include "kernels.h"
+
+struct wt_engine {
+  std::unique_ptr<wt::Engine> impl;
+  std::string last_error;
+};
+
+namespace {
+thread_local std::string g_create_error;
+
+int fail(wt_engine* h, int code, const std::string& msg) {
+  if (h) {
+    h->last_error = msg;
+  } else {
+    g_create_error = msg;
+  }
+  return code;
+}
+
+// Runs fn, translating every exception into a status code.
+template <class F>
+int guarded(wt_engine* h, F&& fn) {
+  try {
+    fn();
+    if (h) h->last_error.clear();
+    return WT_OK;
+  } catch (const wt::Error& e) {
+    return fail(h, e.code, e.what());
+  } catch (const std::bad_alloc&) {
+    return fail(h, WT_ERR_DEVICE, "out of host memory");
+  } catch (const std::exception& e) {
+    const std::string w = e.what();
+    return fail(h, w.rfind("Failed to open", 0) == 0 ? WT_ERR_IO : WT_ERR_FORMAT, w);
+  } catch (...) {
+    return fail(h, WT_ERR_DEVICE, "unknown failure");
+  }
+}
+
+int copy_text(const std::string& s, char* out, size_t cap, size_t* len) {
+  if (len) *len = s.size();
+  if (out && cap > 0) {
+    const size_t n = std::min(s.size(), cap - 1);
+    std::memcpy(out, s.data(), n);
+    out[n] = 0;
+  }
+  return (out && s.size() + 1 <= cap) ? WT_OK : WT_ERR_BUFFER;
+}
+
+void hipchk(hipError_t e, const char* what) {
+  if (e != hipSuccess) throw wt::Error(WT_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+}  // namespace
+
+extern "C" {
+
+int wt_engine_create(int engine_type, const char* model_prefix, const char* vocab_path,
+                     int multilingual, int device_id, wt_engine** out) {
+  if (!out) return fail(nullptr, WT_ERR_INVALID_ARG, "out is NULL");
+  *out = nullptr;
+  if (!model_prefix || !vocab_path) return fail(nullptr, WT_ERR_INVALID_ARG, "NULL path");
+  if (engine_type == WT_ENGINE_MONOLITH) {
+    return fail(nullptr, WT_ERR_UNSUPPORTED,
+                "EngineType::Monolith is not provided by the MI355X build (EncDec only)");
+  }
+  if (engine_type != WT_ENGINE_ENCDEC) return fail(nullptr, WT_ERR_INVALID_ARG, "Unknown engine-type");
+  std::unique_ptr<wt_engine> h(new wt_engine);
+  const int rc = guarded(nullptr, [&] {
+    h->impl.reset(new wt::Engine(model_prefix, vocab_path, multilingual != 0, device_id));
+  });
+  if (rc != WT_OK) return rc;
+  *out = h.release();
+  return WT_OK;
+}
+
+void wt_engine_destroy(wt_engine* h) { delete h; }
+
+const char* wt_last_error(const wt_engine* h) {
+  return h ? h->last_error.c_str() : g_create_error.c_str();
+}
+
+int wt_engine_dims(const wt_engine* h, wt_dims* out) {
+  if (!h || !out) return WT_ERR_INVALID_ARG;
+  static_assert(sizeof(wt_dims) == sizeof(wtw::Dims), "wt_dims mirrors wtw::Dims");
+  std::memcpy(out, &h->impl->dims(), sizeof(wt_dims));
+  return WT_OK;
+}
+
+int wt_engine_set_option(wt_engine* h, const char* key, long value) {
+  if (!h || !key) return WT_ERR_INVALID_ARG;
+  wt::Engine& e = *h->impl;
+  const std::string k(key);
+  if (k == "language") {
+    if (value < 0 || value >= wt::language_count()) return fail(h, WT_ERR_INVALID_ARG, "language id out of range");
+    e.language = value;
+  } else if (k == "max_tokens") {
+    if (value < 4 || value > 31) return fail(h, WT_ERR_INVALID_ARG, "max_tokens must be in [4, 31]");
+    e.max_tokens = value;
+  } else if (k == "stop_at_eot") {
+    e.stop_at_eot = value != 0;
+  } else if (k == "verbose") {
+    e.verbose = value;
+  } else if (k == "cross_chunks") {
+    if (value < 1 || value > 64) return fail(h, WT_ERR_INVALID_ARG, "cross_chunks must be in [1, 64]");
+    e.cross_chunks = value;
+  } else {
+    return fail(h, WT_ERR_INVALID_ARG, "unknown option: " + k);
+  }
+  return WT_OK;
+}
+
+int wt_engine_get_option(const wt_engine* h, const char* key, long* value) {
+  if (!h || !key || !value) return WT_ERR_INVALID_ARG;
+  const wt::Engine& e = *h->impl;
+  const std::string k(key);
+  if (k == "language") *value = e.language;
+  else if (k == "max_tokens") *value = e.max_tokens;
+  else if (k == "stop_at_eot") *value = e.stop_at_eot;
+  else if (k == "verbose") *value = e.verbose;
+  else if (k == "cross_chunks") *value = e.cross_chunks;
+  else return WT_ERR_INVALID_ARG;
+  return WT_OK;
+}
+
+// ------------------------------------------------------------- batches ---
+
+int wt_logmel_batch_dev(wt_engine* h, const float* d_pcm, int batch, float* d_mel) {
+  if (!h || !d_pcm || !d_mel) return WT_ERR_INVALID_ARG;
+  return guarded(h, [&] {
+    h->impl->logmel(d_pcm, batch, d_mel);
+    h->impl->sync();
+  });
+}
+
+int wt_logmel_batch(wt_engine* h, const float* pcm, int batch, float* mel) {
+  if (!h || !pcm || !mel) return WT_ERR_INVALID_ARG;
+  return guarded(h, [&] {
+    wt::Engine& e = *h->impl;
+    float* d_pcm = e.staging_pcm(batch);
+    float* d_mel = e.staging_mel(batch);
+    hipchk(hipMemcpyAsync(d_pcm, pcm, size_t(batch) * e.pcm_elems() * sizeof(float), hipMemcpyHostToDevice, e.stream()), "H2D pcm");
+    e.logmel(d_pcm, batch, d_mel);
+    hipchk(hipMemcpyAsync(mel, d_mel, size_t(batch) * e.mel_elems() * sizeof(float), hipMemcpyDeviceToHost, e.stream()), "D2H mel");
+    e.sync();
+  });
+}
+
+int wt_encdec_tokens_batch_dev(wt_engine* h, const float* d_mel, int batch, int64_t* ids,
+                               int32_t* n_ids) {
+  if (!h || !d_mel || !ids || !n_ids) return WT_ERR_INVALID_ARG;
+  return guarded(h, [&] {
+    h->impl->encode(d_mel, batch);
+    h->impl->decode(batch, ids, n_ids, nullptr, 0);
+  });
+}
+
+int wt_encdec_tokens_batch(wt_engine* h, const float* mel, int batch, int64_t* ids, int32_t* n_ids) {
+  return wt_encdec_debug_batch(h, mel, batch, ids, n_ids, nullptr, nullptr, 0);
+}
+
+int wt_transcribe_tokens_batch_dev(wt_engine* h, const float* d_pcm, int batch, int64_t* ids,
+                                   int32_t* n_ids) {
+  if (!h || !d_pcm || !ids || !n_ids) return WT_ERR_INVALID_ARG;
+  return guarded(h, [&] {
+    wt::Engine& e = *h->impl;
+    float* d_mel = e.staging_mel(batch);
+    e.logmel(d_pcm, batch, d_mel);
+    e.encode(d_mel, batch);
+    e.decode(batch, ids, n_ids, nullptr, 0);
+  });
+}
+
+int wt_encdec_debug_batch(wt_engine* h, const float* mel, int batch, int64_t* ids, int32_t* n_ids,
+                          float* enc_out, float* logits, int logits_steps_cap) {
+  if (!h || !mel || !ids || !n_ids) return WT_ERR_INVALID_ARG;
+  return guarded(h, [&] {
+    wt::Engine& e = *h->impl;
+    float* d_mel = e.staging_mel(batch);
+    hipchk(hipMemcpyAsync(d_mel, mel, size_t(batch) * e.mel_elems() * sizeof(float), hipMemcpyHostToDevice, e.stream()), "H2D mel");
+    e.encode(d_mel, batch);
+    if (enc_out) {
+      const size_t n = size_t(batch) * e.dims().n_audio_ctx * e.dims().n_audio_state;
+      hipchk(hipMemcpyAsync(enc_out, e.enc_out(), n * sizeof(float), hipMemcpyDeviceToHost, e.stream()), "D2H enc_out");
+    }
+    e.decode(batch, ids, n_ids, logits, logits_steps_cap);
+  });
+}
+
+int wt_last_timings(const wt_engine* h, wt_timings* out) {
+  if (!h || !out) return WT_ERR_INVALID_ARG;
+  const wt::Timings& t = h->impl->timings();
+  out->logmel_ms = t.logmel_ms;
+  out->encoder_ms = t.encoder_ms;
+  out->cross_kv_ms = t.cross_kv_ms;
+  out->decoder_ms = t.decoder_ms;
+  out->total_ms = t.total_ms;
+  out->batch = t.batch;
+  out->decoder_steps = t.decoder_steps;
+  return WT_OK;
+}
+
+// --------------------------------------------------------- single clip ---
+
+int wt_transcribe_pcm(wt_engine* h, const float* pcm, size_t n_samples, char* out, size_t cap,
+                      size_t* len) {
+  if (!h || (!pcm && n_samples)) return WT_ERR_INVALID_ARG;
+  std::string text;
+  const int rc = guarded(h, [&] {
+    wt::Engine& e = *h->impl;
+    // pad with zeros or truncate to one 30 s window (whisper.cpp:753)
+    std::vector<float> clip(e.pcm_elems(), 0.0f);
+    std::memcpy(clip.data(), pcm, std::min(n_samples, clip.size()) * sizeof(float));
+    float* d_pcm = e.staging_pcm(1);
+    float* d_mel = e.staging_mel(1);
+    hipchk(hipMemcpyAsync(d_pcm, clip.data(), clip.size() * sizeof(float), hipMemcpyHostToDevice, e.stream()), "H2D pcm");
+    e.logmel(d_pcm, 1, d_mel);
+    e.encode(d_mel, 1);
+    int64_t ids[WT_MAX_IDS];
+    int32_t n = 0;
+    e.decode(1, ids, &n, nullptr, 0);
+    bool missing = false;
+    // omit_special_tokens = false, as EncDec::transcribe passes (whisper.cpp:766-767)
+    text = wt::decode_tokens(e.vocab(), ids, n, false, &missing);
+    if (missing && e.verbose) std::fprintf(stderr, "[wt] token id without a vocab entry skipped\n");
+  });
+  if (rc != WT_OK) {
+    if (len) *len = 0;
+    if (out && cap) out[0] = 0;
+    return rc;
+  }
+  return copy_text(text, out, cap, len);
+}
+
+int wt_transcribe_file(wt_engine* h, const char* wav_path, char* out, size_t cap, size_t* len) {
+  if (!h || !wav_path) return WT_ERR_INVALID_ARG;
+  std::vector<float> pcm;
+  // an unreadable WAV yields an empty vector in the reference and is then padded to 30 s
+  // of silence (whisper.cpp:772-773); same here
+  (void)wt::wav_read_legacy(wav_path, &pcm, h->impl->verbose != 0);
+  return wt_transcribe_pcm(h, pcm.data(), pcm.size(), out, cap, len);
+}
+
+// -------------------------------------------------------------- helpers ---
+
+int wt_decode_text(wt_engine* h, const int64_t* ids, int n, int omit_special_tokens, char* out,
+                   size_t cap, size_t* len) {
+  if (!h || (!ids && n)) return WT_ERR_INVALID_ARG;
+  bool missing = false;
+  const std::string s = wt::decode_tokens(h->impl->vocab(), ids, n, omit_special_tokens != 0, &missing);
+  if (missing) {
+    if (len) *len = 0;
+    return fail(h, WT_ERR_INVALID_ARG, "token id without a vocab entry");
+  }
+  return copy_text(s, out, cap, len);
+}
+
+int wt_language_id(const char* code) { return code ? wt::language_id(code) : wt::language_count(); }
+const char* wt_lang_code(int id) {
+  return (id >= 0 && id < wt::language_count()) ? wt::lang_code(size_t(id)).c_str() : "";
+}
+
+int wt_wav_read_legacy(const char* path, float* out, size_t cap, size_t* n) {
+  if (!path || !n) return WT_ERR_INVALID_ARG;
+  std::vector<float> s;
+  if (!wt::wav_read_legacy(path, &s, false)) {
+    *n = 0;
+    return WT_ERR_IO;
+  }
+  *n = s.size();
+  if (out) std::memcpy(out, s.data(), std::min(cap, s.size()) * sizeof(float));
+  return WT_OK;
+}
+
+int wt_vocab_info(const wt_engine* h, int32_t out[9]) {
+  if (!h || !out) return WT_ERR_INVALID_ARG;
+  const wt::VocabData& v = h->impl->vocab();
+  const int32_t vals[9] = {v.n_vocab,    v.token_eot,  v.token_sot, v.token_translate, v.token_transcribe,
+                           v.token_prev, v.token_solm, v.token_not, v.token_beg};
+  std::memcpy(out, vals, sizeof(vals));
+  return WT_OK;
+}
+
+int wt_filters(const wt_engine* h, float* out, size_t cap, int32_t* n_mel, int32_t* n_fft) {
+  if (!h) return 0;
+  const wt::FilterBank& f = h->impl->filters();
+  if (n_mel) *n_mel = f.n_mel;
+  if (n_fft) *n_fft = f.n_fft;
+  if (out) std::memcpy(out, f.data.data(), std::min(cap, f.data.size()) * sizeof(float));
+  return static_cast<int>(f.data.size());
+}
+
+int wt_write_synthetic_weights(const char* path, const char* arch, uint64_t seed) {
+  if (!path || !arch) return WT_ERR_INVALID_ARG;
+  wtw::Dims dims;
+  if (!wtw::dims_by_name(arch, &dims)) return fail(nullptr, WT_ERR_INVALID_ARG, std::string("unknown arch: ") + arch);
+  std::string err;
+  const int rc = wtw::write_synthetic(path, dims, seed, &err);
+  if (rc != 0) return fail(nullptr, rc == 1 ? WT_ERR_INVALID_ARG : WT_ERR_IO, err);
+  return WT_OK;
+}
+
+int wt_write_synthetic_vocab(const char* path, int n_tokens) {
+  if (!path || n_tokens < 0) return WT_ERR_INVALID_ARG;
+  return guarded(nullptr, [&] {
+    wt::write_vocab_file(path, wt::make_slaney_filterbank(80, 400, 16000), wt::make_synthetic_tokens(n_tokens));
+  });
+}
+
+// ------------------------------------------------- kernel-level debug taps ---
+// Host in / host out wrappers around single kernels so that a parity failure can be
+// localised (tests/test_gpu_kernels.py).  Not part of the drop-in boundary.
+
+namespace {
+struct DevBuf {
+  float* p = nullptr;
+  explicit DevBuf(size_t n) { hipchk(hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(n, 1) * sizeof(float)), "hipMalloc"); }
+  DevBuf(const float* host, size_t n) : DevBuf(n) {
+    if (host && n) hipchk(hipMemcpy(p, host, n * sizeof(float), hipMemcpyHostToDevice), "H2D");
+  }
+  ~DevBuf() { (void)hipFree(p); }
+  void to_host(float* host, size_t n) const { hipchk(hipMemcpy(host, p, n * sizeof(float), hipMemcpyDeviceToHost), "D2H"); }
+};
+}  // namespace
+
+int wt_dbg_gemm(wt_engine* h, int M, int N, int K, const float* A, const float* W, const float* bias,
+                const float* R, const float* pos, int pos_period, int epi, float* C) {
+  if (!h || N % 128 || K % 32) return WT_ERR_INVALID_ARG;
+  return guarded(h, [&] {
+    DevBuf dA(A, size_t(M) * K), dW(W, size_t(N) * K), dB(bias, N), dC(R ? R : nullptr, size_t(M) * N),
+        dP(pos, pos ? size_t(pos_period) * N : 0);
+    wt::GemmArgs g;
+    g.A = dA.p; g.lda = K; g.W = dW.p; g.bias = dB.p; g.C = dC.p; g.R = dC.p; g.ldc = N;
+    g.pos = dP.p; g.pos_period = pos_period > 0 ? pos_period : 1;
+    g.M = M; g.N = N; g.K = K;
+    wt::launch_gemm(g, epi, h->impl->stream());
+    h->impl->sync();
+    dC.to_host(C, size_t(M) * N);
+  });
+}
+
+int wt_dbg_skinny(wt_engine* h, int B, int N, int K, const float* X, const float* W, const float* bias,
+                  const float* R, int epi, float* Y, int64_t* argmax_out) {
+  if (!h) return WT_ERR_INVALID_ARG;
+  return guarded(h, [&] {
+    DevBuf dX(X, size_t(B) * K), dW(W, size_t(N) * K), dB(bias, N), dY(R ? R : nullptr, size_t(B) * N);
+    DevBuf dBest(size_t(B) * 2);
+    hipchk(hipMemset(dBest.p, 0, size_t(B) * 8), "memset");
+    wt::SkinnyArgs s;
+    s.X = dX.p; s.ldx = K; s.W = dW.p; s.bias = dB.p; s.Y = dY.p; s.R = dY.p; s.ldy = N;
+    s.B = B; s.N = N; s.K = K;
+    s.best = argmax_out ? reinterpret_cast<unsigned long long*>(dBest.p) : nullptr;
+    wt::launch_skinny(s, epi, h->impl->stream());
+    h->impl->sync();
+    dY.to_host(Y, size_t(B) * N);
+    if (argmax_out) {
+      std::vector<unsigned long long> best(B);
+      hipchk(hipMemcpy(best.data(), dBest.p, size_t(B) * 8, hipMemcpyDeviceToHost), "D2H");
+      for (int b = 0; b < B; ++b) argmax_out[b] = int64_t(best[b] & 0xffffffffull);
+    }
+  });
+}
+
+int wt_dbg_layernorm(wt_engine* h, int M, int d, const float* x, const float* g, const float* b, float* y) {
+  if (!h || d > 512) return WT_ERR_INVALID_ARG;
+  return guarded(h, [&] {
+    DevBuf dx(x, size_t(M) * d), dg(g, d), db(b, d), dy(size_t(M) * d);
+    wt::launch_layernorm(dx.p, dy.p, dg.p, db.p, M, d, h->impl->stream());
+    h->impl->sync();
+    dy.to_host(y, size_t(M) * d);
+  });
+}
+
+int wt_dbg_encoder_attention(wt_engine* h, int batch, int T, int heads, const float* qkv, float* out) {
+  if (!h) return WT_ERR_INVALID_ARG;
+  return guarded(h, [&] {
+    const size_t d = size_t(heads) * 64;
+    DevBuf dq(qkv, size_t(batch) * T * 3 * d), dout(size_t(batch) * T * d);
+    wt::launch_encoder_attention(dq.p, dout.p, batch, T, heads, h->impl->stream());
+    h->impl->sync();
+    dout.to_host(out, size_t(batch) * T * d);
+  });
+}
+
+int wt_dbg_cross_attention(wt_engine* h, int batch, int heads, int T, int chunks, const float* q,
+                           const float* kc, const float* vc, float* out) {
+  if (!h || chunks < 1 || chunks > 64) return WT_ERR_INVALID_ARG;
+  return guarded(h, [&] {
+    const size_t d = size_t(heads) * 64;
+    DevBuf dq(q, size_t(batch) * d), dk(kc, size_t(batch) * T * d), dv(vc, size_t(batch) * T * d);
+    DevBuf dws(size_t(batch) * heads * chunks * 66), dout(size_t(batch) * d);
+    wt::launch_cross_attention(dq.p, dk.p, dv.p, dws.p, batch, heads, T, chunks, h->impl->stream());
+    wt::launch_cross_combine(dws.p, dout.p, batch, heads, chunks, h->impl->stream());
+    h->impl->sync();
+    dout.to_host(out, size_t(batch) * d);
+  });
+}
+
+int wt_dbg_self_attention(wt_engine* h, int batch, int heads, int cap, int pos, const float* qkv,
+                          float* kcache, float* vcache, float* out) {
+  if (!h || pos >= cap || cap > 64) return WT_ERR_INVALID_ARG;
+  return guarded(h, [&] {
+    const size_t d = size_t(heads) * 64;
+    DevBuf dq(qkv, size_t(batch) * 3 * d), dk(kcache, size_t(batch) * cap * d), dv(vcache, size_t(batch) * cap * d),
+        dout(size_t(batch) * d);
+    wt::launch_self_attention(dq.p, dk.p, dv.p, cap, pos, dout.p, batch, heads, h->impl->stream());
+    h->impl->sync();
+    dout.to_host(out, size_t(batch) * d);
+    dk.to_host(kcache, size_t(batch) * cap * d);
+    dv.to_host(vcache, size_t(batch) * cap * d);
+  });
+}
+
+}  // extern "C"

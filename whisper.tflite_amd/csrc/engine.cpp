@@ -1,0 +1,575 @@
+#include "engine.h"
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+
+#include "kernels.h"
+
+namespace wt {
+
+namespace {
+void hip_check(hipError_t e, const char* what) {
+  if (e != hipSuccess) {
+    throw Error(5, std::string("HIP failure in ") + what + ": " + hipGetErrorString(e));
+  }
+}
+#define HIPCHK(x) hip_check((x), #x)
+
+size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
+}  // namespace
+
+// ------------------------------------------------------------ weights ---
+
+float* Engine::upload(const std::vector<float>& host) {
+  void* p = nullptr;
+  HIPCHK(hipMalloc(&p, std::max<size_t>(host.size(), 1) * sizeof(float)));
+  allocations_.push_back(p);
+  if (!host.empty()) HIPCHK(hipMemcpy(p, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+  return static_cast<float*>(p);
+}
+
+float* Engine::dalloc(size_t n_floats) {
+  void* p = nullptr;
+  HIPCHK(hipMalloc(&p, std::max<size_t>(n_floats, 1) * sizeof(float)));
+  return static_cast<float*>(p);
+}
+
+const float* Engine::dev(const std::string& name) const {
+  auto it = tensors_.find(name);
+  if (it == tensors_.end()) throw Error(3, "weight file: missing tensor " + name);
+  return it->second;
+}
+
+void Engine::upload_weights(const std::string& path) {
+  // Replaces Atom::Atom (whisper.cpp:261-271): instead of mmapping a .tflite FlatBuffer and
+  // building an interpreter, the flat .wtw payload is mapped, re-laid-out for the kernels
+  // and copied to HBM once.
+  const int fd = ::open(path.c_str(), O_RDONLY);
+  if (fd < 0) throw Error(2, "Failed to open file: " + path);
+  struct stat st;
+  if (fstat(fd, &st) != 0 || size_t(st.st_size) < sizeof(wtw::WtwHeader)) {
+    ::close(fd);
+    throw Error(3, "weight file too small: " + path);
+  }
+  void* map = mmap(nullptr, st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+  ::close(fd);
+  if (map == MAP_FAILED) throw Error(2, "Failed to mmap file: " + path);
+  struct Unmap {
+    void* p;
+    size_t n;
+    ~Unmap() { munmap(p, n); }
+  } unmap{map, size_t(st.st_size)};
+  const char* base = static_cast<const char*>(map);
+  wtw::WtwHeader hdr;
+  std::memcpy(&hdr, base, sizeof(hdr));
+  if (hdr.magic != wtw::kMagic || hdr.version != wtw::kVersion ||
+      size_t(hdr.table_offset) + size_t(hdr.n_tensors) * sizeof(wtw::WtwTensor) > size_t(st.st_size)) {
+    throw Error(3, "not a .wtw weight file: " + path);
+  }
+  dims_ = hdr.dims;
+  const wtw::Dims& c = dims_;
+  if (c.n_audio_state != c.n_text_state || c.n_audio_state % 64 != 0 ||
+      c.n_audio_state / c.n_audio_head != 64 || c.n_text_state / c.n_text_head != 64 ||
+      c.n_audio_state % 128 != 0 || c.n_audio_state > 512) {
+    throw Error(3, "unsupported model dims (need d_head 64, d % 128 == 0, d <= 512)");
+  }
+  std::map<std::string, std::pair<const float*, size_t>> host;
+  for (uint32_t i = 0; i < hdr.n_tensors; ++i) {
+    wtw::WtwTensor t;
+    std::memcpy(&t, base + hdr.table_offset + size_t(i) * sizeof(t), sizeof(t));
+    if (t.dtype != 0 || t.offset + t.nbytes > uint64_t(st.st_size)) {
+      throw Error(3, "corrupt tensor table in " + path);
+    }
+    t.name[sizeof(t.name) - 1] = 0;
+    host[t.name] = {reinterpret_cast<const float*>(base + t.offset), t.nbytes / sizeof(float)};
+  }
+  auto H = [&](const std::string& n, size_t expect) -> const float* {
+    auto it = host.find(n);
+    if (it == host.end()) throw Error(3, "weight file: missing tensor " + n);
+    if (it->second.second != expect) throw Error(3, "weight file: bad shape for " + n);
+    return it->second.first;
+  };
+  auto up = [&](const std::string& n, size_t expect) -> const float* {
+    const float* p = H(n, expect);
+    const float* d = upload(std::vector<float>(p, p + expect));
+    tensors_[n] = d;
+    return d;
+  };
+
+  const int d = c.n_audio_state, nm = c.n_mels;
+  // conv1 [d][n_mels][3] -> [d][kpad], k = kk * n_mels + ci  (implicit-GEMM order: the three
+  // taps of output frame t are three consecutive rows of the time-major padded input)
+  conv1_kpad = int(round_up(size_t(3) * nm, 32));
+  {
+    const float* w = H("encoder.conv1.weight", size_t(d) * nm * 3);
+    std::vector<float> r(size_t(d) * conv1_kpad, 0.0f);
+    for (int co = 0; co < d; ++co)
+      for (int ci = 0; ci < nm; ++ci)
+        for (int kk = 0; kk < 3; ++kk)
+          r[size_t(co) * conv1_kpad + kk * nm + ci] = w[(size_t(co) * nm + ci) * 3 + kk];
+    conv1_w = upload(r);
+    conv1_b = up("encoder.conv1.bias", d);
+  }
+  {
+    const float* w = H("encoder.conv2.weight", size_t(d) * d * 3);
+    std::vector<float> r(size_t(d) * 3 * d);
+    for (int co = 0; co < d; ++co)
+      for (int ci = 0; ci < d; ++ci)
+        for (int kk = 0; kk < 3; ++kk)
+          r[size_t(co) * 3 * d + kk * d + ci] = w[(size_t(co) * d + ci) * 3 + kk];
+    conv2_w = upload(r);
+    conv2_b = up("encoder.conv2.bias", d);
+  }
+  enc_pos = up("encoder.positional_embedding", size_t(c.n_audio_ctx) * d);
+
+  auto fused_qkv = [&](const std::string& p, AttnWeights* a) {
+    const size_t dd = size_t(d) * d;
+    std::vector<float> w(3 * dd), b(3 * size_t(d), 0.0f);
+    std::memcpy(w.data(), H(p + ".query.weight", dd), dd * 4);
+    std::memcpy(w.data() + dd, H(p + ".key.weight", dd), dd * 4);
+    std::memcpy(w.data() + 2 * dd, H(p + ".value.weight", dd), dd * 4);
+    std::memcpy(b.data(), H(p + ".query.bias", d), size_t(d) * 4);
+    std::memcpy(b.data() + 2 * size_t(d), H(p + ".value.bias", d), size_t(d) * 4);  // key has no bias
+    a->wqkv = upload(w);
+    a->bqkv = upload(b);
+    a->wo = up(p + ".out.weight", dd);
+    a->bo = up(p + ".out.bias", d);
+  };
+  auto mlp_ln = [&](const std::string& blk, BlockWeights* bw) {
+    bw->mlp_ln_g = up(blk + ".mlp_ln.weight", d);
+    bw->mlp_ln_b = up(blk + ".mlp_ln.bias", d);
+    bw->w1 = up(blk + ".mlp.0.weight", size_t(4) * d * d);
+    bw->b1 = up(blk + ".mlp.0.bias", size_t(4) * d);
+    bw->w2 = up(blk + ".mlp.2.weight", size_t(4) * d * d);
+    bw->b2 = up(blk + ".mlp.2.bias", d);
+  };
+  enc_blocks_.resize(c.n_audio_layer);
+  for (int l = 0; l < c.n_audio_layer; ++l) {
+    const std::string blk = "encoder.blocks." + std::to_string(l);
+    BlockWeights& bw = enc_blocks_[l];
+    bw.attn_ln_g = up(blk + ".attn_ln.weight", d);
+    bw.attn_ln_b = up(blk + ".attn_ln.bias", d);
+    fused_qkv(blk + ".attn", &bw.attn);
+    mlp_ln(blk, &bw);
+  }
+  enc_ln_post_g = up("encoder.ln_post.weight", d);
+  enc_ln_post_b = up("encoder.ln_post.bias", d);
+
+  tok_emb = up("decoder.token_embedding.weight", size_t(c.n_vocab) * d);
+  dec_pos = up("decoder.positional_embedding", size_t(c.n_text_ctx) * d);
+  dec_blocks_.resize(c.n_text_layer);
+  const size_t dd = size_t(d) * d;
+  std::vector<float> ckv_w(size_t(c.n_text_layer) * 2 * dd), ckv_b(size_t(c.n_text_layer) * 2 * d, 0.0f);
+  for (int l = 0; l < c.n_text_layer; ++l) {
+    const std::string blk = "decoder.blocks." + std::to_string(l);
+    BlockWeights& bw = dec_blocks_[l];
+    bw.attn_ln_g = up(blk + ".attn_ln.weight", d);
+    bw.attn_ln_b = up(blk + ".attn_ln.bias", d);
+    fused_qkv(blk + ".attn", &bw.attn);
+    bw.cross_ln_g = up(blk + ".cross_attn_ln.weight", d);
+    bw.cross_ln_b = up(blk + ".cross_attn_ln.bias", d);
+    bw.cross.wq = up(blk + ".cross_attn.query.weight", dd);
+    bw.cross.bq = up(blk + ".cross_attn.query.bias", d);
+    bw.cross.wo = up(blk + ".cross_attn.out.weight", dd);
+    bw.cross.bo = up(blk + ".cross_attn.out.bias", d);
+    // all layers' cross K/V projections act on the same encoder output: one GEMM
+    std::memcpy(ckv_w.data() + (size_t(l) * 2 + 0) * dd, H(blk + ".cross_attn.key.weight", dd), dd * 4);
+    std::memcpy(ckv_w.data() + (size_t(l) * 2 + 1) * dd, H(blk + ".cross_attn.value.weight", dd), dd * 4);
+    std::memcpy(ckv_b.data() + (size_t(l) * 2 + 1) * d, H(blk + ".cross_attn.value.bias", d), size_t(d) * 4);
+    mlp_ln(blk, &bw);
+  }
+  cross_kv_w = upload(ckv_w);
+  cross_kv_b = upload(ckv_b);
+  dec_ln_g = up("decoder.ln.weight", d);
+  dec_ln_b = up("decoder.ln.bias", d);
+}
+
+void Engine::build_frontend_tables() {
+  // STFT as a GEMM against a windowed DFT basis (reference: Hann window whisper.cpp:117-120,
+  // 400-point transform :157, bins 0..200 used after the fold :164-166).
+  const int n_fft = 400, n_bins = 201;
+  if (filters_.n_fft != n_bins || filters_.n_mel != dims_.n_mels) {
+    have_logmel_ = false;  // front end needs the 80x201 bank; encoder/decoder still work
+    return;
+  }
+  dft_k = int(round_up(n_fft, 32));  // 416: samples 400..415 meet zero basis entries
+  dft_im_off = 256;
+  dft_n = 512;
+  std::vector<float> basis(size_t(dft_n) * dft_k, 0.0f);
+  for (int k = 0; k < n_bins; ++k) {
+    for (int n = 0; n < n_fft; ++n) {
+      const double hann = 0.5 * (1.0 - std::cos(2.0 * M_PI * n / n_fft));
+      const int idx = (k * n) % n_fft;  // exact argument reduction
+      const double ang = 2.0 * M_PI * idx / n_fft;
+      basis[size_t(k) * dft_k + n] = static_cast<float>(hann * std::cos(ang));
+      basis[size_t(dft_im_off + k) * dft_k + n] = static_cast<float>(hann * std::sin(ang));
+    }
+  }
+  dft_basis = upload(basis);
+  mel_k = int(round_up(n_bins, 32));  // 224
+  mel_n = int(round_up(size_t(dims_.n_mels), 128));
+  std::vector<float> mw(size_t(mel_n) * mel_k, 0.0f);
+  for (int j = 0; j < dims_.n_mels; ++j)
+    for (int k = 0; k < n_bins; ++k) mw[size_t(j) * mel_k + k] = filters_.data[size_t(j) * n_bins + k];
+  mel_w = upload(mw);
+  have_logmel_ = true;
+}
+
+// ---------------------------------------------------------- lifecycle ---
+
+Engine::Engine(const std::string& model_prefix, const std::string& vocab_path, bool multilingual,
+               int device_id)
+    : device_(device_id) {
+  // vocab first: a missing vocab file throws exactly like the reference's MmapFile
+  read_vocab_file(vocab_path, multilingual, &filters_, &vocab_);
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) {
+    throw Error(5, "no HIP device available: this engine has no CPU fallback");
+  }
+  if (device_id < 0 || device_id >= n_dev) throw Error(5, "device_id out of range");
+  HIPCHK(hipSetDevice(device_));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device_));
+  if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos) {
+    throw Error(5, std::string("device is ") + prop.gcnArchName +
+                            ", kernels are built for gfx950 only");
+  }
+  HIPCHK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  for (auto& e : ev_) HIPCHK(hipEventCreate(&e));
+  upload_weights(model_prefix + ".wtw");
+  if (vocab_.n_vocab != dims_.n_vocab && verbose) {
+    std::fprintf(stderr, "[wt] note: vocab file n_vocab %d != model n_vocab %d\n", vocab_.n_vocab,
+                 dims_.n_vocab);
+  }
+  build_frontend_tables();
+  HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h_ids_), 4096 * 32 * sizeof(long long), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h_n_), 4096 * sizeof(int), hipHostMallocDefault));
+}
+
+Engine::~Engine() {
+  (void)hipSetDevice(device_);
+  if (stream_) (void)hipStreamSynchronize(stream_);
+  for (void* p : ws_.owned) (void)hipFree(p);
+  for (void* p : allocations_) (void)hipFree(p);
+  if (h_ids_) (void)hipHostFree(h_ids_);
+  if (h_n_) (void)hipHostFree(h_n_);
+  for (auto& e : ev_)
+    if (e) (void)hipEventDestroy(e);
+  if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+void Engine::sync() { HIPCHK(hipStreamSynchronize(stream_)); }
+
+void Engine::ensure_batch(int batch) {
+  if (batch <= 0 || batch > 4096) throw Error(1, "batch must be in [1, 4096]");
+  HIPCHK(hipSetDevice(device_));
+  if (batch <= ws_.batch) return;
+  HIPCHK(hipStreamSynchronize(stream_));
+  for (void* p : ws_.owned) (void)hipFree(p);
+  ws_ = Workspace();
+  const wtw::Dims& c = dims_;
+  const size_t B = batch, T0 = mel_frames(), T = c.n_audio_ctx, d = c.n_audio_state;
+  auto alloc = [&](size_t n_floats, bool zero) -> float* {
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, n_floats * sizeof(float)));
+    ws_.owned.push_back(p);
+    if (zero) HIPCHK(hipMemsetAsync(p, 0, n_floats * sizeof(float), stream_));
+    return static_cast<float*>(p);
+  };
+  // time-major, one zero row before and after each clip: the k=3 convolutions become
+  // plain GEMMs over three consecutive rows
+  ws_.melT = alloc(B * (T0 + 2) * c.n_mels + 256, true);
+  ws_.h1p = alloc(B * (T0 + 2) * d + 256, true);
+  ws_.x = alloc(B * T * d, false);
+  ws_.ln = alloc(B * T * d, false);
+  ws_.qkv = alloc(B * T * 3 * d, false);
+  ws_.att = alloc(B * T * d, false);
+  ws_.hid = alloc(B * T * 4 * d, false);
+  ws_.enc_out = alloc(B * T * d, false);
+  ws_.cross_kv = alloc(size_t(c.n_text_layer) * 2 * B * T * d, false);
+  ws_.xd = alloc(B * d, false);
+  ws_.lnd = alloc(B * d, false);
+  ws_.qkvd = alloc(B * 3 * d, false);
+  ws_.attd = alloc(B * d, false);
+  ws_.qd = alloc(B * d, false);
+  ws_.hd = alloc(B * 4 * d, false);
+  ws_.cross_ws = alloc(B * c.n_text_head * 64 * 66, false);
+  ws_.self_kv = alloc(size_t(c.n_text_layer) * 2 * B * self_cap_ * d, true);
+  ws_.logits = alloc(B * c.n_vocab, false);
+  ws_.best = reinterpret_cast<unsigned long long*>(alloc(B * 2, true));
+  ws_.ids = reinterpret_cast<long long*>(alloc(B * 32 * 2, true));
+  ws_.n_ids = reinterpret_cast<int*>(alloc(B, true));
+  ws_.finished = reinterpret_cast<int*>(alloc(B, true));
+  ws_.mel_stage = alloc(B * mel_elems(), false);
+  ws_.batch = batch;
+  HIPCHK(hipStreamSynchronize(stream_));
+}
+
+float* Engine::staging_mel(int batch) {
+  ensure_batch(batch);
+  return ws_.mel_stage;
+}
+
+float* Engine::staging_pcm(int batch) {
+  ensure_batch(batch);
+  if (!ws_.pcm_stage) {
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, size_t(ws_.batch) * pcm_elems() * sizeof(float)));
+    ws_.owned.push_back(p);
+    ws_.pcm_stage = static_cast<float*>(p);
+  }
+  return ws_.pcm_stage;
+}
+
+// ---------------------------------------------------------- front end ---
+
+void Engine::logmel(const float* d_pcm, int batch, float* d_mel) {
+  if (!have_logmel_) throw Error(3, "vocab file carries no 80x201 mel filter bank");
+  ensure_batch(batch);
+  const size_t T0 = mel_frames(), n_samples = pcm_elems(), pad = n_samples + 512;
+  if (!ws_.pcm_pad) {
+    const size_t Bc = ws_.batch;
+    auto alloc = [&](size_t n_floats) -> float* {
+      void* p = nullptr;
+      HIPCHK(hipMalloc(&p, n_floats * sizeof(float)));
+      ws_.owned.push_back(p);
+      HIPCHK(hipMemsetAsync(p, 0, n_floats * sizeof(float), stream_));
+      return static_cast<float*>(p);
+    };
+    ws_.pcm_pad = alloc(Bc * pad + 1024);
+    ws_.spec = alloc(Bc * T0 * dft_n);
+    ws_.pw = alloc(Bc * T0 * mel_k);
+    ws_.melacc = alloc(Bc * T0 * mel_n);
+    ws_.clip_max = reinterpret_cast<unsigned*>(alloc(Bc));
+  }
+  HIPCHK(hipEventRecord(ev_[0], stream_));
+  // zero tail per clip = the reference's zero fill past n_samples (whisper.cpp:149-153)
+  HIPCHK(hipMemcpy2DAsync(ws_.pcm_pad, pad * sizeof(float), d_pcm, n_samples * sizeof(float),
+                          n_samples * sizeof(float), batch, hipMemcpyDeviceToDevice, stream_));
+  const long M = long(batch) * long(T0);
+  GemmArgs g;
+  g.A = ws_.pcm_pad;
+  g.a_rpb = int(T0);
+  g.a_bs = long(pad);
+  g.lda = 160;  // hop: frame i starts at sample 160 * i
+  g.W = dft_basis;
+  g.C = ws_.spec;
+  g.M = int(M);
+  g.N = dft_n;
+  g.K = dft_k;
+  g.ldc = dft_n;
+  launch_gemm(g, 0, stream_);
+  launch_power_fold(ws_.spec, dft_n, dft_im_off, ws_.pw, mel_k, 201, M, stream_);
+  GemmArgs m;
+  m.A = ws_.pw;
+  m.lda = mel_k;
+  m.W = mel_w;
+  m.C = ws_.melacc;
+  m.M = int(M);
+  m.N = mel_n;
+  m.K = mel_k;
+  m.ldc = mel_n;
+  launch_gemm(m, 0, stream_);
+  HIPCHK(hipMemsetAsync(ws_.clip_max, 0, sizeof(unsigned) * batch, stream_));
+  launch_log_clipmax(ws_.melacc, mel_n, d_mel, ws_.clip_max, batch, dims_.n_mels, int(T0), stream_);
+  launch_mel_normalize(d_mel, ws_.clip_max, batch, dims_.n_mels, int(T0), stream_);
+  HIPCHK(hipEventRecord(ev_[1], stream_));
+  timings_.logmel_ms = -1.0f;  // resolved lazily in decode()/sync by the C ABI
+}
+
+// ------------------------------------------------------------ encoder ---
+
+void Engine::encode(const float* d_mel, int batch) {
+  ensure_batch(batch);
+  const wtw::Dims& c = dims_;
+  const int T0 = mel_frames(), T = c.n_audio_ctx, d = c.n_audio_state, M = batch * T;
+  HIPCHK(hipEventRecord(ev_[2], stream_));
+  launch_mel_transpose(d_mel, ws_.melT, batch, c.n_mels, T0, stream_);
+  {
+    GemmArgs g;  // conv1 + GELU: rows (clip, t) read melT rows t..t+2 (input t-1..t+1)
+    g.A = ws_.melT;
+    g.a_rpb = T0;
+    g.a_bs = long(T0 + 2) * c.n_mels;
+    g.lda = c.n_mels;
+    g.W = conv1_w;
+    g.bias = conv1_b;
+    g.C = ws_.h1p + d;  // row t lands at padded row t + 1
+    g.c_rpb = T0;
+    g.c_bs = long(T0 + 2) * d;
+    g.ldc = d;
+    g.M = batch * T0;
+    g.N = d;
+    g.K = conv1_kpad;
+    launch_gemm(g, kEpiBias | kEpiGelu, stream_);
+  }
+  {
+    GemmArgs g;  // conv2 (stride 2) + GELU + positional embedding
+    g.A = ws_.h1p;
+    g.a_rpb = T;
+    g.a_bs = long(T0 + 2) * d;
+    g.lda = 2 * d;  // output t reads padded rows 2t..2t+2
+    g.W = conv2_w;
+    g.bias = conv2_b;
+    g.pos = enc_pos;
+    g.pos_period = T;
+    g.C = ws_.x;
+    g.ldc = d;
+    g.M = M;
+    g.N = d;
+    g.K = 3 * d;
+    launch_gemm(g, kEpiBias | kEpiGelu | kEpiPos, stream_);
+  }
+  for (int l = 0; l < c.n_audio_layer; ++l) {
+    const BlockWeights& w = enc_blocks_[l];
+    launch_layernorm(ws_.x, ws_.ln, w.attn_ln_g, w.attn_ln_b, M, d, stream_);
+    GemmArgs q;
+    q.A = ws_.ln; q.lda = d; q.W = w.attn.wqkv; q.bias = w.attn.bqkv; q.C = ws_.qkv; q.ldc = 3 * d;
+    q.M = M; q.N = 3 * d; q.K = d;
+    launch_gemm(q, kEpiBias, stream_);
+    launch_encoder_attention(ws_.qkv, ws_.att, batch, T, c.n_audio_head, stream_);
+    GemmArgs o;
+    o.A = ws_.att; o.lda = d; o.W = w.attn.wo; o.bias = w.attn.bo; o.C = ws_.x; o.R = ws_.x; o.ldc = d;
+    o.M = M; o.N = d; o.K = d;
+    launch_gemm(o, kEpiBias | kEpiResidual, stream_);
+    launch_layernorm(ws_.x, ws_.ln, w.mlp_ln_g, w.mlp_ln_b, M, d, stream_);
+    GemmArgs f1;
+    f1.A = ws_.ln; f1.lda = d; f1.W = w.w1; f1.bias = w.b1; f1.C = ws_.hid; f1.ldc = 4 * d;
+    f1.M = M; f1.N = 4 * d; f1.K = d;
+    launch_gemm(f1, kEpiBias | kEpiGelu, stream_);
+    GemmArgs f2;
+    f2.A = ws_.hid; f2.lda = 4 * d; f2.W = w.w2; f2.bias = w.b2; f2.C = ws_.x; f2.R = ws_.x; f2.ldc = d;
+    f2.M = M; f2.N = d; f2.K = 4 * d;
+    launch_gemm(f2, kEpiBias | kEpiResidual, stream_);
+  }
+  launch_layernorm(ws_.x, ws_.enc_out, enc_ln_post_g, enc_ln_post_b, M, d, stream_);
+  HIPCHK(hipEventRecord(ev_[3], stream_));
+  {
+    // cross-attention K/V of every decoder layer, projected once per clip into the
+    // persistent cache [layer][k|v][clip][head][t][64] (the reference recomputes them
+    // inside every decoder Invoke(), whisper.cpp:375)
+    GemmArgs g;
+    g.A = ws_.enc_out; g.lda = d; g.W = cross_kv_w; g.bias = cross_kv_b; g.C = ws_.cross_kv;
+    g.M = M; g.N = c.n_text_layer * 2 * d; g.K = d;
+    g.c_rpb = T; g.kv_batch = batch; g.kv_heads = c.n_text_head; g.kv_dmodel = d;
+    launch_gemm(g, kEpiBias | kEpiKvLayout, stream_);
+  }
+  HIPCHK(hipEventRecord(ev_[4], stream_));
+}
+
+// ------------------------------------------------------------ decoder ---
+
+void Engine::decode(int batch, int64_t* ids, int32_t* n_ids, float* logits_host,
+                    int logits_steps_cap) {
+  ensure_batch(batch);
+  const wtw::Dims& c = dims_;
+  const int d = c.n_text_state, T = c.n_audio_ctx, H = c.n_text_head, V = c.n_vocab;
+  // prompt (whisper.cpp:327-339): [sot, 50259 + language, transcribe, notimestamps]
+  const long long prompt[4] = {vocab_.token_sot, 50259 + language, vocab_.token_transcribe,
+                               vocab_.token_not};
+  const int n_prompt = 4, stride = 32;
+  const int max_pos = int(std::min<long>(std::max<long>(max_tokens, n_prompt), 31));
+  for (int b = 0; b < batch; ++b) {
+    for (int i = 0; i < stride; ++i) h_ids_[size_t(b) * stride + i] = i < n_prompt ? prompt[i] : 0;
+    h_n_[b] = n_prompt;
+  }
+  HIPCHK(hipMemcpyAsync(ws_.ids, h_ids_, size_t(batch) * stride * sizeof(long long),
+                        hipMemcpyHostToDevice, stream_));
+  HIPCHK(hipMemcpyAsync(ws_.n_ids, h_n_, size_t(batch) * sizeof(int), hipMemcpyHostToDevice, stream_));
+  HIPCHK(hipMemsetAsync(ws_.finished, 0, size_t(batch) * sizeof(int), stream_));
+  HIPCHK(hipMemsetAsync(ws_.best, 0, size_t(batch) * sizeof(unsigned long long), stream_));
+
+  const int chunks = int(std::min<long>(std::max<long>(cross_chunks, 1), 64));
+  const size_t kv_slab = size_t(batch) * T * d;          // one (layer, k|v) slab of the cross cache
+  const size_t self_slab = size_t(batch) * self_cap_ * d;
+  int steps = 0;
+  for (int pos = 0; pos < max_pos; ++pos) {
+    launch_embed(tok_emb, dec_pos, ws_.ids, stride, pos, ws_.xd, batch, d, stream_);
+    for (int l = 0; l < c.n_text_layer; ++l) {
+      const BlockWeights& w = dec_blocks_[l];
+      launch_layernorm(ws_.xd, ws_.lnd, w.attn_ln_g, w.attn_ln_b, batch, d, stream_);
+      SkinnyArgs q;
+      q.X = ws_.lnd; q.ldx = d; q.W = w.attn.wqkv; q.bias = w.attn.bqkv; q.Y = ws_.qkvd; q.ldy = 3 * d;
+      q.B = batch; q.N = 3 * d; q.K = d;
+      launch_skinny(q, kEpiBias, stream_);
+      launch_self_attention(ws_.qkvd, ws_.self_kv + (size_t(l) * 2 + 0) * self_slab,
+                            ws_.self_kv + (size_t(l) * 2 + 1) * self_slab, self_cap_, pos, ws_.attd,
+                            batch, H, stream_);
+      SkinnyArgs o;
+      o.X = ws_.attd; o.ldx = d; o.W = w.attn.wo; o.bias = w.attn.bo; o.Y = ws_.xd; o.R = ws_.xd; o.ldy = d;
+      o.B = batch; o.N = d; o.K = d;
+      launch_skinny(o, kEpiBias | kEpiResidual, stream_);
+
+      launch_layernorm(ws_.xd, ws_.lnd, w.cross_ln_g, w.cross_ln_b, batch, d, stream_);
+      SkinnyArgs cq;
+      cq.X = ws_.lnd; cq.ldx = d; cq.W = w.cross.wq; cq.bias = w.cross.bq; cq.Y = ws_.qd; cq.ldy = d;
+      cq.B = batch; cq.N = d; cq.K = d;
+      launch_skinny(cq, kEpiBias, stream_);
+      launch_cross_attention(ws_.qd, ws_.cross_kv + (size_t(l) * 2 + 0) * kv_slab,
+                             ws_.cross_kv + (size_t(l) * 2 + 1) * kv_slab, ws_.cross_ws, batch, H, T,
+                             chunks, stream_);
+      launch_cross_combine(ws_.cross_ws, ws_.attd, batch, H, chunks, stream_);
+      SkinnyArgs co;
+      co.X = ws_.attd; co.ldx = d; co.W = w.cross.wo; co.bias = w.cross.bo; co.Y = ws_.xd; co.R = ws_.xd;
+      co.ldy = d; co.B = batch; co.N = d; co.K = d;
+      launch_skinny(co, kEpiBias | kEpiResidual, stream_);
+
+      launch_layernorm(ws_.xd, ws_.lnd, w.mlp_ln_g, w.mlp_ln_b, batch, d, stream_);
+      SkinnyArgs f1;
+      f1.X = ws_.lnd; f1.ldx = d; f1.W = w.w1; f1.bias = w.b1; f1.Y = ws_.hd; f1.ldy = 4 * d;
+      f1.B = batch; f1.N = 4 * d; f1.K = d;
+      launch_skinny(f1, kEpiBias | kEpiGelu, stream_);
+      SkinnyArgs f2;
+      f2.X = ws_.hd; f2.ldx = 4 * d; f2.W = w.w2; f2.bias = w.b2; f2.Y = ws_.xd; f2.R = ws_.xd; f2.ldy = d;
+      f2.B = batch; f2.N = d; f2.K = 4 * d;
+      launch_skinny(f2, kEpiBias | kEpiResidual, stream_);
+    }
+    if (pos >= n_prompt - 1) {
+      // logits against the tied embedding + greedy argmax (whisper.cpp:379-399); only the
+      // last position's row exists here, the reference computes and drops the others
+      launch_layernorm(ws_.xd, ws_.lnd, dec_ln_g, dec_ln_b, batch, d, stream_);
+      SkinnyArgs lg;
+      lg.X = ws_.lnd; lg.ldx = d; lg.W = tok_emb; lg.B = batch; lg.N = V; lg.K = d;
+      lg.Y = logits_host ? ws_.logits : nullptr; lg.ldy = V;
+      lg.best = ws_.best;
+      launch_skinny(lg, 0, stream_);
+      if (logits_host && steps < logits_steps_cap) {
+        HIPCHK(hipMemcpy2DAsync(logits_host + size_t(steps) * V, size_t(logits_steps_cap) * V * sizeof(float),
+                                ws_.logits, size_t(V) * sizeof(float), size_t(V) * sizeof(float), batch,
+                                hipMemcpyDeviceToHost, stream_));
+      }
+      launch_select_token(ws_.best, ws_.ids, stride, pos, ws_.n_ids, ws_.finished, vocab_.token_eot,
+                          int(stop_at_eot), batch, stream_);
+      ++steps;
+    }
+  }
+  HIPCHK(hipEventRecord(ev_[5], stream_));
+  HIPCHK(hipMemcpyAsync(h_ids_, ws_.ids, size_t(batch) * stride * sizeof(long long),
+                        hipMemcpyDeviceToHost, stream_));
+  HIPCHK(hipMemcpyAsync(h_n_, ws_.n_ids, size_t(batch) * sizeof(int), hipMemcpyDeviceToHost, stream_));
+  HIPCHK(hipStreamSynchronize(stream_));
+  HIPCHK(hipGetLastError());
+  for (int b = 0; b < batch; ++b) {
+    n_ids[b] = h_n_[b];
+    for (int i = 0; i < stride; ++i) ids[size_t(b) * stride + i] = i < h_n_[b] ? h_ids_[size_t(b) * stride + i] : 0;
+  }
+  float ms = 0;
+  timings_.batch = batch;
+  timings_.decoder_steps = steps;
+  if (hipEventElapsedTime(&ms, ev_[2], ev_[3]) == hipSuccess) timings_.encoder_ms = ms;
+  if (hipEventElapsedTime(&ms, ev_[3], ev_[4]) == hipSuccess) timings_.cross_kv_ms = ms;
+  if (hipEventElapsedTime(&ms, ev_[4], ev_[5]) == hipSuccess) timings_.decoder_ms = ms;
+  if (hipEventElapsedTime(&ms, ev_[2], ev_[5]) == hipSuccess) timings_.total_ms = ms;
+  if (timings_.logmel_ms < 0) {
+    timings_.logmel_ms = 0;
+    if (hipEventElapsedTime(&ms, ev_[0], ev_[1]) == hipSuccess) timings_.logmel_ms = ms;
+  }
+}
+
+}  // namespace wt

@@ -1,0 +1,135 @@
+// Engine: weights resident in HBM + the launch sequence of the EncDec hot path
+// (reference EncDec::transcribe, whisper.tflite/whisper.cpp:752-769), batch-first.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "host_util.h"
+#include "wtw_format.h"
+
+namespace wt {
+
+// Failure with the wt_status code the C ABI reports (wt_capi.h).
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string& what) : std::runtime_error(what), code(c) {}
+};
+
+struct Timings {
+  float logmel_ms = 0, encoder_ms = 0, cross_kv_ms = 0, decoder_ms = 0, total_ms = 0;
+  int batch = 0, decoder_steps = 0;
+};
+
+struct AttnWeights {
+  const float *wqkv = nullptr, *bqkv = nullptr;  // fused [3d][d] (self attention)
+  const float *wq = nullptr, *bq = nullptr;      // cross attention query
+  const float *wo = nullptr, *bo = nullptr;
+};
+struct BlockWeights {
+  const float *attn_ln_g, *attn_ln_b;
+  AttnWeights attn;
+  const float *cross_ln_g = nullptr, *cross_ln_b = nullptr;
+  AttnWeights cross;
+  const float *mlp_ln_g, *mlp_ln_b, *w1, *b1, *w2, *b2;
+};
+
+class Engine {
+ public:
+  // Throws std::runtime_error with a message; the C ABI maps it to a status code.
+  Engine(const std::string& model_prefix, const std::string& vocab_path, bool multilingual,
+         int device_id);
+  ~Engine();
+  Engine(const Engine&) = delete;
+  Engine& operator=(const Engine&) = delete;
+
+  const wtw::Dims& dims() const { return dims_; }
+  const VocabData& vocab() const { return vocab_; }
+  const FilterBank& filters() const { return filters_; }
+  const Timings& timings() const { return timings_; }
+  hipStream_t stream() const { return stream_; }
+
+  // options (reference hard-codes them, see wt_capi.h)
+  long language = 2;  // language_id("de")
+  long max_tokens = 30;
+  long stop_at_eot = 1;
+  long verbose = 0;
+  long cross_chunks = 4;
+
+  int mel_frames() const { return 2 * dims_.n_audio_ctx; }
+  size_t mel_elems() const { return size_t(dims_.n_mels) * mel_frames(); }
+  size_t pcm_elems() const { return size_t(mel_frames()) * 160; }
+
+  // d_pcm [B][pcm_elems] -> d_mel [B][n_mels][frames]; device pointers, async on stream()
+  void logmel(const float* d_pcm, int batch, float* d_mel);
+  // d_mel -> encoder output (internal) -> cross KV cache (internal); async
+  void encode(const float* d_mel, int batch);
+  // greedy loop; fills pinned host staging and synchronises.  ids [B][32], n [B].
+  void decode(int batch, int64_t* ids, int32_t* n_ids, float* logits_host, int logits_steps_cap);
+  void sync();
+
+  const float* enc_out() const { return ws_.enc_out; }
+  void ensure_batch(int batch);
+  float* staging_mel(int batch);  // device buffer [B][mel_elems]
+  float* staging_pcm(int batch);  // device buffer [B][pcm_elems]
+
+  // raw device allocator for debug entry points
+  float* dalloc(size_t n_floats);
+
+ private:
+  void upload_weights(const std::string& path);
+  const float* dev(const std::string& name) const;
+  float* upload(const std::vector<float>& host);
+  void build_frontend_tables();
+
+  int device_ = 0;
+  hipStream_t stream_ = nullptr;
+  hipEvent_t ev_[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  wtw::Dims dims_{};
+  VocabData vocab_;
+  FilterBank filters_;
+  Timings timings_;
+  bool have_logmel_ = false;
+
+  std::vector<void*> allocations_;
+  std::map<std::string, const float*> tensors_;  // raw tensors by .wtw name
+
+  // derived, re-laid-out weights
+  const float *conv1_w = nullptr, *conv1_b = nullptr, *conv2_w = nullptr, *conv2_b = nullptr;
+  int conv1_kpad = 0;
+  const float* enc_pos = nullptr;
+  std::vector<BlockWeights> enc_blocks_, dec_blocks_;
+  const float *enc_ln_post_g = nullptr, *enc_ln_post_b = nullptr;
+  const float *cross_kv_w = nullptr, *cross_kv_b = nullptr;  // [L*2*d][d], [L*2*d]
+  const float *tok_emb = nullptr, *dec_pos = nullptr, *dec_ln_g = nullptr, *dec_ln_b = nullptr;
+  // front end
+  const float* dft_basis = nullptr;  // [dft_n][dft_k]  windowed cos | sin rows
+  const float* mel_w = nullptr;      // [mel_n][mel_k]
+  int dft_n = 0, dft_k = 0, dft_im_off = 0, mel_n = 0, mel_k = 0;
+
+  struct Workspace {
+    int batch = 0;
+    float *melT = nullptr, *h1p = nullptr, *x = nullptr, *ln = nullptr, *qkv = nullptr,
+          *att = nullptr, *hid = nullptr, *enc_out = nullptr, *cross_kv = nullptr;
+    // decoder
+    float *xd = nullptr, *lnd = nullptr, *qkvd = nullptr, *attd = nullptr, *qd = nullptr,
+          *hd = nullptr, *cross_ws = nullptr, *self_kv = nullptr, *logits = nullptr;
+    unsigned long long* best = nullptr;
+    long long* ids = nullptr;
+    int *n_ids = nullptr, *finished = nullptr;
+    // front end
+    float *pcm_pad = nullptr, *spec = nullptr, *pw = nullptr, *melacc = nullptr;
+    unsigned* clip_max = nullptr;
+    float *mel_stage = nullptr, *pcm_stage = nullptr;
+    std::vector<void*> owned;
+  } ws_;
+  int self_cap_ = 32;
+  long long* h_ids_ = nullptr;  // pinned
+  int* h_n_ = nullptr;          // pinned
+};
+
+}  // namespace wt

@@ -1,0 +1,345 @@
+// Attention kernels for gfx950: the encoder's 1500x1500 self-attention (dense QK^T / PV
+// contractions on fp32 MFMA with in-register online softmax) and the decoder's
+// single-row self / cross attention over the persistent KV caches (HBM streaming).
+// Together with k_gemm.hip these replace the attention ops inside the graphs the
+// reference runs through tflite::Interpreter::Invoke() (whisper.tflite/whisper.cpp:295,
+// :375; graph per export/generate_onnx.py:85-120).
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace wt {
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// ------------------------------------------------------ encoder attention ---
+// Block = 4 wavefronts = 128 query rows of one (clip, head); K/V tiles of 64 keys go
+// global -> registers -> LDS once per block and are shared by the 4 wavefronts.
+//
+// "Swapped" products keep the softmax row on the lane:
+//   S^T[key][q] = K . Q^T      A = K tile (LDS, ds_read_b128), B = Q (registers)
+//   O^T[d][q]  += V^T . P^T    A = V tile (LDS, ds_read_b32),  B = P = exp2(S^T - m)
+// The C/D layout puts query q = lane & 31 on the lane and 16 keys in the registers
+// (row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)), so register r of S^T is, unmoved,
+// the B operand of PV step r when V is read at that same key order.
+constexpr int AQ = 128;      // queries per block
+constexpr int AK = 64;       // keys per tile
+constexpr int KLD = 68;      // K tile row stride (floats): conflict-free ds_read_b128
+constexpr int VLD = 64;
+
+__device__ __forceinline__ int crow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+__global__ __launch_bounds__(256) void encoder_attention_f32(const float* __restrict__ qkv,
+                                                             float* __restrict__ out, int T,
+                                                             int heads) {
+  __shared__ __attribute__((aligned(16))) float Ks[AK * KLD];
+  __shared__ __attribute__((aligned(16))) float Vs[AK * VLD];
+
+  const int d_model = heads * 64, ld = 3 * d_model;
+  const int q_blocks = (T + AQ - 1) / AQ;
+  // consecutive blocks on one XCD (blockIdx % 8 equal) walk the q-blocks of one
+  // (clip, head), so its K/V stay in that XCD's L2
+  const int nb = gridDim.x, bid = blockIdx.x;
+  const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int bh = logical / q_blocks, qb = logical % q_blocks;
+  const int b = bh / heads, h = bh % heads;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const float* base = qkv + (long)b * T * ld + h * 64;
+
+  // Q fragment: lane (q = l31, half lh) holds Q[q][8c + 4lh + j], pre-scaled by
+  // d_head^-1/2 * log2(e) so that softmax is exp2(s - max)
+  const int q_row = qb * AQ + wid * 32 + l31;
+  const int q_ld = q_row < T ? q_row : T - 1;
+  const float qscale = 0.125f * 1.44269504088896340736f;
+  f32x4 qf[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    qf[c] = *reinterpret_cast<const f32x4*>(base + (long)q_ld * ld + 8 * c + 4 * lh);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) qf[c][j] *= qscale;
+  }
+
+  f32x16 o0, o1;  // O^T tiles: d in [0,32) and [32,64)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.0f;
+  float m_run = -1e30f, l_run = 0.0f;
+
+  // staging map: 64 rows x 16 float4 = 1024 float4 per operand, 4 per thread
+  const int srow = tid >> 4, scol = (tid & 15) * 4;
+  const float* kbase = base + d_model + scol;
+  const float* vbase = base + 2 * d_model + scol;
+  f32x4 rk[4], rv[4];
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int key = kt * AK + srow + 16 * i;
+      if (key < T) {
+        rk[i] = *reinterpret_cast<const f32x4*>(kbase + (long)key * ld);
+        rv[i] = *reinterpret_cast<const f32x4*>(vbase + (long)key * ld);
+      } else {
+        rk[i] = f32x4{0, 0, 0, 0};
+        rv[i] = f32x4{0, 0, 0, 0};
+      }
+    }
+  };
+  const int n_tiles = (T + AK - 1) / AK;
+  load_tile(0);
+
+  for (int kt = 0; kt < n_tiles; ++kt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<f32x4*>(&Ks[(srow + 16 * i) * KLD + scol]) = rk[i];
+      *reinterpret_cast<f32x4*>(&Vs[(srow + 16 * i) * VLD + scol]) = rv[i];
+    }
+    __syncthreads();
+    if (kt + 1 < n_tiles) load_tile(kt + 1);
+
+    // S^T for the two 32-key halves of the tile
+    f32x16 s0, s1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s0[r] = s1[r] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const f32x4 k0 = *reinterpret_cast<const f32x4*>(&Ks[l31 * KLD + 8 * c + 4 * lh]);
+      const f32x4 k1 = *reinterpret_cast<const f32x4*>(&Ks[(32 + l31) * KLD + 8 * c + 4 * lh]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(k0[j], qf[c][j], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(k1[j], qf[c][j], s1, 0, 0, 0);
+      }
+    }
+    if ((kt + 1) * AK > T) {  // last tile: keys past T do not exist
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (kt * AK + crow(r, lh) >= T) s0[r] = -1e30f;
+        if (kt * AK + 32 + crow(r, lh) >= T) s1[r] = -1e30f;
+      }
+    }
+    // online softmax; the row (query) lives on lanes l and l ^ 32
+    float tmax = s0[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s0[r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s1[r]);
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m_run, tmax);
+    const float alpha = exp2f(m_run - m_new);
+    float psum = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s0[r] = exp2f(s0[r] - m_new);
+      s1[r] = exp2f(s1[r] - m_new);
+      psum += s0[r] + s1[r];
+    }
+    psum += __shfl_xor(psum, 32, 64);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      o0[r] *= alpha;
+      o1[r] *= alpha;
+    }
+    // O^T += V^T . P^T : step r contracts key crow(r, lh) (+32 for the second half)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = crow(r, lh);
+      const float v00 = Vs[key * VLD + l31];
+      const float v01 = Vs[key * VLD + 32 + l31];
+      o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v00, s0[r], o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v01, s0[r], o1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = 32 + crow(r, lh);
+      const float v10 = Vs[key * VLD + l31];
+      const float v11 = Vs[key * VLD + 32 + l31];
+      o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v10, s1[r], o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v11, s1[r], o1, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  if (q_row < T) {
+    const float inv = 1.0f / l_run;
+    float* orow = out + ((long)b * T + q_row) * d_model + h * 64;
+    // lane holds d = crow(r, lh) (+32): groups of 4 consecutive d -> 16-byte stores
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 a, c;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        a[j] = o0[4 * g + j] * inv;
+        c[j] = o1[4 * g + j] * inv;
+      }
+      *reinterpret_cast<f32x4*>(orow + 8 * g + 4 * lh) = a;
+      *reinterpret_cast<f32x4*>(orow + 32 + 8 * g + 4 * lh) = c;
+    }
+  }
+}
+
+// ------------------------------------------------- decoder self attention ---
+// One block per clip, one wavefront per head.  Appends this position's k, v to the
+// cache, then lane j scores position j (pos < 64), and lane d accumulates output d.
+__global__ void self_attention_step(const float* __restrict__ qkv, float* __restrict__ kcache,
+                                    float* __restrict__ vcache, int cap, int pos,
+                                    float* __restrict__ out, int heads) {
+  const int b = blockIdx.x, h = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int d = heads * 64;
+  const float* row = qkv + (long)b * 3 * d;
+  float* kc = kcache + ((long)b * cap) * d + h * 64;
+  float* vc = vcache + ((long)b * cap) * d + h * 64;
+  const float q = row[h * 64 + lane] * 0.125f;
+  const float knew = row[d + h * 64 + lane];
+  const float vnew = row[2 * d + h * 64 + lane];
+  kc[(long)pos * d + lane] = knew;
+  vc[(long)pos * d + lane] = vnew;
+  __shared__ float qs[8][64];
+  __shared__ float ps[8][64];
+  qs[h][lane] = q;
+  __syncthreads();  // also orders this block's cache writes before its reads below
+  const int n = pos + 1;
+  float s = -1e30f;
+  if (lane < n) {
+    const float* kr = kc + (long)lane * d;
+    float acc = 0.0f;
+#pragma unroll 8
+    for (int c = 0; c < 64; ++c) acc += qs[h][c] * kr[c];
+    s = acc;
+  }
+  float mx = s;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+  const float p = lane < n ? __expf(s - mx) : 0.0f;
+  float sum = p;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+  ps[h][lane] = p / sum;
+  __syncthreads();
+  float o = 0.0f;
+  for (int j = 0; j < n; ++j) o += ps[h][j] * vc[(long)j * d + lane];
+  out[(long)b * d + h * 64 + lane] = o;
+}
+
+// ------------------------------------------------ decoder cross attention ---
+// One block per (clip, head, key chunk): streams its contiguous K then V slab
+// ([keys][64] floats, 256 B per key) with 16-byte loads, 16 lanes per key.
+__global__ __launch_bounds__(256) void cross_attention_step(const float* __restrict__ q,
+                                                            const float* __restrict__ kc,
+                                                            const float* __restrict__ vc,
+                                                            float* __restrict__ ws, int heads,
+                                                            int T, int chunks) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int chunk = blockIdx.x % chunks, bh = blockIdx.x / chunks;
+  const int b = bh / heads, h = bh % heads;
+  const int per = (T + chunks - 1) / chunks;
+  const int k_begin = chunk * per, k_end = min(T, k_begin + per), nk = k_end - k_begin;
+  const int tid = threadIdx.x, grp = tid >> 4, gl = tid & 15;
+  const int per4 = (per + 3) & ~3;
+  float* sc = smem;               // [per4] scores -> probabilities
+  float* red = smem + per4;       // [16][64] partial outputs (16-byte aligned)
+  float* wred = red + 16 * 64;    // [8] per-wavefront max / sum
+
+  const f32x4 qv = *reinterpret_cast<const f32x4*>(q + ((long)b * heads + h) * 64 + gl * 4);
+  const float* kb = kc + ((long)bh * T + k_begin) * 64 + gl * 4;
+  const float* vb = vc + ((long)bh * T + k_begin) * 64 + gl * 4;
+
+  float lmax = -1e30f;
+  for (int k = grp; k < nk; k += 16) {
+    const f32x4 kv = *reinterpret_cast<const f32x4*>(kb + (long)k * 64);
+    float s = kv[0] * qv[0] + kv[1] * qv[1] + kv[2] * qv[2] + kv[3] * qv[3];
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    s *= 0.125f;
+    if (gl == 0) sc[k] = s;
+    lmax = fmaxf(lmax, s);
+  }
+  // block max
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, off, 64));
+  if ((tid & 63) == 0) wred[tid >> 6] = lmax;
+  __syncthreads();
+  const float mx = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
+  float lsum = 0.0f;
+  for (int k = tid; k < nk; k += 256) {
+    const float p = __expf(sc[k] - mx);
+    sc[k] = p;
+    lsum += p;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) lsum += __shfl_xor(lsum, off, 64);
+  if ((tid & 63) == 0) wred[4 + (tid >> 6)] = lsum;
+  __syncthreads();
+  const float total = wred[4] + wred[5] + wred[6] + wred[7];
+
+  f32x4 acc = {0, 0, 0, 0};
+  for (int k = grp; k < nk; k += 16) {
+    const f32x4 vv = *reinterpret_cast<const f32x4*>(vb + (long)k * 64);
+    const float p = sc[k];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] += p * vv[j];
+  }
+  *reinterpret_cast<f32x4*>(&red[grp * 64 + gl * 4]) = acc;
+  __syncthreads();
+  float* dst = ws + ((long)bh * chunks + chunk) * 66;
+  if (tid < 64) {
+    float o = 0.0f;
+#pragma unroll
+    for (int gI = 0; gI < 16; ++gI) o += red[gI * 64 + tid];
+    dst[tid] = o;
+  }
+  if (tid == 0) {
+    dst[64] = mx;
+    dst[65] = total;
+  }
+}
+
+__global__ void cross_combine(const float* __restrict__ ws, float* __restrict__ out, int heads,
+                              int chunks) {
+  const int bh = blockIdx.x, lane = threadIdx.x;  // 64 threads
+  const float* p = ws + (long)bh * chunks * 66;
+  float mx = -1e30f;
+  for (int c = 0; c < chunks; ++c) mx = fmaxf(mx, p[c * 66 + 64]);
+  float o = 0.0f, l = 0.0f;
+  for (int c = 0; c < chunks; ++c) {
+    const float w = __expf(p[c * 66 + 64] - mx);
+    o += w * p[c * 66 + lane];
+    l += w * p[c * 66 + 65];
+  }
+  const int b = bh / heads, h = bh % heads;
+  out[((long)b * heads + h) * 64 + lane] = o / l;
+}
+
+}  // namespace
+
+void launch_encoder_attention(const float* qkv, float* out, int batch, int T, int heads,
+                              hipStream_t s) {
+  const int q_blocks = (T + AQ - 1) / AQ;
+  hipLaunchKernelGGL(encoder_attention_f32, dim3(batch * heads * q_blocks), dim3(256), 0, s, qkv,
+                     out, T, heads);
+}
+
+void launch_self_attention(const float* qkv, float* kcache, float* vcache, int cap, int pos,
+                           float* out, int batch, int heads, hipStream_t s) {
+  hipLaunchKernelGGL(self_attention_step, dim3(batch), dim3(heads * 64), 0, s, qkv, kcache, vcache,
+                     cap, pos, out, heads);
+}
+
+void launch_cross_attention(const float* q, const float* kc, const float* vc, float* ws, int batch,
+                            int heads, int T, int chunks, hipStream_t s) {
+  const int per = (T + chunks - 1) / chunks;
+  const size_t smem = (size_t)(((per + 3) & ~3) + 16 * 64 + 8) * sizeof(float);
+  hipLaunchKernelGGL(cross_attention_step, dim3(batch * heads * chunks), dim3(256), smem, s, q, kc,
+                     vc, ws, heads, T, chunks);
+}
+
+void launch_cross_combine(const float* ws, float* out, int batch, int heads, int chunks,
+                          hipStream_t s) {
+  hipLaunchKernelGGL(cross_combine, dim3(batch * heads), dim3(64), 0, s, ws, out, heads, chunks);
+}
+
+}  // namespace wt

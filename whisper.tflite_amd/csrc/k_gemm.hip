@@ -1,0 +1,322 @@
+// fp32 GEMM kernels for gfx950 on v_mfma_f32_32x32x2_f32 (exact f32: a k-ordered
+// fmaf chain, 64 FLOP/clk/SIMD).  These replace the arithmetic the reference runs
+// inside tflite::Interpreter::Invoke() (whisper.tflite/whisper.cpp:295, :375) for
+// every Conv1D / Linear of the encoder and decoder graphs.
+//
+// gemm_f32_128x128: 256 threads = 4 wavefronts (2x2), each wavefront owns a 64x64
+// output sub-tile as 2x2 MFMA tiles (64 accumulator VGPRs).  A and W tiles are staged
+// global -> registers -> LDS (issue-early / write-late), LDS rows padded to 36 floats
+// so the ds_read_b128 fragment reads are bank-conflict-free.  blockIdx is remapped so
+// that the tiles of one XCD (blockIdx % 8) are consecutive in (m, n) order and share
+// their A panel through that XCD's L2.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace wt {
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int BM = 128, BN = 128, BK = 32, LDS_LD = BK + 4;
+
+__device__ __forceinline__ float gelu_erf(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+struct GemmDev {
+  const float* A;
+  const float* W;
+  float* C;
+  const float* bias;
+  const float* R;
+  const float* pos;
+  int M, N, K;
+  int a_rpb;
+  long a_bs;
+  int lda;
+  int c_rpb;
+  long c_bs;
+  int ldc;
+  int pos_period;
+  int kv_batch, kv_heads, kv_dmodel;
+};
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_128x128(GemmDev g) {
+  __shared__ __attribute__((aligned(16))) float As[BM * LDS_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[BN * LDS_LD];
+
+  // XCD-aware bijective remap: blocks with equal blockIdx % 8 share an XCD (speed only).
+  const int nb = gridDim.x, bid = blockIdx.x;
+  const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int n_tiles = g.N / BN;
+  const int m0 = (logical / n_tiles) * BM;
+  const int n0 = (logical % n_tiles) * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  // staging map: 128 rows x 8 float4 per operand tile, 4 float4 per thread per operand
+  const int srow = tid >> 3, scol = (tid & 7) * 4;
+  const float* a_ptr[4];
+  const float* w_ptr[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int m = m0 + srow + 32 * i;
+    m = m < g.M ? m : g.M - 1;  // clamp: rows past M are computed and discarded
+    a_ptr[i] = g.A + (long)(m / g.a_rpb) * g.a_bs + (long)(m % g.a_rpb) * g.lda + scol;
+    w_ptr[i] = g.W + (long)(n0 + srow + 32 * i) * g.K + scol;
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  f32x4 ra[4], rb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    ra[i] = *reinterpret_cast<const f32x4*>(a_ptr[i]);
+    rb[i] = *reinterpret_cast<const f32x4*>(w_ptr[i]);
+  }
+
+  const int nkt = g.K / BK;
+  for (int kt = 0; kt < nkt; ++kt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<f32x4*>(&As[(srow + 32 * i) * LDS_LD + scol]) = ra[i];
+      *reinterpret_cast<f32x4*>(&Bs[(srow + 32 * i) * LDS_LD + scol]) = rb[i];
+    }
+    __syncthreads();
+    if (kt + 1 < nkt) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ra[i] = *reinterpret_cast<const f32x4*>(a_ptr[i] + (kt + 1) * BK);
+        rb[i] = *reinterpret_cast<const f32x4*>(w_ptr[i] + (kt + 1) * BK);
+      }
+    }
+#pragma unroll
+    for (int kq = 0; kq < BK / 8; ++kq) {
+      // lane (row l31, half lh) takes k = 8*kq + 4*lh + j for MFMA step j: A and B use
+      // the same k permutation, so the contraction is complete and exact.
+      const int kof = kq * 8 + 4 * lh;
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(&As[(wm * 64 + l31) * LDS_LD + kof]);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(&As[(wm * 64 + 32 + l31) * LDS_LD + kof]);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(&Bs[(wn * 64 + l31) * LDS_LD + kof]);
+      const f32x4 b1 = *reinterpret_cast<const f32x4*>(&Bs[(wn * 64 + 32 + l31) * LDS_LD + kof]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc[1][1], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m >= g.M) continue;
+      const int mb = m / g.c_rpb, mt = m % g.c_rpb;
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int n = n0 + wn * 64 + ni * 32 + l31;
+        float v = acc[mi][ni][r];
+        if (EPI & kEpiBias) v += g.bias[n];
+        if (EPI & kEpiGelu) v = gelu_erf(v);
+        if (EPI & kEpiPos) v += g.pos[(long)(m % g.pos_period) * g.N + n];
+        if (EPI & kEpiKvLayout) {
+          const int slab = n / g.kv_dmodel, rem = n % g.kv_dmodel;
+          const int head = rem >> 6, dd = rem & 63;
+          const long o = (((long)slab * g.kv_batch + mb) * g.kv_heads + head) * (long)g.c_rpb * 64 +
+                         (long)mt * 64 + dd;
+          g.C[o] = v;
+        } else {
+          const long o = (long)mb * g.c_bs + (long)mt * g.ldc + n;
+          if (EPI & kEpiResidual) v += g.R[o];
+          g.C[o] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int EPI>
+void launch_gemm_t(const GemmDev& g, int blocks, hipStream_t s) {
+  hipLaunchKernelGGL(gemm_f32_128x128<EPI>, dim3(blocks), dim3(256), 0, s, g);
+}
+
+// ---------------------------------------------------------------- skinny ---
+// out[B][N] = x[B][K] . W[N][K]^T for B <= 64 (decoder steps: one row per clip).
+// The batch is the MFMA M dimension (one or two 32-row tiles); every wavefront owns a
+// 32-column tile of W and streams it straight from global memory into VGPRs (operand
+// read once, no LDS round trip).  SPLITK wavefronts of a block share one column tile
+// and combine through LDS.
+__device__ __forceinline__ unsigned ordered_bits(float v) {
+  v = v + 0.0f;  // -0.0 -> +0.0 so that equal values compare equal
+  const unsigned u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+struct SkinnyDev {
+  const float* X;
+  const float* W;
+  float* Y;
+  const float* bias;
+  const float* R;
+  int B, N, K, ldx, ldy;
+  unsigned long long* best;
+};
+
+template <int EPI, int SPLITK, int MT>
+__global__ __launch_bounds__(256) void skinny_f32(SkinnyDev g) {
+  __shared__ float red[SPLITK > 1 ? (SPLITK - 1) * MT * 16 * 64 : 1];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int tile = SPLITK > 1 ? blockIdx.x : blockIdx.x * 4 + wid;
+  const int n_tiles = (g.N + 31) / 32;
+  if (tile >= n_tiles) return;  // whole wavefronts only (SPLITK == 1); no barrier follows
+  const int n0 = tile * 32;
+  const int kslice = g.K / SPLITK;
+  const int k0 = SPLITK > 1 ? wid * kslice : 0;
+
+  int wrow = n0 + l31;
+  wrow = wrow < g.N ? wrow : g.N - 1;
+  const float* wp = g.W + (long)wrow * g.K + k0 + 4 * lh;
+  const float* xp[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    int b = t * 32 + l31;
+    b = b < g.B ? b : g.B - 1;
+    xp[t] = g.X + (long)b * g.ldx + k0 + 4 * lh;
+  }
+  f32x16 acc[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+  for (int k = 0; k < kslice; k += 8) {
+    const f32x4 w = *reinterpret_cast<const f32x4*>(wp + k);
+    f32x4 x[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) x[t] = *reinterpret_cast<const f32x4*>(xp[t] + k);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[t][j], w[j], acc[t], 0, 0, 0);
+  }
+
+  if (SPLITK > 1) {
+    if (wid > 0) {
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(((wid - 1) * MT + t) * 16 + r) * 64 + lane] = acc[t][r];
+    }
+    __syncthreads();
+    if (wid > 0) return;
+#pragma unroll
+    for (int w = 0; w < SPLITK - 1; ++w)
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] += red[((w * MT + t) * 16 + r) * 64 + lane];
+  }
+
+  const int n = n0 + l31;
+  const bool n_ok = n < g.N;
+  const float bias = (EPI & kEpiBias) && n_ok ? g.bias[n] : 0.0f;
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int b = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      float v = acc[t][r] + bias;
+      if (EPI & kEpiGelu) v = gelu_erf(v);
+      const bool ok = n_ok && b < g.B;
+      if (ok) {
+        const long o = (long)b * g.ldy + n;
+        if (EPI & kEpiResidual) v += g.R[o];
+        if (g.Y) g.Y[o] = v;
+      }
+      if (g.best) {
+        // row b lives in the 32 lanes of this half-wave: fold (value, column) packed so
+        // that the larger value wins and, among equal values, the larger column — the
+        // reference's `>=` scan keeps the LAST maximal index (whisper.cpp:353).
+        unsigned long long p = ok ? (((unsigned long long)ordered_bits(v) << 32) | (unsigned)n) : 0ull;
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) {
+          const unsigned long long o2 = __shfl_xor(p, off, 64);
+          p = o2 > p ? o2 : p;
+        }
+        if (l31 == 0 && b < g.B) atomicMax(&g.best[b], p);
+      }
+    }
+  }
+}
+
+template <int EPI>
+void launch_skinny_t(const SkinnyDev& g, bool splitk, hipStream_t s) {
+  const int n_tiles = (g.N + 31) / 32;
+  if (g.B <= 32) {
+    if (splitk) {
+      hipLaunchKernelGGL((skinny_f32<EPI, 4, 1>), dim3(n_tiles), dim3(256), 0, s, g);
+    } else {
+      hipLaunchKernelGGL((skinny_f32<EPI, 1, 1>), dim3((n_tiles + 3) / 4), dim3(256), 0, s, g);
+    }
+  } else {
+    if (splitk) {
+      hipLaunchKernelGGL((skinny_f32<EPI, 4, 2>), dim3(n_tiles), dim3(256), 0, s, g);
+    } else {
+      hipLaunchKernelGGL((skinny_f32<EPI, 1, 2>), dim3((n_tiles + 3) / 4), dim3(256), 0, s, g);
+    }
+  }
+}
+
+}  // namespace
+
+void launch_gemm(const GemmArgs& a, int epi, hipStream_t s) {
+  GemmDev g{a.A,   a.W,   a.C,    a.bias, a.R,   a.pos,        a.M,        a.N,        a.K,
+            a.a_rpb, a.a_bs, a.lda, a.c_rpb, a.c_bs, a.ldc, a.pos_period, a.kv_batch, a.kv_heads,
+            a.kv_dmodel};
+  const int blocks = ((a.M + BM - 1) / BM) * (a.N / BN);
+  switch (epi) {
+    case 0: launch_gemm_t<0>(g, blocks, s); break;
+    case kEpiBias: launch_gemm_t<kEpiBias>(g, blocks, s); break;
+    case kEpiBias | kEpiGelu: launch_gemm_t<kEpiBias | kEpiGelu>(g, blocks, s); break;
+    case kEpiBias | kEpiResidual: launch_gemm_t<kEpiBias | kEpiResidual>(g, blocks, s); break;
+    case kEpiBias | kEpiGelu | kEpiPos: launch_gemm_t<kEpiBias | kEpiGelu | kEpiPos>(g, blocks, s); break;
+    case kEpiBias | kEpiKvLayout: launch_gemm_t<kEpiBias | kEpiKvLayout>(g, blocks, s); break;
+    default: abort();
+  }
+}
+
+void launch_skinny(const SkinnyArgs& a, int epi, hipStream_t s) {
+  SkinnyDev g{a.X, a.W, a.Y, a.bias, a.R, a.B, a.N, a.K, a.ldx, a.ldy, a.best};
+  // split K over the block's 4 wavefronts when there are few column tiles
+  const bool splitk = (a.N <= 4096) && (a.K % 32 == 0);
+  switch (epi) {
+    case 0: launch_skinny_t<0>(g, splitk, s); break;
+    case kEpiBias: launch_skinny_t<kEpiBias>(g, splitk, s); break;
+    case kEpiBias | kEpiGelu: launch_skinny_t<kEpiBias | kEpiGelu>(g, splitk, s); break;
+    case kEpiBias | kEpiResidual: launch_skinny_t<kEpiBias | kEpiResidual>(g, splitk, s); break;
+    default: abort();
+  }
+}
+
+}  // namespace wt

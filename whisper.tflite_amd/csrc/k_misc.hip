@@ -1,0 +1,226 @@
+// Bandwidth-bound helper kernels of the EncDec path: LayerNorm, layout changes around
+// the Conv1D stem, the log-mel epilogue (reference whisper.tflite/whisper.cpp:159-213)
+// and the decoder's token embedding / greedy selection (whisper.cpp:346-361, :392-399).
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace wt {
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// One wavefront per row, row held in registers (d <= 64 * PER), two-pass variance.
+template <int PER>
+__global__ __launch_bounds__(256) void layernorm_rows(const float* __restrict__ x,
+                                                      float* __restrict__ y,
+                                                      const float* __restrict__ g,
+                                                      const float* __restrict__ b, int M, int d) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xr = x + row * d;
+  float v[PER];
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int c = lane + 64 * i;
+    v[i] = c < d ? xr[c] : 0.0f;
+    s += v[i];
+  }
+  const float mean = wave_sum(s) / (float)d;
+  float q = 0.0f;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int c = lane + 64 * i;
+    const float t = c < d ? v[i] - mean : 0.0f;
+    q += t * t;
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)d + 1e-5f);
+  float* yr = y + row * d;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int c = lane + 64 * i;
+    if (c < d) yr[c] = (v[i] - mean) * rstd * g[c] + b[c];
+  }
+}
+
+// mel [B][C][T] -> melT [B][T + 2][C] (rows 1..T).  32x32 LDS tile transpose.
+__global__ __launch_bounds__(256) void mel_transpose(const float* __restrict__ mel,
+                                                     float* __restrict__ melT, int C, int T) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z, t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const float* src = mel + (long)b * C * T;
+  float* dst = melT + (long)b * (T + 2) * C;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, t = t0 + tx;
+    tile[ty + 8 * i][tx] = (c < C && t < T) ? src[(long)c * T + t] : 0.0f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int t = t0 + ty + 8 * i, c = c0 + tx;
+    if (c < C && t < T) dst[(long)(t + 1) * C + c] = tile[tx][ty + 8 * i];
+  }
+}
+
+__global__ __launch_bounds__(256) void power_fold(const float* __restrict__ spec, int ld,
+                                                  int im_off, float* __restrict__ pw, int ldp,
+                                                  int n_bins, long M) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long m = idx / ldp;
+  const int k = (int)(idx % ldp);
+  if (m >= M) return;
+  float p = 0.0f;
+  if (k < n_bins) {
+    const float re = spec[m * ld + k], im = spec[m * ld + im_off + k];
+    p = re * re + im * im;
+    // whisper.cpp:164-166 adds the mirror bin N-k into bins 1..N/2-1; for real input the
+    // mirror bin carries the same power
+    if (k >= 1 && k < n_bins - 1) p += p;
+  }
+  pw[m * ldp + k] = p;
+}
+
+__device__ __forceinline__ unsigned ordered_bits(float v) {
+  const unsigned u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float from_ordered(unsigned o) {
+  return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+
+// melacc [B*T][ld] -> logmel [B][n_mel][T] (transposed through LDS), per-clip max.
+__global__ __launch_bounds__(256) void log_clipmax(const float* __restrict__ melacc, int ld,
+                                                   float* __restrict__ logmel,
+                                                   unsigned* __restrict__ clip_max, int n_mel,
+                                                   int T) {
+  __shared__ float tile[32][33];
+  __shared__ unsigned smax;
+  const int b = blockIdx.z, t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  if (threadIdx.x == 0) smax = 0u;
+  __syncthreads();
+  unsigned lmax = 0u;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int t = t0 + ty + 8 * i, c = c0 + tx;
+    float v = 0.0f;
+    if (t < T && c < n_mel) {
+      float e = melacc[((long)b * T + t) * ld + c];
+      e = e < 1e-10f ? 1e-10f : e;  // whisper.cpp:176-180
+      v = log10f(e);
+      const unsigned o = ordered_bits(v);
+      lmax = o > lmax ? o : lmax;
+    }
+    tile[ty + 8 * i][tx] = v;
+  }
+  atomicMax(&smax, lmax);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, t = t0 + tx;
+    if (c < n_mel && t < T) logmel[((long)b * n_mel + c) * T + t] = tile[tx][ty + 8 * i];
+  }
+  if (threadIdx.x == 0 && smax != 0u) atomicMax(&clip_max[b], smax);
+}
+
+__global__ __launch_bounds__(256) void mel_normalize(float* __restrict__ logmel,
+                                                     const unsigned* __restrict__ clip_max,
+                                                     long per_clip) {
+  const int b = blockIdx.y;
+  const float floor_v = from_ordered(clip_max[b]) - 8.0f;  // whisper.cpp:205
+  float* p = logmel + (long)b * per_clip;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per_clip; i += (long)gridDim.x * 256) {
+    float v = p[i];
+    v = v < floor_v ? floor_v : v;
+    p[i] = (v + 4.0f) / 4.0f;  // whisper.cpp:212
+  }
+}
+
+__global__ __launch_bounds__(256) void embed_rows(const float* __restrict__ tok_emb,
+                                                  const float* __restrict__ pos_emb,
+                                                  const long long* __restrict__ ids, int ids_stride,
+                                                  int pos, float* __restrict__ x, int d) {
+  const int b = blockIdx.x;
+  const long long id = ids[(long)b * ids_stride + pos];
+  for (int c = threadIdx.x; c < d; c += 256) x[(long)b * d + c] = tok_emb[id * d + c] + pos_emb[(long)pos * d + c];
+}
+
+__global__ void select_token(unsigned long long* best, long long* ids, int ids_stride, int pos,
+                             int* n_ids, int* finished, long long eot, int stop_at_eot, int batch) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  const unsigned long long p = best[b];
+  best[b] = 0ull;
+  const long long tok = (long long)(unsigned)(p & 0xffffffffull);
+  // ids always receives the token so the next position has a defined input; n_ids stops
+  // growing once the clip has emitted EOT (reference loop break, whisper.cpp:397-399)
+  ids[(long)b * ids_stride + pos + 1] = tok;
+  if (!finished[b]) {
+    n_ids[b] = pos + 2;
+    if (stop_at_eot && tok == eot) finished[b] = 1;
+  }
+}
+
+}  // namespace
+
+void launch_layernorm(const float* x, float* y, const float* g, const float* b, int M, int d,
+                      hipStream_t s) {
+  const int blocks = (M + 3) / 4;
+  if (d <= 128) {
+    hipLaunchKernelGGL(layernorm_rows<2>, dim3(blocks), dim3(256), 0, s, x, y, g, b, M, d);
+  } else if (d <= 384) {
+    hipLaunchKernelGGL(layernorm_rows<6>, dim3(blocks), dim3(256), 0, s, x, y, g, b, M, d);
+  } else if (d <= 512) {
+    hipLaunchKernelGGL(layernorm_rows<8>, dim3(blocks), dim3(256), 0, s, x, y, g, b, M, d);
+  } else {
+    abort();
+  }
+}
+
+void launch_mel_transpose(const float* mel, float* melT, int batch, int n_mels, int T,
+                          hipStream_t s) {
+  hipLaunchKernelGGL(mel_transpose, dim3((T + 31) / 32, (n_mels + 31) / 32, batch), dim3(256), 0, s,
+                     mel, melT, n_mels, T);
+}
+
+void launch_power_fold(const float* spec, int ld, int im_off, float* pw, int ldp, int n_bins,
+                       long M, hipStream_t s) {
+  const long total = M * ldp;
+  hipLaunchKernelGGL(power_fold, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, spec, ld,
+                     im_off, pw, ldp, n_bins, M);
+}
+
+void launch_log_clipmax(const float* melacc, int ld, float* logmel, unsigned* clip_max, int batch,
+                        int n_mel, int T, hipStream_t s) {
+  hipLaunchKernelGGL(log_clipmax, dim3((T + 31) / 32, (n_mel + 31) / 32, batch), dim3(256), 0, s,
+                     melacc, ld, logmel, clip_max, n_mel, T);
+}
+
+void launch_mel_normalize(float* logmel, const unsigned* clip_max, int batch, int n_mel, int T,
+                          hipStream_t s) {
+  hipLaunchKernelGGL(mel_normalize, dim3(64, batch), dim3(256), 0, s, logmel, clip_max,
+                     (long)n_mel * T);
+}
+
+void launch_embed(const float* tok_emb, const float* pos_emb, const long long* ids, int ids_stride,
+                  int pos, float* x, int batch, int d, hipStream_t s) {
+  hipLaunchKernelGGL(embed_rows, dim3(batch), dim3(256), 0, s, tok_emb, pos_emb, ids, ids_stride,
+                     pos, x, d);
+}
+
+void launch_select_token(unsigned long long* best, long long* ids, int ids_stride, int pos,
+                         int* n_ids, int* finished, long long eot, int stop_at_eot, int batch,
+                         hipStream_t s) {
+  hipLaunchKernelGGL(select_token, dim3((batch + 63) / 64), dim3(64), 0, s, best, ids, ids_stride,
+                     pos, n_ids, finished, eot, stop_at_eot, batch);
+}
+
+}  // namespace wt

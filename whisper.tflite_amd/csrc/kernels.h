@@ -1,0 +1,110 @@
+// Host-side launchers for the gfx950 kernels of the EncDec hot path.
+// Every launcher enqueues on the given stream and never synchronises or
+// allocates, so a caller may capture a sequence of them into a hipGraph.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace wt {
+
+// ------------------------------------------------------------------ GEMM ---
+// C = epilogue(A . W^T): A [M][K] activations (row m at
+// A + (m / a_rpb) * a_bs + (m % a_rpb) * lda), W [N][K] row-major (torch Linear
+// layout), fp32 in, fp32 MFMA (v_mfma_f32_32x32x2_f32) accumulate: bit-for-bit a
+// k-ordered fmaf chain.  Requires N % 128 == 0 and K % 32 == 0; M is arbitrary.
+enum GemmEpi : int {
+  kEpiBias = 1,      // + bias[n]
+  kEpiGelu = 2,      // exact erf GELU
+  kEpiResidual = 4,  // + R[row m][n]  (R addressed like C; R may alias C)
+  kEpiPos = 8,       // + pos[(m % pos_period)][n]   (encoder positional embedding)
+  kEpiKvLayout = 16  // scatter into the cross-attention KV cache layout (see below)
+};
+
+struct GemmArgs {
+  const float* A = nullptr;
+  const float* W = nullptr;
+  float* C = nullptr;
+  const float* bias = nullptr;
+  const float* R = nullptr;
+  const float* pos = nullptr;
+  int M = 0, N = 0, K = 0;
+  int a_rpb = 1 << 30;  // rows per batch item for A addressing
+  long a_bs = 0;        // element stride between batch items of A
+  int lda = 0;
+  int c_rpb = 1 << 30;
+  long c_bs = 0;
+  int ldc = 0;
+  int pos_period = 1;
+  // kEpiKvLayout: column n = (slab * d_model + head * 64 + dd), row m = (b * T + t)
+  //   -> C[((slab * kv_batch + b) * kv_heads + head) * T * 64 + t * 64 + dd]
+  // where slab enumerates (layer, k|v); T = c_rpb.
+  int kv_batch = 0, kv_heads = 0, kv_dmodel = 0;
+};
+void launch_gemm(const GemmArgs& a, int epi, hipStream_t s);
+
+// Skinny GEMM for decoder steps: out[B][N] = epi(x[B][K] . W[N][K]^T), B <= 64.
+// One 32-column tile per wave (split_k = 1) or per 4-wave block (split_k = 4).
+struct SkinnyArgs {
+  const float* X = nullptr;  // [B][K] (ldx)
+  const float* W = nullptr;  // [N][K]
+  float* Y = nullptr;        // [B][N] (ldy)
+  const float* bias = nullptr;
+  const float* R = nullptr;  // residual [B][N] (ldy), may alias Y
+  int B = 0, N = 0, K = 0, ldx = 0, ldy = 0;
+  // fused argmax (logits): when best != nullptr every tile folds its
+  // per-row (value, column) maximum into best[b] with the reference's tie rule.
+  unsigned long long* best = nullptr;
+};
+void launch_skinny(const SkinnyArgs& a, int epi, hipStream_t s);
+
+// ------------------------------------------------------------- LayerNorm ---
+// y[m][:] = (x[m][:] - mean) * rstd * g + b, eps 1e-5, one wavefront per row.
+void launch_layernorm(const float* x, float* y, const float* g, const float* b, int M, int d,
+                      hipStream_t s);
+
+// ------------------------------------------------------ encoder attention ---
+// qkv [B*T][3*d] (q | k | v, heads of 64 inside each third) -> out [B*T][d].
+// Non-causal softmax(q k^T / 8) v per (clip, head), flash-style, fp32 MFMA.
+void launch_encoder_attention(const float* qkv, float* out, int batch, int T, int heads,
+                              hipStream_t s);
+
+// ------------------------------------------------------------- front end ---
+// mel [B][n_mels][T] -> melT [B][T + 2][n_mels] rows 1..T (rows 0 and T+1 stay zero).
+void launch_mel_transpose(const float* mel, float* melT, int batch, int n_mels, int T,
+                          hipStream_t s);
+// spec [M][ld] holding (re | im) halves for bins [0, n_bins) at columns [0,n_bins) and
+// [im_off, im_off+n_bins) -> pw [M][ldp]: |X|^2 with the reference's mirror fold
+// (bins 1..n_bins-2 doubled); columns >= n_bins zeroed up to ldp.
+void launch_power_fold(const float* spec, int ld, int im_off, float* pw, int ldp, int n_bins,
+                       long M, hipStream_t s);
+// melacc [B*T][ld] (first n_mel columns) -> logmel [B][n_mel][T] = log10(max(x,1e-10)),
+// and per-clip maximum into clip_max[b] (ordered-uint encoding, pre-zeroed).
+void launch_log_clipmax(const float* melacc, int ld, float* logmel, unsigned* clip_max, int batch,
+                        int n_mel, int T, hipStream_t s);
+// in place: x = (max(x, clipmax[b] - 8) + 4) / 4
+void launch_mel_normalize(float* logmel, const unsigned* clip_max, int batch, int n_mel, int T,
+                          hipStream_t s);
+
+// --------------------------------------------------------------- decoder ---
+// x[b][:] = tok_emb[ids[b][pos]][:] + pos_emb[pos][:]
+void launch_embed(const float* tok_emb, const float* pos_emb, const long long* ids, int ids_stride,
+                  int pos, float* x, int batch, int d, hipStream_t s);
+// Appends k,v of position `pos` (from qkv [B][3d]) to the self-attention cache
+// [2][B][cap][d] and attends q over positions 0..pos.  out [B][d].
+void launch_self_attention(const float* qkv, float* kcache, float* vcache, int cap, int pos,
+                           float* out, int batch, int heads, hipStream_t s);
+// Cross attention of one query row per clip over T cached keys.
+// q [B][d]; kc, vc [B][heads][T][64]; partial results per key chunk in ws
+// [B][heads][chunks][66] (o[64], m, l); launch_cross_combine -> out [B][d].
+void launch_cross_attention(const float* q, const float* kc, const float* vc, float* ws, int batch,
+                            int heads, int T, int chunks, hipStream_t s);
+void launch_cross_combine(const float* ws, float* out, int batch, int heads, int chunks,
+                          hipStream_t s);
+// Greedy selection after the logits GEMM: decodes best[b], appends to ids, applies the
+// EOT stop (reference whisper.cpp:397-399) and re-arms best[b].
+void launch_select_token(unsigned long long* best, long long* ids, int ids_stride, int pos,
+                         int* n_ids, int* finished, long long eot, int stop_at_eot, int batch,
+                         hipStream_t s);
+
+}  // namespace wt

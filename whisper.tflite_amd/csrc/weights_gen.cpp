@@ -1,0 +1,225 @@
+// Deterministic synthetic Whisper weights -> .wtw file.
+//
+// Stands in for the reference's offline export step (export/generate_onnx.py:80-163
+// downloads OpenAI "tiny" and converts it to a .tflite pair): there is no network
+// and no checkpoint in this environment, so both the test container and the GPU
+// box materialise bit-identical random-init weights of the right architecture
+// from (dims, seed) alone.  Only integer hashing and one double multiply per
+// element are used, so the bytes do not depend on libm or the host CPU.
+#include "weights_gen.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace wtw {
+namespace {
+
+inline uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+inline uint64_t fnv1a(const char* s) {
+  uint64_t h = 0xcbf29ce484222325ull;
+  for (; *s; ++s) {
+    h ^= static_cast<unsigned char>(*s);
+    h *= 0x100000001b3ull;
+  }
+  return h;
+}
+
+// Irwin-Hall(4) on 16-bit uniforms: bell-shaped, unit variance after scaling,
+// pure integer arithmetic.
+inline float unit_normal(uint64_t key, uint64_t i) {
+  uint64_t h = splitmix64(key ^ splitmix64(i));
+  int64_t s = static_cast<int64_t>((h & 0xFFFF) + ((h >> 16) & 0xFFFF) +
+                                   ((h >> 32) & 0xFFFF) + ((h >> 48) & 0xFFFF)) -
+              2 * 65535;
+  // var = 4 * (65536^2 - 1) / 12
+  constexpr double kInvStd = 1.0 / 37837.22704534247;
+  return static_cast<float>(static_cast<double>(s) * kInvStd);
+}
+
+enum class Init { Normal, OnePlusNormal, Sinusoid };
+
+struct Spec {
+  std::string name;
+  std::vector<uint32_t> shape;
+  Init init;
+  double std;
+};
+
+void add_attn(std::vector<Spec>& specs, const std::string& p, uint32_t d) {
+  const double s = 1.0 / std::sqrt(static_cast<double>(d));
+  specs.push_back({p + ".query.weight", {d, d}, Init::Normal, s});
+  specs.push_back({p + ".query.bias", {d}, Init::Normal, 0.02});
+  specs.push_back({p + ".key.weight", {d, d}, Init::Normal, s});
+  specs.push_back({p + ".value.weight", {d, d}, Init::Normal, s});
+  specs.push_back({p + ".value.bias", {d}, Init::Normal, 0.02});
+  specs.push_back({p + ".out.weight", {d, d}, Init::Normal, s});
+  specs.push_back({p + ".out.bias", {d}, Init::Normal, 0.02});
+}
+
+void add_ln(std::vector<Spec>& specs, const std::string& p, uint32_t d) {
+  specs.push_back({p + ".weight", {d}, Init::OnePlusNormal, 0.1});
+  specs.push_back({p + ".bias", {d}, Init::Normal, 0.1});
+}
+
+void add_mlp(std::vector<Spec>& specs, const std::string& p, uint32_t d) {
+  specs.push_back({p + ".0.weight", {4 * d, d}, Init::Normal, 1.0 / std::sqrt(double(d))});
+  specs.push_back({p + ".0.bias", {4 * d}, Init::Normal, 0.02});
+  specs.push_back({p + ".2.weight", {d, 4 * d}, Init::Normal, 1.0 / std::sqrt(4.0 * d)});
+  specs.push_back({p + ".2.bias", {d}, Init::Normal, 0.02});
+}
+
+std::vector<Spec> build_specs(const Dims& c) {
+  std::vector<Spec> specs;
+  const uint32_t da = c.n_audio_state, dt = c.n_text_state;
+  specs.push_back({"encoder.conv1.weight", {da, uint32_t(c.n_mels), 3}, Init::Normal,
+                   1.0 / std::sqrt(3.0 * c.n_mels)});
+  specs.push_back({"encoder.conv1.bias", {da}, Init::Normal, 0.02});
+  specs.push_back({"encoder.conv2.weight", {da, da, 3}, Init::Normal, 1.0 / std::sqrt(3.0 * da)});
+  specs.push_back({"encoder.conv2.bias", {da}, Init::Normal, 0.02});
+  specs.push_back({"encoder.positional_embedding", {uint32_t(c.n_audio_ctx), da}, Init::Sinusoid, 0});
+  for (int i = 0; i < c.n_audio_layer; ++i) {
+    const std::string b = "encoder.blocks." + std::to_string(i);
+    add_ln(specs, b + ".attn_ln", da);
+    add_attn(specs, b + ".attn", da);
+    add_ln(specs, b + ".mlp_ln", da);
+    add_mlp(specs, b + ".mlp", da);
+  }
+  add_ln(specs, "encoder.ln_post", da);
+  specs.push_back({"decoder.token_embedding.weight", {uint32_t(c.n_vocab), dt}, Init::Normal, 0.02});
+  specs.push_back({"decoder.positional_embedding", {uint32_t(c.n_text_ctx), dt}, Init::Normal, 0.02});
+  for (int i = 0; i < c.n_text_layer; ++i) {
+    const std::string b = "decoder.blocks." + std::to_string(i);
+    add_ln(specs, b + ".attn_ln", dt);
+    add_attn(specs, b + ".attn", dt);
+    add_ln(specs, b + ".cross_attn_ln", dt);
+    add_attn(specs, b + ".cross_attn", dt);
+    add_ln(specs, b + ".mlp_ln", dt);
+    add_mlp(specs, b + ".mlp", dt);
+  }
+  add_ln(specs, "decoder.ln", dt);
+  return specs;
+}
+
+uint64_t numel(const std::vector<uint32_t>& s) {
+  uint64_t n = 1;
+  for (uint32_t v : s) n *= v;
+  return n;
+}
+
+// OpenAI whisper/model.py sinusoids(): [sin | cos] halves over log-spaced timescales.
+// Evaluated in double; the table is written to the file, so readers never recompute it.
+void fill_sinusoid(float* out, uint32_t length, uint32_t channels) {
+  const uint32_t half = channels / 2;
+  const double inc = std::log(10000.0) / (half > 1 ? (half - 1) : 1);
+  for (uint32_t t = 0; t < length; ++t) {
+    for (uint32_t j = 0; j < half; ++j) {
+      const double st = double(t) * std::exp(-inc * double(j));
+      out[size_t(t) * channels + j] = static_cast<float>(std::sin(st));
+      out[size_t(t) * channels + half + j] = static_cast<float>(std::cos(st));
+    }
+  }
+}
+
+}  // namespace
+
+bool dims_by_name(const char* name, Dims* out) {
+  const std::string n(name ? name : "");
+  if (n == "tiny") {
+    *out = Dims{80, 1500, 384, 6, 4, 51865, 448, 384, 6, 4};
+  } else if (n == "tiny.en") {
+    *out = Dims{80, 1500, 384, 6, 4, 51864, 448, 384, 6, 4};
+  } else if (n == "base") {
+    *out = Dims{80, 1500, 512, 8, 6, 51865, 448, 512, 8, 6};
+  } else if (n == "micro") {  // test-sized: same graph, seconds on a CPU
+    *out = Dims{80, 100, 128, 2, 2, 1024, 64, 128, 2, 2};
+  } else {
+    return false;
+  }
+  return true;
+}
+
+int write_synthetic(const char* path, const Dims& dims, uint64_t seed, std::string* err) {
+  if (dims.n_audio_state % dims.n_audio_head != 0 || dims.n_text_state % dims.n_text_head != 0 ||
+      dims.n_audio_state != dims.n_text_state) {
+    if (err) *err = "inconsistent dims";
+    return 1;
+  }
+  const std::vector<Spec> specs = build_specs(dims);
+  WtwHeader hdr;
+  std::memset(&hdr, 0, sizeof(hdr));
+  hdr.magic = kMagic;
+  hdr.version = kVersion;
+  hdr.n_tensors = static_cast<uint32_t>(specs.size());
+  hdr.table_offset = sizeof(WtwHeader);
+  hdr.dims = dims;
+  hdr.seed = seed;
+  std::vector<WtwTensor> table(specs.size());
+  uint64_t off = sizeof(WtwHeader) + sizeof(WtwTensor) * specs.size();
+  off = (off + kAlign - 1) / kAlign * kAlign;
+  hdr.payload_offset = off;
+  for (size_t i = 0; i < specs.size(); ++i) {
+    WtwTensor& t = table[i];
+    std::memset(&t, 0, sizeof(t));
+    std::snprintf(t.name, sizeof(t.name), "%s", specs[i].name.c_str());
+    t.dtype = 0;
+    t.ndim = static_cast<uint32_t>(specs[i].shape.size());
+    for (size_t k = 0; k < specs[i].shape.size(); ++k) t.shape[k] = specs[i].shape[k];
+    t.offset = off;
+    t.nbytes = numel(specs[i].shape) * sizeof(float);
+    off += (t.nbytes + kAlign - 1) / kAlign * kAlign;
+  }
+  hdr.file_bytes = off;
+
+  FILE* f = std::fopen(path, "wb");
+  if (!f) {
+    if (err) *err = std::string("cannot open for writing: ") + path;
+    return 2;
+  }
+  bool ok = std::fwrite(&hdr, sizeof(hdr), 1, f) == 1;
+  ok = ok && std::fwrite(table.data(), sizeof(WtwTensor), table.size(), f) == table.size();
+  std::vector<float> buf;
+  uint64_t pos = sizeof(WtwHeader) + sizeof(WtwTensor) * specs.size();
+  static const char zeros[kAlign] = {0};
+  for (size_t i = 0; ok && i < specs.size(); ++i) {
+    while (pos < table[i].offset) {
+      const uint64_t n = std::min<uint64_t>(kAlign, table[i].offset - pos);
+      ok = ok && std::fwrite(zeros, 1, n, f) == n;
+      pos += n;
+    }
+    const uint64_t n = numel(specs[i].shape);
+    buf.resize(n);
+    if (specs[i].init == Init::Sinusoid) {
+      fill_sinusoid(buf.data(), specs[i].shape[0], specs[i].shape[1]);
+    } else {
+      const uint64_t key = splitmix64(seed ^ fnv1a(specs[i].name.c_str()));
+      const float sd = static_cast<float>(specs[i].std);
+      const float base = specs[i].init == Init::OnePlusNormal ? 1.0f : 0.0f;
+      for (uint64_t e = 0; e < n; ++e) buf[e] = base + sd * unit_normal(key, e);
+    }
+    ok = ok && std::fwrite(buf.data(), sizeof(float), n, f) == n;
+    pos += n * sizeof(float);
+  }
+  while (ok && pos < hdr.file_bytes) {
+    const uint64_t n = std::min<uint64_t>(kAlign, hdr.file_bytes - pos);
+    ok = ok && std::fwrite(zeros, 1, n, f) == n;
+    pos += n;
+  }
+  ok = (std::fclose(f) == 0) && ok;
+  if (!ok) {
+    if (err) *err = std::string("short write: ") + path;
+    return 2;
+  }
+  return 0;
+}
+
+}  // namespace wtw
