@@ -72,6 +72,10 @@ int wt_engine_dims(const wt_engine* h, wt_dims* out);
  * "cross_chunks" (key chunks per (clip, head) in the decoder cross attention). */
 int wt_engine_set_option(wt_engine* h, const char* key, long value);
 int wt_engine_get_option(const wt_engine* h, const char* key, long* value);
+/* Replaces the reference's hard-coded prompt [sot, 50259+language, transcribe, notimestamps]
+ * (whisper.cpp:327-339) with n (1..8) caller ids; n = 0 restores the default.  Needed for
+ * test-sized vocabularies that do not contain the multilingual special ids. */
+int wt_engine_set_prompt(wt_engine* h, const int64_t* ids, int n);
 
 /* ---- single-clip entry points (the reference's two virtuals) ----------------------------
  * Replace Engine::transcribe(std::vector<float>&) (whisper.h:160, whisper.cpp:752-769; JNI

@@ -1,0 +1,186 @@
+"""GPU (-m gpu): each gfx950 kernel, through the C ABI debug taps (include/wt_debug.h),
+against a float64 numpy reference of the same op.  fp32 MFMA is a k-ordered fmaf chain, so
+the error budget is a few 1e-7 * sum|a*b|; tolerances are stated per test."""
+import numpy as np
+import pytest
+from scipy.special import erf
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng(pkg, assets):
+    prefix, vocab = assets("micro")
+    e = pkg.Engine(prefix, vocab, True)
+    yield e
+    e.close()
+
+
+def gelu(x):
+    return 0.5 * x * (1.0 + erf(x / np.sqrt(2.0)))
+
+
+def rel_err(a, ref):
+    return np.abs(a - ref).max() / max(1e-30, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (300, 256, 96), (1, 128, 64), (257, 384, 416), (1500, 384, 1152)])
+def test_gemm_plain(eng, M, N, K):
+    rng = np.random.default_rng(M * 7 + N + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = rng.standard_normal((N, K)).astype(np.float32)
+    C = eng.dbg_gemm(A, W)
+    ref = A.astype(np.float64) @ W.astype(np.float64).T
+    assert rel_err(C, ref) < 2e-6
+
+
+def test_gemm_is_exact_on_integers(eng):
+    """A = I (padded) against an ASYMMETRIC integer W catches a swapped C/D row-col map."""
+    K, N = 128, 256
+    W = (np.arange(N)[:, None] * 3 + np.arange(K)[None, :] * 7).astype(np.float32) % 251
+    A = np.zeros((K, K), np.float32)
+    A[np.arange(K), np.arange(K)] = 1.0
+    C = eng.dbg_gemm(A, W)
+    assert np.array_equal(C, W.T)
+    A2 = (np.arange(200)[:, None] % 5 - 2 + (np.arange(K)[None, :] % 3)).astype(np.float32)
+    assert np.array_equal(eng.dbg_gemm(A2, W), (A2.astype(np.float64) @ W.astype(np.float64).T).astype(np.float32))
+
+
+@pytest.mark.parametrize("epi", [1, 3, 5, 11])
+def test_gemm_epilogues(eng, epi):
+    rng = np.random.default_rng(epi)
+    M, N, K, P = 400, 256, 64, 100
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / 8).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    R = rng.standard_normal((M, N)).astype(np.float32)
+    pos = rng.standard_normal((P, N)).astype(np.float32)
+    C = eng.dbg_gemm(A, W, bias=bias, R=R if epi & 4 else None, pos=pos if epi & 8 else None, epi=epi)
+    ref = A.astype(np.float64) @ W.astype(np.float64).T + bias
+    if epi & 2:
+        ref = gelu(ref)
+    if epi & 8:
+        ref = ref + pos[np.arange(M) % P]
+    if epi & 4:
+        ref = ref + R
+    assert np.abs(C - ref).max() < 5e-6
+
+
+@pytest.mark.parametrize("B,N,K", [(32, 384, 384), (32, 128, 512), (7, 1536, 384), (64, 384, 1536), (33, 1000, 128), (32, 51865, 384)])
+def test_skinny_gemm_and_argmax(eng, B, N, K):
+    rng = np.random.default_rng(B + N + K)
+    X = rng.standard_normal((B, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / 16).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    Y, am = eng.dbg_skinny(X, W, bias=bias, epi=1, want_argmax=True)
+    ref = X.astype(np.float64) @ W.astype(np.float64).T + bias
+    assert np.abs(Y - ref).max() < 5e-6
+    # the fused argmax is exact w.r.t. the values the kernel itself produced, last index on ties
+    expect = [int(N - 1 - np.argmax(Y[b][::-1])) for b in range(B)]
+    assert list(am) == expect
+
+
+def test_skinny_argmax_tie_rule(eng):
+    """Duplicate rows of W give bit-identical logits: the LAST index must win (whisper.cpp:353)."""
+    rng = np.random.default_rng(5)
+    B, N, K = 4, 512, 128
+    X = rng.standard_normal((B, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / 64).astype(np.float32)
+    W[100] = W[7] = W[400] = X[0] / 4  # large identical logit at 7, 100, 400 for row 0
+    W[33] = W[300] = X[1] / 4
+    Y, am = eng.dbg_skinny(X, W, epi=0, want_argmax=True)
+    assert Y[0, 7] == Y[0, 100] == Y[0, 400] and am[0] == 400
+    assert am[1] == 300
+
+
+def test_skinny_epilogues(eng):
+    rng = np.random.default_rng(11)
+    B, N, K = 32, 384, 1536
+    X = rng.standard_normal((B, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / 40).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    R = rng.standard_normal((B, N)).astype(np.float32)
+    Y = eng.dbg_skinny(X, W, bias=bias, R=R, epi=5)
+    assert np.abs(Y - (X.astype(np.float64) @ W.astype(np.float64).T + bias + R)).max() < 5e-6
+    Y = eng.dbg_skinny(X, W, bias=bias, epi=3)
+    assert np.abs(Y - gelu(X.astype(np.float64) @ W.astype(np.float64).T + bias)).max() < 5e-6
+
+
+@pytest.mark.parametrize("M,d", [(5, 128), (1000, 384), (33, 512)])
+def test_layernorm(eng, M, d):
+    rng = np.random.default_rng(M + d)
+    x = (rng.standard_normal((M, d)) * 3 + 1).astype(np.float32)
+    g = rng.standard_normal(d).astype(np.float32)
+    b = rng.standard_normal(d).astype(np.float32)
+    y = eng.dbg_layernorm(x, g, b)
+    xd = x.astype(np.float64)
+    ref = (xd - xd.mean(1, keepdims=True)) / np.sqrt(xd.var(1, keepdims=True) + 1e-5) * g + b
+    assert np.abs(y - ref).max() < 5e-6
+
+
+def attn_ref(q, k, v, mask_from=None):
+    s = (q @ k.T) / 8.0
+    s = s - s.max(-1, keepdims=True)
+    p = np.exp(s)
+    return (p / p.sum(-1, keepdims=True)) @ v
+
+
+@pytest.mark.parametrize("B,T,H", [(1, 64, 1), (2, 100, 2), (1, 1500, 6), (3, 333, 2)])
+def test_encoder_attention(eng, B, T, H):
+    rng = np.random.default_rng(B * 1000 + T + H)
+    d = 64 * H
+    qkv = rng.standard_normal((B * T, 3 * d)).astype(np.float32)
+    out = eng.dbg_encoder_attention(qkv, B, T, H)
+    q64 = qkv.astype(np.float64).reshape(B, T, 3, H, 64)
+    for b in range(B):
+        for h in range(H):
+            ref = attn_ref(q64[b, :, 0, h], q64[b, :, 1, h], q64[b, :, 2, h])
+            got = out.reshape(B, T, H, 64)[b, :, h]
+            assert np.abs(got - ref).max() < 2e-5, (b, h)
+
+
+def test_encoder_attention_forces_rescale(eng):
+    """Online softmax: spike one key late in the sequence so the running max jumps at a chosen
+    tile (the rare branch), and check the FULL tensor against fp64."""
+    rng = np.random.default_rng(77)
+    B, T, H = 1, 300, 1
+    qkv = rng.standard_normal((T, 192)).astype(np.float32)
+    qkv[250, 64:128] = qkv[10, 0:64] * 6.0  # key 250 lines up with query 10: score >> others
+    qkv[120, 64:128] = qkv[11, 0:64] * 4.0
+    out = eng.dbg_encoder_attention(qkv, B, T, H)
+    q = qkv.astype(np.float64)
+    ref = attn_ref(q[:, 0:64], q[:, 64:128], q[:, 128:192])
+    assert np.abs(out - ref).max() < 2e-5
+
+
+@pytest.mark.parametrize("B,H,T,chunks", [(2, 2, 100, 4), (3, 6, 1500, 4), (1, 2, 1500, 1), (2, 2, 37, 8)])
+def test_cross_attention(eng, B, H, T, chunks):
+    rng = np.random.default_rng(B + H + T + chunks)
+    q = rng.standard_normal((B, H * 64)).astype(np.float32)
+    kc = rng.standard_normal((B, H, T, 64)).astype(np.float32)
+    vc = rng.standard_normal((B, H, T, 64)).astype(np.float32)
+    out = eng.dbg_cross_attention(q, kc, vc, chunks)
+    for b in range(B):
+        for h in range(H):
+            ref = attn_ref(q[b, h * 64:(h + 1) * 64].astype(np.float64)[None], kc[b, h].astype(np.float64), vc[b, h].astype(np.float64))[0]
+            assert np.abs(out[b, h * 64:(h + 1) * 64] - ref).max() < 1e-5
+
+
+def test_self_attention_appends_and_attends(eng):
+    rng = np.random.default_rng(3)
+    B, H, cap = 3, 2, 32
+    d = 64 * H
+    kc = np.zeros((B, cap, d), np.float32)
+    vc = np.zeros((B, cap, d), np.float32)
+    for pos in range(6):
+        qkv = rng.standard_normal((B, 3 * d)).astype(np.float32)
+        out, kc2, vc2 = eng.dbg_self_attention(qkv, kc, vc, pos)
+        kc[:, pos] = qkv[:, d:2 * d]
+        vc[:, pos] = qkv[:, 2 * d:]
+        assert np.array_equal(kc2, kc) and np.array_equal(vc2, vc)
+        for b in range(B):
+            for h in range(H):
+                sl = slice(h * 64, (h + 1) * 64)
+                ref = attn_ref(qkv[b, sl].astype(np.float64)[None], kc[b, :pos + 1, sl].astype(np.float64),
+                               vc[b, :pos + 1, sl].astype(np.float64))[0]
+                assert np.abs(out[b, sl] - ref).max() < 1e-5

@@ -1,0 +1,217 @@
+"""GPU (-m gpu): the whole EncDec hot path through the C ABI against the CPU oracle and the
+committed golden vectors.  Bar: token ids bit-exact; fp32 encoder output / logits within the
+tolerance written next to each assert."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, synth_pcm
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = 1e-4   # north star: fp32 logits within 1e-4 (logits are O(1))
+ENC_TOL = 1e-4
+MEL_TOL = 1e-4     # |delta| on the normalised log-mel (SURVEY §7 hard parts)
+
+
+@pytest.fixture(scope="module")
+def micro(pkg, assets):
+    prefix, vocab = assets("micro")
+    e = pkg.Engine(prefix, vocab, True)
+    e.set_option("stop_at_eot", 0)
+    yield e, prefix
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def tiny(pkg, assets):
+    prefix, vocab = assets("tiny")
+    e = pkg.Engine(prefix, vocab, True)
+    e.set_option("stop_at_eot", 0)
+    yield e, prefix
+    e.close()
+
+
+def prompt_of(e):
+    info = e.vocab_info()
+    return [info["sot"], 50259 + e.get_option("language"), info["transcribe"], info["not"]]
+
+
+def test_micro_matches_hf_golden(micro):
+    """Complete tensors (encoder output, all 27 logit rows, ids) for three clips."""
+    e, _ = micro
+    g = np.load(os.path.join(GOLD, "model_micro.npz"))
+    e.set_prompt(g["prompt"])  # [3,5,7,11]: the micro vocabulary (1024) has no special ids
+    ids, n, enc, logits = e.encdec_debug_batch(g["mel"])
+    assert np.abs(enc - g["enc_out"]).max() < ENC_TOL
+    assert np.abs(logits - g["logits"]).max() < LOGIT_TOL
+    assert np.array_equal(ids[:, :31], g["ids"]) and list(n) == [31, 31, 31]
+
+
+def test_micro_vs_oracle_ragged_batches(micro, orc):
+    """Batch sizes that do not fill a tile (1, 5, 33 clips) against the oracle, clip by clip."""
+    e, prefix = micro
+    m = orc.Model(prefix + ".wtw")
+    prompt = [3, 5, 7, 11]
+    e.set_prompt(prompt)
+    rng = np.random.default_rng(99)
+    mel = rng.uniform(-1.0, 1.5, size=(33,) + e.mel_shape).astype(np.float32)
+    for B in (1, 5, 33):
+        ids, n, enc, logits = e.encdec_debug_batch(mel[:B])
+        ids_ref, n_ref = m.encdec_batch(mel[:B], prompt, 30, -1, False, True, n_threads=8)
+        assert np.array_equal(ids[:, :31], ids_ref) and list(n) == list(n_ref)
+        enc0 = m.encode(mel[B - 1], 4)
+        assert np.abs(enc[B - 1] - enc0).max() < ENC_TOL
+    # a prompt id outside the vocabulary is refused, not read out of bounds
+    e.set_prompt([50258, 50261, 50359, 50363])
+    with pytest.raises(Exception):
+        e.encdec_tokens_batch(mel[:1])
+    e.set_prompt(prompt)
+    m.close()
+
+
+def test_tiny_two_clips_vs_oracle_and_golden(tiny, orc):
+    e, prefix = tiny
+    g = np.load(os.path.join(GOLD, "model_tiny.npz"))
+    rng = np.random.default_rng(int(g["mel_seed"]))
+    mel = rng.uniform(-1.0, 1.5, size=(2, 80, 3000)).astype(np.float32)
+    ids, n, enc, logits = e.encdec_debug_batch(mel)
+    assert list(prompt_of(e)) == list(g["prompt"])
+    # golden (HF transformers, independent implementation)
+    assert np.abs(enc[:, 0:4, 0:8] - g["enc_head"]).max() < ENC_TOL
+    assert np.abs(enc[:, -4:, -8:] - g["enc_tail"]).max() < ENC_TOL
+    assert np.abs(enc[:, ::250] - g["enc_rows"]).max() < ENC_TOL
+    assert np.abs(logits[:, :, ::997] - g["logits_cols"]).max() < LOGIT_TOL
+    assert np.array_equal(ids[:, :31], g["ids"])  # token ids bit-exact
+    assert list(n) == [31, 31]
+    # oracle, full tensors, clip 0
+    m = orc.Model(prefix + ".wtw")
+    enc_ref = m.encode(mel[0], n_threads=16)
+    assert np.abs(enc[0] - enc_ref).max() < ENC_TOL
+    ids_ref, logits_ref = m.decode_greedy(enc_ref, g["prompt"], 30, eot=-1, stop_at_eot=False, n_threads=16, want_logits=True)
+    assert np.abs(logits[0] - logits_ref).max() < LOGIT_TOL
+    assert list(ids[0, :31]) == list(ids_ref)
+    m.close()
+
+
+def test_tiny_eot_and_max_tokens(tiny):
+    e, _ = tiny
+    g = np.load(os.path.join(GOLD, "model_tiny.npz"))
+    rng = np.random.default_rng(int(g["mel_seed"]))
+    mel = rng.uniform(-1.0, 1.5, size=(2, 80, 3000)).astype(np.float32)
+    e.set_option("max_tokens", 10)
+    ids, n = e.encdec_tokens_batch(mel)
+    assert list(n) == [11, 11] and np.array_equal(ids[:, :11], g["ids"][:, :11]) and not ids[:, 11:].any()
+    e.set_option("max_tokens", 30)
+    # EOT stop: with random weights EOT never wins on its own; the loop's stop rule is covered
+    # through ids that stay zero past n (kernel select_token) in test_gpu_kernels / oracle tests
+    e.set_option("stop_at_eot", 1)
+    ids2, n2 = e.encdec_tokens_batch(mel)
+    eot = e.vocab_info()["eot"]
+    for b in range(2):
+        row = list(g["ids"][b])
+        cut = row.index(eot) + 1 if eot in row[4:] else 31
+        assert n2[b] == cut and list(ids2[b, :cut]) == row[:cut]
+    e.set_option("stop_at_eot", 0)
+
+
+def test_tiny_batch32_properties(tiny):
+    """BASELINE config 2 size (batch 32 x 30 s): size-independent properties — a clip's ids do
+    not depend on its batch neighbours or position, repeated runs are bit-identical, and
+    the two golden clips embedded in the batch reproduce their golden ids."""
+    e, _ = tiny
+    g = np.load(os.path.join(GOLD, "model_tiny.npz"))
+    rng = np.random.default_rng(int(g["mel_seed"]))
+    two = rng.uniform(-1.0, 1.5, size=(2, 80, 3000)).astype(np.float32)
+    rng2 = np.random.default_rng(4321)
+    mel = rng2.uniform(-1.0, 1.5, size=(32, 80, 3000)).astype(np.float32)
+    mel[5], mel[31] = two[0], two[1]
+    ids, n = e.encdec_tokens_batch(mel)
+    assert list(n) == [31] * 32
+    assert list(ids[5, :31]) == list(g["ids"][0]) and list(ids[31, :31]) == list(g["ids"][1])
+    perm = rng2.permutation(32)
+    ids_p, _ = e.encdec_tokens_batch(mel[perm])
+    assert np.array_equal(ids_p, ids[perm])
+    ids_again, _ = e.encdec_tokens_batch(mel)
+    assert np.array_equal(ids_again, ids)
+    ids_small, _ = e.encdec_tokens_batch(mel[3:7])
+    assert np.array_equal(ids_small, ids[3:7])
+
+
+@pytest.mark.parametrize("kind", ["noise", "sweep", "speechlike"])
+def test_logmel_vs_reference_golden(tiny, orc, kind):
+    e, _ = tiny
+    gm = np.load(os.path.join(GOLD, "frontend_logmel.npz"))
+    key = f"{kind}_480000"
+    pcm = synth_pcm(kind, 480000, int(gm[key + "_seed"]))
+    mel = e.logmel_batch(pcm[None])[0]
+    assert np.abs(mel[:, ::97] - gm[key + "_cols"]).max() < MEL_TOL
+    assert np.abs(mel[::13, :] - gm[key + "_rows"]).max() < MEL_TOL
+    ref = orc.frontend().logmel(pcm, e.filters(), 8)  # bit-exact restatement of the reference
+    assert np.abs(mel - ref).max() < MEL_TOL
+
+
+def test_logmel_batch_edge_cases(tiny, orc):
+    e, _ = tiny
+    pcm = np.zeros((3, 480000), np.float32)
+    pcm[1] = synth_pcm("noise", 480000, 21)
+    pcm[2, :16000] = synth_pcm("sweep", 16000, 22)  # short clip padded with silence
+    mel = e.logmel_batch(pcm)
+    assert np.all(mel[0] == np.float32(-1.5))  # silence
+    for b in (1, 2):
+        ref = orc.frontend().logmel(pcm[b], e.filters(), 8)
+        assert np.abs(mel[b] - ref).max() < MEL_TOL
+
+
+def test_transcribe_single_clip_surface(tiny, orc, tmp_path):
+    """Engine::transcribe(samples) / transcribe(path): text = decode(ids) incl. specials."""
+    e, prefix = tiny
+    e.set_option("stop_at_eot", 1)
+    pcm = synth_pcm("speechlike", 200000, 31)  # shorter than 30 s: padded like whisper.cpp:753
+    text = e.transcribe(pcm)
+    padded = np.zeros(480000, np.float32)
+    padded[:200000] = pcm
+    mel = orc.frontend().logmel(padded, e.filters(), 8)
+    ids, n = e.encdec_tokens_batch(mel[None])
+    assert text == e.decode_text(ids[0, :n[0]])
+    assert text.startswith("<|startoftranscript_|><|lang-de|><|transcribe|><|notimestamps|>")
+    # file entry point with the legacy WAV quirks
+    import struct
+    pcm16 = np.clip(np.round(pcm * 32767), -32768, 32767).astype("<i2")
+    wav = tmp_path / "clip.wav"
+    wav.write_bytes(b"RIFF" + struct.pack("<I", 36 + pcm16.nbytes) + b"WAVEfmt " +
+                    struct.pack("<IHHIIHH", 16, 1, 1, 16000, 32000, 2, 16) + b"data" +
+                    struct.pack("<I", pcm16.nbytes) + pcm16.tobytes())
+    text_file = e.transcribe(str(wav))
+    samples = orc.frontend().wav_read_legacy(str(wav))
+    assert text_file == e.transcribe(samples)
+    # unreadable file -> 30 s of silence, still a transcript (reference behaviour)
+    assert e.transcribe(str(tmp_path / "missing.wav")) == e.transcribe(np.zeros(10, np.float32))
+    e.set_option("stop_at_eot", 0)
+
+
+def test_encdec_cli(tiny, tmp_path):
+    """app/encdec: same flags as the reference; transcript is the last stdout line."""
+    import struct
+    import subprocess
+    from conftest import ROOT
+    e, prefix = tiny
+    exe = os.path.join(ROOT, "whisper.tflite_amd", "bin", "encdec")
+    if not os.path.exists(exe):
+        pytest.skip("encdec binary not built")
+    pcm = synth_pcm("noise", 48000, 41)
+    pcm16 = np.clip(np.round(pcm * 32767), -32768, 32767).astype("<i2")
+    wav = tmp_path / "c.wav"
+    wav.write_bytes(b"RIFF" + struct.pack("<I", 36 + pcm16.nbytes) + b"WAVEfmt " +
+                    struct.pack("<IHHIIHH", 16, 1, 1, 16000, 32000, 2, 16) + b"data" +
+                    struct.pack("<I", pcm16.nbytes) + pcm16.tobytes())
+    vocab = os.path.join(os.path.dirname(prefix), "filters_vocab_synthetic.bin")
+    r = subprocess.run([exe, "--model-prefix", prefix, "--vocab", vocab, "--input", str(wav)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    e.set_option("stop_at_eot", 1)
+    assert r.stdout.splitlines()[-1] == e.transcribe(str(wav))
+    e.set_option("stop_at_eot", 0)
+    r = subprocess.run([exe, "--vocab", vocab], capture_output=True, text=True)
+    assert r.returncode != 0

@@ -1,0 +1,104 @@
+"""CPU: the C-ABI library loads without a GPU, exports every declared symbol, and its
+host-side helpers (no device compute) agree with the oracle / reference goldens."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, ROOT
+
+
+def _declared(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(wt_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    L = pkg.lib()
+    declared = _declared("wt_capi.h") + _declared("wt_debug.h")
+    assert len(declared) >= 25
+    for sym in declared:
+        assert hasattr(L, sym), f"{sym} declared in include/ but not exported"
+    assert sorted(pkg.CAPI_SYMBOLS) == _declared("wt_capi.h")
+    assert sorted(pkg.DEBUG_SYMBOLS) == _declared("wt_debug.h")
+
+
+def test_no_cpu_fallback_without_gpu(pkg, assets):
+    """Creating an engine needs a gfx950 device; without one the ABI reports WT_ERR_DEVICE
+    instead of computing anywhere else."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    prefix, vocab = assets("micro")
+    with pytest.raises(pkg.WtError) as e:
+        pkg.Engine(prefix, vocab, True)
+    assert e.value.code == 5  # WT_ERR_DEVICE
+
+
+def test_error_conventions(pkg, assets, tmp_path):
+    prefix, vocab = assets("micro")
+    h = ctypes.c_void_p()
+    L = pkg.lib()
+    # Monolith is out of scope -> unsupported, handle stays NULL
+    assert L.wt_engine_create(0, prefix.encode(), vocab.encode(), 1, 0, ctypes.byref(h)) == 4
+    assert not h.value and b"Monolith" in L.wt_last_error(None)
+    assert L.wt_engine_create(7, prefix.encode(), vocab.encode(), 1, 0, ctypes.byref(h)) == 1
+    # missing vocab file -> IO error with the reference's message (mmap_file.cpp:16)
+    rc = L.wt_engine_create(1, prefix.encode(), str(tmp_path / "nope.bin").encode(), 1, 0, ctypes.byref(h))
+    assert rc == 2 and L.wt_last_error(None).startswith(b"Failed to open file")
+    assert pkg.create_engine(0, prefix, vocab, True) is None
+    assert pkg.create_engine(9, prefix, vocab, True) is None
+    L.wt_engine_destroy(None)  # no-op
+
+
+def test_language_table_matches_oracle(pkg, orc):
+    fe = orc.frontend()
+    for i in range(100):
+        assert pkg.lang_code(i) == fe.lang_code(i)
+        assert pkg.language_id(fe.lang_code(i)) == i
+    assert pkg.language_id("de") == 2 and pkg.language_id("zz") == 100
+
+
+def test_wav_reader_matches_reference_golden(pkg, tmp_path):
+    g = np.load(os.path.join(GOLD, "frontend_host.npz"))
+    p = tmp_path / "ramp.wav"
+    p.write_bytes(g["wav_bytes"].tobytes())
+    s = pkg.wav_read_legacy(str(p))
+    assert np.array_equal(s.view(np.uint32), g["wav_samples"].view(np.uint32))
+    assert len(pkg.wav_read_legacy(str(tmp_path / "missing.wav"))) == 0
+
+
+def test_synthetic_vocab_file_round_trip(pkg, orc, tmp_path):
+    """The asset writer produces the reference layout: the oracle's (reference-pinned) reader
+    parses it, and the Slaney bank equals the HuggingFace/librosa one."""
+    path = str(tmp_path / "v.bin")
+    pkg.write_synthetic_vocab(path, 1000)
+    v = orc.frontend().open_vocab(path, True)
+    f = v.filters()
+    assert f.shape == (80, 201) and v.info()["n_vocab"] == 51865
+    assert v.token(65) == b"A" and v.token(999) == b" t999"
+    v.close()
+    from transformers.audio_utils import mel_filter_bank
+    hf = mel_filter_bank(num_frequency_bins=201, num_mel_filters=80, min_frequency=0.0, max_frequency=8000.0,
+                         sampling_rate=16000, norm="slaney", mel_scale="slaney").T
+    assert np.abs(f - hf).max() < 1e-7
+    raw = open(path, "rb").read()
+    assert int.from_bytes(raw[:8], "little") == len(raw) - 8 and raw[8:12] == b"NESU"
+
+
+def test_synthetic_weights_are_deterministic(pkg, tmp_path):
+    from wtw import read_wtw
+    a, b = str(tmp_path / "a.wtw"), str(tmp_path / "b.wtw")
+    pkg.write_synthetic_weights(a, "micro", 3)
+    pkg.write_synthetic_weights(b, "micro", 3)
+    assert open(a, "rb").read() == open(b, "rb").read()
+    dims, t = read_wtw(a)
+    assert dims["n_audio_ctx"] == 100 and t["decoder.token_embedding.weight"].shape == (1024, 128)
+    w = t["encoder.blocks.0.attn.query.weight"]
+    assert abs(float(w.std()) - 128 ** -0.5) < 0.01 and abs(float(w.mean())) < 0.01
+    assert abs(float(t["encoder.blocks.1.attn_ln.weight"].mean()) - 1.0) < 0.05
+    with pytest.raises(pkg.WtError):
+        pkg.write_synthetic_weights(a, "huge", 0)

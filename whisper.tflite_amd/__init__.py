@@ -36,7 +36,7 @@ STATUS_NAMES = {0: "WT_OK", 1: "WT_ERR_INVALID_ARG", 2: "WT_ERR_IO", 3: "WT_ERR_
 # Every symbol include/wt_capi.h and include/wt_debug.h declare.
 CAPI_SYMBOLS = [
     "wt_engine_create", "wt_engine_destroy", "wt_last_error", "wt_engine_dims",
-    "wt_engine_set_option", "wt_engine_get_option", "wt_transcribe_pcm", "wt_transcribe_file",
+    "wt_engine_set_option", "wt_engine_get_option", "wt_engine_set_prompt", "wt_transcribe_pcm", "wt_transcribe_file",
     "wt_logmel_batch", "wt_logmel_batch_dev", "wt_encdec_tokens_batch",
     "wt_encdec_tokens_batch_dev", "wt_transcribe_tokens_batch_dev", "wt_encdec_debug_batch",
     "wt_last_timings", "wt_decode_text", "wt_language_id", "wt_lang_code", "wt_wav_read_legacy",
@@ -92,6 +92,7 @@ def lib() -> ctypes.CDLL:
         L.wt_engine_dims.argtypes = [c_void_p, POINTER(Dims)]
         L.wt_engine_set_option.argtypes = [c_void_p, c_char_p, c_long]
         L.wt_engine_get_option.argtypes = [c_void_p, c_char_p, POINTER(c_long)]
+        L.wt_engine_set_prompt.argtypes = [c_void_p, ip64, c_int]
         L.wt_transcribe_pcm.argtypes = [c_void_p, fp, c_size_t, c_char_p, c_size_t, POINTER(c_size_t)]
         L.wt_transcribe_file.argtypes = [c_void_p, c_char_p, c_char_p, c_size_t, POINTER(c_size_t)]
         L.wt_logmel_batch.argtypes = [c_void_p, fp, c_int, fp]
@@ -200,6 +201,10 @@ class Engine:
         v = c_long(0)
         self._check(lib().wt_engine_get_option(self._h, key.encode(), byref(v)))
         return v.value
+
+    def set_prompt(self, ids) -> None:
+        ids = np.ascontiguousarray(ids, dtype=np.int64).reshape(-1)
+        self._check(lib().wt_engine_set_prompt(self._h, ids.ctypes.data_as(POINTER(c_int64)), ids.size))
 
     # -- shapes ----------------------------------------------------------------------
     @property

@@ -121,6 +121,12 @@ int wt_engine_set_option(wt_engine* h, const char* key, long value) {
   return WT_OK;
 }
 
+int wt_engine_set_prompt(wt_engine* h, const int64_t* ids, int n) {
+  if (!h || n < 0 || n > 8 || (n && !ids)) return WT_ERR_INVALID_ARG;
+  h->impl->prompt_override.assign(ids, ids + n);
+  return WT_OK;
+}
+
 int wt_engine_get_option(const wt_engine* h, const char* key, long* value) {
   if (!h || !key || !value) return WT_ERR_INVALID_ARG;
   const wt::Engine& e = *h->impl;

@@ -471,9 +471,13 @@ void Engine::decode(int batch, int64_t* ids, int32_t* n_ids, float* logits_host,
   const wtw::Dims& c = dims_;
   const int d = c.n_text_state, T = c.n_audio_ctx, H = c.n_text_head, V = c.n_vocab;
   // prompt (whisper.cpp:327-339): [sot, 50259 + language, transcribe, notimestamps]
-  const long long prompt[4] = {vocab_.token_sot, 50259 + language, vocab_.token_transcribe,
-                               vocab_.token_not};
-  const int n_prompt = 4, stride = 32;
+  std::vector<long long> prompt = {vocab_.token_sot, 50259 + language, vocab_.token_transcribe,
+                                   vocab_.token_not};
+  if (!prompt_override.empty()) prompt = prompt_override;
+  const int n_prompt = int(prompt.size()), stride = 32;
+  for (long long id : prompt) {
+    if (id < 0 || id >= V) throw Error(1, "prompt token id outside the model's vocabulary");
+  }
   const int max_pos = int(std::min<long>(std::max<long>(max_tokens, n_prompt), 31));
   for (int b = 0; b < batch; ++b) {
     for (int i = 0; i < stride; ++i) h_ids_[size_t(b) * stride + i] = i < n_prompt ? prompt[i] : 0;
@@ -490,7 +494,7 @@ void Engine::decode(int batch, int64_t* ids, int32_t* n_ids, float* logits_host,
   const size_t self_slab = size_t(batch) * self_cap_ * d;
   int steps = 0;
   for (int pos = 0; pos < max_pos; ++pos) {
-    launch_embed(tok_emb, dec_pos, ws_.ids, stride, pos, ws_.xd, batch, d, stream_);
+    launch_embed(tok_emb, dec_pos, ws_.ids, stride, pos, ws_.xd, batch, d, V, stream_);
     for (int l = 0; l < c.n_text_layer; ++l) {
       const BlockWeights& w = dec_blocks_[l];
       launch_layernorm(ws_.xd, ws_.lnd, w.attn_ln_g, w.attn_ln_b, batch, d, stream_);

@@ -59,6 +59,8 @@ class Engine {
   long stop_at_eot = 1;
   long verbose = 0;
   long cross_chunks = 4;
+  // non-empty: replaces the reference's hard-coded prompt (test-sized vocabularies)
+  std::vector<long long> prompt_override;
 
   int mel_frames() const { return 2 * dims_.n_audio_ctx; }
   size_t mel_elems() const { return size_t(dims_.n_mels) * mel_frames(); }

@@ -89,7 +89,7 @@ void launch_mel_normalize(float* logmel, const unsigned* clip_max, int batch, in
 // --------------------------------------------------------------- decoder ---
 // x[b][:] = tok_emb[ids[b][pos]][:] + pos_emb[pos][:]
 void launch_embed(const float* tok_emb, const float* pos_emb, const long long* ids, int ids_stride,
-                  int pos, float* x, int batch, int d, hipStream_t s);
+                  int pos, float* x, int batch, int d, int n_vocab, hipStream_t s);
 // Appends k,v of position `pos` (from qkv [B][3d]) to the self-attention cache
 // [2][B][cap][d] and attends q over positions 0..pos.  out [B][d].
 void launch_self_attention(const float* qkv, float* kcache, float* vcache, int cap, int pos,
