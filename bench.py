@@ -1,0 +1,299 @@
+#!/usr/bin/env python3
+"""bench.py — audio-sec/s of the EncDec hot path (BASELINE.json metric) on N MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic input per rank:
+device-resident mel [32][80][3000] fp32 (configs[1]: whisper-tiny, batch 32 x 30 s) ->
+encoder -> cross-KV -> 30 decoder positions / 27 greedy argmax steps -> token ids on the
+host (wt_encdec_tokens_batch_dev), then (N > 1) one RCCL all_gather of the fixed-stride id
+records.  Inputs are already in HBM when the timed region starts.
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+      --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  `--dry-run-gloo` exercises only the sharding + gather
+plumbing on CPU (world_size-2 gloo test in tests/test_distributed.py).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BATCH_PER_GPU = 32
+CLIP_SECONDS = 30.0
+MEL_SEED = 1234
+ID_STRIDE = 32  # int64 ids per clip record (wt_capi.h WT_MAX_IDS)
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+PEAK_HBM_GBPS = 8000.0
+
+
+# ---------------------------------------------------------------- sharding / gather ---
+
+def shard_range(rank: int, world: int, total: int):
+    """Contiguous clip range of `rank`: clips [r*B/R, (r+1)*B/R)."""
+    per = total // world
+    rem = total % world
+    lo = rank * per + min(rank, rem)
+    return lo, lo + per + (1 if rank < rem else 0)
+
+
+def pack_records(ids: np.ndarray, n: np.ndarray) -> np.ndarray:
+    """Fixed-stride record per clip: 32 int64 ids followed by the id count."""
+    rec = np.zeros((ids.shape[0], ID_STRIDE + 1), np.int64)
+    rec[:, :ID_STRIDE] = ids
+    rec[:, ID_STRIDE] = n
+    return rec
+
+
+def gather_records(rec_tensor, world: int):
+    """The path's only collective: all_gather of the per-rank id records (RCCL over xGMI on
+    GPUs; gloo in the CPU rehearsal).  Returns [world * B][33]."""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return rec_tensor
+    out = [torch.empty_like(rec_tensor) for _ in range(world)]
+    dist.all_gather(out, rec_tensor)
+    return torch.cat(out, dim=0)
+
+
+def synthetic_mel(lo: int, hi: int, shape) -> np.ndarray:
+    """mel ~ U(-1, 1.5), one independent stream per GLOBAL clip index, so a clip's content
+    does not depend on how the batch is sharded."""
+    out = np.empty((hi - lo,) + tuple(shape), np.float32)
+    for i, g in enumerate(range(lo, hi)):
+        out[i] = np.random.default_rng([MEL_SEED, g]).uniform(-1.0, 1.5, size=shape).astype(np.float32)
+    return out
+
+
+# ------------------------------------------------------------------------ dry run ---
+
+def dry_run_gloo(args) -> None:
+    """CPU rehearsal of the N > 1 plumbing: same sharding, same records, same collective, with
+    a deterministic stand-in for the engine (ids derived from the clip's global index)."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    total = world * args.batch
+    lo, hi = shard_range(rank, world, total)
+    ids = np.zeros((hi - lo, ID_STRIDE), np.int64)
+    n = np.zeros(hi - lo, np.int32)
+    for i, g in enumerate(range(lo, hi)):
+        n[i] = 5 + g % 27
+        ids[i, : n[i]] = (np.arange(n[i]) * 7 + g * 13) % 51865
+    rec = gather_records(torch.from_numpy(pack_records(ids, n)), world).numpy()
+    ok = rec.shape == (total, ID_STRIDE + 1)
+    for g in range(total):
+        cnt = 5 + g % 27
+        ok = ok and rec[g, ID_STRIDE] == cnt and np.array_equal(rec[g, :cnt], (np.arange(cnt) * 7 + g * 13) % 51865)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "world": world, "clips": int(total), "ok": bool(ok)}))
+    if not ok:
+        sys.exit(1)
+
+
+# -------------------------------------------------------------------- cpu baseline ---
+
+def cpu_baseline(prefix: str, mel: np.ndarray, prompt, eot: int) -> dict:
+    """TEST-INFRASTRUCTURE leg: the oracle (CPU port of the same path) timed on this host's
+    cores over a bounded sample of the same workload.  Reported beside the GPU number; never
+    the thing measured as `value`."""
+    import __graft_entry__ as ge
+    orc = ge.load_oracle()
+    cores = min(os.cpu_count() or 1, 16)
+    model = orc.Model(prefix + ".wtw")
+    sample = mel[: min(cores, mel.shape[0])]
+    t0 = time.perf_counter()
+    ids_c, n_c = model.encdec_batch(sample, prompt, 30, eot, False, True, n_threads=cores)
+    t_cached = time.perf_counter() - t0
+    # reference-faithful structure (whisper.cpp:367-375): no KV cache, whole prefix per step
+    few = sample[: max(1, cores // 4)]
+    t0 = time.perf_counter()
+    model.encdec_batch(few, prompt, 30, eot, False, False, n_threads=cores)
+    t_nocache = time.perf_counter() - t0
+    model.close()
+    return {
+        "value": round(sample.shape[0] * CLIP_SECONDS / t_cached, 2),
+        "unit": "audio-sec/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{sample.shape[0]} clips of the same synthetic batch, KV-cached oracle, one clip per thread "
+                  f"({t_cached:.1f} s); reference-structure (no KV cache) on {few.shape[0]} clips: "
+                  f"{few.shape[0] * CLIP_SECONDS / t_nocache:.2f} audio-sec/s ({t_nocache:.1f} s)",
+        "nocache_value": round(few.shape[0] * CLIP_SECONDS / t_nocache, 2),
+        "reference_tflite_cpu_path": "unavailable (no TFLite runtime / .tflite model in this environment)",
+        "ids": ids_c,
+        "n": n_c,
+    }
+
+
+# ---------------------------------------------------------------------------- main ---
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="clips per GPU")
+    ap.add_argument("--arch", default="tiny")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run-gloo", action="store_true")
+    args = ap.parse_args()
+    if args.dry_run_gloo:
+        dry_run_gloo(args)
+        return
+
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the engine")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    pkg = ge.load_package()
+    tmp = tempfile.mkdtemp(prefix=f"wt_bench_r{rank}_")
+    prefix, vocab = ge._assets(tmp, args.arch, 0)
+    eng = pkg.Engine(prefix, vocab, True, device_id=local_rank)
+    eng.set_option("stop_at_eot", 0)  # full-length decode: 30 positions, 27 argmax steps
+    B = args.batch
+    lo, hi = shard_range(rank, world, world * B)
+    mel_host = synthetic_mel(lo, hi, eng.mel_shape)
+    d_mel = torch.from_numpy(mel_host).cuda()  # resident in HBM before the timed region
+    torch.cuda.synchronize()
+
+    def step():
+        ids, n = eng.encdec_tokens_batch_dev(d_mel.data_ptr(), B)
+        rec = torch.from_numpy(pack_records(ids, n))
+        if world > 1:
+            rec = gather_records(rec.cuda(), world)
+        return ids, n, rec
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    stage = {"encoder_ms": 0.0, "cross_kv_ms": 0.0, "decoder_ms": 0.0}
+    kstats = {}
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ids, n, rec = step()
+        t = eng.timings()
+        for k in stage:
+            stage[k] += getattr(t, k)
+        for name, v in eng.kernel_stats().items():
+            acc = kstats.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            for k in acc:
+                acc[k] += v[k]
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        total_clips = world * B * args.steps
+        value = total_clips * CLIP_SECONDS / elapsed
+        for k in stage:
+            stage[k] = round(stage[k] / args.steps, 4)
+        # dominant kernel = the class with the most device time inside the timed region
+        dom = max(kstats, key=lambda k: kstats[k]["ms"]) if kstats else None
+        roof = None
+        detail = {}
+        for name, v in kstats.items():
+            if v["launches"] == 0 or v["ms"] <= 0:
+                continue
+            if v["flops"] > 0:
+                ach = v["flops"] / (v["ms"] * 1e-3) / 1e12
+                detail[name] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                                "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                                "avg_launch_us": round(1e3 * v["ms"] / v["launches"], 2),
+                                "launches_per_step": v["launches"] // args.steps,
+                                "ms_per_step": round(v["ms"] / args.steps, 4)}
+            else:
+                ach = v["bytes"] / (v["ms"] * 1e-3) / 1e9
+                detail[name] = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                                "frac": round(ach / PEAK_HBM_GBPS, 4),
+                                "avg_launch_us": round(1e3 * v["ms"] / v["launches"], 2),
+                                "launches_per_step": v["launches"] // args.steps,
+                                "ms_per_step": round(v["ms"] / args.steps, 4)}
+        if dom and dom in detail:
+            d = detail[dom]
+            roof = {"kernel": dom, "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"],
+                    "unit": d["unit"], "frac": d["frac"], "traffic": None,
+                    "avg_launch_us": d["avg_launch_us"]}
+        # decoder phase against HBM: algorithmic bytes per step of this batch
+        dm = eng.dims
+        dstate, L, T, V = dm.n_text_state, dm.n_text_layer, dm.n_audio_ctx, dm.n_vocab
+        kv_bytes = L * 2 * T * dstate * 4 * B                        # cross KV read once per position
+        w_bytes = (L * 12 * dstate * dstate + V * dstate) * 4          # layer weights + tied embedding
+        dec_bytes = 30 * kv_bytes + 30 * (w_bytes - V * dstate * 4) + 27 * V * dstate * 4
+        dec_ach = dec_bytes / (stage["decoder_ms"] * 1e-3) / 1e9 if stage["decoder_ms"] > 0 else 0.0
+        out = {
+            "metric": "audio-sec/s (RTF) whisper-tiny 30s clips batch=32 per MI355X",
+            "value": round(value, 1),
+            "unit": "audio-sec/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"whisper-{args.arch} batch={B}x30s synthetic mel U(-1,1.5), fp32, random-init "
+                                   "weights (BASELINE.json configs[1]); mel resident in HBM -> token ids on host",
+                       "clips_per_gpu": B, "global_batch": world * B, "decoder_positions": 30,
+                       "argmax_steps": 27, "parallelism": f"clip-parallel dp{world}, RCCL all_gather of id records"},
+            "roofline": roof,
+            "roofline_detail": detail,
+            "decoder_roofline": {"bound": "hbm", "achieved": round(dec_ach, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                                 "frac": round(dec_ach / PEAK_HBM_GBPS, 4),
+                                 "algorithmic_bytes_per_step": int(dec_bytes)},
+            "stage_ms_per_step": stage,
+        }
+        if not args.no_cpu_baseline:
+            info = eng.vocab_info()
+            prompt = [info["sot"], 50259 + eng.get_option("language"), info["transcribe"], info["not"]]
+            cb = cpu_baseline(prefix, mel_host, prompt, info["eot"])
+            ids_c, n_c = cb.pop("ids"), cb.pop("n")
+            k = ids_c.shape[0]
+            cb["ids_match_gpu"] = bool(np.array_equal(ids_c[:, :31], ids[:k, :31]) and np.array_equal(n_c, n[:k]))
+            out["cpu_baseline"] = cb
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -111,6 +111,19 @@ int wt_encdec_debug_batch(wt_engine* h, const float* mel, int batch, int64_t* id
 
 int wt_last_timings(const wt_engine* h, wt_timings* out);
 
+/* Per-kernel-class device time of the encoder phase of the last batch call: HIP event pairs
+ * recorded on the engine's stream around every launch of the class.  flops / bytes are the
+ * ALGORITHMIC work of those launches (2*M*N*K per GEMM with the true K, 4*B*H*T*T*64 per
+ * attention, read+write bytes for bandwidth-bound kernels).  Returns the number of classes
+ * (<= cap entries written). */
+typedef struct wt_kernel_stat {
+  char name[48];
+  int32_t launches;
+  int32_t reserved;
+  double ms, flops, bytes;
+} wt_kernel_stat;
+int wt_last_kernel_stats(const wt_engine* h, wt_kernel_stat* out, int cap);
+
 /* ---- host-side helpers of the path ------------------------------------------------------ */
 /* whisper.cpp:634-665 decode() over the engine's vocab. */
 int wt_decode_text(wt_engine* h, const int64_t* ids, int n, int omit_special_tokens, char* out,

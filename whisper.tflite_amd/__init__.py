@@ -39,7 +39,7 @@ CAPI_SYMBOLS = [
     "wt_engine_set_option", "wt_engine_get_option", "wt_engine_set_prompt", "wt_transcribe_pcm", "wt_transcribe_file",
     "wt_logmel_batch", "wt_logmel_batch_dev", "wt_encdec_tokens_batch",
     "wt_encdec_tokens_batch_dev", "wt_transcribe_tokens_batch_dev", "wt_encdec_debug_batch",
-    "wt_last_timings", "wt_decode_text", "wt_language_id", "wt_lang_code", "wt_wav_read_legacy",
+    "wt_last_timings", "wt_last_kernel_stats", "wt_decode_text", "wt_language_id", "wt_lang_code", "wt_wav_read_legacy",
     "wt_vocab_info", "wt_filters", "wt_write_synthetic_weights", "wt_write_synthetic_vocab",
 ]
 DEBUG_SYMBOLS = [
@@ -69,6 +69,11 @@ class Timings(ctypes.Structure):
     _fields_ = [("logmel_ms", c_float), ("encoder_ms", c_float), ("cross_kv_ms", c_float),
                 ("decoder_ms", c_float), ("total_ms", c_float), ("batch", c_int32),
                 ("decoder_steps", c_int32)]
+
+
+class KernelStat(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 48), ("launches", c_int32), ("reserved", c_int32),
+                ("ms", ctypes.c_double), ("flops", ctypes.c_double), ("bytes", ctypes.c_double)]
 
 
 _lib = None
@@ -102,6 +107,7 @@ def lib() -> ctypes.CDLL:
         L.wt_transcribe_tokens_batch_dev.argtypes = [c_void_p, c_void_p, c_int, ip64, ip32]
         L.wt_encdec_debug_batch.argtypes = [c_void_p, fp, c_int, ip64, ip32, fp, fp, c_int]
         L.wt_last_timings.argtypes = [c_void_p, POINTER(Timings)]
+        L.wt_last_kernel_stats.argtypes = [c_void_p, POINTER(KernelStat), c_int]
         L.wt_decode_text.argtypes = [c_void_p, ip64, c_int, c_int, c_char_p, c_size_t, POINTER(c_size_t)]
         L.wt_language_id.argtypes = [c_char_p]
         L.wt_lang_code.argtypes = [c_int]
@@ -278,6 +284,12 @@ class Engine:
         t = Timings()
         self._check(lib().wt_last_timings(self._h, byref(t)))
         return t
+
+    def kernel_stats(self) -> dict:
+        arr = (KernelStat * 8)()
+        n = lib().wt_last_kernel_stats(self._h, arr, 8)
+        return {arr[i].name.decode(): {"launches": arr[i].launches, "ms": arr[i].ms, "flops": arr[i].flops,
+                                       "bytes": arr[i].bytes} for i in range(min(n, 8))}
 
     # -- host helpers ----------------------------------------------------------------
     def decode_text(self, ids, omit_special_tokens: bool = False) -> str:

@@ -217,6 +217,20 @@ int wt_last_timings(const wt_engine* h, wt_timings* out) {
   return WT_OK;
 }
 
+int wt_last_kernel_stats(const wt_engine* h, wt_kernel_stat* out, int cap) {
+  if (!h || (!out && cap > 0)) return 0;
+  const wt::KernelStat* k = h->impl->kernel_stats();
+  for (int i = 0; i < wt::kKcCount && i < cap; ++i) {
+    std::memset(&out[i], 0, sizeof(out[i]));
+    std::snprintf(out[i].name, sizeof(out[i].name), "%s", k[i].name);
+    out[i].launches = k[i].launches;
+    out[i].ms = k[i].ms;
+    out[i].flops = k[i].flops;
+    out[i].bytes = k[i].bytes;
+  }
+  return wt::kKcCount;
+}
+
 // --------------------------------------------------------- single clip ---
 
 int wt_transcribe_pcm(wt_engine* h, const float* pcm, size_t n_samples, char* out, size_t cap,

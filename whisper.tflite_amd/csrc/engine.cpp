@@ -262,6 +262,7 @@ Engine::~Engine() {
   if (h_n_) (void)hipHostFree(h_n_);
   for (auto& e : ev_)
     if (e) (void)hipEventDestroy(e);
+  for (auto& e : kt_events_) (void)hipEventDestroy(e);
   if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -384,14 +385,45 @@ void Engine::logmel(const float* d_pcm, int batch, float* d_mel) {
   timings_.logmel_ms = -1.0f;  // resolved lazily in decode()/sync by the C ABI
 }
 
+// ------------------------------------------------------- kernel timer ---
+
+void Engine::kt_begin(int cls, double flops, double bytes) {
+  const int idx = int(kt_recs_.size()) * 2;
+  while (int(kt_events_.size()) < idx + 2) {
+    hipEvent_t e;
+    HIPCHK(hipEventCreate(&e));
+    kt_events_.push_back(e);
+  }
+  kt_recs_.push_back({cls, idx, flops, bytes});
+  HIPCHK(hipEventRecord(kt_events_[idx], stream_));
+}
+
+void Engine::kt_end() { HIPCHK(hipEventRecord(kt_events_[kt_recs_.back().ev + 1], stream_)); }
+
+void Engine::resolve_kernel_stats() {
+  for (auto& k : kstats_) k.launches = 0, k.ms = 0, k.flops = 0, k.bytes = 0;
+  for (const KtRec& r : kt_recs_) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, kt_events_[r.ev], kt_events_[r.ev + 1]) != hipSuccess) continue;
+    KernelStat& k = kstats_[r.cls];
+    k.launches += 1;
+    k.ms += ms;
+    k.flops += r.flops;
+    k.bytes += r.bytes;
+  }
+}
+
 // ------------------------------------------------------------ encoder ---
 
 void Engine::encode(const float* d_mel, int batch) {
   ensure_batch(batch);
   const wtw::Dims& c = dims_;
   const int T0 = mel_frames(), T = c.n_audio_ctx, d = c.n_audio_state, M = batch * T;
+  kt_recs_.clear();
   HIPCHK(hipEventRecord(ev_[2], stream_));
+  kt_begin(kKcTranspose, 0, 2.0 * batch * c.n_mels * T0 * 4);
   launch_mel_transpose(d_mel, ws_.melT, batch, c.n_mels, T0, stream_);
+  kt_end();
   {
     GemmArgs g;  // conv1 + GELU: rows (clip, t) read melT rows t..t+2 (input t-1..t+1)
     g.A = ws_.melT;
@@ -407,7 +439,9 @@ void Engine::encode(const float* d_mel, int batch) {
     g.M = batch * T0;
     g.N = d;
     g.K = conv1_kpad;
+    kt_begin(kKcGemm, 2.0 * g.M * g.N * (3.0 * c.n_mels), 0);
     launch_gemm(g, kEpiBias | kEpiGelu, stream_);
+    kt_end();
   }
   {
     GemmArgs g;  // conv2 (stride 2) + GELU + positional embedding
@@ -424,31 +458,49 @@ void Engine::encode(const float* d_mel, int batch) {
     g.M = M;
     g.N = d;
     g.K = 3 * d;
+    kt_begin(kKcGemm, 2.0 * g.M * g.N * g.K, 0);
     launch_gemm(g, kEpiBias | kEpiGelu | kEpiPos, stream_);
+    kt_end();
   }
   for (int l = 0; l < c.n_audio_layer; ++l) {
     const BlockWeights& w = enc_blocks_[l];
+    kt_begin(kKcLayerNorm, 0, 2.0 * M * d * 4);
     launch_layernorm(ws_.x, ws_.ln, w.attn_ln_g, w.attn_ln_b, M, d, stream_);
+    kt_end();
     GemmArgs q;
     q.A = ws_.ln; q.lda = d; q.W = w.attn.wqkv; q.bias = w.attn.bqkv; q.C = ws_.qkv; q.ldc = 3 * d;
     q.M = M; q.N = 3 * d; q.K = d;
+    kt_begin(kKcGemm, 2.0 * q.M * q.N * q.K, 0);
     launch_gemm(q, kEpiBias, stream_);
+    kt_end();
+    kt_begin(kKcEncAttn, 4.0 * batch * c.n_audio_head * double(T) * T * 64, 0);
     launch_encoder_attention(ws_.qkv, ws_.att, batch, T, c.n_audio_head, stream_);
+    kt_end();
     GemmArgs o;
     o.A = ws_.att; o.lda = d; o.W = w.attn.wo; o.bias = w.attn.bo; o.C = ws_.x; o.R = ws_.x; o.ldc = d;
     o.M = M; o.N = d; o.K = d;
+    kt_begin(kKcGemm, 2.0 * o.M * o.N * o.K, 0);
     launch_gemm(o, kEpiBias | kEpiResidual, stream_);
+    kt_end();
+    kt_begin(kKcLayerNorm, 0, 2.0 * M * d * 4);
     launch_layernorm(ws_.x, ws_.ln, w.mlp_ln_g, w.mlp_ln_b, M, d, stream_);
+    kt_end();
     GemmArgs f1;
     f1.A = ws_.ln; f1.lda = d; f1.W = w.w1; f1.bias = w.b1; f1.C = ws_.hid; f1.ldc = 4 * d;
     f1.M = M; f1.N = 4 * d; f1.K = d;
+    kt_begin(kKcGemm, 2.0 * f1.M * f1.N * f1.K, 0);
     launch_gemm(f1, kEpiBias | kEpiGelu, stream_);
+    kt_end();
     GemmArgs f2;
     f2.A = ws_.hid; f2.lda = 4 * d; f2.W = w.w2; f2.bias = w.b2; f2.C = ws_.x; f2.R = ws_.x; f2.ldc = d;
     f2.M = M; f2.N = d; f2.K = 4 * d;
+    kt_begin(kKcGemm, 2.0 * f2.M * f2.N * f2.K, 0);
     launch_gemm(f2, kEpiBias | kEpiResidual, stream_);
+    kt_end();
   }
+  kt_begin(kKcLayerNorm, 0, 2.0 * M * d * 4);
   launch_layernorm(ws_.x, ws_.enc_out, enc_ln_post_g, enc_ln_post_b, M, d, stream_);
+  kt_end();
   HIPCHK(hipEventRecord(ev_[3], stream_));
   {
     // cross-attention K/V of every decoder layer, projected once per clip into the
@@ -458,7 +510,9 @@ void Engine::encode(const float* d_mel, int batch) {
     g.A = ws_.enc_out; g.lda = d; g.W = cross_kv_w; g.bias = cross_kv_b; g.C = ws_.cross_kv;
     g.M = M; g.N = c.n_text_layer * 2 * d; g.K = d;
     g.c_rpb = T; g.kv_batch = batch; g.kv_heads = c.n_text_head; g.kv_dmodel = d;
+    kt_begin(kKcGemm, 2.0 * g.M * g.N * g.K, 0);
     launch_gemm(g, kEpiBias | kEpiKvLayout, stream_);
+    kt_end();
   }
   HIPCHK(hipEventRecord(ev_[4], stream_));
 }
@@ -563,6 +617,7 @@ void Engine::decode(int batch, int64_t* ids, int32_t* n_ids, float* logits_host,
     n_ids[b] = h_n_[b];
     for (int i = 0; i < stride; ++i) ids[size_t(b) * stride + i] = i < h_n_[b] ? h_ids_[size_t(b) * stride + i] : 0;
   }
+  resolve_kernel_stats();
   float ms = 0;
   timings_.batch = batch;
   timings_.decoder_steps = steps;

@@ -25,6 +25,17 @@ struct Timings {
   int batch = 0, decoder_steps = 0;
 };
 
+// Per-kernel-class device time of the last encode(), from HIP event pairs recorded on the
+// engine's stream around every launch of that class (bench.py's roofline figures).
+struct KernelStat {
+  const char* name;
+  int launches;
+  double ms;     // sum of launch durations
+  double flops;  // algorithmic FLOPs of those launches
+  double bytes;  // algorithmic bytes (bandwidth-bound kernels)
+};
+enum KernelClass { kKcGemm = 0, kKcEncAttn, kKcLayerNorm, kKcTranspose, kKcCount };
+
 struct AttnWeights {
   const float *wqkv = nullptr, *bqkv = nullptr;  // fused [3d][d] (self attention)
   const float *wq = nullptr, *bq = nullptr;      // cross attention query
@@ -82,6 +93,10 @@ class Engine {
   // raw device allocator for debug entry points
   float* dalloc(size_t n_floats);
 
+  // Resolved by decode()/sync_stats(); index = KernelClass.
+  const KernelStat* kernel_stats() const { return kstats_; }
+  void resolve_kernel_stats();
+
  private:
   void upload_weights(const std::string& path);
   const float* dev(const std::string& name) const;
@@ -129,6 +144,16 @@ class Engine {
     float *mel_stage = nullptr, *pcm_stage = nullptr;
     std::vector<void*> owned;
   } ws_;
+  // kernel-class timer
+  void kt_begin(int cls, double flops, double bytes);
+  void kt_end();
+  struct KtRec { int cls; int ev; double flops, bytes; };
+  std::vector<hipEvent_t> kt_events_;
+  std::vector<KtRec> kt_recs_;
+  KernelStat kstats_[kKcCount] = {{"gemm_f32_128x128", 0, 0, 0, 0},
+                                  {"encoder_attention_f32", 0, 0, 0, 0},
+                                  {"layernorm_rows", 0, 0, 0, 0},
+                                  {"mel_transpose", 0, 0, 0, 0}};
   int self_cap_ = 32;
   long long* h_ids_ = nullptr;  // pinned
   int* h_n_ = nullptr;          // pinned
