@@ -6,6 +6,7 @@
 #include <unistd.h>
 
 #include <cmath>
+#include <complex>
 #include <cstdio>
 #include <cstring>
 #include <stdexcept>
@@ -191,25 +192,80 @@ void Engine::upload_weights(const std::string& path) {
   dec_ln_b = up("decoder.ln.bias", d);
 }
 
+namespace {
+// The linear map the reference's transform actually applies.  whisper.cpp:58-106 is a
+// radix-2 recursion (400 -> 200 -> 100 -> 50 -> 25) over a naive 25-point DFT (:37-54) whose
+// twiddles are cosf/sinf of an angle already rounded to float (:46, :92): at the leaf the
+// angle reaches 2*pi*24*24/25 = 145 rad, so the rounded argument is off by up to ~1e-5 rad.
+// That systematic deviation from the ideal DFT is 100x above fp32 rounding noise and shows in
+// every bin that sits 40 dB below a frame's peak, so the device transform is built from the
+// SAME twiddle values: the recursion is evaluated here in double on unit impulses, giving
+// the effective 400x400 complex matrix, which the GPU then applies as one fp32 MFMA GEMM.
+using cd = std::complex<double>;
+void effective_fft(const std::vector<cd>& in, std::vector<cd>& out) {
+  const int N = int(in.size());
+  out.assign(N, cd(0, 0));
+  if (N == 1) {
+    out[0] = in[0];
+    return;
+  }
+  if (N % 2 == 1) {
+    for (int k = 0; k < N; ++k) {
+      cd acc(0, 0);
+      for (int n = 0; n < N; ++n) {
+        double a = 2 * M_PI;
+        a = a * k;
+        a = a * n;
+        a = a / N;
+        const float angle = static_cast<float>(a);
+        acc += in[n] * cd(double(cosf(angle)), -double(sinf(angle)));
+      }
+      out[k] = acc;
+    }
+    return;
+  }
+  std::vector<cd> even(N / 2), odd(N / 2), fe, fo;
+  for (int i = 0; i < N / 2; ++i) {
+    even[i] = in[2 * i];
+    odd[i] = in[2 * i + 1];
+  }
+  effective_fft(even, fe);
+  effective_fft(odd, fo);
+  for (int k = 0; k < N / 2; ++k) {
+    double a = 2 * M_PI;
+    a = a * k;
+    a = a / N;
+    const float theta = static_cast<float>(a);
+    const cd w(double(cosf(theta)), -double(sinf(theta)));
+    out[k] = fe[k] + w * fo[k];
+    out[k + N / 2] = fe[k] - w * fo[k];
+  }
+}
+}  // namespace
+
 void Engine::build_frontend_tables() {
-  // STFT as a GEMM against a windowed DFT basis (reference: Hann window whisper.cpp:117-120,
-  // 400-point transform :157, bins 0..200 used after the fold :164-166).
+  // STFT as a GEMM: rows of the basis are the reference's effective transform with the Hann
+  // window (whisper.cpp:117-120: double cos, float store) folded in.  All 400 output bins are
+  // kept because the reference adds the mirror bin's power computed by the same inexact
+  // transform (:164-166).
   const int n_fft = 400, n_bins = 201;
   if (filters_.n_fft != n_bins || filters_.n_mel != dims_.n_mels) {
     have_logmel_ = false;  // front end needs the 80x201 bank; encoder/decoder still work
     return;
   }
   dft_k = int(round_up(n_fft, 32));  // 416: samples 400..415 meet zero basis entries
-  dft_im_off = 256;
-  dft_n = 512;
+  dft_im_off = n_fft;                // rows [0,400) real parts, [400,800) imaginary parts
+  dft_n = int(round_up(2 * n_fft, 128));  // 896
   std::vector<float> basis(size_t(dft_n) * dft_k, 0.0f);
-  for (int k = 0; k < n_bins; ++k) {
-    for (int n = 0; n < n_fft; ++n) {
-      const double hann = 0.5 * (1.0 - std::cos(2.0 * M_PI * n / n_fft));
-      const int idx = (k * n) % n_fft;  // exact argument reduction
-      const double ang = 2.0 * M_PI * idx / n_fft;
-      basis[size_t(k) * dft_k + n] = static_cast<float>(hann * std::cos(ang));
-      basis[size_t(dft_im_off + k) * dft_k + n] = static_cast<float>(hann * std::sin(ang));
+  std::vector<cd> impulse(n_fft), col;
+  for (int n = 0; n < n_fft; ++n) {
+    const float hann = static_cast<float>(0.5 * (1.0 - std::cos((2.0 * M_PI * n) / n_fft)));
+    std::fill(impulse.begin(), impulse.end(), cd(0, 0));
+    impulse[n] = cd(double(hann), 0);
+    effective_fft(impulse, col);
+    for (int k = 0; k < n_fft; ++k) {
+      basis[size_t(k) * dft_k + n] = static_cast<float>(col[k].real());
+      basis[size_t(dft_im_off + k) * dft_k + n] = static_cast<float>(col[k].imag());
     }
   }
   dft_basis = upload(basis);
@@ -367,7 +423,7 @@ void Engine::logmel(const float* d_pcm, int batch, float* d_mel) {
   g.K = dft_k;
   g.ldc = dft_n;
   launch_gemm(g, 0, stream_);
-  launch_power_fold(ws_.spec, dft_n, dft_im_off, ws_.pw, mel_k, 201, M, stream_);
+  launch_power_fold(ws_.spec, dft_n, dft_im_off, ws_.pw, mel_k, 400, M, stream_);
   GemmArgs m;
   m.A = ws_.pw;
   m.lda = mel_k;

@@ -72,18 +72,22 @@ __global__ __launch_bounds__(256) void mel_transpose(const float* __restrict__ m
 
 __global__ __launch_bounds__(256) void power_fold(const float* __restrict__ spec, int ld,
                                                   int im_off, float* __restrict__ pw, int ldp,
-                                                  int n_bins, long M) {
+                                                  int n_fft, long M) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   const long m = idx / ldp;
   const int k = (int)(idx % ldp);
   if (m >= M) return;
+  const float* row = spec + m * ld;
   float p = 0.0f;
-  if (k < n_bins) {
-    const float re = spec[m * ld + k], im = spec[m * ld + im_off + k];
-    p = re * re + im * im;
-    // whisper.cpp:164-166 adds the mirror bin N-k into bins 1..N/2-1; for real input the
-    // mirror bin carries the same power
-    if (k >= 1 && k < n_bins - 1) p += p;
+  if (k <= n_fft / 2) {
+    // whisper.cpp:159-166: |X[k]|^2 for all bins, then bins 1..N/2-1 gain the mirror bin's
+    // power; same operation order, no fused multiply-add
+    const float re = row[k], im = row[im_off + k];
+    p = __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
+    if (k >= 1 && k < n_fft / 2) {
+      const float rm = row[n_fft - k], jm = row[im_off + n_fft - k];
+      p = __fadd_rn(p, __fadd_rn(__fmul_rn(rm, rm), __fmul_rn(jm, jm)));
+    }
   }
   pw[m * ldp + k] = p;
 }
@@ -114,8 +118,8 @@ __global__ __launch_bounds__(256) void log_clipmax(const float* __restrict__ mel
     float v = 0.0f;
     if (t < T && c < n_mel) {
       float e = melacc[((long)b * T + t) * ld + c];
-      e = e < 1e-10f ? 1e-10f : e;  // whisper.cpp:176-180
-      v = log10f(e);
+      e = e < 1e-10f ? 1e-10f : e;         // whisper.cpp:176-180 (a float epsilon)
+      v = (float)log10((double)e);          // :182 log10 in double, stored as float
       const unsigned o = ordered_bits(v);
       lmax = o > lmax ? o : lmax;
     }
@@ -135,12 +139,12 @@ __global__ __launch_bounds__(256) void mel_normalize(float* __restrict__ logmel,
                                                      const unsigned* __restrict__ clip_max,
                                                      long per_clip) {
   const int b = blockIdx.y;
-  const float floor_v = from_ordered(clip_max[b]) - 8.0f;  // whisper.cpp:205
+  const double floor_v = (double)from_ordered(clip_max[b]) - 8.0;  // whisper.cpp:198-205, double
   float* p = logmel + (long)b * per_clip;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per_clip; i += (long)gridDim.x * 256) {
     float v = p[i];
-    v = v < floor_v ? floor_v : v;
-    p[i] = (v + 4.0f) / 4.0f;  // whisper.cpp:212
+    if ((double)v < floor_v) v = (float)floor_v;  // :208-210
+    p[i] = (float)(((double)v + 4.0) / 4.0);       // :212
   }
 }
 
@@ -193,11 +197,11 @@ void launch_mel_transpose(const float* mel, float* melT, int batch, int n_mels, 
                      mel, melT, n_mels, T);
 }
 
-void launch_power_fold(const float* spec, int ld, int im_off, float* pw, int ldp, int n_bins,
+void launch_power_fold(const float* spec, int ld, int im_off, float* pw, int ldp, int n_fft,
                        long M, hipStream_t s) {
   const long total = M * ldp;
   hipLaunchKernelGGL(power_fold, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, spec, ld,
-                     im_off, pw, ldp, n_bins, M);
+                     im_off, pw, ldp, n_fft, M);
 }
 
 void launch_log_clipmax(const float* melacc, int ld, float* logmel, unsigned* clip_max, int batch,

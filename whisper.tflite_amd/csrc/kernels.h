@@ -73,10 +73,10 @@ void launch_encoder_attention(const float* qkv, float* out, int batch, int T, in
 // mel [B][n_mels][T] -> melT [B][T + 2][n_mels] rows 1..T (rows 0 and T+1 stay zero).
 void launch_mel_transpose(const float* mel, float* melT, int batch, int n_mels, int T,
                           hipStream_t s);
-// spec [M][ld] holding (re | im) halves for bins [0, n_bins) at columns [0,n_bins) and
-// [im_off, im_off+n_bins) -> pw [M][ldp]: |X|^2 with the reference's mirror fold
-// (bins 1..n_bins-2 doubled); columns >= n_bins zeroed up to ldp.
-void launch_power_fold(const float* spec, int ld, int im_off, float* pw, int ldp, int n_bins,
+// spec [M][ld] holding re parts of all n_fft bins at columns [0,n_fft) and im parts at
+// [im_off, im_off+n_fft) -> pw [M][ldp]: |X[k]|^2 (+ |X[n_fft-k]|^2 for 0 < k < n_fft/2, the
+// reference's mirror fold) for k <= n_fft/2; columns above zeroed up to ldp.
+void launch_power_fold(const float* spec, int ld, int im_off, float* pw, int ldp, int n_fft,
                        long M, hipStream_t s);
 // melacc [B*T][ld] (first n_mel columns) -> logmel [B][n_mel][T] = log10(max(x,1e-10)),
 // and per-clip maximum into clip_max[b] (ordered-uint encoding, pre-zeroed).
