@@ -11,9 +11,18 @@ extern "C" {
 /* C[M][N] = epi(A[M][K] . W[N][K]^T); needs N % 128 == 0, K % 32 == 0 */
 int wt_dbg_gemm(wt_engine* h, int M, int N, int K, const float* A, const float* W, const float* bias,
                 const float* R, const float* pos, int pos_period, int epi, float* C);
-/* Y[B][N] = epi(X[B][K] . W[N][K]^T), B <= 64; argmax_out[B] (optional) = last maximal column */
-int wt_dbg_skinny(wt_engine* h, int B, int N, int K, const float* X, const float* W, const float* bias,
-                  const float* R, int epi, float* Y, int64_t* argmax_out);
+/* decoder-step GEMM (k_decoder.hip), plain input X[B][K], W[N][K] (tiled internally):
+ * mode 0: Y = X.W^T + bias   1: gelu(...)   2: raw split-K slabs Y[ksplit][B][N]
+ * mode 3: Y = X.W^T and argmax_out[B] = last maximal column (reference tie rule) */
+int wt_dbg_dec_gemm(wt_engine* h, int mode, int B, int N, int K, int ksplit, const float* X,
+                    const float* W, const float* bias, float* Y, int64_t* argmax_out);
+/* LN-fused decoder GEMM: x = xin + bias_in + sum(slabs_in[n_slabs][B][K])  (or, when ids != NULL,
+ * x[b] = tok_emb[ids[b]] + pos_emb[pos]); xout = x; Y = act(LayerNorm(x).W^T + bias) */
+int wt_dbg_dec_ln_gemm(wt_engine* h, int B, int N, int K, const float* xin, const float* slabs_in,
+                       int n_slabs, const float* bias_in, const int64_t* ids, int pos,
+                       const float* tok_emb, const float* pos_emb, int n_vocab, int n_pos,
+                       const float* ln_g, const float* ln_b, const float* W, const float* bias,
+                       int gelu, float* Y, float* xout);
 int wt_dbg_layernorm(wt_engine* h, int M, int d, const float* x, const float* g, const float* b, float* y);
 /* qkv [B*T][3*heads*64] -> out [B*T][heads*64] */
 int wt_dbg_encoder_attention(wt_engine* h, int batch, int T, int heads, const float* qkv, float* out);

@@ -67,20 +67,36 @@ def test_gemm_epilogues(eng, epi):
 
 
 @pytest.mark.parametrize("B,N,K", [(32, 384, 384), (32, 128, 512), (7, 1536, 384), (64, 384, 1536), (33, 1000, 128), (32, 51865, 384)])
-def test_skinny_gemm_and_argmax(eng, B, N, K):
+def test_decoder_gemm_and_argmax(eng, B, N, K):
     rng = np.random.default_rng(B + N + K)
     X = rng.standard_normal((B, K)).astype(np.float32)
     W = (rng.standard_normal((N, K)) / 16).astype(np.float32)
     bias = rng.standard_normal(N).astype(np.float32)
-    Y, am = eng.dbg_skinny(X, W, bias=bias, epi=1, want_argmax=True)
-    ref = X.astype(np.float64) @ W.astype(np.float64).T + bias
+    ref = X.astype(np.float64) @ W.astype(np.float64).T
+    assert rel_err(eng.dbg_dec_gemm(X, W, bias, mode=0), ref + bias) < 3e-6
+    assert rel_err(eng.dbg_dec_gemm(X, W, bias, mode=1), gelu(ref + bias)) < 3e-6
+    Y, am = eng.dbg_dec_gemm(X, W, mode=3)
     assert rel_err(Y, ref) < 3e-6
     # the fused argmax is exact w.r.t. the values the kernel itself produced, last index on ties
-    expect = [int(N - 1 - np.argmax(Y[b][::-1])) for b in range(B)]
-    assert list(am) == expect
+    assert list(am) == [int(N - 1 - np.argmax(Y[b][::-1])) for b in range(B)]
 
 
-def test_skinny_argmax_tie_rule(eng):
+@pytest.mark.parametrize("B,N,K,ksplit", [(32, 384, 384, 4), (32, 384, 1536, 4), (5, 128, 128, 4), (64, 512, 2048, 2)])
+def test_decoder_gemm_split_k_slabs(eng, B, N, K, ksplit):
+    rng = np.random.default_rng(B * N + K)
+    X = rng.standard_normal((B, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / 16).astype(np.float32)
+    slabs = eng.dbg_dec_gemm(X, W, mode=2, ksplit=ksplit)
+    assert slabs.shape == (ksplit, B, N)
+    kb = K // ksplit
+    for s_ in range(ksplit):  # every slab is exactly its K slice
+        ref = X[:, s_ * kb:(s_ + 1) * kb].astype(np.float64) @ W[:, s_ * kb:(s_ + 1) * kb].astype(np.float64).T
+        assert rel_err(slabs[s_], ref) < 3e-6
+    again = eng.dbg_dec_gemm(X, W, mode=2, ksplit=ksplit)
+    assert np.array_equal(slabs, again)  # deterministic: fixed reduction order, no atomics
+
+
+def test_decoder_argmax_tie_rule(eng):
     """Duplicate rows of W give bit-identical logits: the LAST index must win (whisper.cpp:353)."""
     rng = np.random.default_rng(5)
     B, N, K = 4, 512, 128
@@ -88,22 +104,42 @@ def test_skinny_argmax_tie_rule(eng):
     W = (rng.standard_normal((N, K)) / 64).astype(np.float32)
     W[100] = W[7] = W[400] = X[0] / 4  # large identical logit at 7, 100, 400 for row 0
     W[33] = W[300] = X[1] / 4
-    Y, am = eng.dbg_skinny(X, W, epi=0, want_argmax=True)
+    Y, am = eng.dbg_dec_gemm(X, W, mode=3)
     assert Y[0, 7] == Y[0, 100] == Y[0, 400] and am[0] == 400
     assert am[1] == 300
 
 
-def test_skinny_epilogues(eng):
-    rng = np.random.default_rng(11)
-    B, N, K = 32, 384, 1536
-    X = rng.standard_normal((B, K)).astype(np.float32)
-    W = (rng.standard_normal((N, K)) / 40).astype(np.float32)
+@pytest.mark.parametrize("B,K,N,gelu_on", [(32, 384, 1152, False), (9, 128, 512, True), (64, 512, 512, False)])
+def test_decoder_ln_fused_gemm(eng, B, K, N, gelu_on):
+    rng = np.random.default_rng(B + K + N)
+    xin = rng.standard_normal((B, K)).astype(np.float32)
+    slabs = rng.standard_normal((4, B, K)).astype(np.float32)
+    bias_in = rng.standard_normal(K).astype(np.float32)
+    g_, b_ = rng.standard_normal(K).astype(np.float32), rng.standard_normal(K).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / 16).astype(np.float32)
     bias = rng.standard_normal(N).astype(np.float32)
-    R = rng.standard_normal((B, N)).astype(np.float32)
-    Y = eng.dbg_skinny(X, W, bias=bias, R=R, epi=5)
-    assert rel_err(Y, X.astype(np.float64) @ W.astype(np.float64).T + bias + R) < 3e-6
-    Y = eng.dbg_skinny(X, W, bias=bias, epi=3)
-    assert rel_err(Y, gelu(X.astype(np.float64) @ W.astype(np.float64).T + bias)) < 3e-6
+    Y, xout = eng.dbg_dec_ln_gemm(W, bias, g_, b_, xin=xin, slabs=slabs, bias_in=bias_in, gelu=gelu_on)
+    x = xin.astype(np.float64) + bias_in + slabs.astype(np.float64).sum(0)
+    assert np.abs(xout - x).max() < 5e-6
+    ln = (x - x.mean(1, keepdims=True)) / np.sqrt(x.var(1, keepdims=True) + 1e-5) * g_ + b_
+    ref = ln @ W.astype(np.float64).T + bias
+    assert rel_err(Y, gelu(ref) if gelu_on else ref) < 5e-6
+    # no pending slabs / bias: x = xin
+    Y2, xout2 = eng.dbg_dec_ln_gemm(W, bias, g_, b_, xin=xin, gelu=gelu_on)
+    assert np.array_equal(xout2, xin)
+
+
+def test_decoder_ln_fused_embedding(eng):
+    rng = np.random.default_rng(8)
+    B, K, N, V = 6, 128, 384, 50
+    tok = rng.standard_normal((V, K)).astype(np.float32)
+    pos = rng.standard_normal((10, K)).astype(np.float32)
+    ids = np.array([3, 49, 0, 7, 7, 12], np.int64)
+    g_, b_ = np.ones(K, np.float32), np.zeros(K, np.float32)
+    W = (rng.standard_normal((N, K)) / 16).astype(np.float32)
+    bias = np.zeros(N, np.float32)
+    Y, xout = eng.dbg_dec_ln_gemm(W, bias, g_, b_, ids=ids, pos=4, tok_emb=tok, pos_emb=pos)
+    assert np.array_equal(xout, tok[ids] + pos[4])
 
 
 @pytest.mark.parametrize("M,d", [(5, 128), (1000, 384), (33, 512)])

@@ -370,25 +370,59 @@ int wt_dbg_gemm(wt_engine* h, int M, int N, int K, const float* A, const float* 
   });
 }
 
-int wt_dbg_skinny(wt_engine* h, int B, int N, int K, const float* X, const float* W, const float* bias,
-                  const float* R, int epi, float* Y, int64_t* argmax_out) {
-  if (!h) return WT_ERR_INVALID_ARG;
+int wt_dbg_dec_gemm(wt_engine* h, int mode, int B, int N, int K, int ksplit, const float* X,
+                    const float* W, const float* bias, float* Y, int64_t* argmax_out) {
+  if (!h || mode < 0 || mode > 3 || B < 1 || B > 64 || ksplit < 1 || K % (32 * ksplit) != 0 ||
+      (mode != 2 && ksplit != 1)) {
+    return WT_ERR_INVALID_ARG;
+  }
   return guarded(h, [&] {
-    DevBuf dX(X, size_t(B) * K), dW(W, size_t(N) * K), dB(bias, N), dY(R ? R : nullptr, size_t(B) * N);
-    DevBuf dBest(size_t(B) * 2);
+    const std::vector<float> tiled = wt::tile_weights(W, N, K);
+    const size_t out_n = size_t(mode == 2 ? ksplit : 1) * B * N;
+    DevBuf dX(X, size_t(B) * K), dW(tiled.data(), tiled.size()), dB(bias, N), dY(out_n), dBest(size_t(B) * 2);
     hipchk(hipMemset(dBest.p, 0, size_t(B) * 8), "memset");
-    wt::SkinnyArgs s;
-    s.X = dX.p; s.ldx = K; s.W = dW.p; s.bias = dB.p; s.Y = dY.p; s.R = dY.p; s.ldy = N;
-    s.B = B; s.N = N; s.K = K;
-    s.best = argmax_out ? reinterpret_cast<unsigned long long*>(dBest.p) : nullptr;
-    wt::launch_skinny(s, epi, h->impl->stream());
+    wt::DecGemmArgs g;
+    g.Wt = dW.p; g.N = N; g.K = K; g.B = B; g.ksplit = ksplit; g.X = dX.p; g.ldx = K;
+    g.bias = dB.p; g.Y = dY.p; g.ldy = N; g.slab_out = dY.p;
+    g.best = reinterpret_cast<unsigned long long*>(dBest.p);
+    const int epi = mode == 0 ? wt::kDecBias : mode == 1 ? wt::kDecBiasGelu : mode == 2 ? wt::kDecSlab : wt::kDecLogits;
+    wt::launch_dec_gemm(g, wt::kProNone, epi, h->impl->stream());
     h->impl->sync();
-    dY.to_host(Y, size_t(B) * N);
-    if (argmax_out) {
+    dY.to_host(Y, out_n);
+    if (argmax_out && mode == 3) {
       std::vector<unsigned long long> best(B);
       hipchk(hipMemcpy(best.data(), dBest.p, size_t(B) * 8, hipMemcpyDeviceToHost), "D2H");
       for (int b = 0; b < B; ++b) argmax_out[b] = int64_t(best[b] & 0xffffffffull);
     }
+  });
+}
+
+int wt_dbg_dec_ln_gemm(wt_engine* h, int B, int N, int K, const float* xin, const float* slabs_in,
+                       int n_slabs, const float* bias_in, const int64_t* ids, int pos,
+                       const float* tok_emb, const float* pos_emb, int n_vocab, int n_pos,
+                       const float* ln_g, const float* ln_b, const float* W, const float* bias,
+                       int gelu, float* Y, float* xout) {
+  if (!h || B < 1 || B > 64 || K > 512 || K % 32 != 0) return WT_ERR_INVALID_ARG;
+  return guarded(h, [&] {
+    const std::vector<float> tiled = wt::tile_weights(W, N, K);
+    DevBuf dxin(xin, xin ? size_t(B) * K : 0), dsl(slabs_in, size_t(n_slabs) * B * K), dbi(bias_in, bias_in ? K : 0);
+    DevBuf dtok(tok_emb, ids ? size_t(n_vocab) * K : 0), dpos(pos_emb, ids ? size_t(n_pos) * K : 0);
+    DevBuf dg(ln_g, K), db(ln_b, K), dW(tiled.data(), tiled.size()), dB(bias, N), dY(size_t(B) * N), dxo(size_t(B) * K);
+    DevBuf dids(size_t(B) * 2);
+    if (ids) hipchk(hipMemcpy(dids.p, ids, size_t(B) * 8, hipMemcpyHostToDevice), "H2D ids");
+    wt::DecGemmArgs g;
+    g.Wt = dW.p; g.N = N; g.K = K; g.B = B;
+    g.xin = dxin.p; g.slabs_in = dsl.p; g.n_slabs_in = n_slabs; g.bias_in = bias_in ? dbi.p : nullptr;
+    g.xout = dxo.p; g.ln_g = dg.p; g.ln_b = db.p;
+    if (ids) {
+      g.ids = reinterpret_cast<const long long*>(dids.p); g.ids_stride = 1; g.pos = 0;
+      g.tok_emb = dtok.p; g.pos_emb = dpos.p + size_t(pos) * K; g.n_vocab = n_vocab;
+    }
+    g.bias = dB.p; g.Y = dY.p; g.ldy = N;
+    wt::launch_dec_gemm(g, wt::kProLn, gelu ? wt::kDecBiasGelu : wt::kDecBias, h->impl->stream());
+    h->impl->sync();
+    dY.to_host(Y, size_t(B) * N);
+    if (xout) dxo.to_host(xout, size_t(B) * K);
   });
 }
 
@@ -415,13 +449,22 @@ int wt_dbg_encoder_attention(wt_engine* h, int batch, int T, int heads, const fl
 
 int wt_dbg_cross_attention(wt_engine* h, int batch, int heads, int T, int chunks, const float* q,
                            const float* kc, const float* vc, float* out) {
-  if (!h || chunks < 1 || chunks > 64) return WT_ERR_INVALID_ARG;
+  if (!h || chunks < 1 || chunks > 64 || batch > 64) return WT_ERR_INVALID_ARG;
   return guarded(h, [&] {
     const size_t d = size_t(heads) * 64;
     DevBuf dq(q, size_t(batch) * d), dk(kc, size_t(batch) * T * d), dv(vc, size_t(batch) * T * d);
     DevBuf dws(size_t(batch) * heads * chunks * 66), dout(size_t(batch) * d);
+    // the product combines the chunk partials in the out-projection's prologue; an identity
+    // projection exposes exactly that combined row
+    std::vector<float> eye(d * d, 0.0f);
+    for (size_t i = 0; i < d; ++i) eye[i * d + i] = 1.0f;
+    const std::vector<float> tiled = wt::tile_weights(eye.data(), int(d), int(d));
+    DevBuf dW(tiled.data(), tiled.size());
     wt::launch_cross_attention(dq.p, dk.p, dv.p, dws.p, batch, heads, T, chunks, h->impl->stream());
-    wt::launch_cross_combine(dws.p, dout.p, batch, heads, chunks, h->impl->stream());
+    wt::DecGemmArgs g;
+    g.Wt = dW.p; g.N = int(d); g.K = int(d); g.B = batch; g.ksplit = 1;
+    g.cross_ws = dws.p; g.heads = heads; g.chunks = chunks; g.slab_out = dout.p;
+    wt::launch_dec_gemm(g, wt::kProCombine, wt::kDecSlab, h->impl->stream());
     h->impl->sync();
     dout.to_host(out, size_t(batch) * d);
   });

@@ -28,6 +28,24 @@ size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
 
 // ------------------------------------------------------------ weights ---
 
+// W [N][K] -> MFMA-fragment order [ceil(N/32)][K/8][64 lanes][4] (rows past N are zero): lane
+// (l & 31, l >> 5) of tile t, chunk c holds W[32t + (l & 31)][8c + 4(l >> 5) .. +3], so one
+// wave-instruction of the decoder GEMM reads 1 KiB contiguous.
+std::vector<float> tile_weights(const float* W, int N, int K) {
+  const int n_tiles = (N + 31) / 32, chunks = K / 8;
+  std::vector<float> out(size_t(n_tiles) * chunks * 256, 0.0f);
+  for (int t = 0; t < n_tiles; ++t)
+    for (int c = 0; c < chunks; ++c)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int n = t * 32 + (lane & 31);
+        if (n >= N) continue;
+        const float* src = W + size_t(n) * K + 8 * c + 4 * (lane >> 5);
+        float* dst = out.data() + ((size_t(t) * chunks + c) * 64 + lane) * 4;
+        dst[0] = src[0], dst[1] = src[1], dst[2] = src[2], dst[3] = src[3];
+      }
+  return out;
+}
+
 float* Engine::upload(const std::vector<float>& host) {
   void* p = nullptr;
   HIPCHK(hipMalloc(&p, std::max<size_t>(host.size(), 1) * sizeof(float)));
@@ -130,7 +148,10 @@ void Engine::upload_weights(const std::string& path) {
   }
   enc_pos = up("encoder.positional_embedding", size_t(c.n_audio_ctx) * d);
 
-  auto fused_qkv = [&](const std::string& p, AttnWeights* a) {
+  auto up_tiled = [&](const std::string& n, int N, int K) -> const float* {
+    return upload(tile_weights(H(n, size_t(N) * K), N, K));
+  };
+  auto fused_qkv = [&](const std::string& p, AttnWeights* a, bool tiled) {
     const size_t dd = size_t(d) * d;
     std::vector<float> w(3 * dd), b(3 * size_t(d), 0.0f);
     std::memcpy(w.data(), H(p + ".query.weight", dd), dd * 4);
@@ -138,17 +159,17 @@ void Engine::upload_weights(const std::string& path) {
     std::memcpy(w.data() + 2 * dd, H(p + ".value.weight", dd), dd * 4);
     std::memcpy(b.data(), H(p + ".query.bias", d), size_t(d) * 4);
     std::memcpy(b.data() + 2 * size_t(d), H(p + ".value.bias", d), size_t(d) * 4);  // key has no bias
-    a->wqkv = upload(w);
+    a->wqkv = tiled ? upload(tile_weights(w.data(), 3 * d, d)) : upload(w);
     a->bqkv = upload(b);
-    a->wo = up(p + ".out.weight", dd);
+    a->wo = tiled ? up_tiled(p + ".out.weight", d, d) : up(p + ".out.weight", dd);
     a->bo = up(p + ".out.bias", d);
   };
-  auto mlp_ln = [&](const std::string& blk, BlockWeights* bw) {
+  auto mlp_ln = [&](const std::string& blk, BlockWeights* bw, bool tiled) {
     bw->mlp_ln_g = up(blk + ".mlp_ln.weight", d);
     bw->mlp_ln_b = up(blk + ".mlp_ln.bias", d);
-    bw->w1 = up(blk + ".mlp.0.weight", size_t(4) * d * d);
+    bw->w1 = tiled ? up_tiled(blk + ".mlp.0.weight", 4 * d, d) : up(blk + ".mlp.0.weight", size_t(4) * d * d);
     bw->b1 = up(blk + ".mlp.0.bias", size_t(4) * d);
-    bw->w2 = up(blk + ".mlp.2.weight", size_t(4) * d * d);
+    bw->w2 = tiled ? up_tiled(blk + ".mlp.2.weight", d, 4 * d) : up(blk + ".mlp.2.weight", size_t(4) * d * d);
     bw->b2 = up(blk + ".mlp.2.bias", d);
   };
   enc_blocks_.resize(c.n_audio_layer);
@@ -157,13 +178,14 @@ void Engine::upload_weights(const std::string& path) {
     BlockWeights& bw = enc_blocks_[l];
     bw.attn_ln_g = up(blk + ".attn_ln.weight", d);
     bw.attn_ln_b = up(blk + ".attn_ln.bias", d);
-    fused_qkv(blk + ".attn", &bw.attn);
-    mlp_ln(blk, &bw);
+    fused_qkv(blk + ".attn", &bw.attn, false);
+    mlp_ln(blk, &bw, false);
   }
   enc_ln_post_g = up("encoder.ln_post.weight", d);
   enc_ln_post_b = up("encoder.ln_post.bias", d);
 
-  tok_emb = up("decoder.token_embedding.weight", size_t(c.n_vocab) * d);
+  tok_emb = up("decoder.token_embedding.weight", size_t(c.n_vocab) * d);  // row lookup
+  tok_emb_tiled = up_tiled("decoder.token_embedding.weight", c.n_vocab, d);  // logits GEMM
   dec_pos = up("decoder.positional_embedding", size_t(c.n_text_ctx) * d);
   dec_blocks_.resize(c.n_text_layer);
   const size_t dd = size_t(d) * d;
@@ -173,18 +195,18 @@ void Engine::upload_weights(const std::string& path) {
     BlockWeights& bw = dec_blocks_[l];
     bw.attn_ln_g = up(blk + ".attn_ln.weight", d);
     bw.attn_ln_b = up(blk + ".attn_ln.bias", d);
-    fused_qkv(blk + ".attn", &bw.attn);
+    fused_qkv(blk + ".attn", &bw.attn, true);  // decoder Linears: MFMA-fragment order
     bw.cross_ln_g = up(blk + ".cross_attn_ln.weight", d);
     bw.cross_ln_b = up(blk + ".cross_attn_ln.bias", d);
-    bw.cross.wq = up(blk + ".cross_attn.query.weight", dd);
+    bw.cross.wq = up_tiled(blk + ".cross_attn.query.weight", d, d);
     bw.cross.bq = up(blk + ".cross_attn.query.bias", d);
-    bw.cross.wo = up(blk + ".cross_attn.out.weight", dd);
+    bw.cross.wo = up_tiled(blk + ".cross_attn.out.weight", d, d);
     bw.cross.bo = up(blk + ".cross_attn.out.bias", d);
     // all layers' cross K/V projections act on the same encoder output: one GEMM
     std::memcpy(ckv_w.data() + (size_t(l) * 2 + 0) * dd, H(blk + ".cross_attn.key.weight", dd), dd * 4);
     std::memcpy(ckv_w.data() + (size_t(l) * 2 + 1) * dd, H(blk + ".cross_attn.value.weight", dd), dd * 4);
     std::memcpy(ckv_b.data() + (size_t(l) * 2 + 1) * d, H(blk + ".cross_attn.value.bias", d), size_t(d) * 4);
-    mlp_ln(blk, &bw);
+    mlp_ln(blk, &bw, true);
   }
   cross_kv_w = upload(ckv_w);
   cross_kv_b = upload(ckv_b);
@@ -352,6 +374,8 @@ void Engine::ensure_batch(int batch) {
   ws_.enc_out = alloc(B * T * d, false);
   ws_.cross_kv = alloc(size_t(c.n_text_layer) * 2 * B * T * d, false);
   ws_.xd = alloc(B * d, false);
+  ws_.xd2 = alloc(B * d, false);
+  ws_.slabs = alloc(size_t(3) * dec_ksplit_ * B * d, false);
   ws_.lnd = alloc(B * d, false);
   ws_.qkvd = alloc(B * 3 * d, false);
   ws_.attd = alloc(B * d, false);
@@ -578,6 +602,7 @@ void Engine::encode(const float* d_mel, int batch) {
 void Engine::decode(int batch, int64_t* ids, int32_t* n_ids, float* logits_host,
                     int logits_steps_cap) {
   ensure_batch(batch);
+  if (batch > 64) throw Error(1, "decoder batches are limited to 64 clips per call");
   const wtw::Dims& c = dims_;
   const int d = c.n_text_state, T = c.n_audio_ctx, H = c.n_text_head, V = c.n_vocab;
   // prompt (whisper.cpp:327-339): [sot, 50259 + language, transcribe, notimestamps]
@@ -600,59 +625,81 @@ void Engine::decode(int batch, int64_t* ids, int32_t* n_ids, float* logits_host,
   HIPCHK(hipMemsetAsync(ws_.best, 0, size_t(batch) * sizeof(unsigned long long), stream_));
 
   const int chunks = int(std::min<long>(std::max<long>(cross_chunks, 1), 64));
-  const size_t kv_slab = size_t(batch) * T * d;          // one (layer, k|v) slab of the cross cache
+  const size_t kv_slab = size_t(batch) * T * d;  // one (layer, k|v) slab of the cross cache
   const size_t self_slab = size_t(batch) * self_cap_ * d;
+  const int ks = dec_ksplit_;                    // split-K blocks of the narrow (N = d) GEMMs
+  float* const slab1 = ws_.slabs;                           // self out-proj partials
+  float* const slab2 = ws_.slabs + size_t(ks) * batch * d;  // cross out-proj partials
+  float* const slab3 = ws_.slabs + size_t(2 * ks) * batch * d;  // fc2 partials
   int steps = 0;
   for (int pos = 0; pos < max_pos; ++pos) {
-    launch_embed(tok_emb, dec_pos, ws_.ids, stride, pos, ws_.xd, batch, d, V, stream_);
+    // residual stream ping-pongs between xa/xb: every LN-fused GEMM reads the old stream
+    // plus the pending Linear's (bias, slabs) and writes the updated stream once
+    float* xin = ws_.xd;
+    float* xout = ws_.xd2;
+    const float* pend_slabs = nullptr;
+    const float* pend_bias = nullptr;
+    int pend_n = 0;
     for (int l = 0; l < c.n_text_layer; ++l) {
       const BlockWeights& w = dec_blocks_[l];
-      launch_layernorm(ws_.xd, ws_.lnd, w.attn_ln_g, w.attn_ln_b, batch, d, stream_);
-      SkinnyArgs q;
-      q.X = ws_.lnd; q.ldx = d; q.W = w.attn.wqkv; q.bias = w.attn.bqkv; q.Y = ws_.qkvd; q.ldy = 3 * d;
-      q.B = batch; q.N = 3 * d; q.K = d;
-      launch_skinny(q, kEpiBias, stream_);
+      DecGemmArgs q;  // LN + fused q|k|v projection (+ embedding at layer 0)
+      q.Wt = w.attn.wqkv; q.N = 3 * d; q.K = d; q.B = batch;
+      q.xin = xin; q.xout = xout; q.slabs_in = pend_slabs; q.n_slabs_in = pend_n; q.bias_in = pend_bias;
+      q.ln_g = w.attn_ln_g; q.ln_b = w.attn_ln_b;
+      if (l == 0) {
+        q.ids = ws_.ids; q.ids_stride = stride; q.pos = pos; q.tok_emb = tok_emb; q.pos_emb = dec_pos;
+        q.n_vocab = V;
+      }
+      q.bias = w.attn.bqkv; q.Y = ws_.qkvd; q.ldy = 3 * d;
+      launch_dec_gemm(q, kProLn, kDecBias, stream_);
+      std::swap(xin, xout);
       launch_self_attention(ws_.qkvd, ws_.self_kv + (size_t(l) * 2 + 0) * self_slab,
                             ws_.self_kv + (size_t(l) * 2 + 1) * self_slab, self_cap_, pos, ws_.attd,
                             batch, H, stream_);
-      SkinnyArgs o;
-      o.X = ws_.attd; o.ldx = d; o.W = w.attn.wo; o.bias = w.attn.bo; o.Y = ws_.xd; o.R = ws_.xd; o.ldy = d;
-      o.B = batch; o.N = d; o.K = d;
-      launch_skinny(o, kEpiBias | kEpiResidual, stream_);
+      DecGemmArgs o;  // self-attention out-projection -> split-K slabs
+      o.Wt = w.attn.wo; o.N = d; o.K = d; o.B = batch; o.ksplit = ks; o.X = ws_.attd; o.ldx = d;
+      o.slab_out = slab1;
+      launch_dec_gemm(o, kProNone, kDecSlab, stream_);
 
-      launch_layernorm(ws_.xd, ws_.lnd, w.cross_ln_g, w.cross_ln_b, batch, d, stream_);
-      SkinnyArgs cq;
-      cq.X = ws_.lnd; cq.ldx = d; cq.W = w.cross.wq; cq.bias = w.cross.bq; cq.Y = ws_.qd; cq.ldy = d;
-      cq.B = batch; cq.N = d; cq.K = d;
-      launch_skinny(cq, kEpiBias, stream_);
+      DecGemmArgs cq;  // residual + LN + cross-attention query projection
+      cq.Wt = w.cross.wq; cq.N = d; cq.K = d; cq.B = batch;
+      cq.xin = xin; cq.xout = xout; cq.slabs_in = slab1; cq.n_slabs_in = ks; cq.bias_in = w.attn.bo;
+      cq.ln_g = w.cross_ln_g; cq.ln_b = w.cross_ln_b;
+      cq.bias = w.cross.bq; cq.Y = ws_.qd; cq.ldy = d;
+      launch_dec_gemm(cq, kProLn, kDecBias, stream_);
+      std::swap(xin, xout);
       launch_cross_attention(ws_.qd, ws_.cross_kv + (size_t(l) * 2 + 0) * kv_slab,
                              ws_.cross_kv + (size_t(l) * 2 + 1) * kv_slab, ws_.cross_ws, batch, H, T,
                              chunks, stream_);
-      launch_cross_combine(ws_.cross_ws, ws_.attd, batch, H, chunks, stream_);
-      SkinnyArgs co;
-      co.X = ws_.attd; co.ldx = d; co.W = w.cross.wo; co.bias = w.cross.bo; co.Y = ws_.xd; co.R = ws_.xd;
-      co.ldy = d; co.B = batch; co.N = d; co.K = d;
-      launch_skinny(co, kEpiBias | kEpiResidual, stream_);
+      DecGemmArgs co;  // chunk combine + cross out-projection -> slabs
+      co.Wt = w.cross.wo; co.N = d; co.K = d; co.B = batch; co.ksplit = ks;
+      co.cross_ws = ws_.cross_ws; co.heads = H; co.chunks = chunks; co.slab_out = slab2;
+      launch_dec_gemm(co, kProCombine, kDecSlab, stream_);
 
-      launch_layernorm(ws_.xd, ws_.lnd, w.mlp_ln_g, w.mlp_ln_b, batch, d, stream_);
-      SkinnyArgs f1;
-      f1.X = ws_.lnd; f1.ldx = d; f1.W = w.w1; f1.bias = w.b1; f1.Y = ws_.hd; f1.ldy = 4 * d;
-      f1.B = batch; f1.N = 4 * d; f1.K = d;
-      launch_skinny(f1, kEpiBias | kEpiGelu, stream_);
-      SkinnyArgs f2;
-      f2.X = ws_.hd; f2.ldx = 4 * d; f2.W = w.w2; f2.bias = w.b2; f2.Y = ws_.xd; f2.R = ws_.xd; f2.ldy = d;
-      f2.B = batch; f2.N = d; f2.K = 4 * d;
-      launch_skinny(f2, kEpiBias | kEpiResidual, stream_);
+      DecGemmArgs f1;  // residual + LN + fc1 + GELU
+      f1.Wt = w.w1; f1.N = 4 * d; f1.K = d; f1.B = batch;
+      f1.xin = xin; f1.xout = xout; f1.slabs_in = slab2; f1.n_slabs_in = ks; f1.bias_in = w.cross.bo;
+      f1.ln_g = w.mlp_ln_g; f1.ln_b = w.mlp_ln_b;
+      f1.bias = w.b1; f1.Y = ws_.hd; f1.ldy = 4 * d;
+      launch_dec_gemm(f1, kProLn, kDecBiasGelu, stream_);
+      std::swap(xin, xout);
+      DecGemmArgs f2;  // fc2 -> slabs
+      f2.Wt = w.w2; f2.N = d; f2.K = 4 * d; f2.B = batch; f2.ksplit = ks; f2.X = ws_.hd; f2.ldx = 4 * d;
+      f2.slab_out = slab3;
+      launch_dec_gemm(f2, kProNone, kDecSlab, stream_);
+      pend_slabs = slab3;
+      pend_n = ks;
+      pend_bias = w.b2;
     }
     if (pos >= n_prompt - 1) {
       // logits against the tied embedding + greedy argmax (whisper.cpp:379-399); only the
       // last position's row exists here, the reference computes and drops the others
-      launch_layernorm(ws_.xd, ws_.lnd, dec_ln_g, dec_ln_b, batch, d, stream_);
-      SkinnyArgs lg;
-      lg.X = ws_.lnd; lg.ldx = d; lg.W = tok_emb; lg.B = batch; lg.N = V; lg.K = d;
-      lg.Y = logits_host ? ws_.logits : nullptr; lg.ldy = V;
-      lg.best = ws_.best;
-      launch_skinny(lg, 0, stream_);
+      launch_dec_finalize_ln(xin, pend_slabs, pend_n, pend_bias, dec_ln_g, dec_ln_b, ws_.lnd, batch, d,
+                             stream_);
+      DecGemmArgs lg;
+      lg.Wt = tok_emb_tiled; lg.N = V; lg.K = d; lg.B = batch; lg.X = ws_.lnd; lg.ldx = d;
+      lg.Y = logits_host ? ws_.logits : nullptr; lg.ldy = V; lg.best = ws_.best;
+      launch_dec_gemm(lg, kProNone, kDecLogits, stream_);
       if (logits_host && steps < logits_steps_cap) {
         HIPCHK(hipMemcpy2DAsync(logits_host + size_t(steps) * V, size_t(logits_steps_cap) * V * sizeof(float),
                                 ws_.logits, size_t(V) * sizeof(float), size_t(V) * sizeof(float), batch,

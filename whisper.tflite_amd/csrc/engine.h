@@ -49,6 +49,8 @@ struct BlockWeights {
   const float *mlp_ln_g, *mlp_ln_b, *w1, *b1, *w2, *b2;
 };
 
+std::vector<float> tile_weights(const float* W, int N, int K);
+
 class Engine {
  public:
   // Throws std::runtime_error with a message; the C ABI maps it to a status code.
@@ -122,7 +124,7 @@ class Engine {
   std::vector<BlockWeights> enc_blocks_, dec_blocks_;
   const float *enc_ln_post_g = nullptr, *enc_ln_post_b = nullptr;
   const float *cross_kv_w = nullptr, *cross_kv_b = nullptr;  // [L*2*d][d], [L*2*d]
-  const float *tok_emb = nullptr, *dec_pos = nullptr, *dec_ln_g = nullptr, *dec_ln_b = nullptr;
+  const float *tok_emb = nullptr, *tok_emb_tiled = nullptr, *dec_pos = nullptr, *dec_ln_g = nullptr, *dec_ln_b = nullptr;
   // front end
   const float* dft_basis = nullptr;  // [dft_n][dft_k]  windowed cos | sin rows
   const float* mel_w = nullptr;      // [mel_n][mel_k]
@@ -133,7 +135,7 @@ class Engine {
     float *melT = nullptr, *h1p = nullptr, *x = nullptr, *ln = nullptr, *qkv = nullptr,
           *att = nullptr, *hid = nullptr, *enc_out = nullptr, *cross_kv = nullptr;
     // decoder
-    float *xd = nullptr, *lnd = nullptr, *qkvd = nullptr, *attd = nullptr, *qd = nullptr,
+    float *xd = nullptr, *xd2 = nullptr, *slabs = nullptr, *lnd = nullptr, *qkvd = nullptr, *attd = nullptr, *qd = nullptr,
           *hd = nullptr, *cross_ws = nullptr, *self_kv = nullptr, *logits = nullptr;
     unsigned long long* best = nullptr;
     long long* ids = nullptr;
@@ -155,6 +157,7 @@ class Engine {
                                   {"layernorm_rows", 0, 0, 0, 0},
                                   {"mel_transpose", 0, 0, 0, 0}};
   int self_cap_ = 32;
+  int dec_ksplit_ = 4;  // split-K blocks of the decoder's N = d GEMMs
   long long* h_ids_ = nullptr;  // pinned
   int* h_n_ = nullptr;          // pinned
 };

@@ -298,22 +298,6 @@ __global__ __launch_bounds__(256) void cross_attention_step(const float* __restr
   }
 }
 
-__global__ void cross_combine(const float* __restrict__ ws, float* __restrict__ out, int heads,
-                              int chunks) {
-  const int bh = blockIdx.x, lane = threadIdx.x;  // 64 threads
-  const float* p = ws + (long)bh * chunks * 66;
-  float mx = -1e30f;
-  for (int c = 0; c < chunks; ++c) mx = fmaxf(mx, p[c * 66 + 64]);
-  float o = 0.0f, l = 0.0f;
-  for (int c = 0; c < chunks; ++c) {
-    const float w = __expf(p[c * 66 + 64] - mx);
-    o += w * p[c * 66 + lane];
-    l += w * p[c * 66 + 65];
-  }
-  const int b = bh / heads, h = bh % heads;
-  out[((long)b * heads + h) * 64 + lane] = o / l;
-}
-
 }  // namespace
 
 void launch_encoder_attention(const float* qkv, float* out, int batch, int T, int heads,
@@ -335,11 +319,6 @@ void launch_cross_attention(const float* q, const float* kc, const float* vc, fl
   const size_t smem = (size_t)(((per + 3) & ~3) + 16 * 64 + 8) * sizeof(float);
   hipLaunchKernelGGL(cross_attention_step, dim3(batch * heads * chunks), dim3(256), smem, s, q, kc,
                      vc, ws, heads, T, chunks);
-}
-
-void launch_cross_combine(const float* ws, float* out, int batch, int heads, int chunks,
-                          hipStream_t s) {
-  hipLaunchKernelGGL(cross_combine, dim3(batch * heads), dim3(64), 0, s, ws, out, heads, chunks);
 }
 
 }  // namespace wt

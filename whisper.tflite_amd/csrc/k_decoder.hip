@@ -1,0 +1,323 @@
+// Decoder-step GEMMs for gfx950: out[B][N] = x[B][K] . W[N][K]^T with B = clips in the batch
+// (<= 64), i.e. one or two 32-row MFMA tiles, fp32 v_mfma_f32_32x32x2_f32.  These replace the
+// Linear ops the reference runs inside every decoder Invoke() (whisper.tflite/whisper.cpp:375).
+//
+// A decoder position is a chain of ~35 tiny dependent launches, each costing a kernel
+// boundary plus one memory-latency chain, so the design minimises the number of launches and
+// maximises loads in flight per launch:
+//   * weights are pre-tiled at load time into MFMA-fragment order ([tile][k/8][lane][4]), so
+//     one wave-instruction reads 1 KiB contiguous and a wave issues ALL its weight loads
+//     (<= 12 x 16 B per lane) before the first MFMA — operand streamed once, straight to VGPRs;
+//   * every block = 4 wavefronts splitting K, combined through LDS; narrow outputs also split
+//     K over blockIdx.y into partial slabs that the NEXT kernel's prologue sums in a fixed
+//     order (deterministic, no atomics, no separate reduce launch);
+//   * prologues fuse what used to be separate launches: residual update + LayerNorm
+//     (+ token/positional embedding at layer 0), and the cross-attention chunk combine.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace wt {
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+__device__ __forceinline__ float gelu_erf(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ unsigned ordered_bits(float v) {
+  v = v + 0.0f;  // -0.0 -> +0.0 so that equal values compare equal
+  const unsigned u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+struct DecGemmDev {
+  const float* Wt;
+  int N, K, B, ksplit;
+  const float* X;
+  int ldx;
+  const float* xin;
+  const float* slabs_in;
+  int n_slabs_in;
+  const float* bias_in;
+  float* xout;
+  const float* ln_g;
+  const float* ln_b;
+  const long long* ids;
+  int ids_stride, pos;
+  const float* tok_emb;
+  const float* pos_emb;
+  int n_vocab;
+  const float* cross_ws;
+  int heads, chunks;
+  const float* bias;
+  float* Y;
+  int ldy;
+  float* slab_out;
+  unsigned long long* best;
+};
+
+constexpr int kGroup = 12;  // weight chunks (8 k each) a wave keeps in flight
+
+template <int PRO, int EPI, int MT>
+__global__ __launch_bounds__(256) void dec_gemm(DecGemmDev g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* red = smem;                       // [3][MT][16][64] split-K partials of waves 1..3
+  float* xs = smem + 3 * MT * 16 * 64;     // [MT*32][K + 4] prologue output (PRO != none)
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int tile = blockIdx.x, ky = blockIdx.y;
+  const int K = g.K, B = g.B, xld = K + 4;
+
+  if (PRO == kProLn) {
+    // x = x_old (+ bias of the producing Linear) (+ its split-K slabs, fixed order); the
+    // residual stream is written back once; LayerNorm rows land in LDS.
+    const bool writer = blockIdx.x == 0 && blockIdx.y == 0 && g.xout != nullptr;
+    for (int row = wid; row < MT * 32; row += 4) {
+      float v[8];
+      if (row < B) {
+        long long id = 0;
+        if (g.ids) {
+          id = g.ids[(long)row * g.ids_stride + g.pos];
+          id = id < 0 ? 0 : (id >= g.n_vocab ? g.n_vocab - 1 : id);
+        }
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int c = lane + 64 * i;
+          float x = 0.0f;
+          if (c < K) {
+            x = g.ids ? g.tok_emb[id * K + c] + g.pos_emb[(long)g.pos * K + c] : g.xin[(long)row * K + c];
+            if (g.bias_in) x += g.bias_in[c];
+            for (int sl = 0; sl < g.n_slabs_in; ++sl) x += g.slabs_in[((long)sl * B + row) * K + c];
+            if (writer) g.xout[(long)row * K + c] = x;
+          }
+          v[i] = x;
+          s += x;
+        }
+        const float mean = wave_sum(s) / (float)K;
+        float q = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float t = (lane + 64 * i < K) ? v[i] - mean : 0.0f;
+          q += t * t;
+        }
+        const float rstd = rsqrtf(wave_sum(q) / (float)K + 1e-5f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int c = lane + 64 * i;
+          if (c < K) xs[row * xld + c] = (v[i] - mean) * rstd * g.ln_g[c] + g.ln_b[c];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int c = lane + 64 * i;
+          if (c < K) xs[row * xld + c] = 0.0f;
+        }
+      }
+    }
+    __syncthreads();
+  } else if (PRO == kProCombine) {
+    // attention output row = combine of the key-chunk partials (o[64], m, l) of every head
+    for (int row = wid; row < MT * 32; row += 4) {
+      for (int h = 0; h < g.heads; ++h) {
+        float o = 0.0f;
+        if (row < B) {
+          const float* p = g.cross_ws + ((long)(row * g.heads + h) * g.chunks) * 66;
+          float mx = -1e30f;
+          for (int c = 0; c < g.chunks; ++c) mx = fmaxf(mx, p[c * 66 + 64]);
+          float l = 0.0f;
+          for (int c = 0; c < g.chunks; ++c) {
+            const float w = __expf(p[c * 66 + 64] - mx);
+            o += w * p[c * 66 + lane];
+            l += w * p[c * 66 + 65];
+          }
+          o = o / l;
+        }
+        xs[row * xld + h * 64 + lane] = o;
+      }
+    }
+    __syncthreads();
+  }
+
+  const int kblock = K / g.ksplit, kwave = kblock >> 2;
+  const int k0 = ky * kblock + wid * kwave;
+  const int nchunks = kwave >> 3;
+  const float* wp = g.Wt + ((long)tile * (K >> 3) + (k0 >> 3)) * 256 + lane * 4;
+  const float* xp[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    int b = t * 32 + l31;
+    b = b < B ? b : B - 1;
+    xp[t] = (PRO == kProNone ? g.X + (long)b * g.ldx : xs + (t * 32 + l31) * xld) + k0 + 4 * lh;
+  }
+  f32x16 acc[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+  for (int c0 = 0; c0 < nchunks; c0 += kGroup) {
+    f32x4 w[kGroup];
+#pragma unroll
+    for (int i = 0; i < kGroup; ++i)
+      if (c0 + i < nchunks) w[i] = *reinterpret_cast<const f32x4*>(wp + (long)(c0 + i) * 256);
+#pragma unroll
+    for (int i = 0; i < kGroup; ++i) {
+      if (c0 + i < nchunks) {
+        f32x4 x[MT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) x[t] = *reinterpret_cast<const f32x4*>(xp[t] + (c0 + i) * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int t = 0; t < MT; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[t][j], w[i][j], acc[t], 0, 0, 0);
+      }
+    }
+  }
+
+  if (wid > 0) {
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[(((wid - 1) * MT + t) * 16 + r) * 64 + lane] = acc[t][r];
+  }
+  __syncthreads();
+  if (wid > 0) return;
+#pragma unroll
+  for (int w = 0; w < 3; ++w)  // fixed order: wave 1, 2, 3
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] += red[((w * MT + t) * 16 + r) * 64 + lane];
+
+  const int n = tile * 32 + l31;
+  const bool n_ok = n < g.N;
+  const float bias = (EPI == kDecBias || EPI == kDecBiasGelu) && n_ok ? g.bias[n] : 0.0f;
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int b = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      float v = acc[t][r] + bias;
+      if (EPI == kDecBiasGelu) v = gelu_erf(v);
+      const bool ok = n_ok && b < B;
+      if (EPI == kDecSlab) {
+        if (ok) g.slab_out[((long)ky * B + b) * g.N + n] = v;
+      } else {
+        if (ok && g.Y) g.Y[(long)b * g.ldy + n] = v;
+      }
+      if (EPI == kDecLogits) {
+        // fold (value, column): larger value wins, then the larger column — the reference's
+        // `>=` scan keeps the LAST maximal index (whisper.cpp:353)
+        unsigned long long p = ok ? (((unsigned long long)ordered_bits(v) << 32) | (unsigned)n) : 0ull;
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) {
+          const unsigned long long o2 = __shfl_xor(p, off, 64);
+          p = o2 > p ? o2 : p;
+        }
+        if (l31 == 0 && b < B) atomicMax(&g.best[b], p);
+      }
+    }
+  }
+}
+
+// x = xin + bias + sum(slabs) -> LayerNorm -> y   (input of the logits GEMM)
+__global__ __launch_bounds__(256) void dec_finalize_ln(const float* __restrict__ xin,
+                                                       const float* __restrict__ slabs, int n_slabs,
+                                                       const float* __restrict__ bias,
+                                                       const float* __restrict__ g,
+                                                       const float* __restrict__ b,
+                                                       float* __restrict__ y, int B, int K) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B) return;
+  float v[8];
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = lane + 64 * i;
+    float x = 0.0f;
+    if (c < K) {
+      x = xin[(long)row * K + c];
+      if (bias) x += bias[c];
+      for (int sl = 0; sl < n_slabs; ++sl) x += slabs[((long)sl * B + row) * K + c];
+    }
+    v[i] = x;
+    s += x;
+  }
+  const float mean = wave_sum(s) / (float)K;
+  float q = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float t = (lane + 64 * i < K) ? v[i] - mean : 0.0f;
+    q += t * t;
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)K + 1e-5f);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = lane + 64 * i;
+    if (c < K) y[(long)row * K + c] = (v[i] - mean) * rstd * g[c] + b[c];
+  }
+}
+
+template <int PRO, int EPI>
+void launch_t(const DecGemmDev& g, hipStream_t s) {
+  const int n_tiles = (g.N + 31) / 32;
+  const int MT = g.B <= 32 ? 1 : 2;
+  const size_t smem = (size_t)(3 * MT * 16 * 64 + (PRO != kProNone ? MT * 32 * (g.K + 4) : 0)) * sizeof(float);
+  const dim3 grid(n_tiles, g.ksplit);
+  // dynamic LDS beyond the 64 KiB default needs an opt-in, once per kernel
+  static const bool raised = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_gemm<PRO, EPI, 1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_gemm<PRO, EPI, 2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return true;
+  }();
+  (void)raised;
+  if (MT == 1) {
+    hipLaunchKernelGGL((dec_gemm<PRO, EPI, 1>), grid, dim3(256), smem, s, g);
+  } else {
+    hipLaunchKernelGGL((dec_gemm<PRO, EPI, 2>), grid, dim3(256), smem, s, g);
+  }
+}
+
+}  // namespace
+
+void launch_dec_gemm(const DecGemmArgs& a, int pro, int epi, hipStream_t s) {
+  DecGemmDev g{a.Wt,     a.N,      a.K,       a.B,         a.ksplit, a.X,        a.ldx,      a.xin,
+               a.slabs_in, a.n_slabs_in, a.bias_in, a.xout, a.ln_g,   a.ln_b,     a.ids,      a.ids_stride,
+               a.pos,    a.tok_emb, a.pos_emb, a.n_vocab,  a.cross_ws, a.heads,  a.chunks,   a.bias,
+               a.Y,      a.ldy,    a.slab_out, a.best};
+  if (a.B < 1 || a.B > 64 || a.K > 512 * 4 || (pro != kProNone && a.K > 512) || a.ksplit < 1 ||
+      a.K % (32 * a.ksplit) != 0 || (epi != kDecSlab && a.ksplit != 1)) {
+    abort();  // host-side shape contract: operands must match what the kernel indexes
+  }
+  const int key = pro * 8 + epi;
+  switch (key) {
+    case kProNone * 8 + kDecSlab: launch_t<kProNone, kDecSlab>(g, s); break;
+    case kProNone * 8 + kDecBias: launch_t<kProNone, kDecBias>(g, s); break;
+    case kProNone * 8 + kDecBiasGelu: launch_t<kProNone, kDecBiasGelu>(g, s); break;
+    case kProNone * 8 + kDecLogits: launch_t<kProNone, kDecLogits>(g, s); break;
+    case kProLn * 8 + kDecBias: launch_t<kProLn, kDecBias>(g, s); break;
+    case kProLn * 8 + kDecBiasGelu: launch_t<kProLn, kDecBiasGelu>(g, s); break;
+    case kProCombine * 8 + kDecSlab: launch_t<kProCombine, kDecSlab>(g, s); break;
+    default: abort();
+  }
+}
+
+void launch_dec_finalize_ln(const float* xin, const float* slabs, int n_slabs, const float* bias,
+                            const float* g, const float* b, float* y, int B, int K, hipStream_t s) {
+  hipLaunchKernelGGL(dec_finalize_ln, dim3((B + 3) / 4), dim3(256), 0, s, xin, slabs, n_slabs, bias, g, b,
+                     y, B, K);
+}
+
+}  // namespace wt

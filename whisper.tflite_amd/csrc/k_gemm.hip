@@ -159,135 +159,6 @@ void launch_gemm_t(const GemmDev& g, int blocks, hipStream_t s) {
   hipLaunchKernelGGL(gemm_f32_128x128<EPI>, dim3(blocks), dim3(256), 0, s, g);
 }
 
-// ---------------------------------------------------------------- skinny ---
-// out[B][N] = x[B][K] . W[N][K]^T for B <= 64 (decoder steps: one row per clip).
-// The batch is the MFMA M dimension (one or two 32-row tiles); every wavefront owns a
-// 32-column tile of W and streams it straight from global memory into VGPRs (operand
-// read once, no LDS round trip).  SPLITK wavefronts of a block share one column tile
-// and combine through LDS.
-__device__ __forceinline__ unsigned ordered_bits(float v) {
-  v = v + 0.0f;  // -0.0 -> +0.0 so that equal values compare equal
-  const unsigned u = __float_as_uint(v);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-
-struct SkinnyDev {
-  const float* X;
-  const float* W;
-  float* Y;
-  const float* bias;
-  const float* R;
-  int B, N, K, ldx, ldy;
-  unsigned long long* best;
-};
-
-template <int EPI, int SPLITK, int MT>
-__global__ __launch_bounds__(256) void skinny_f32(SkinnyDev g) {
-  __shared__ float red[SPLITK > 1 ? (SPLITK - 1) * MT * 16 * 64 : 1];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int l31 = lane & 31, lh = lane >> 5;
-  const int tile = SPLITK > 1 ? blockIdx.x : blockIdx.x * 4 + wid;
-  const int n_tiles = (g.N + 31) / 32;
-  if (tile >= n_tiles) return;  // whole wavefronts only (SPLITK == 1); no barrier follows
-  const int n0 = tile * 32;
-  const int kslice = g.K / SPLITK;
-  const int k0 = SPLITK > 1 ? wid * kslice : 0;
-
-  int wrow = n0 + l31;
-  wrow = wrow < g.N ? wrow : g.N - 1;
-  const float* wp = g.W + (long)wrow * g.K + k0 + 4 * lh;
-  const float* xp[MT];
-#pragma unroll
-  for (int t = 0; t < MT; ++t) {
-    int b = t * 32 + l31;
-    b = b < g.B ? b : g.B - 1;
-    xp[t] = g.X + (long)b * g.ldx + k0 + 4 * lh;
-  }
-  f32x16 acc[MT];
-#pragma unroll
-  for (int t = 0; t < MT; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-
-  for (int k = 0; k < kslice; k += 8) {
-    const f32x4 w = *reinterpret_cast<const f32x4*>(wp + k);
-    f32x4 x[MT];
-#pragma unroll
-    for (int t = 0; t < MT; ++t) x[t] = *reinterpret_cast<const f32x4*>(xp[t] + k);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int t = 0; t < MT; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[t][j], w[j], acc[t], 0, 0, 0);
-  }
-
-  if (SPLITK > 1) {
-    if (wid > 0) {
-#pragma unroll
-      for (int t = 0; t < MT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) red[(((wid - 1) * MT + t) * 16 + r) * 64 + lane] = acc[t][r];
-    }
-    __syncthreads();
-    if (wid > 0) return;
-#pragma unroll
-    for (int w = 0; w < SPLITK - 1; ++w)
-#pragma unroll
-      for (int t = 0; t < MT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] += red[((w * MT + t) * 16 + r) * 64 + lane];
-  }
-
-  const int n = n0 + l31;
-  const bool n_ok = n < g.N;
-  const float bias = (EPI & kEpiBias) && n_ok ? g.bias[n] : 0.0f;
-#pragma unroll
-  for (int t = 0; t < MT; ++t) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int b = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      float v = acc[t][r] + bias;
-      if (EPI & kEpiGelu) v = gelu_erf(v);
-      const bool ok = n_ok && b < g.B;
-      if (ok) {
-        const long o = (long)b * g.ldy + n;
-        if (EPI & kEpiResidual) v += g.R[o];
-        if (g.Y) g.Y[o] = v;
-      }
-      if (g.best) {
-        // row b lives in the 32 lanes of this half-wave: fold (value, column) packed so
-        // that the larger value wins and, among equal values, the larger column — the
-        // reference's `>=` scan keeps the LAST maximal index (whisper.cpp:353).
-        unsigned long long p = ok ? (((unsigned long long)ordered_bits(v) << 32) | (unsigned)n) : 0ull;
-#pragma unroll
-        for (int off = 16; off >= 1; off >>= 1) {
-          const unsigned long long o2 = __shfl_xor(p, off, 64);
-          p = o2 > p ? o2 : p;
-        }
-        if (l31 == 0 && b < g.B) atomicMax(&g.best[b], p);
-      }
-    }
-  }
-}
-
-template <int EPI>
-void launch_skinny_t(const SkinnyDev& g, bool splitk, hipStream_t s) {
-  const int n_tiles = (g.N + 31) / 32;
-  if (g.B <= 32) {
-    if (splitk) {
-      hipLaunchKernelGGL((skinny_f32<EPI, 4, 1>), dim3(n_tiles), dim3(256), 0, s, g);
-    } else {
-      hipLaunchKernelGGL((skinny_f32<EPI, 1, 1>), dim3((n_tiles + 3) / 4), dim3(256), 0, s, g);
-    }
-  } else {
-    if (splitk) {
-      hipLaunchKernelGGL((skinny_f32<EPI, 4, 2>), dim3(n_tiles), dim3(256), 0, s, g);
-    } else {
-      hipLaunchKernelGGL((skinny_f32<EPI, 1, 2>), dim3((n_tiles + 3) / 4), dim3(256), 0, s, g);
-    }
-  }
-}
-
 }  // namespace
 
 void launch_gemm(const GemmArgs& a, int epi, hipStream_t s) {
@@ -302,19 +173,6 @@ void launch_gemm(const GemmArgs& a, int epi, hipStream_t s) {
     case kEpiBias | kEpiResidual: launch_gemm_t<kEpiBias | kEpiResidual>(g, blocks, s); break;
     case kEpiBias | kEpiGelu | kEpiPos: launch_gemm_t<kEpiBias | kEpiGelu | kEpiPos>(g, blocks, s); break;
     case kEpiBias | kEpiKvLayout: launch_gemm_t<kEpiBias | kEpiKvLayout>(g, blocks, s); break;
-    default: abort();
-  }
-}
-
-void launch_skinny(const SkinnyArgs& a, int epi, hipStream_t s) {
-  SkinnyDev g{a.X, a.W, a.Y, a.bias, a.R, a.B, a.N, a.K, a.ldx, a.ldy, a.best};
-  // split K over the block's 4 wavefronts when there are few column tiles
-  const bool splitk = (a.N <= 4096) && (a.K % 32 == 0);
-  switch (epi) {
-    case 0: launch_skinny_t<0>(g, splitk, s); break;
-    case kEpiBias: launch_skinny_t<kEpiBias>(g, splitk, s); break;
-    case kEpiBias | kEpiGelu: launch_skinny_t<kEpiBias | kEpiGelu>(g, splitk, s); break;
-    case kEpiBias | kEpiResidual: launch_skinny_t<kEpiBias | kEpiResidual>(g, splitk, s); break;
     default: abort();
   }
 }

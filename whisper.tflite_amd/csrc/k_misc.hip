@@ -148,17 +148,6 @@ __global__ __launch_bounds__(256) void mel_normalize(float* __restrict__ logmel,
   }
 }
 
-__global__ __launch_bounds__(256) void embed_rows(const float* __restrict__ tok_emb,
-                                                  const float* __restrict__ pos_emb,
-                                                  const long long* __restrict__ ids, int ids_stride,
-                                                  int pos, float* __restrict__ x, int d,
-                                                  int n_vocab) {
-  const int b = blockIdx.x;
-  long long id = ids[(long)b * ids_stride + pos];
-  id = id < 0 ? 0 : (id >= n_vocab ? n_vocab - 1 : id);  // never index outside the table
-  for (int c = threadIdx.x; c < d; c += 256) x[(long)b * d + c] = tok_emb[id * d + c] + pos_emb[(long)pos * d + c];
-}
-
 __global__ void select_token(unsigned long long* best, long long* ids, int ids_stride, int pos,
                              int* n_ids, int* finished, long long eot, int stop_at_eot, int batch) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -214,12 +203,6 @@ void launch_mel_normalize(float* logmel, const unsigned* clip_max, int batch, in
                           hipStream_t s) {
   hipLaunchKernelGGL(mel_normalize, dim3(64, batch), dim3(256), 0, s, logmel, clip_max,
                      (long)n_mel * T);
-}
-
-void launch_embed(const float* tok_emb, const float* pos_emb, const long long* ids, int ids_stride,
-                  int pos, float* x, int batch, int d, int n_vocab, hipStream_t s) {
-  hipLaunchKernelGGL(embed_rows, dim3(batch), dim3(256), 0, s, tok_emb, pos_emb, ids, ids_stride,
-                     pos, x, d, n_vocab);
 }
 
 void launch_select_token(unsigned long long* best, long long* ids, int ids_stride, int pos,

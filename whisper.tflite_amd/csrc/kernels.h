@@ -43,20 +43,49 @@ struct GemmArgs {
 };
 void launch_gemm(const GemmArgs& a, int epi, hipStream_t s);
 
-// Skinny GEMM for decoder steps: out[B][N] = epi(x[B][K] . W[N][K]^T), B <= 64.
-// One 32-column tile per wave (split_k = 1) or per 4-wave block (split_k = 4).
-struct SkinnyArgs {
-  const float* X = nullptr;  // [B][K] (ldx)
-  const float* W = nullptr;  // [N][K]
-  float* Y = nullptr;        // [B][N] (ldy)
+// Decoder-step GEMM: out[B][N] = epi(pro(x)[B][K] . W[N][K]^T), B <= 64 (k_decoder.hip).
+// Wt is W pre-tiled by tile_weights(): [ceil(N/32)][K/8][64 lanes][4].
+enum DecPro : int {
+  kProNone = 0,    // A operand = X [B][K] (ldx) from global memory
+  kProLn = 1,      // x = xin (+bias_in) (+slabs_in[0..n)) [or token+positional embedding when
+                   // ids != nullptr]; block (0,0) stores x to xout; A = LayerNorm(x) * ln_g + ln_b
+  kProCombine = 2  // A = combine of the cross-attention key-chunk partials cross_ws
+};
+enum DecEpi : int {
+  kDecSlab = 0,      // raw split-K partials -> slab_out[blockIdx.y][B][N]   (ksplit >= 1)
+  kDecBias = 1,      // Y = acc + bias                                       (ksplit == 1)
+  kDecBiasGelu = 2,  // Y = gelu(acc + bias)
+  kDecLogits = 3     // (optional Y = acc) + fused argmax into best[b], reference tie rule
+};
+struct DecGemmArgs {
+  const float* Wt = nullptr;
+  int N = 0, K = 0, B = 0, ksplit = 1;
+  const float* X = nullptr;
+  int ldx = 0;
+  const float* xin = nullptr;
+  const float* slabs_in = nullptr;
+  int n_slabs_in = 0;
+  const float* bias_in = nullptr;
+  float* xout = nullptr;
+  const float* ln_g = nullptr;
+  const float* ln_b = nullptr;
+  const long long* ids = nullptr;
+  int ids_stride = 0, pos = 0;
+  const float* tok_emb = nullptr;
+  const float* pos_emb = nullptr;
+  int n_vocab = 0;
+  const float* cross_ws = nullptr;
+  int heads = 0, chunks = 0;
   const float* bias = nullptr;
-  const float* R = nullptr;  // residual [B][N] (ldy), may alias Y
-  int B = 0, N = 0, K = 0, ldx = 0, ldy = 0;
-  // fused argmax (logits): when best != nullptr every tile folds its
-  // per-row (value, column) maximum into best[b] with the reference's tie rule.
+  float* Y = nullptr;
+  int ldy = 0;
+  float* slab_out = nullptr;
   unsigned long long* best = nullptr;
 };
-void launch_skinny(const SkinnyArgs& a, int epi, hipStream_t s);
+void launch_dec_gemm(const DecGemmArgs& a, int pro, int epi, hipStream_t s);
+// y = LayerNorm(xin + bias + sum(slabs)) : input rows of the logits GEMM
+void launch_dec_finalize_ln(const float* xin, const float* slabs, int n_slabs, const float* bias,
+                            const float* g, const float* b, float* y, int B, int K, hipStream_t s);
 
 // ------------------------------------------------------------- LayerNorm ---
 // y[m][:] = (x[m][:] - mean) * rstd * g + b, eps 1e-5, one wavefront per row.
@@ -87,20 +116,15 @@ void launch_mel_normalize(float* logmel, const unsigned* clip_max, int batch, in
                           hipStream_t s);
 
 // --------------------------------------------------------------- decoder ---
-// x[b][:] = tok_emb[ids[b][pos]][:] + pos_emb[pos][:]
-void launch_embed(const float* tok_emb, const float* pos_emb, const long long* ids, int ids_stride,
-                  int pos, float* x, int batch, int d, int n_vocab, hipStream_t s);
 // Appends k,v of position `pos` (from qkv [B][3d]) to the self-attention cache
 // [2][B][cap][d] and attends q over positions 0..pos.  out [B][d].
 void launch_self_attention(const float* qkv, float* kcache, float* vcache, int cap, int pos,
                            float* out, int batch, int heads, hipStream_t s);
 // Cross attention of one query row per clip over T cached keys.
 // q [B][d]; kc, vc [B][heads][T][64]; partial results per key chunk in ws
-// [B][heads][chunks][66] (o[64], m, l); launch_cross_combine -> out [B][d].
+// [B][heads][chunks][66] (o[64], m, l), combined by the out-projection's prologue (kProCombine).
 void launch_cross_attention(const float* q, const float* kc, const float* vc, float* ws, int batch,
                             int heads, int T, int chunks, hipStream_t s);
-void launch_cross_combine(const float* ws, float* out, int batch, int heads, int chunks,
-                          hipStream_t s);
 // Greedy selection after the logits GEMM: decodes best[b], appends to ids, applies the
 // EOT stop (reference whisper.cpp:397-399) and re-arms best[b].
 void launch_select_token(unsigned long long* best, long long* ids, int ids_stride, int pos,
