@@ -379,8 +379,10 @@ int wt_dbg_dec_gemm(wt_engine* h, int mode, int B, int N, int K, int ksplit, con
   return guarded(h, [&] {
     const std::vector<float> tiled = wt::tile_weights(W, N, K);
     const size_t out_n = size_t(mode == 2 ? ksplit : 1) * B * N;
-    DevBuf dX(X, size_t(B) * K), dW(tiled.data(), tiled.size()), dB(bias, N), dY(out_n), dBest(size_t(B) * 2);
-    hipchk(hipMemset(dBest.p, 0, size_t(B) * 8), "memset");
+    const int n_tiles = (N + 31) / 32;
+    DevBuf dX(X, size_t(B) * K), dW(tiled.data(), tiled.size()), dB(bias, N), dY(out_n);
+    DevBuf dBest(size_t(B) * 2 * n_tiles);
+    hipchk(hipMemset(dBest.p, 0, size_t(B) * 8 * n_tiles), "memset");
     wt::DecGemmArgs g;
     g.Wt = dW.p; g.N = N; g.K = K; g.B = B; g.ksplit = ksplit; g.X = dX.p; g.ldx = K;
     g.bias = dB.p; g.Y = dY.p; g.ldy = N; g.slab_out = dY.p;
@@ -390,9 +392,14 @@ int wt_dbg_dec_gemm(wt_engine* h, int mode, int B, int N, int K, int ksplit, con
     h->impl->sync();
     dY.to_host(Y, out_n);
     if (argmax_out && mode == 3) {
-      std::vector<unsigned long long> best(B);
-      hipchk(hipMemcpy(best.data(), dBest.p, size_t(B) * 8, hipMemcpyDeviceToHost), "D2H");
-      for (int b = 0; b < B; ++b) argmax_out[b] = int64_t(best[b] & 0xffffffffull);
+      // reduce the per-tile records exactly as select_token does (max of the packed keys)
+      std::vector<unsigned long long> best(size_t(B) * n_tiles);
+      hipchk(hipMemcpy(best.data(), dBest.p, best.size() * 8, hipMemcpyDeviceToHost), "D2H");
+      for (int b = 0; b < B; ++b) {
+        unsigned long long m = 0;
+        for (int t = 0; t < n_tiles; ++t) m = std::max(m, best[size_t(b) * n_tiles + t]);
+        argmax_out[b] = int64_t(m & 0xffffffffull);
+      }
     }
   });
 }
@@ -453,7 +460,8 @@ int wt_dbg_cross_attention(wt_engine* h, int batch, int heads, int T, int chunks
   return guarded(h, [&] {
     const size_t d = size_t(heads) * 64;
     DevBuf dq(q, size_t(batch) * d), dk(kc, size_t(batch) * T * d), dv(vc, size_t(batch) * T * d);
-    DevBuf dws(size_t(batch) * heads * chunks * 66), dout(size_t(batch) * d);
+    const int ks = (d % 128 == 0) ? 4 : 1;
+    DevBuf dws(size_t(batch) * heads * chunks * 68), dout(size_t(ks) * batch * d);
     // the product combines the chunk partials in the out-projection's prologue; an identity
     // projection exposes exactly that combined row
     std::vector<float> eye(d * d, 0.0f);
@@ -462,11 +470,18 @@ int wt_dbg_cross_attention(wt_engine* h, int batch, int heads, int T, int chunks
     DevBuf dW(tiled.data(), tiled.size());
     wt::launch_cross_attention(dq.p, dk.p, dv.p, dws.p, batch, heads, T, chunks, h->impl->stream());
     wt::DecGemmArgs g;
-    g.Wt = dW.p; g.N = int(d); g.K = int(d); g.B = batch; g.ksplit = 1;
+    g.Wt = dW.p; g.N = int(d); g.K = int(d); g.B = batch; g.ksplit = ks;
     g.cross_ws = dws.p; g.heads = heads; g.chunks = chunks; g.slab_out = dout.p;
     wt::launch_dec_gemm(g, wt::kProCombine, wt::kDecSlab, h->impl->stream());
     h->impl->sync();
-    dout.to_host(out, size_t(batch) * d);
+    // with an identity projection slab ky holds exactly the columns of its K range
+    std::vector<float> slabs(size_t(ks) * batch * d);
+    dout.to_host(slabs.data(), slabs.size());
+    for (size_t i = 0; i < size_t(batch) * d; ++i) {
+      float v = 0.0f;
+      for (int k = 0; k < ks; ++k) v += slabs[size_t(k) * batch * d + i];
+      out[i] = v;
+    }
   });
 }
 

@@ -381,10 +381,10 @@ void Engine::ensure_batch(int batch) {
   ws_.attd = alloc(B * d, false);
   ws_.qd = alloc(B * d, false);
   ws_.hd = alloc(B * 4 * d, false);
-  ws_.cross_ws = alloc(B * c.n_text_head * 64 * 66, false);
+  ws_.cross_ws = alloc(B * c.n_text_head * 64 * 68, false);
   ws_.self_kv = alloc(size_t(c.n_text_layer) * 2 * B * self_cap_ * d, true);
   ws_.logits = alloc(B * c.n_vocab, false);
-  ws_.best = reinterpret_cast<unsigned long long*>(alloc(B * 2, true));
+  ws_.best = reinterpret_cast<unsigned long long*>(alloc(B * 2 * size_t((c.n_vocab + 31) / 32), true));
   ws_.ids = reinterpret_cast<long long*>(alloc(B * 32 * 2, true));
   ws_.n_ids = reinterpret_cast<int*>(alloc(B, true));
   ws_.finished = reinterpret_cast<int*>(alloc(B, true));
@@ -622,7 +622,6 @@ void Engine::decode(int batch, int64_t* ids, int32_t* n_ids, float* logits_host,
                         hipMemcpyHostToDevice, stream_));
   HIPCHK(hipMemcpyAsync(ws_.n_ids, h_n_, size_t(batch) * sizeof(int), hipMemcpyHostToDevice, stream_));
   HIPCHK(hipMemsetAsync(ws_.finished, 0, size_t(batch) * sizeof(int), stream_));
-  HIPCHK(hipMemsetAsync(ws_.best, 0, size_t(batch) * sizeof(unsigned long long), stream_));
 
   const int chunks = int(std::min<long>(std::max<long>(cross_chunks, 1), 64));
   const size_t kv_slab = size_t(batch) * T * d;  // one (layer, k|v) slab of the cross cache
@@ -705,8 +704,8 @@ void Engine::decode(int batch, int64_t* ids, int32_t* n_ids, float* logits_host,
                                 ws_.logits, size_t(V) * sizeof(float), size_t(V) * sizeof(float), batch,
                                 hipMemcpyDeviceToHost, stream_));
       }
-      launch_select_token(ws_.best, ws_.ids, stride, pos, ws_.n_ids, ws_.finished, vocab_.token_eot,
-                          int(stop_at_eot), batch, stream_);
+      launch_select_token(ws_.best, (V + 31) / 32, ws_.ids, stride, pos, ws_.n_ids, ws_.finished,
+                          vocab_.token_eot, int(stop_at_eot), batch, stream_);
       ++steps;
     }
   }

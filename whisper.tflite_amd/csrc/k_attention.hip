@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void cross_attention_step(const float* __restr
   }
   *reinterpret_cast<f32x4*>(&red[grp * 64 + gl * 4]) = acc;
   __syncthreads();
-  float* dst = ws + ((long)bh * chunks + chunk) * 66;
+  float* dst = ws + ((long)bh * chunks + chunk) * 68;
   if (tid < 64) {
     float o = 0.0f;
 #pragma unroll

@@ -69,7 +69,7 @@ template <int PRO, int EPI, int MT>
 __global__ __launch_bounds__(256) void dec_gemm(DecGemmDev g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* red = smem;                       // [3][MT][16][64] split-K partials of waves 1..3
-  float* xs = smem + 3 * MT * 16 * 64;     // [MT*32][K + 4] prologue output (PRO != none)
+  float* xs = smem + 3 * MT * 16 * 64;     // [MT*32][K + 4] LayerNorm rows (kProLn)
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
   const int tile = blockIdx.x, ky = blockIdx.y;
@@ -77,70 +77,87 @@ __global__ __launch_bounds__(256) void dec_gemm(DecGemmDev g) {
 
   if (PRO == kProLn) {
     // x = x_old (+ bias of the producing Linear) (+ its split-K slabs, fixed order); the
-    // residual stream is written back once; LayerNorm rows land in LDS.
+    // residual stream is written back once; LayerNorm rows land in LDS.  8 lanes own one
+    // row (16-byte columns sub, sub+8, ...), a wavefront owns 8 rows at once, and every load
+    // of a pass is issued before the first reduction: one memory round trip per pass.
     const bool writer = blockIdx.x == 0 && blockIdx.y == 0 && g.xout != nullptr;
-    for (int row = wid; row < MT * 32; row += 4) {
-      float v[8];
+    const int r8 = lane >> 3, sub = lane & 7;
+    const int nf4 = K >> 5;  // float4 per lane per row (<= 16 for K <= 512)
+#pragma unroll 1
+    for (int pass = 0; pass < MT; ++pass) {
+      const int row = pass * 32 + wid * 8 + r8;
+      f32x4 v[16];
       if (row < B) {
-        long long id = 0;
+        const float* src = g.xin + (long)row * K;
+        const float* pe = nullptr;
         if (g.ids) {
-          id = g.ids[(long)row * g.ids_stride + g.pos];
+          long long id = g.ids[(long)row * g.ids_stride + g.pos];
           id = id < 0 ? 0 : (id >= g.n_vocab ? g.n_vocab - 1 : id);
+          src = g.tok_emb + id * K;
+          pe = g.pos_emb + (long)g.pos * K;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+          if (j < nf4) v[j] = *reinterpret_cast<const f32x4*>(src + (sub + 8 * j) * 4);
+        if (pe) {
+#pragma unroll
+          for (int j = 0; j < 16; ++j)
+            if (j < nf4) v[j] += *reinterpret_cast<const f32x4*>(pe + (sub + 8 * j) * 4);
+        }
+        if (g.bias_in) {
+#pragma unroll
+          for (int j = 0; j < 16; ++j)
+            if (j < nf4) v[j] += *reinterpret_cast<const f32x4*>(g.bias_in + (sub + 8 * j) * 4);
+        }
+        for (int sl = 0; sl < g.n_slabs_in; ++sl) {
+          const float* sp = g.slabs_in + ((long)sl * B + row) * K;
+#pragma unroll
+          for (int j = 0; j < 16; ++j)
+            if (j < nf4) v[j] += *reinterpret_cast<const f32x4*>(sp + (sub + 8 * j) * 4);
         }
         float s = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int c = lane + 64 * i;
-          float x = 0.0f;
-          if (c < K) {
-            x = g.ids ? g.tok_emb[id * K + c] + g.pos_emb[(long)g.pos * K + c] : g.xin[(long)row * K + c];
-            if (g.bias_in) x += g.bias_in[c];
-            for (int sl = 0; sl < g.n_slabs_in; ++sl) x += g.slabs_in[((long)sl * B + row) * K + c];
-            if (writer) g.xout[(long)row * K + c] = x;
+        for (int j = 0; j < 16; ++j) {
+          if (j < nf4) {
+            if (writer) *reinterpret_cast<f32x4*>(g.xout + (long)row * K + (sub + 8 * j) * 4) = v[j];
+            s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
           }
-          v[i] = x;
-          s += x;
         }
-        const float mean = wave_sum(s) / (float)K;
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
+        const float mean = s / (float)K;
         float q = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const float t = (lane + 64 * i < K) ? v[i] - mean : 0.0f;
-          q += t * t;
-        }
-        const float rstd = rsqrtf(wave_sum(q) / (float)K + 1e-5f);
+        for (int j = 0; j < 16; ++j) {
+          if (j < nf4) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int c = lane + 64 * i;
-          if (c < K) xs[row * xld + c] = (v[i] - mean) * rstd * g.ln_g[c] + g.ln_b[c];
+            for (int e = 0; e < 4; ++e) {
+              const float t = v[j][e] - mean;
+              q += t * t;
+            }
+          }
+        }
+        q += __shfl_xor(q, 1, 64);
+        q += __shfl_xor(q, 2, 64);
+        q += __shfl_xor(q, 4, 64);
+        const float rstd = rsqrtf(q / (float)K + 1e-5f);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          if (j < nf4) {
+            const int c = (sub + 8 * j) * 4;
+            const f32x4 gg = *reinterpret_cast<const f32x4*>(g.ln_g + c);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(g.ln_b + c);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[j][e] - mean) * rstd * gg[e] + bb[e];
+            *reinterpret_cast<f32x4*>(&xs[row * xld + c]) = o;
+          }
         }
       } else {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int c = lane + 64 * i;
-          if (c < K) xs[row * xld + c] = 0.0f;
-        }
-      }
-    }
-    __syncthreads();
-  } else if (PRO == kProCombine) {
-    // attention output row = combine of the key-chunk partials (o[64], m, l) of every head
-    for (int row = wid; row < MT * 32; row += 4) {
-      for (int h = 0; h < g.heads; ++h) {
-        float o = 0.0f;
-        if (row < B) {
-          const float* p = g.cross_ws + ((long)(row * g.heads + h) * g.chunks) * 66;
-          float mx = -1e30f;
-          for (int c = 0; c < g.chunks; ++c) mx = fmaxf(mx, p[c * 66 + 64]);
-          float l = 0.0f;
-          for (int c = 0; c < g.chunks; ++c) {
-            const float w = __expf(p[c * 66 + 64] - mx);
-            o += w * p[c * 66 + lane];
-            l += w * p[c * 66 + 65];
-          }
-          o = o / l;
-        }
-        xs[row * xld + h * 64 + lane] = o;
+        for (int j = 0; j < 16; ++j)
+          if (j < nf4) *reinterpret_cast<f32x4*>(&xs[row * xld + (sub + 8 * j) * 4]) = f32x4{0, 0, 0, 0};
       }
     }
     __syncthreads();
@@ -155,7 +172,40 @@ __global__ __launch_bounds__(256) void dec_gemm(DecGemmDev g) {
   for (int t = 0; t < MT; ++t) {
     int b = t * 32 + l31;
     b = b < B ? b : B - 1;
-    xp[t] = (PRO == kProNone ? g.X + (long)b * g.ldx : xs + (t * 32 + l31) * xld) + k0 + 4 * lh;
+    xp[t] = (PRO == kProLn ? xs + (t * 32 + l31) * xld : g.X + (long)b * g.ldx) + k0 + 4 * lh;
+  }
+  // kProCombine: the A fragment is the combine of the cross-attention key-chunk partials
+  // (o[64], m, l, pad; 68-float records), computed by the lane that consumes it — no LDS,
+  // every load independent (host guarantees nchunks <= kGroup for this prologue)
+  f32x4 xa[PRO == kProCombine ? kGroup : 1][MT];
+  if (PRO == kProCombine) {
+#pragma unroll
+    for (int i = 0; i < kGroup; ++i) {
+      if (i < nchunks) {
+        const int col = k0 + 8 * i + 4 * lh;
+        const int hh = col >> 6, dd = col & 63;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          const int rowb = t * 32 + l31;
+          f32x4 o = {0, 0, 0, 0};
+          if (rowb < B) {
+            const float* p = g.cross_ws + ((long)(rowb * g.heads + hh) * g.chunks) * 68;
+            float mx = -1e30f;
+            for (int c = 0; c < g.chunks; ++c) mx = fmaxf(mx, p[c * 68 + 64]);
+            float l = 0.0f;
+            for (int c = 0; c < g.chunks; ++c) {
+              const float w = __expf(p[c * 68 + 64] - mx);
+              const f32x4 pv = *reinterpret_cast<const f32x4*>(p + c * 68 + dd);
+              o += w * pv;
+              l += w * p[c * 68 + 65];
+            }
+            const float inv = 1.0f / l;
+            o *= inv;
+          }
+          xa[i][t] = o;
+        }
+      }
+    }
   }
   f32x16 acc[MT];
 #pragma unroll
@@ -173,7 +223,13 @@ __global__ __launch_bounds__(256) void dec_gemm(DecGemmDev g) {
       if (c0 + i < nchunks) {
         f32x4 x[MT];
 #pragma unroll
-        for (int t = 0; t < MT; ++t) x[t] = *reinterpret_cast<const f32x4*>(xp[t] + (c0 + i) * 8);
+        for (int t = 0; t < MT; ++t) {
+          if (PRO == kProCombine) {
+            x[t] = xa[i][t];
+          } else {
+            x[t] = *reinterpret_cast<const f32x4*>(xp[t] + (c0 + i) * 8);
+          }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -223,7 +279,8 @@ __global__ __launch_bounds__(256) void dec_gemm(DecGemmDev g) {
           const unsigned long long o2 = __shfl_xor(p, off, 64);
           p = o2 > p ? o2 : p;
         }
-        if (l31 == 0 && b < B) atomicMax(&g.best[b], p);
+        // one record per (clip, tile); select_token reduces them (no same-address atomics)
+        if (l31 == 0 && b < B) g.best[(long)b * gridDim.x + tile] = p;
       }
     }
   }
@@ -272,7 +329,7 @@ template <int PRO, int EPI>
 void launch_t(const DecGemmDev& g, hipStream_t s) {
   const int n_tiles = (g.N + 31) / 32;
   const int MT = g.B <= 32 ? 1 : 2;
-  const size_t smem = (size_t)(3 * MT * 16 * 64 + (PRO != kProNone ? MT * 32 * (g.K + 4) : 0)) * sizeof(float);
+  const size_t smem = (size_t)(3 * MT * 16 * 64 + (PRO == kProLn ? MT * 32 * (g.K + 4) : 0)) * sizeof(float);
   const dim3 grid(n_tiles, g.ksplit);
   // dynamic LDS beyond the 64 KiB default needs an opt-in, once per kernel
   static const bool raised = [] {
@@ -298,7 +355,8 @@ void launch_dec_gemm(const DecGemmArgs& a, int pro, int epi, hipStream_t s) {
                a.pos,    a.tok_emb, a.pos_emb, a.n_vocab,  a.cross_ws, a.heads,  a.chunks,   a.bias,
                a.Y,      a.ldy,    a.slab_out, a.best};
   if (a.B < 1 || a.B > 64 || a.K > 512 * 4 || (pro != kProNone && a.K > 512) || a.ksplit < 1 ||
-      a.K % (32 * a.ksplit) != 0 || (epi != kDecSlab && a.ksplit != 1)) {
+      a.K % (32 * a.ksplit) != 0 || (epi != kDecSlab && a.ksplit != 1) ||
+      (pro == kProCombine && a.K / (32 * a.ksplit) > kGroup)) {
     abort();  // host-side shape contract: operands must match what the kernel indexes
   }
   const int key = pro * 8 + epi;

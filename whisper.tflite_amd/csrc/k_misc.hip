@@ -148,12 +148,28 @@ __global__ __launch_bounds__(256) void mel_normalize(float* __restrict__ logmel,
   }
 }
 
-__global__ void select_token(unsigned long long* best, long long* ids, int ids_stride, int pos,
-                             int* n_ids, int* finished, long long eot, int stop_at_eot, int batch) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= batch) return;
-  const unsigned long long p = best[b];
-  best[b] = 0ull;
+// One block per clip: reduce the per-tile (value, column) records of the logits GEMM with the
+// reference's tie rule (larger value, then larger column), then apply the greedy step.
+__global__ __launch_bounds__(256) void select_token(const unsigned long long* __restrict__ best,
+                                                    int n_tiles, long long* ids, int ids_stride,
+                                                    int pos, int* n_ids, int* finished, long long eot,
+                                                    int stop_at_eot) {
+  __shared__ unsigned long long wmax[4];
+  const int b = blockIdx.x;
+  unsigned long long p = 0ull;
+  for (int t = threadIdx.x; t < n_tiles; t += 256) {
+    const unsigned long long v = best[(long)b * n_tiles + t];
+    p = v > p ? v : p;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const unsigned long long o = __shfl_xor(p, off, 64);
+    p = o > p ? o : p;
+  }
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = p;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  for (int w = 1; w < 4; ++w) p = wmax[w] > p ? wmax[w] : p;
   const long long tok = (long long)(unsigned)(p & 0xffffffffull);
   // ids always receives the token so the next position has a defined input; n_ids stops
   // growing once the clip has emitted EOT (reference loop break, whisper.cpp:397-399)
@@ -205,11 +221,11 @@ void launch_mel_normalize(float* logmel, const unsigned* clip_max, int batch, in
                      (long)n_mel * T);
 }
 
-void launch_select_token(unsigned long long* best, long long* ids, int ids_stride, int pos,
-                         int* n_ids, int* finished, long long eot, int stop_at_eot, int batch,
+void launch_select_token(const unsigned long long* best, int n_tiles, long long* ids, int ids_stride,
+                         int pos, int* n_ids, int* finished, long long eot, int stop_at_eot, int batch,
                          hipStream_t s) {
-  hipLaunchKernelGGL(select_token, dim3((batch + 63) / 64), dim3(64), 0, s, best, ids, ids_stride,
-                     pos, n_ids, finished, eot, stop_at_eot, batch);
+  hipLaunchKernelGGL(select_token, dim3(batch), dim3(256), 0, s, best, n_tiles, ids, ids_stride, pos,
+                     n_ids, finished, eot, stop_at_eot);
 }
 
 }  // namespace wt

@@ -55,7 +55,7 @@ enum DecEpi : int {
   kDecSlab = 0,      // raw split-K partials -> slab_out[blockIdx.y][B][N]   (ksplit >= 1)
   kDecBias = 1,      // Y = acc + bias                                       (ksplit == 1)
   kDecBiasGelu = 2,  // Y = gelu(acc + bias)
-  kDecLogits = 3     // (optional Y = acc) + fused argmax into best[b], reference tie rule
+  kDecLogits = 3     // (optional Y = acc) + per-tile argmax records best[b][tile], reference tie rule
 };
 struct DecGemmArgs {
   const float* Wt = nullptr;
@@ -122,13 +122,13 @@ void launch_self_attention(const float* qkv, float* kcache, float* vcache, int c
                            float* out, int batch, int heads, hipStream_t s);
 // Cross attention of one query row per clip over T cached keys.
 // q [B][d]; kc, vc [B][heads][T][64]; partial results per key chunk in ws
-// [B][heads][chunks][66] (o[64], m, l), combined by the out-projection's prologue (kProCombine).
+// [B][heads][chunks][68] (o[64], m, l, pad), combined by the out-projection's prologue (kProCombine).
 void launch_cross_attention(const float* q, const float* kc, const float* vc, float* ws, int batch,
                             int heads, int T, int chunks, hipStream_t s);
-// Greedy selection after the logits GEMM: decodes best[b], appends to ids, applies the
-// EOT stop (reference whisper.cpp:397-399) and re-arms best[b].
-void launch_select_token(unsigned long long* best, long long* ids, int ids_stride, int pos,
-                         int* n_ids, int* finished, long long eot, int stop_at_eot, int batch,
+// Greedy selection after the logits GEMM: reduces the per-tile (value, column) records
+// best[B][n_tiles], appends to ids and applies the EOT stop (reference whisper.cpp:397-399).
+void launch_select_token(const unsigned long long* best, int n_tiles, long long* ids, int ids_stride,
+                         int pos, int* n_ids, int* finished, long long eot, int stop_at_eot, int batch,
                          hipStream_t s);
 
 }  // namespace wt
