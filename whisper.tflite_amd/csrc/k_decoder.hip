@@ -63,7 +63,8 @@ struct DecGemmDev {
   unsigned long long* best;
 };
 
-constexpr int kGroup = 12;  // weight chunks (8 k each) a wave keeps in flight
+constexpr int kGroup = 12;    // weight chunks (8 k each) a wave keeps in flight
+constexpr int kMaxSlabs = 4;  // split-K slabs a prologue can fold in
 
 template <int PRO, int EPI, int MT>
 __global__ __launch_bounds__(256) void dec_gemm(DecGemmDev g) {
@@ -74,6 +75,17 @@ __global__ __launch_bounds__(256) void dec_gemm(DecGemmDev g) {
   const int l31 = lane & 31, lh = lane >> 5;
   const int tile = blockIdx.x, ky = blockIdx.y;
   const int K = g.K, B = g.B, xld = K + 4;
+
+  const int kblock = K / g.ksplit, kwave = kblock >> 2;
+  const int k0 = ky * kblock + wid * kwave;
+  const int nchunks = kwave >> 3;
+  const float* wp = g.Wt + ((long)tile * (K >> 3) + (k0 >> 3)) * 256 + lane * 4;
+  // the weight stream does not depend on the prologue: put its first group in flight now so
+  // that its HBM/L2 latency overlaps the residual / LayerNorm / combine work below
+  f32x4 w[kGroup];
+#pragma unroll
+  for (int i = 0; i < kGroup; ++i)
+    if (i < nchunks) w[i] = *reinterpret_cast<const f32x4*>(wp + (long)i * 256);
 
   if (PRO == kProLn) {
     // x = x_old (+ bias of the producing Linear) (+ its split-K slabs, fixed order); the
@@ -109,11 +121,14 @@ __global__ __launch_bounds__(256) void dec_gemm(DecGemmDev g) {
           for (int j = 0; j < 16; ++j)
             if (j < nf4) v[j] += *reinterpret_cast<const f32x4*>(g.bias_in + (sub + 8 * j) * 4);
         }
-        for (int sl = 0; sl < g.n_slabs_in; ++sl) {
-          const float* sp = g.slabs_in + ((long)sl * B + row) * K;
 #pragma unroll
-          for (int j = 0; j < 16; ++j)
-            if (j < nf4) v[j] += *reinterpret_cast<const f32x4*>(sp + (sub + 8 * j) * 4);
+        for (int sl = 0; sl < kMaxSlabs; ++sl) {  // fixed order; bound known at compile time
+          if (sl < g.n_slabs_in) {
+            const float* sp = g.slabs_in + ((long)sl * B + row) * K;
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+              if (j < nf4) v[j] += *reinterpret_cast<const f32x4*>(sp + (sub + 8 * j) * 4);
+          }
         }
         float s = 0.0f;
 #pragma unroll
@@ -163,10 +178,6 @@ __global__ __launch_bounds__(256) void dec_gemm(DecGemmDev g) {
     __syncthreads();
   }
 
-  const int kblock = K / g.ksplit, kwave = kblock >> 2;
-  const int k0 = ky * kblock + wid * kwave;
-  const int nchunks = kwave >> 3;
-  const float* wp = g.Wt + ((long)tile * (K >> 3) + (k0 >> 3)) * 256 + lane * 4;
   const float* xp[MT];
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
@@ -214,10 +225,11 @@ __global__ __launch_bounds__(256) void dec_gemm(DecGemmDev g) {
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
   for (int c0 = 0; c0 < nchunks; c0 += kGroup) {
-    f32x4 w[kGroup];
+    if (c0 > 0) {
 #pragma unroll
-    for (int i = 0; i < kGroup; ++i)
-      if (c0 + i < nchunks) w[i] = *reinterpret_cast<const f32x4*>(wp + (long)(c0 + i) * 256);
+      for (int i = 0; i < kGroup; ++i)
+        if (c0 + i < nchunks) w[i] = *reinterpret_cast<const f32x4*>(wp + (long)(c0 + i) * 256);
+    }
 #pragma unroll
     for (int i = 0; i < kGroup; ++i) {
       if (c0 + i < nchunks) {
@@ -286,42 +298,71 @@ __global__ __launch_bounds__(256) void dec_gemm(DecGemmDev g) {
   }
 }
 
-// x = xin + bias + sum(slabs) -> LayerNorm -> y   (input of the logits GEMM)
+// x = xin + bias + sum(slabs) -> LayerNorm -> y   (input rows of the logits GEMM).
+// Same row layout as the kProLn prologue: 8 lanes per row, every load in flight at once.
 __global__ __launch_bounds__(256) void dec_finalize_ln(const float* __restrict__ xin,
                                                        const float* __restrict__ slabs, int n_slabs,
                                                        const float* __restrict__ bias,
                                                        const float* __restrict__ g,
                                                        const float* __restrict__ b,
                                                        float* __restrict__ y, int B, int K) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= B) return;
-  float v[8];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int r8 = lane >> 3, sub = lane & 7;
+  const int row = blockIdx.x * 32 + wid * 8 + r8;
+  const int nf4 = K >> 5;
+  if (row >= B) return;  // whole 8-lane groups leave together; the shuffles below stay inside a group
+  f32x4 v[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j)
+    if (j < nf4) v[j] = *reinterpret_cast<const f32x4*>(xin + (long)row * K + (sub + 8 * j) * 4);
+  if (bias) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (j < nf4) v[j] += *reinterpret_cast<const f32x4*>(bias + (sub + 8 * j) * 4);
+  }
+#pragma unroll
+  for (int sl = 0; sl < kMaxSlabs; ++sl) {
+    if (sl < n_slabs) {
+      const float* sp = slabs + ((long)sl * B + row) * K;
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (j < nf4) v[j] += *reinterpret_cast<const f32x4*>(sp + (sub + 8 * j) * 4);
+    }
+  }
   float s = 0.0f;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int c = lane + 64 * i;
-    float x = 0.0f;
-    if (c < K) {
-      x = xin[(long)row * K + c];
-      if (bias) x += bias[c];
-      for (int sl = 0; sl < n_slabs; ++sl) x += slabs[((long)sl * B + row) * K + c];
-    }
-    v[i] = x;
-    s += x;
-  }
-  const float mean = wave_sum(s) / (float)K;
+  for (int j = 0; j < 16; ++j)
+    if (j < nf4) s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+  s += __shfl_xor(s, 1, 64);
+  s += __shfl_xor(s, 2, 64);
+  s += __shfl_xor(s, 4, 64);
+  const float mean = s / (float)K;
   float q = 0.0f;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const float t = (lane + 64 * i < K) ? v[i] - mean : 0.0f;
-    q += t * t;
-  }
-  const float rstd = rsqrtf(wave_sum(q) / (float)K + 1e-5f);
+  for (int j = 0; j < 16; ++j) {
+    if (j < nf4) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int c = lane + 64 * i;
-    if (c < K) y[(long)row * K + c] = (v[i] - mean) * rstd * g[c] + b[c];
+      for (int e = 0; e < 4; ++e) {
+        const float t = v[j][e] - mean;
+        q += t * t;
+      }
+    }
+  }
+  q += __shfl_xor(q, 1, 64);
+  q += __shfl_xor(q, 2, 64);
+  q += __shfl_xor(q, 4, 64);
+  const float rstd = rsqrtf(q / (float)K + 1e-5f);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    if (j < nf4) {
+      const int c = (sub + 8 * j) * 4;
+      const f32x4 gg = *reinterpret_cast<const f32x4*>(g + c);
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(b + c);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[j][e] - mean) * rstd * gg[e] + bb[e];
+      *reinterpret_cast<f32x4*>(y + (long)row * K + c) = o;
+    }
   }
 }
 
@@ -356,7 +397,7 @@ void launch_dec_gemm(const DecGemmArgs& a, int pro, int epi, hipStream_t s) {
                a.Y,      a.ldy,    a.slab_out, a.best};
   if (a.B < 1 || a.B > 64 || a.K > 512 * 4 || (pro != kProNone && a.K > 512) || a.ksplit < 1 ||
       a.K % (32 * a.ksplit) != 0 || (epi != kDecSlab && a.ksplit != 1) ||
-      (pro == kProCombine && a.K / (32 * a.ksplit) > kGroup)) {
+      (pro == kProCombine && a.K / (32 * a.ksplit) > kGroup) || a.n_slabs_in > kMaxSlabs) {
     abort();  // host-side shape contract: operands must match what the kernel indexes
   }
   const int key = pro * 8 + epi;
@@ -374,7 +415,8 @@ void launch_dec_gemm(const DecGemmArgs& a, int pro, int epi, hipStream_t s) {
 
 void launch_dec_finalize_ln(const float* xin, const float* slabs, int n_slabs, const float* bias,
                             const float* g, const float* b, float* y, int B, int K, hipStream_t s) {
-  hipLaunchKernelGGL(dec_finalize_ln, dim3((B + 3) / 4), dim3(256), 0, s, xin, slabs, n_slabs, bias, g, b,
+  if (n_slabs > kMaxSlabs || K > 512 || K % 32 != 0) abort();  // shape contract of the kernel
+  hipLaunchKernelGGL(dec_finalize_ln, dim3((B + 31) / 32), dim3(256), 0, s, xin, slabs, n_slabs, bias, g, b,
                      y, B, K);
 }
 
