@@ -151,6 +151,8 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="clips per GPU")
     ap.add_argument("--arch", default="tiny")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="synchronous steps (encoder then decoder) instead of the two-deep pipeline")
     ap.add_argument("--dry-run-gloo", action="store_true")
     args = ap.parse_args()
     if args.dry_run_gloo:
@@ -183,15 +185,41 @@ def main() -> None:
     d_mel = torch.from_numpy(mel_host).cuda()  # resident in HBM before the timed region
     torch.cuda.synchronize()
 
-    def step():
-        ids, n = eng.encdec_tokens_batch_dev(d_mel.data_ptr(), B)
+    pipelined = not args.no_pipeline
+
+    def finish(ids, n):
         rec = torch.from_numpy(pack_records(ids, n))
         if world > 1:
             rec = gather_records(rec.cuda(), world)
         return ids, n, rec
 
-    for _ in range(args.warmup):
-        step()
+    def step():
+        return finish(*eng.encdec_tokens_batch_dev(d_mel.data_ptr(), B))
+
+    def run_steps(k, on_step=None):
+        """k passes of the hot path.  Pipelined: batch i+1 is submitted (encoder on one HIP
+        stream) before batch i is collected (decoder on a second stream), all k batches start
+        and finish inside the call."""
+        out = None
+        if not pipelined:
+            for _ in range(k):
+                out = step()
+                if on_step:
+                    on_step()
+            return out
+        eng.pipeline_submit_dev(d_mel.data_ptr(), B)
+        for _ in range(k - 1):
+            eng.pipeline_submit_dev(d_mel.data_ptr(), B)
+            out = finish(*eng.pipeline_collect())
+            if on_step:
+                on_step()
+        out = finish(*eng.pipeline_collect())
+        if on_step:
+            on_step()
+        return out
+
+    if args.warmup:
+        run_steps(args.warmup)
 
     def fence():
         if world > 1:
@@ -200,10 +228,7 @@ def main() -> None:
 
     stage = {"encoder_ms": 0.0, "cross_kv_ms": 0.0, "decoder_ms": 0.0}
     kstats = {}
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ids, n, rec = step()
+    def accumulate():
         t = eng.timings()
         for k in stage:
             stage[k] += getattr(t, k)
@@ -211,6 +236,10 @@ def main() -> None:
             acc = kstats.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
             for k in acc:
                 acc[k] += v[k]
+
+    fence()
+    t0 = time.perf_counter()
+    ids, n, rec = run_steps(args.steps, accumulate)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -272,7 +301,8 @@ def main() -> None:
             "config": {"workload": f"whisper-{args.arch} batch={B}x30s synthetic mel U(-1,1.5), fp32, random-init "
                                    "weights (BASELINE.json configs[1]); mel resident in HBM -> token ids on host",
                        "clips_per_gpu": B, "global_batch": world * B, "decoder_positions": 30,
-                       "argmax_steps": 27, "parallelism": f"clip-parallel dp{world}, RCCL all_gather of id records"},
+                       "argmax_steps": 27, "parallelism": f"clip-parallel dp{world}, RCCL all_gather of id records",
+                       "pipelined": pipelined},
             "roofline": roof,
             "roofline_detail": detail,
             "decoder_roofline": {"bound": "hbm", "achieved": round(dec_ach, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",

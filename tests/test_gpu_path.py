@@ -215,3 +215,33 @@ def test_encdec_cli(tiny, tmp_path):
     e.set_option("stop_at_eot", 0)
     r = subprocess.run([exe, "--vocab", vocab], capture_output=True, text=True)
     assert r.returncode != 0
+
+
+def test_pipeline_submit_collect_matches_sync(tiny):
+    """Two-deep encoder/decoder pipeline (wt_pipeline_submit_dev / wt_pipeline_collect):
+    batches come back in submission order with exactly the ids of the synchronous call."""
+    import torch
+    e, _ = tiny
+    rng = np.random.default_rng(777)
+    mels = [rng.uniform(-1.0, 1.5, size=(b, 80, 3000)).astype(np.float32) for b in (3, 5, 2, 4)]
+    want = [e.encdec_tokens_batch(m) for m in mels]
+    dev = [torch.from_numpy(m).cuda() for m in mels]
+    torch.cuda.synchronize()
+    got = []
+    e.pipeline_submit_dev(dev[0].data_ptr(), 3)
+    for k in range(1, 4):
+        e.pipeline_submit_dev(dev[k].data_ptr(), mels[k].shape[0])
+        got.append(e.pipeline_collect())
+    got.append(e.pipeline_collect())
+    for (ids_w, n_w), (ids_g, n_g) in zip(want, got):
+        assert np.array_equal(ids_w, ids_g) and np.array_equal(n_w, n_g)
+    # a third uncollected submit is refused, and so is a sync call with batches in flight
+    e.pipeline_submit_dev(dev[0].data_ptr(), 3)
+    e.pipeline_submit_dev(dev[1].data_ptr(), 5)
+    with pytest.raises(Exception):
+        e.pipeline_submit_dev(dev[2].data_ptr(), 2)
+    with pytest.raises(Exception):
+        e.encdec_tokens_batch(mels[0])
+    a = e.pipeline_collect()
+    b = e.pipeline_collect()
+    assert np.array_equal(a[0], want[0][0]) and np.array_equal(b[0], want[1][0])

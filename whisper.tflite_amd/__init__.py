@@ -38,7 +38,8 @@ CAPI_SYMBOLS = [
     "wt_engine_create", "wt_engine_destroy", "wt_last_error", "wt_engine_dims",
     "wt_engine_set_option", "wt_engine_get_option", "wt_engine_set_prompt", "wt_transcribe_pcm", "wt_transcribe_file",
     "wt_logmel_batch", "wt_logmel_batch_dev", "wt_encdec_tokens_batch",
-    "wt_encdec_tokens_batch_dev", "wt_transcribe_tokens_batch_dev", "wt_encdec_debug_batch",
+    "wt_encdec_tokens_batch_dev", "wt_transcribe_tokens_batch_dev", "wt_pipeline_submit_dev", "wt_pipeline_collect",
+    "wt_encdec_debug_batch",
     "wt_last_timings", "wt_last_kernel_stats", "wt_decode_text", "wt_language_id", "wt_lang_code", "wt_wav_read_legacy",
     "wt_vocab_info", "wt_filters", "wt_write_synthetic_weights", "wt_write_synthetic_vocab",
 ]
@@ -105,6 +106,8 @@ def lib() -> ctypes.CDLL:
         L.wt_encdec_tokens_batch.argtypes = [c_void_p, fp, c_int, ip64, ip32]
         L.wt_encdec_tokens_batch_dev.argtypes = [c_void_p, c_void_p, c_int, ip64, ip32]
         L.wt_transcribe_tokens_batch_dev.argtypes = [c_void_p, c_void_p, c_int, ip64, ip32]
+        L.wt_pipeline_submit_dev.argtypes = [c_void_p, c_void_p, c_int]
+        L.wt_pipeline_collect.argtypes = [c_void_p, ip64, ip32]
         L.wt_encdec_debug_batch.argtypes = [c_void_p, fp, c_int, ip64, ip32, fp, fp, c_int]
         L.wt_last_timings.argtypes = [c_void_p, POINTER(Timings)]
         L.wt_last_kernel_stats.argtypes = [c_void_p, POINTER(KernelStat), c_int]
@@ -265,6 +268,19 @@ class Engine:
         self._check(lib().wt_transcribe_tokens_batch_dev(
             self._h, c_void_p(d_pcm_ptr), batch, ids.ctypes.data_as(POINTER(c_int64)),
             n.ctypes.data_as(POINTER(c_int32))))
+        return ids, n
+
+    def pipeline_submit_dev(self, d_mel_ptr: int, batch: int) -> None:
+        self._check(lib().wt_pipeline_submit_dev(self._h, c_void_p(d_mel_ptr), batch))
+        self._submitted = getattr(self, "_submitted", [])
+        self._submitted.append(batch)
+
+    def pipeline_collect(self):
+        batch = self._submitted.pop(0)
+        ids = np.zeros((batch, WT_MAX_IDS), np.int64)
+        n = np.zeros(batch, np.int32)
+        self._check(lib().wt_pipeline_collect(
+            self._h, ids.ctypes.data_as(POINTER(c_int64)), n.ctypes.data_as(POINTER(c_int32))))
         return ids, n
 
     def logmel_batch_dev(self, d_pcm_ptr: int, batch: int, d_mel_ptr: int) -> None:

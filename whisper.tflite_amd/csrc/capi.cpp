@@ -172,6 +172,16 @@ int wt_encdec_tokens_batch_dev(wt_engine* h, const float* d_mel, int batch, int6
   });
 }
 
+int wt_pipeline_submit_dev(wt_engine* h, const float* d_mel, int batch) {
+  if (!h || !d_mel) return WT_ERR_INVALID_ARG;
+  return guarded(h, [&] { h->impl->submit(d_mel, batch); });
+}
+
+int wt_pipeline_collect(wt_engine* h, int64_t* ids, int32_t* n_ids) {
+  if (!h || !ids || !n_ids) return WT_ERR_INVALID_ARG;
+  return guarded(h, [&] { h->impl->collect(ids, n_ids); });
+}
+
 int wt_encdec_tokens_batch(wt_engine* h, const float* mel, int batch, int64_t* ids, int32_t* n_ids) {
   return wt_encdec_debug_batch(h, mel, batch, ids, n_ids, nullptr, nullptr, 0);
 }
@@ -201,6 +211,7 @@ int wt_encdec_debug_batch(wt_engine* h, const float* mel, int batch, int64_t* id
       hipchk(hipMemcpyAsync(enc_out, e.enc_out(), n * sizeof(float), hipMemcpyDeviceToHost, e.stream()), "D2H enc_out");
     }
     e.decode(batch, ids, n_ids, logits, logits_steps_cap);
+    e.sync();  // the enc_out copy rides the encoder stream
   });
 }
 

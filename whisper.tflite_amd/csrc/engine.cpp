@@ -319,38 +319,58 @@ Engine::Engine(const std::string& model_prefix, const std::string& vocab_path, b
     throw Error(5, std::string("device is ") + prop.gcnArchName +
                             ", kernels are built for gfx950 only");
   }
-  HIPCHK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  int prio_lo = 0, prio_hi = 0;
+  HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+  HIPCHK(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, prio_lo));
+  // the decoder's tiny dependent launches go ahead of the encoder's big grids
+  HIPCHK(hipStreamCreateWithPriority(&dstream_, hipStreamNonBlocking, prio_hi));
   for (auto& e : ev_) HIPCHK(hipEventCreate(&e));
+  for (Slot& sl : slots_) {
+    for (hipEvent_t* e : {&sl.enc_begin, &sl.enc_mid, &sl.enc_done, &sl.dec_begin, &sl.dec_done}) {
+      HIPCHK(hipEventCreate(e));
+    }
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&sl.h_ids), 4096 * 32 * sizeof(long long), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&sl.h_n), 4096 * sizeof(int), hipHostMallocDefault));
+  }
   upload_weights(model_prefix + ".wtw");
   if (vocab_.n_vocab != dims_.n_vocab && verbose) {
     std::fprintf(stderr, "[wt] note: vocab file n_vocab %d != model n_vocab %d\n", vocab_.n_vocab,
                  dims_.n_vocab);
   }
   build_frontend_tables();
-  HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h_ids_), 4096 * 32 * sizeof(long long), hipHostMallocDefault));
-  HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h_n_), 4096 * sizeof(int), hipHostMallocDefault));
 }
 
 Engine::~Engine() {
   (void)hipSetDevice(device_);
   if (stream_) (void)hipStreamSynchronize(stream_);
+  if (dstream_) (void)hipStreamSynchronize(dstream_);
   for (void* p : ws_.owned) (void)hipFree(p);
   for (void* p : allocations_) (void)hipFree(p);
-  if (h_ids_) (void)hipHostFree(h_ids_);
-  if (h_n_) (void)hipHostFree(h_n_);
   for (auto& e : ev_)
     if (e) (void)hipEventDestroy(e);
-  for (auto& e : kt_events_) (void)hipEventDestroy(e);
+  for (Slot& sl : slots_) {
+    for (hipEvent_t e : {sl.enc_begin, sl.enc_mid, sl.enc_done, sl.dec_begin, sl.dec_done})
+      if (e) (void)hipEventDestroy(e);
+    for (auto& e : sl.kt_events) (void)hipEventDestroy(e);
+    if (sl.h_ids) (void)hipHostFree(sl.h_ids);
+    if (sl.h_n) (void)hipHostFree(sl.h_n);
+  }
   if (stream_) (void)hipStreamDestroy(stream_);
+  if (dstream_) (void)hipStreamDestroy(dstream_);
 }
 
-void Engine::sync() { HIPCHK(hipStreamSynchronize(stream_)); }
+void Engine::sync() {
+  HIPCHK(hipStreamSynchronize(stream_));
+  HIPCHK(hipStreamSynchronize(dstream_));
+}
 
 void Engine::ensure_batch(int batch) {
   if (batch <= 0 || batch > 4096) throw Error(1, "batch must be in [1, 4096]");
   HIPCHK(hipSetDevice(device_));
   if (batch <= ws_.batch) return;
+  if (!inflight_.empty()) throw Error(1, "cannot grow the workspace while batches are in flight");
   HIPCHK(hipStreamSynchronize(stream_));
+  HIPCHK(hipStreamSynchronize(dstream_));
   for (void* p : ws_.owned) (void)hipFree(p);
   ws_ = Workspace();
   const wtw::Dims& c = dims_;
@@ -372,7 +392,10 @@ void Engine::ensure_batch(int batch) {
   ws_.att = alloc(B * T * d, false);
   ws_.hid = alloc(B * T * 4 * d, false);
   ws_.enc_out = alloc(B * T * d, false);
-  ws_.cross_kv = alloc(size_t(c.n_text_layer) * 2 * B * T * d, false);
+  for (Slot& sl : slots_) {
+    sl.cross_kv = alloc(size_t(c.n_text_layer) * 2 * B * T * d, false);
+    sl.used = false;
+  }
   ws_.xd = alloc(B * d, false);
   ws_.xd2 = alloc(B * d, false);
   ws_.slabs = alloc(size_t(3) * dec_ksplit_ * B * d, false);
@@ -468,28 +491,35 @@ void Engine::logmel(const float* d_pcm, int batch, float* d_mel) {
 // ------------------------------------------------------- kernel timer ---
 
 void Engine::kt_begin(int cls, double flops, double bytes) {
-  const int idx = int(kt_recs_.size()) * 2;
-  while (int(kt_events_.size()) < idx + 2) {
+  Slot& sl = slots_[enc_slot_];
+  const size_t idx = sl.kt_cls.size() * 2;
+  while (sl.kt_events.size() < idx + 2) {
     hipEvent_t e;
     HIPCHK(hipEventCreate(&e));
-    kt_events_.push_back(e);
+    sl.kt_events.push_back(e);
   }
-  kt_recs_.push_back({cls, idx, flops, bytes});
-  HIPCHK(hipEventRecord(kt_events_[idx], stream_));
+  sl.kt_cls.push_back(cls);
+  sl.kt_flops.push_back(flops);
+  sl.kt_bytes.push_back(bytes);
+  HIPCHK(hipEventRecord(sl.kt_events[idx], stream_));
 }
 
-void Engine::kt_end() { HIPCHK(hipEventRecord(kt_events_[kt_recs_.back().ev + 1], stream_)); }
+void Engine::kt_end() {
+  Slot& sl = slots_[enc_slot_];
+  HIPCHK(hipEventRecord(sl.kt_events[(sl.kt_cls.size() - 1) * 2 + 1], stream_));
+}
 
-void Engine::resolve_kernel_stats() {
+void Engine::resolve_kernel_stats(int slot) {
+  Slot& sl = slots_[slot];
   for (auto& k : kstats_) k.launches = 0, k.ms = 0, k.flops = 0, k.bytes = 0;
-  for (const KtRec& r : kt_recs_) {
+  for (size_t i = 0; i < sl.kt_cls.size(); ++i) {
     float ms = 0;
-    if (hipEventElapsedTime(&ms, kt_events_[r.ev], kt_events_[r.ev + 1]) != hipSuccess) continue;
-    KernelStat& k = kstats_[r.cls];
+    if (hipEventElapsedTime(&ms, sl.kt_events[2 * i], sl.kt_events[2 * i + 1]) != hipSuccess) continue;
+    KernelStat& k = kstats_[sl.kt_cls[i]];
     k.launches += 1;
     k.ms += ms;
-    k.flops += r.flops;
-    k.bytes += r.bytes;
+    k.flops += sl.kt_flops[i];
+    k.bytes += sl.kt_bytes[i];
   }
 }
 
@@ -499,8 +529,14 @@ void Engine::encode(const float* d_mel, int batch) {
   ensure_batch(batch);
   const wtw::Dims& c = dims_;
   const int T0 = mel_frames(), T = c.n_audio_ctx, d = c.n_audio_state, M = batch * T;
-  kt_recs_.clear();
-  HIPCHK(hipEventRecord(ev_[2], stream_));
+  Slot& slot = slots_[enc_slot_];
+  // the slot's cross-KV cache may still be read by the decoder of the batch before last
+  if (slot.used) HIPCHK(hipStreamWaitEvent(stream_, slot.dec_done, 0));
+  slot.kt_cls.clear();
+  slot.kt_flops.clear();
+  slot.kt_bytes.clear();
+  slot.batch = batch;
+  HIPCHK(hipEventRecord(slot.enc_begin, stream_));
   kt_begin(kKcTranspose, 0, 2.0 * batch * c.n_mels * T0 * 4);
   launch_mel_transpose(d_mel, ws_.melT, batch, c.n_mels, T0, stream_);
   kt_end();
@@ -581,27 +617,57 @@ void Engine::encode(const float* d_mel, int batch) {
   kt_begin(kKcLayerNorm, 0, 2.0 * M * d * 4);
   launch_layernorm(ws_.x, ws_.enc_out, enc_ln_post_g, enc_ln_post_b, M, d, stream_);
   kt_end();
-  HIPCHK(hipEventRecord(ev_[3], stream_));
+  HIPCHK(hipEventRecord(slot.enc_mid, stream_));
   {
     // cross-attention K/V of every decoder layer, projected once per clip into the
     // persistent cache [layer][k|v][clip][head][t][64] (the reference recomputes them
     // inside every decoder Invoke(), whisper.cpp:375)
     GemmArgs g;
-    g.A = ws_.enc_out; g.lda = d; g.W = cross_kv_w; g.bias = cross_kv_b; g.C = ws_.cross_kv;
+    g.A = ws_.enc_out; g.lda = d; g.W = cross_kv_w; g.bias = cross_kv_b; g.C = slot.cross_kv;
     g.M = M; g.N = c.n_text_layer * 2 * d; g.K = d;
     g.c_rpb = T; g.kv_batch = batch; g.kv_heads = c.n_text_head; g.kv_dmodel = d;
     kt_begin(kKcGemm, 2.0 * g.M * g.N * g.K, 0);
     launch_gemm(g, kEpiBias | kEpiKvLayout, stream_);
     kt_end();
   }
-  HIPCHK(hipEventRecord(ev_[4], stream_));
+  HIPCHK(hipEventRecord(slot.enc_done, stream_));
+  slot.used = true;
+  last_enc_slot_ = enc_slot_;
+  enc_slot_ ^= 1;
 }
 
 // ------------------------------------------------------------ decoder ---
 
 void Engine::decode(int batch, int64_t* ids, int32_t* n_ids, float* logits_host,
                     int logits_steps_cap) {
+  if (!inflight_.empty()) throw Error(1, "collect the submitted batches before a synchronous call");
+  decode_enqueue(batch, last_enc_slot_, logits_host, logits_steps_cap);
+  decode_collect(last_enc_slot_, ids, n_ids);
+}
+
+void Engine::submit(const float* d_mel, int batch) {
+  if (inflight_.size() >= 2) throw Error(1, "pipeline is two batches deep: collect() first");
+  if (batch > 64) throw Error(1, "decoder batches are limited to 64 clips per call");
+  encode(d_mel, batch);
+  decode_enqueue(batch, last_enc_slot_, nullptr, 0);
+  inflight_.push_back(last_enc_slot_);
+}
+
+void Engine::collect(int64_t* ids, int32_t* n_ids) {
+  if (inflight_.empty()) throw Error(1, "collect() without a submitted batch");
+  const int slot = inflight_.front();
+  inflight_.erase(inflight_.begin());
+  decode_collect(slot, ids, n_ids);
+}
+
+void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int logits_steps_cap) {
   ensure_batch(batch);
+  Slot& slot = slots_[slot_idx];
+  hipStream_t const stream_ = dstream_;  // everything below runs on the decoder stream
+  HIPCHK(hipStreamWaitEvent(stream_, slot.enc_done, 0));
+  HIPCHK(hipEventRecord(slot.dec_begin, stream_));
+  long long* const h_ids_ = slot.h_ids;
+  int* const h_n_ = slot.h_n;
   if (batch > 64) throw Error(1, "decoder batches are limited to 64 clips per call");
   const wtw::Dims& c = dims_;
   const int d = c.n_text_state, T = c.n_audio_ctx, H = c.n_text_head, V = c.n_vocab;
@@ -667,8 +733,8 @@ void Engine::decode(int batch, int64_t* ids, int32_t* n_ids, float* logits_host,
       cq.bias = w.cross.bq; cq.Y = ws_.qd; cq.ldy = d;
       launch_dec_gemm(cq, kProLn, kDecBias, stream_);
       std::swap(xin, xout);
-      launch_cross_attention(ws_.qd, ws_.cross_kv + (size_t(l) * 2 + 0) * kv_slab,
-                             ws_.cross_kv + (size_t(l) * 2 + 1) * kv_slab, ws_.cross_ws, batch, H, T,
+      launch_cross_attention(ws_.qd, slot.cross_kv + (size_t(l) * 2 + 0) * kv_slab,
+                             slot.cross_kv + (size_t(l) * 2 + 1) * kv_slab, ws_.cross_ws, batch, H, T,
                              chunks, stream_);
       DecGemmArgs co;  // chunk combine + cross out-projection -> slabs
       co.Wt = w.cross.wo; co.N = d; co.K = d; co.B = batch; co.ksplit = ks;
@@ -709,24 +775,31 @@ void Engine::decode(int batch, int64_t* ids, int32_t* n_ids, float* logits_host,
       ++steps;
     }
   }
-  HIPCHK(hipEventRecord(ev_[5], stream_));
   HIPCHK(hipMemcpyAsync(h_ids_, ws_.ids, size_t(batch) * stride * sizeof(long long),
                         hipMemcpyDeviceToHost, stream_));
   HIPCHK(hipMemcpyAsync(h_n_, ws_.n_ids, size_t(batch) * sizeof(int), hipMemcpyDeviceToHost, stream_));
-  HIPCHK(hipStreamSynchronize(stream_));
+  HIPCHK(hipEventRecord(slot.dec_done, stream_));
+  slot.steps = steps;
+}
+
+void Engine::decode_collect(int slot_idx, int64_t* ids, int32_t* n_ids) {
+  Slot& slot = slots_[slot_idx];
+  HIPCHK(hipEventSynchronize(slot.dec_done));
   HIPCHK(hipGetLastError());
+  const int batch = slot.batch, stride = 32;
   for (int b = 0; b < batch; ++b) {
-    n_ids[b] = h_n_[b];
-    for (int i = 0; i < stride; ++i) ids[size_t(b) * stride + i] = i < h_n_[b] ? h_ids_[size_t(b) * stride + i] : 0;
+    n_ids[b] = slot.h_n[b];
+    for (int i = 0; i < stride; ++i)
+      ids[size_t(b) * stride + i] = i < slot.h_n[b] ? slot.h_ids[size_t(b) * stride + i] : 0;
   }
-  resolve_kernel_stats();
+  resolve_kernel_stats(slot_idx);
   float ms = 0;
   timings_.batch = batch;
-  timings_.decoder_steps = steps;
-  if (hipEventElapsedTime(&ms, ev_[2], ev_[3]) == hipSuccess) timings_.encoder_ms = ms;
-  if (hipEventElapsedTime(&ms, ev_[3], ev_[4]) == hipSuccess) timings_.cross_kv_ms = ms;
-  if (hipEventElapsedTime(&ms, ev_[4], ev_[5]) == hipSuccess) timings_.decoder_ms = ms;
-  if (hipEventElapsedTime(&ms, ev_[2], ev_[5]) == hipSuccess) timings_.total_ms = ms;
+  timings_.decoder_steps = slot.steps;
+  if (hipEventElapsedTime(&ms, slot.enc_begin, slot.enc_mid) == hipSuccess) timings_.encoder_ms = ms;
+  if (hipEventElapsedTime(&ms, slot.enc_mid, slot.enc_done) == hipSuccess) timings_.cross_kv_ms = ms;
+  if (hipEventElapsedTime(&ms, slot.dec_begin, slot.dec_done) == hipSuccess) timings_.decoder_ms = ms;
+  if (hipEventElapsedTime(&ms, slot.enc_begin, slot.dec_done) == hipSuccess) timings_.total_ms = ms;
   if (timings_.logmel_ms < 0) {
     timings_.logmel_ms = 0;
     if (hipEventElapsedTime(&ms, ev_[0], ev_[1]) == hipSuccess) timings_.logmel_ms = ms;

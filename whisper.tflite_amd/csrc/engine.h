@@ -81,10 +81,18 @@ class Engine {
 
   // d_pcm [B][pcm_elems] -> d_mel [B][n_mels][frames]; device pointers, async on stream()
   void logmel(const float* d_pcm, int batch, float* d_mel);
-  // d_mel -> encoder output (internal) -> cross KV cache (internal); async
+  // d_mel -> encoder output (internal) -> cross KV cache of the next pipeline slot; async on
+  // the encoder stream
   void encode(const float* d_mel, int batch);
-  // greedy loop; fills pinned host staging and synchronises.  ids [B][32], n [B].
+  // greedy loop over the slot encode() just filled, on the decoder stream; synchronises and
+  // returns ids [B][32], n [B].
   void decode(int batch, int64_t* ids, int32_t* n_ids, float* logits_host, int logits_steps_cap);
+  // Two-deep pipeline: submit() enqueues encoder (stream E) + decoder (stream D, higher
+  // priority) for one batch and returns; the encoder of batch i+1 then overlaps the
+  // latency-bound decoder of batch i.  collect() waits for the OLDEST submitted batch.
+  void submit(const float* d_mel, int batch);
+  void collect(int64_t* ids, int32_t* n_ids);
+  int in_flight() const { return int(inflight_.size()); }
   void sync();
 
   const float* enc_out() const { return ws_.enc_out; }
@@ -97,7 +105,6 @@ class Engine {
 
   // Resolved by decode()/sync_stats(); index = KernelClass.
   const KernelStat* kernel_stats() const { return kstats_; }
-  void resolve_kernel_stats();
 
  private:
   void upload_weights(const std::string& path);
@@ -105,9 +112,28 @@ class Engine {
   float* upload(const std::vector<float>& host);
   void build_frontend_tables();
 
+  void decode_enqueue(int batch, int slot, float* logits_host, int logits_steps_cap);
+  void decode_collect(int slot, int64_t* ids, int32_t* n_ids);
+
   int device_ = 0;
-  hipStream_t stream_ = nullptr;
-  hipEvent_t ev_[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipStream_t stream_ = nullptr;   // encoder + front end
+  hipStream_t dstream_ = nullptr;  // decoder
+  hipEvent_t ev_[2] = {nullptr, nullptr};  // front end begin / end
+  struct Slot {
+    float* cross_kv = nullptr;  // [layer][k|v][clip][head][t][64]
+    hipEvent_t enc_begin = nullptr, enc_mid = nullptr, enc_done = nullptr;
+    hipEvent_t dec_begin = nullptr, dec_done = nullptr;
+    long long* h_ids = nullptr;  // pinned [4096][32]
+    int* h_n = nullptr;          // pinned [4096]
+    int batch = 0, steps = 0;
+    bool used = false;
+    std::vector<hipEvent_t> kt_events;
+    std::vector<int> kt_cls;
+    std::vector<double> kt_flops, kt_bytes;
+  } slots_[2];
+  int enc_slot_ = 0;        // slot the next encode() fills
+  int last_enc_slot_ = 0;   // slot the last encode() filled
+  std::vector<int> inflight_;
   wtw::Dims dims_{};
   VocabData vocab_;
   FilterBank filters_;
@@ -133,7 +159,7 @@ class Engine {
   struct Workspace {
     int batch = 0;
     float *melT = nullptr, *h1p = nullptr, *x = nullptr, *ln = nullptr, *qkv = nullptr,
-          *att = nullptr, *hid = nullptr, *enc_out = nullptr, *cross_kv = nullptr;
+          *att = nullptr, *hid = nullptr, *enc_out = nullptr;
     // decoder
     float *xd = nullptr, *xd2 = nullptr, *slabs = nullptr, *lnd = nullptr, *qkvd = nullptr, *attd = nullptr, *qd = nullptr,
           *hd = nullptr, *cross_ws = nullptr, *self_kv = nullptr, *logits = nullptr;
@@ -146,20 +172,16 @@ class Engine {
     float *mel_stage = nullptr, *pcm_stage = nullptr;
     std::vector<void*> owned;
   } ws_;
-  // kernel-class timer
+  // kernel-class timer (events live in the pipeline slot being encoded)
   void kt_begin(int cls, double flops, double bytes);
   void kt_end();
-  struct KtRec { int cls; int ev; double flops, bytes; };
-  std::vector<hipEvent_t> kt_events_;
-  std::vector<KtRec> kt_recs_;
+  void resolve_kernel_stats(int slot);
   KernelStat kstats_[kKcCount] = {{"gemm_f32_128x128", 0, 0, 0, 0},
                                   {"encoder_attention_f32", 0, 0, 0, 0},
                                   {"layernorm_rows", 0, 0, 0, 0},
                                   {"mel_transpose", 0, 0, 0, 0}};
   int self_cap_ = 32;
-  int dec_ksplit_ = 4;  // split-K blocks of the decoder's N = d GEMMs
-  long long* h_ids_ = nullptr;  // pinned
-  int* h_n_ = nullptr;          // pinned
+  int dec_ksplit_ = 4;  // == kDecSlabs (kernels.h): split-K blocks of the decoder's N = d GEMMs
 };
 
 }  // namespace wt

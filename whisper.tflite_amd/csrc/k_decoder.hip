@@ -7,12 +7,14 @@
 // maximises loads in flight per launch:
 //   * weights are pre-tiled at load time into MFMA-fragment order ([tile][k/8][lane][4]), so
 //     one wave-instruction reads 1 KiB contiguous and a wave issues ALL its weight loads
-//     (<= 12 x 16 B per lane) before the first MFMA — operand streamed once, straight to VGPRs;
+//     (<= 12 x 16 B per lane) before anything else — operand streamed once, straight to VGPRs;
 //   * every block = 4 wavefronts splitting K, combined through LDS; narrow outputs also split
 //     K over blockIdx.y into partial slabs that the NEXT kernel's prologue sums in a fixed
 //     order (deterministic, no atomics, no separate reduce launch);
 //   * prologues fuse what used to be separate launches: residual update + LayerNorm
-//     (+ token/positional embedding at layer 0), and the cross-attention chunk combine.
+//     (+ token/positional embedding at layer 0), and the cross-attention chunk combine;
+//   * every trip count that guards a load is a template constant: a runtime-predicated load
+//     makes hipcc branch around it and wait vmcnt(0) per element (measured: 6x slower).
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
@@ -23,13 +25,10 @@ namespace {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
+constexpr int kGroup = 12;  // weight chunks (8 k each) a wave keeps in flight
+
 __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
-}
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
 }
 __device__ __forceinline__ unsigned ordered_bits(float v) {
   v = v + 0.0f;  // -0.0 -> +0.0 so that equal values compare equal
@@ -44,7 +43,6 @@ struct DecGemmDev {
   int ldx;
   const float* xin;
   const float* slabs_in;
-  int n_slabs_in;
   const float* bias_in;
   float* xout;
   const float* ln_g;
@@ -57,20 +55,87 @@ struct DecGemmDev {
   const float* cross_ws;
   int heads, chunks;
   const float* bias;
+  int gelu;
   float* Y;
   int ldy;
   float* slab_out;
   unsigned long long* best;
 };
 
-constexpr int kGroup = 12;    // weight chunks (8 k each) a wave keeps in flight
-constexpr int kMaxSlabs = 4;  // split-K slabs a prologue can fold in
+// Row sources of the residual stream.  LNMODE 0: x = xin;  1: x = xin + bias_in + the
+// kDecSlabs split-K slabs of the pending Linear (fixed order);  2: x = tok_emb[id] + pos_emb.
+struct RowSrc {
+  const float* xin;
+  const float* bias_in;
+  const float* slabs_in;
+  const long long* ids;
+  int ids_stride, pos;
+  const float* tok_emb;
+  const float* pos_emb;
+  int n_vocab;
+};
 
-template <int PRO, int EPI, int MT>
+// 8 lanes own one row (16-byte columns sub, sub + 8, ...); all NF4 * (1 + 1 + kDecSlabs) loads
+// of the row are independent and issued before the first use.
+template <int NF4, int LNMODE>
+__device__ __forceinline__ void load_row(f32x4 (&v)[NF4], const RowSrc& r, int row, int sub, int B,
+                                         int K) {
+  const float* src = r.xin + (long)row * K;
+  if (LNMODE == 2) {
+    long long id = r.ids[(long)row * r.ids_stride + r.pos];
+    id = id < 0 ? 0 : (id >= r.n_vocab ? r.n_vocab - 1 : id);  // never index outside the table
+    src = r.tok_emb + id * K;
+  }
+#pragma unroll
+  for (int j = 0; j < NF4; ++j) v[j] = *reinterpret_cast<const f32x4*>(src + (sub + 8 * j) * 4);
+  if (LNMODE == 2) {
+    const float* pe = r.pos_emb + (long)r.pos * K;
+#pragma unroll
+    for (int j = 0; j < NF4; ++j) v[j] += *reinterpret_cast<const f32x4*>(pe + (sub + 8 * j) * 4);
+  }
+  if (LNMODE == 1) {
+#pragma unroll
+    for (int j = 0; j < NF4; ++j) v[j] += *reinterpret_cast<const f32x4*>(r.bias_in + (sub + 8 * j) * 4);
+#pragma unroll
+    for (int sl = 0; sl < kDecSlabs; ++sl) {
+      const float* sp = r.slabs_in + ((long)sl * B + row) * K;
+#pragma unroll
+      for (int j = 0; j < NF4; ++j) v[j] += *reinterpret_cast<const f32x4*>(sp + (sub + 8 * j) * 4);
+    }
+  }
+}
+
+// LayerNorm statistics of a row spread over 8 lanes (two-pass, eps 1e-5).
+template <int NF4>
+__device__ __forceinline__ void row_stats(const f32x4 (&v)[NF4], int K, float* mean, float* rstd) {
+  float s = 0.0f;
+#pragma unroll
+  for (int j = 0; j < NF4; ++j) s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+  s += __shfl_xor(s, 1, 64);
+  s += __shfl_xor(s, 2, 64);
+  s += __shfl_xor(s, 4, 64);
+  const float m = s / (float)K;
+  float q = 0.0f;
+#pragma unroll
+  for (int j = 0; j < NF4; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float t = v[j][e] - m;
+      q += t * t;
+    }
+  q += __shfl_xor(q, 1, 64);
+  q += __shfl_xor(q, 2, 64);
+  q += __shfl_xor(q, 4, 64);
+  *mean = m;
+  *rstd = rsqrtf(q / (float)K + 1e-5f);
+}
+
+// PRO: kProNone / kProLn / kProCombine; LNMODE as above (kProLn only); NF4 = K / 32 (kProLn only).
+template <int PRO, int EPI, int MT, int NF4, int LNMODE>
 __global__ __launch_bounds__(256) void dec_gemm(DecGemmDev g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* red = smem;                       // [3][MT][16][64] split-K partials of waves 1..3
-  float* xs = smem + 3 * MT * 16 * 64;     // [MT*32][K + 4] LayerNorm rows (kProLn)
+  float* red = smem;                    // [3][MT][16][64] split-K partials of waves 1..3
+  float* xs = smem + 3 * MT * 16 * 64;  // [MT*32][K + 4] LayerNorm rows (kProLn)
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
   const int tile = blockIdx.x, ky = blockIdx.y;
@@ -80,99 +145,49 @@ __global__ __launch_bounds__(256) void dec_gemm(DecGemmDev g) {
   const int k0 = ky * kblock + wid * kwave;
   const int nchunks = kwave >> 3;
   const float* wp = g.Wt + ((long)tile * (K >> 3) + (k0 >> 3)) * 256 + lane * 4;
-  // the weight stream does not depend on the prologue: put its first group in flight now so
-  // that its HBM/L2 latency overlaps the residual / LayerNorm / combine work below
+  // the weight stream does not depend on the prologue: its first group goes in flight now so
+  // that its HBM/L2 latency overlaps the residual / LayerNorm / combine work below.  Chunks
+  // past nchunks re-read the last valid chunk (no branch around a load) and are never used.
   f32x4 w[kGroup];
 #pragma unroll
-  for (int i = 0; i < kGroup; ++i)
-    if (i < nchunks) w[i] = *reinterpret_cast<const f32x4*>(wp + (long)i * 256);
+  for (int i = 0; i < kGroup; ++i) {
+    const int ci = i < nchunks ? i : nchunks - 1;
+    w[i] = *reinterpret_cast<const f32x4*>(wp + (long)ci * 256);
+  }
 
   if (PRO == kProLn) {
-    // x = x_old (+ bias of the producing Linear) (+ its split-K slabs, fixed order); the
-    // residual stream is written back once; LayerNorm rows land in LDS.  8 lanes own one
-    // row (16-byte columns sub, sub+8, ...), a wavefront owns 8 rows at once, and every load
-    // of a pass is issued before the first reduction: one memory round trip per pass.
+    // residual update + LayerNorm; a wavefront handles 8 rows at once, one round trip per pass
     const bool writer = blockIdx.x == 0 && blockIdx.y == 0 && g.xout != nullptr;
     const int r8 = lane >> 3, sub = lane & 7;
-    const int nf4 = K >> 5;  // float4 per lane per row (<= 16 for K <= 512)
+    const RowSrc src{g.xin, g.bias_in, g.slabs_in, g.ids, g.ids_stride, g.pos, g.tok_emb, g.pos_emb, g.n_vocab};
+    constexpr int NV = NF4 > 0 ? NF4 : 1;
 #pragma unroll 1
     for (int pass = 0; pass < MT; ++pass) {
       const int row = pass * 32 + wid * 8 + r8;
-      f32x4 v[16];
+      f32x4 v[NV];
       if (row < B) {
-        const float* src = g.xin + (long)row * K;
-        const float* pe = nullptr;
-        if (g.ids) {
-          long long id = g.ids[(long)row * g.ids_stride + g.pos];
-          id = id < 0 ? 0 : (id >= g.n_vocab ? g.n_vocab - 1 : id);
-          src = g.tok_emb + id * K;
-          pe = g.pos_emb + (long)g.pos * K;
+        load_row<NV, LNMODE>(v, src, row, sub, B, K);
+        if (writer) {
+#pragma unroll
+          for (int j = 0; j < NV; ++j)
+            *reinterpret_cast<f32x4*>(g.xout + (long)row * K + (sub + 8 * j) * 4) = v[j];
         }
+        float mean, rstd;
+        row_stats<NV>(v, K, &mean, &rstd);
 #pragma unroll
-        for (int j = 0; j < 16; ++j)
-          if (j < nf4) v[j] = *reinterpret_cast<const f32x4*>(src + (sub + 8 * j) * 4);
-        if (pe) {
+        for (int j = 0; j < NV; ++j) {
+          const int c = (sub + 8 * j) * 4;
+          const f32x4 gg = *reinterpret_cast<const f32x4*>(g.ln_g + c);
+          const f32x4 bb = *reinterpret_cast<const f32x4*>(g.ln_b + c);
+          f32x4 o;
 #pragma unroll
-          for (int j = 0; j < 16; ++j)
-            if (j < nf4) v[j] += *reinterpret_cast<const f32x4*>(pe + (sub + 8 * j) * 4);
-        }
-        if (g.bias_in) {
-#pragma unroll
-          for (int j = 0; j < 16; ++j)
-            if (j < nf4) v[j] += *reinterpret_cast<const f32x4*>(g.bias_in + (sub + 8 * j) * 4);
-        }
-#pragma unroll
-        for (int sl = 0; sl < kMaxSlabs; ++sl) {  // fixed order; bound known at compile time
-          if (sl < g.n_slabs_in) {
-            const float* sp = g.slabs_in + ((long)sl * B + row) * K;
-#pragma unroll
-            for (int j = 0; j < 16; ++j)
-              if (j < nf4) v[j] += *reinterpret_cast<const f32x4*>(sp + (sub + 8 * j) * 4);
-          }
-        }
-        float s = 0.0f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          if (j < nf4) {
-            if (writer) *reinterpret_cast<f32x4*>(g.xout + (long)row * K + (sub + 8 * j) * 4) = v[j];
-            s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
-          }
-        }
-        s += __shfl_xor(s, 1, 64);
-        s += __shfl_xor(s, 2, 64);
-        s += __shfl_xor(s, 4, 64);
-        const float mean = s / (float)K;
-        float q = 0.0f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          if (j < nf4) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float t = v[j][e] - mean;
-              q += t * t;
-            }
-          }
-        }
-        q += __shfl_xor(q, 1, 64);
-        q += __shfl_xor(q, 2, 64);
-        q += __shfl_xor(q, 4, 64);
-        const float rstd = rsqrtf(q / (float)K + 1e-5f);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          if (j < nf4) {
-            const int c = (sub + 8 * j) * 4;
-            const f32x4 gg = *reinterpret_cast<const f32x4*>(g.ln_g + c);
-            const f32x4 bb = *reinterpret_cast<const f32x4*>(g.ln_b + c);
-            f32x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (v[j][e] - mean) * rstd * gg[e] + bb[e];
-            *reinterpret_cast<f32x4*>(&xs[row * xld + c]) = o;
-          }
+          for (int e = 0; e < 4; ++e) o[e] = (v[j][e] - mean) * rstd * gg[e] + bb[e];
+          *reinterpret_cast<f32x4*>(&xs[row * xld + c]) = o;
         }
       } else {
 #pragma unroll
-        for (int j = 0; j < 16; ++j)
-          if (j < nf4) *reinterpret_cast<f32x4*>(&xs[row * xld + (sub + 8 * j) * 4]) = f32x4{0, 0, 0, 0};
+        for (int j = 0; j < NV; ++j)
+          *reinterpret_cast<f32x4*>(&xs[row * xld + (sub + 8 * j) * 4]) = f32x4{0, 0, 0, 0};
       }
     }
     __syncthreads();
@@ -205,10 +220,10 @@ __global__ __launch_bounds__(256) void dec_gemm(DecGemmDev g) {
             for (int c = 0; c < g.chunks; ++c) mx = fmaxf(mx, p[c * 68 + 64]);
             float l = 0.0f;
             for (int c = 0; c < g.chunks; ++c) {
-              const float w = __expf(p[c * 68 + 64] - mx);
+              const float wgt = __expf(p[c * 68 + 64] - mx);
               const f32x4 pv = *reinterpret_cast<const f32x4*>(p + c * 68 + dd);
-              o += w * pv;
-              l += w * p[c * 68 + 65];
+              o += wgt * pv;
+              l += wgt * p[c * 68 + 65];
             }
             const float inv = 1.0f / l;
             o *= inv;
@@ -218,6 +233,7 @@ __global__ __launch_bounds__(256) void dec_gemm(DecGemmDev g) {
       }
     }
   }
+
   f32x16 acc[MT];
 #pragma unroll
   for (int t = 0; t < MT; ++t)
@@ -227,8 +243,21 @@ __global__ __launch_bounds__(256) void dec_gemm(DecGemmDev g) {
   for (int c0 = 0; c0 < nchunks; c0 += kGroup) {
     if (c0 > 0) {
 #pragma unroll
-      for (int i = 0; i < kGroup; ++i)
-        if (c0 + i < nchunks) w[i] = *reinterpret_cast<const f32x4*>(wp + (long)(c0 + i) * 256);
+      for (int i = 0; i < kGroup; ++i) {
+        const int ci = c0 + i < nchunks ? c0 + i : nchunks - 1;
+        w[i] = *reinterpret_cast<const f32x4*>(wp + (long)ci * 256);
+      }
+    }
+    // kProNone reads its A fragments from global memory: issue them all, unguarded (clamped
+    // index), before the first MFMA
+    f32x4 xg[PRO == kProNone ? kGroup : 1][MT];
+    if (PRO == kProNone) {
+#pragma unroll
+      for (int i = 0; i < kGroup; ++i) {
+        const int ci = c0 + i < nchunks ? c0 + i : nchunks - 1;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) xg[i][t] = *reinterpret_cast<const f32x4*>(xp[t] + ci * 8);
+      }
     }
 #pragma unroll
     for (int i = 0; i < kGroup; ++i) {
@@ -238,6 +267,8 @@ __global__ __launch_bounds__(256) void dec_gemm(DecGemmDev g) {
         for (int t = 0; t < MT; ++t) {
           if (PRO == kProCombine) {
             x[t] = xa[i][t];
+          } else if (PRO == kProNone) {
+            x[t] = xg[i][t];
           } else {
             x[t] = *reinterpret_cast<const f32x4*>(xp[t] + (c0 + i) * 8);
           }
@@ -260,22 +291,22 @@ __global__ __launch_bounds__(256) void dec_gemm(DecGemmDev g) {
   __syncthreads();
   if (wid > 0) return;
 #pragma unroll
-  for (int w = 0; w < 3; ++w)  // fixed order: wave 1, 2, 3
+  for (int wv = 0; wv < 3; ++wv)  // fixed order: wave 1, 2, 3
 #pragma unroll
     for (int t = 0; t < MT; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][r] += red[((w * MT + t) * 16 + r) * 64 + lane];
+      for (int r = 0; r < 16; ++r) acc[t][r] += red[((wv * MT + t) * 16 + r) * 64 + lane];
 
   const int n = tile * 32 + l31;
   const bool n_ok = n < g.N;
-  const float bias = (EPI == kDecBias || EPI == kDecBiasGelu) && n_ok ? g.bias[n] : 0.0f;
+  const float bias = (EPI == kDecBias && n_ok) ? g.bias[n] : 0.0f;
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int b = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
       float v = acc[t][r] + bias;
-      if (EPI == kDecBiasGelu) v = gelu_erf(v);
+      if (EPI == kDecBias && g.gelu) v = gelu_erf(v);
       const bool ok = n_ok && b < B;
       if (EPI == kDecSlab) {
         if (ok) g.slab_out[((long)ky * B + b) * g.N + n] = v;
@@ -299,125 +330,109 @@ __global__ __launch_bounds__(256) void dec_gemm(DecGemmDev g) {
 }
 
 // x = xin + bias + sum(slabs) -> LayerNorm -> y   (input rows of the logits GEMM).
-// Same row layout as the kProLn prologue: 8 lanes per row, every load in flight at once.
-__global__ __launch_bounds__(256) void dec_finalize_ln(const float* __restrict__ xin,
-                                                       const float* __restrict__ slabs, int n_slabs,
-                                                       const float* __restrict__ bias,
-                                                       const float* __restrict__ g,
+template <int NF4>
+__global__ __launch_bounds__(256) void dec_finalize_ln(RowSrc src, const float* __restrict__ g,
                                                        const float* __restrict__ b,
                                                        float* __restrict__ y, int B, int K) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int r8 = lane >> 3, sub = lane & 7;
   const int row = blockIdx.x * 32 + wid * 8 + r8;
-  const int nf4 = K >> 5;
-  if (row >= B) return;  // whole 8-lane groups leave together; the shuffles below stay inside a group
-  f32x4 v[16];
+  if (row >= B) return;  // whole 8-lane groups leave together; the shuffles stay inside a group
+  f32x4 v[NF4];
+  load_row<NF4, 1>(v, src, row, sub, B, K);
+  float mean, rstd;
+  row_stats<NF4>(v, K, &mean, &rstd);
 #pragma unroll
-  for (int j = 0; j < 16; ++j)
-    if (j < nf4) v[j] = *reinterpret_cast<const f32x4*>(xin + (long)row * K + (sub + 8 * j) * 4);
-  if (bias) {
+  for (int j = 0; j < NF4; ++j) {
+    const int c = (sub + 8 * j) * 4;
+    const f32x4 gg = *reinterpret_cast<const f32x4*>(g + c);
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(b + c);
+    f32x4 o;
 #pragma unroll
-    for (int j = 0; j < 16; ++j)
-      if (j < nf4) v[j] += *reinterpret_cast<const f32x4*>(bias + (sub + 8 * j) * 4);
-  }
-#pragma unroll
-  for (int sl = 0; sl < kMaxSlabs; ++sl) {
-    if (sl < n_slabs) {
-      const float* sp = slabs + ((long)sl * B + row) * K;
-#pragma unroll
-      for (int j = 0; j < 16; ++j)
-        if (j < nf4) v[j] += *reinterpret_cast<const f32x4*>(sp + (sub + 8 * j) * 4);
-    }
-  }
-  float s = 0.0f;
-#pragma unroll
-  for (int j = 0; j < 16; ++j)
-    if (j < nf4) s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
-  s += __shfl_xor(s, 1, 64);
-  s += __shfl_xor(s, 2, 64);
-  s += __shfl_xor(s, 4, 64);
-  const float mean = s / (float)K;
-  float q = 0.0f;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    if (j < nf4) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float t = v[j][e] - mean;
-        q += t * t;
-      }
-    }
-  }
-  q += __shfl_xor(q, 1, 64);
-  q += __shfl_xor(q, 2, 64);
-  q += __shfl_xor(q, 4, 64);
-  const float rstd = rsqrtf(q / (float)K + 1e-5f);
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    if (j < nf4) {
-      const int c = (sub + 8 * j) * 4;
-      const f32x4 gg = *reinterpret_cast<const f32x4*>(g + c);
-      const f32x4 bb = *reinterpret_cast<const f32x4*>(b + c);
-      f32x4 o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (v[j][e] - mean) * rstd * gg[e] + bb[e];
-      *reinterpret_cast<f32x4*>(y + (long)row * K + c) = o;
-    }
+    for (int e = 0; e < 4; ++e) o[e] = (v[j][e] - mean) * rstd * gg[e] + bb[e];
+    *reinterpret_cast<f32x4*>(y + (long)row * K + c) = o;
   }
 }
 
-template <int PRO, int EPI>
-void launch_t(const DecGemmDev& g, hipStream_t s) {
+template <int PRO, int EPI, int NF4, int LNMODE>
+void launch_mt(const DecGemmDev& g, hipStream_t s) {
   const int n_tiles = (g.N + 31) / 32;
   const int MT = g.B <= 32 ? 1 : 2;
   const size_t smem = (size_t)(3 * MT * 16 * 64 + (PRO == kProLn ? MT * 32 * (g.K + 4) : 0)) * sizeof(float);
   const dim3 grid(n_tiles, g.ksplit);
   // dynamic LDS beyond the 64 KiB default needs an opt-in, once per kernel
   static const bool raised = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_gemm<PRO, EPI, 1>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_gemm<PRO, EPI, 1, NF4, LNMODE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_gemm<PRO, EPI, 2>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_gemm<PRO, EPI, 2, NF4, LNMODE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return true;
   }();
   (void)raised;
   if (MT == 1) {
-    hipLaunchKernelGGL((dec_gemm<PRO, EPI, 1>), grid, dim3(256), smem, s, g);
+    hipLaunchKernelGGL((dec_gemm<PRO, EPI, 1, NF4, LNMODE>), grid, dim3(256), smem, s, g);
   } else {
-    hipLaunchKernelGGL((dec_gemm<PRO, EPI, 2>), grid, dim3(256), smem, s, g);
+    hipLaunchKernelGGL((dec_gemm<PRO, EPI, 2, NF4, LNMODE>), grid, dim3(256), smem, s, g);
+  }
+}
+
+template <int LNMODE>
+void launch_ln(const DecGemmDev& g, hipStream_t s) {
+  switch (g.K) {
+    case 128: launch_mt<kProLn, kDecBias, 4, LNMODE>(g, s); break;
+    case 384: launch_mt<kProLn, kDecBias, 12, LNMODE>(g, s); break;
+    case 512: launch_mt<kProLn, kDecBias, 16, LNMODE>(g, s); break;
+    default: abort();  // d_model of the supported architectures (micro / tiny / base)
   }
 }
 
 }  // namespace
 
 void launch_dec_gemm(const DecGemmArgs& a, int pro, int epi, hipStream_t s) {
-  DecGemmDev g{a.Wt,     a.N,      a.K,       a.B,         a.ksplit, a.X,        a.ldx,      a.xin,
-               a.slabs_in, a.n_slabs_in, a.bias_in, a.xout, a.ln_g,   a.ln_b,     a.ids,      a.ids_stride,
-               a.pos,    a.tok_emb, a.pos_emb, a.n_vocab,  a.cross_ws, a.heads,  a.chunks,   a.bias,
-               a.Y,      a.ldy,    a.slab_out, a.best};
-  if (a.B < 1 || a.B > 64 || a.K > 512 * 4 || (pro != kProNone && a.K > 512) || a.ksplit < 1 ||
-      a.K % (32 * a.ksplit) != 0 || (epi != kDecSlab && a.ksplit != 1) ||
-      (pro == kProCombine && a.K / (32 * a.ksplit) > kGroup) || a.n_slabs_in > kMaxSlabs) {
-    abort();  // host-side shape contract: operands must match what the kernel indexes
+  const int gelu = epi == kDecBiasGelu ? 1 : 0;
+  if (epi == kDecBiasGelu) epi = kDecBias;
+  DecGemmDev g{a.Wt,      a.N,       a.K,       a.B,        a.ksplit, a.X,      a.ldx,        a.xin,
+               a.slabs_in, a.bias_in, a.xout,   a.ln_g,     a.ln_b,   a.ids,    a.ids_stride, a.pos,
+               a.tok_emb, a.pos_emb, a.n_vocab, a.cross_ws, a.heads,  a.chunks, a.bias,       gelu,
+               a.Y,       a.ldy,     a.slab_out, a.best};
+  // host-side shape contract: operands must match what the kernel indexes
+  if (a.B < 1 || a.B > 64 || a.K > 2048 || a.ksplit < 1 || a.K % (32 * a.ksplit) != 0 ||
+      (epi != kDecSlab && a.ksplit != 1) || (pro == kProCombine && a.K / (32 * a.ksplit) > kGroup) ||
+      (a.n_slabs_in != 0 && a.n_slabs_in != kDecSlabs) || (a.n_slabs_in != 0 && !a.bias_in)) {
+    abort();
+  }
+  if (pro == kProLn) {
+    if (epi != kDecBias) abort();
+    if (a.ids) {
+      launch_ln<2>(g, s);
+    } else if (a.n_slabs_in) {
+      launch_ln<1>(g, s);
+    } else {
+      launch_ln<0>(g, s);
+    }
+    return;
   }
   const int key = pro * 8 + epi;
   switch (key) {
-    case kProNone * 8 + kDecSlab: launch_t<kProNone, kDecSlab>(g, s); break;
-    case kProNone * 8 + kDecBias: launch_t<kProNone, kDecBias>(g, s); break;
-    case kProNone * 8 + kDecBiasGelu: launch_t<kProNone, kDecBiasGelu>(g, s); break;
-    case kProNone * 8 + kDecLogits: launch_t<kProNone, kDecLogits>(g, s); break;
-    case kProLn * 8 + kDecBias: launch_t<kProLn, kDecBias>(g, s); break;
-    case kProLn * 8 + kDecBiasGelu: launch_t<kProLn, kDecBiasGelu>(g, s); break;
-    case kProCombine * 8 + kDecSlab: launch_t<kProCombine, kDecSlab>(g, s); break;
+    case kProNone * 8 + kDecSlab: launch_mt<kProNone, kDecSlab, 0, 0>(g, s); break;
+    case kProNone * 8 + kDecBias: launch_mt<kProNone, kDecBias, 0, 0>(g, s); break;
+    case kProNone * 8 + kDecLogits: launch_mt<kProNone, kDecLogits, 0, 0>(g, s); break;
+    case kProCombine * 8 + kDecSlab: launch_mt<kProCombine, kDecSlab, 0, 0>(g, s); break;
     default: abort();
   }
 }
 
 void launch_dec_finalize_ln(const float* xin, const float* slabs, int n_slabs, const float* bias,
                             const float* g, const float* b, float* y, int B, int K, hipStream_t s) {
-  if (n_slabs > kMaxSlabs || K > 512 || K % 32 != 0) abort();  // shape contract of the kernel
-  hipLaunchKernelGGL(dec_finalize_ln, dim3((B + 31) / 32), dim3(256), 0, s, xin, slabs, n_slabs, bias, g, b,
-                     y, B, K);
+  if (n_slabs != kDecSlabs || !bias) abort();  // shape contract of the kernel
+  const RowSrc src{xin, bias, slabs, nullptr, 0, 0, nullptr, nullptr, 0};
+  const dim3 grid((B + 31) / 32);
+  switch (K) {
+    case 128: hipLaunchKernelGGL(dec_finalize_ln<4>, grid, dim3(256), 0, s, src, g, b, y, B, K); break;
+    case 384: hipLaunchKernelGGL(dec_finalize_ln<12>, grid, dim3(256), 0, s, src, g, b, y, B, K); break;
+    case 512: hipLaunchKernelGGL(dec_finalize_ln<16>, grid, dim3(256), 0, s, src, g, b, y, B, K); break;
+    default: abort();
+  }
 }
 
 }  // namespace wt

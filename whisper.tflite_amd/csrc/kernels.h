@@ -45,9 +45,10 @@ void launch_gemm(const GemmArgs& a, int epi, hipStream_t s);
 
 // Decoder-step GEMM: out[B][N] = epi(pro(x)[B][K] . W[N][K]^T), B <= 64 (k_decoder.hip).
 // Wt is W pre-tiled by tile_weights(): [ceil(N/32)][K/8][64 lanes][4].
+constexpr int kDecSlabs = 4;  // split-K slabs of the decoder's N = d_model GEMMs (ksplit)
 enum DecPro : int {
   kProNone = 0,    // A operand = X [B][K] (ldx) from global memory
-  kProLn = 1,      // x = xin (+bias_in) (+slabs_in[0..n)) [or token+positional embedding when
+  kProLn = 1,      // x = xin (+ bias_in + kDecSlabs slabs_in when n_slabs_in != 0) [or embedding when
                    // ids != nullptr]; block (0,0) stores x to xout; A = LayerNorm(x) * ln_g + ln_b
   kProCombine = 2  // A = combine of the cross-attention key-chunk partials cross_ws
 };
