@@ -12,14 +12,13 @@ extern "C" {
 int wt_dbg_gemm(wt_engine* h, int M, int N, int K, const float* A, const float* W, const float* bias,
                 const float* R, const float* pos, int pos_period, int epi, float* C);
 /* decoder-step GEMM (k_decoder.hip), plain input X[B][K], W[N][K] (tiled internally):
- * mode 0: Y = X.W^T + bias   1: gelu(...)   2: raw split-K slabs Y[ksplit][B][N]
+ * mode 0: Y = X.W^T + bias   1: gelu(...)   2: Y = R + bias + X.W^T (in-place residual form)
  * mode 3: Y = X.W^T and argmax_out[B] = last maximal column (reference tie rule) */
-int wt_dbg_dec_gemm(wt_engine* h, int mode, int B, int N, int K, int ksplit, const float* X,
-                    const float* W, const float* bias, float* Y, int64_t* argmax_out);
-/* LN-fused decoder GEMM: x = xin + bias_in + sum(slabs_in[n_slabs][B][K])  (or, when ids != NULL,
- * x[b] = tok_emb[ids[b]] + pos_emb[pos]); xout = x; Y = act(LayerNorm(x).W^T + bias) */
-int wt_dbg_dec_ln_gemm(wt_engine* h, int B, int N, int K, const float* xin, const float* slabs_in,
-                       int n_slabs, const float* bias_in, const int64_t* ids, int pos,
+int wt_dbg_dec_gemm(wt_engine* h, int mode, int B, int N, int K, const float* X, const float* W,
+                    const float* bias, const float* R, float* Y, int64_t* argmax_out);
+/* LN-fused decoder GEMM: x = xin (or, when ids != NULL, x[b] = tok_emb[ids[b]] + pos_emb[pos], also
+ * returned in xout); Y = act(LayerNorm(x).W^T + bias).  K in {128, 384, 512}. */
+int wt_dbg_dec_ln_gemm(wt_engine* h, int B, int N, int K, const float* xin, const int64_t* ids, int pos,
                        const float* tok_emb, const float* pos_emb, int n_vocab, int n_pos,
                        const float* ln_g, const float* ln_b, const float* W, const float* bias,
                        int gelu, float* Y, float* xout);

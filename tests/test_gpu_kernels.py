@@ -81,19 +81,16 @@ def test_decoder_gemm_and_argmax(eng, B, N, K):
     assert list(am) == [int(N - 1 - np.argmax(Y[b][::-1])) for b in range(B)]
 
 
-@pytest.mark.parametrize("B,N,K,ksplit", [(32, 384, 384, 4), (32, 384, 1536, 4), (5, 128, 128, 4), (64, 512, 2048, 2)])
-def test_decoder_gemm_split_k_slabs(eng, B, N, K, ksplit):
+@pytest.mark.parametrize("B,N,K", [(32, 384, 384), (32, 384, 1536), (5, 128, 128), (64, 512, 2048)])
+def test_decoder_gemm_residual_in_place(eng, B, N, K):
     rng = np.random.default_rng(B * N + K)
     X = rng.standard_normal((B, K)).astype(np.float32)
     W = (rng.standard_normal((N, K)) / 16).astype(np.float32)
-    slabs = eng.dbg_dec_gemm(X, W, mode=2, ksplit=ksplit)
-    assert slabs.shape == (ksplit, B, N)
-    kb = K // ksplit
-    for s_ in range(ksplit):  # every slab is exactly its K slice
-        ref = X[:, s_ * kb:(s_ + 1) * kb].astype(np.float64) @ W[:, s_ * kb:(s_ + 1) * kb].astype(np.float64).T
-        assert rel_err(slabs[s_], ref) < 3e-6
-    again = eng.dbg_dec_gemm(X, W, mode=2, ksplit=ksplit)
-    assert np.array_equal(slabs, again)  # deterministic: fixed reduction order, no atomics
+    bias = rng.standard_normal(N).astype(np.float32)
+    R = rng.standard_normal((B, N)).astype(np.float32)
+    Y = eng.dbg_dec_gemm(X, W, bias, mode=2, R=R)
+    assert rel_err(Y, R + bias + X.astype(np.float64) @ W.astype(np.float64).T) < 3e-6
+    assert np.array_equal(Y, eng.dbg_dec_gemm(X, W, bias, mode=2, R=R))  # fixed reduction order, no atomics
 
 
 def test_decoder_argmax_tie_rule(eng):
@@ -112,21 +109,15 @@ def test_decoder_argmax_tie_rule(eng):
 @pytest.mark.parametrize("B,K,N,gelu_on", [(32, 384, 1152, False), (9, 128, 512, True), (64, 512, 512, False)])
 def test_decoder_ln_fused_gemm(eng, B, K, N, gelu_on):
     rng = np.random.default_rng(B + K + N)
-    xin = rng.standard_normal((B, K)).astype(np.float32)
-    slabs = rng.standard_normal((4, B, K)).astype(np.float32)
-    bias_in = rng.standard_normal(K).astype(np.float32)
+    xin = (rng.standard_normal((B, K)) * 2 + 0.5).astype(np.float32)
     g_, b_ = rng.standard_normal(K).astype(np.float32), rng.standard_normal(K).astype(np.float32)
     W = (rng.standard_normal((N, K)) / 16).astype(np.float32)
     bias = rng.standard_normal(N).astype(np.float32)
-    Y, xout = eng.dbg_dec_ln_gemm(W, bias, g_, b_, xin=xin, slabs=slabs, bias_in=bias_in, gelu=gelu_on)
-    x = xin.astype(np.float64) + bias_in + slabs.astype(np.float64).sum(0)
-    assert np.abs(xout - x).max() < 5e-6
+    Y, _ = eng.dbg_dec_ln_gemm(W, bias, g_, b_, xin=xin, gelu=gelu_on)
+    x = xin.astype(np.float64)
     ln = (x - x.mean(1, keepdims=True)) / np.sqrt(x.var(1, keepdims=True) + 1e-5) * g_ + b_
     ref = ln @ W.astype(np.float64).T + bias
     assert rel_err(Y, gelu(ref) if gelu_on else ref) < 5e-6
-    # no pending slabs / bias: x = xin
-    Y2, xout2 = eng.dbg_dec_ln_gemm(W, bias, g_, b_, xin=xin, gelu=gelu_on)
-    assert np.array_equal(xout2, xin)
 
 
 def test_decoder_ln_fused_embedding(eng):

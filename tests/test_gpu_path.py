@@ -220,13 +220,23 @@ def test_encdec_cli(tiny, tmp_path):
 def test_pipeline_submit_collect_matches_sync(tiny):
     """Two-deep encoder/decoder pipeline (wt_pipeline_submit_dev / wt_pipeline_collect):
     batches come back in submission order with exactly the ids of the synchronous call."""
-    import torch
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    class Dev:  # caller-owned device buffer (what bench.py gets from torch)
+        def __init__(self, a):
+            self.p = ctypes.c_void_p()
+            assert hip.hipMalloc(ctypes.byref(self.p), ctypes.c_size_t(a.nbytes)) == 0
+            assert hip.hipMemcpy(self.p, a.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(a.nbytes), 1) == 0
+
+        def data_ptr(self):
+            return self.p.value
+
     e, _ = tiny
     rng = np.random.default_rng(777)
     mels = [rng.uniform(-1.0, 1.5, size=(b, 80, 3000)).astype(np.float32) for b in (3, 5, 2, 4)]
     want = [e.encdec_tokens_batch(m) for m in mels]
-    dev = [torch.from_numpy(m).cuda() for m in mels]
-    torch.cuda.synchronize()
+    dev = [Dev(m) for m in mels]
     got = []
     e.pipeline_submit_dev(dev[0].data_ptr(), 3)
     for k in range(1, 4):

@@ -121,8 +121,8 @@ def lib() -> ctypes.CDLL:
         L.wt_write_synthetic_weights.argtypes = [c_char_p, c_char_p, c_uint64]
         L.wt_write_synthetic_vocab.argtypes = [c_char_p, c_int]
         L.wt_dbg_gemm.argtypes = [c_void_p, c_int, c_int, c_int, fp, fp, fp, fp, fp, c_int, c_int, fp]
-        L.wt_dbg_dec_gemm.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, fp, fp, fp, fp, ip64]
-        L.wt_dbg_dec_ln_gemm.argtypes = [c_void_p, c_int, c_int, c_int, fp, fp, c_int, fp, ip64, c_int, fp, fp,
+        L.wt_dbg_dec_gemm.argtypes = [c_void_p, c_int, c_int, c_int, c_int, fp, fp, fp, fp, fp, ip64]
+        L.wt_dbg_dec_ln_gemm.argtypes = [c_void_p, c_int, c_int, c_int, fp, ip64, c_int, fp, fp,
                                          c_int, c_int, fp, fp, fp, fp, c_int, fp, fp]
         L.wt_dbg_layernorm.argtypes = [c_void_p, c_int, c_int, fp, fp, fp, fp]
         L.wt_dbg_encoder_attention.argtypes = [c_void_p, c_int, c_int, c_int, fp, fp]
@@ -344,27 +344,24 @@ class Engine:
                                       pos.shape[0] if pos is not None else 0, epi, _fp(C)))
         return C
 
-    def dbg_dec_gemm(self, X, W, bias=None, mode=0, ksplit=1):
-        """mode 0 bias, 1 bias+gelu, 2 raw slabs [ksplit][B][N], 3 logits + argmax."""
+    def dbg_dec_gemm(self, X, W, bias=None, mode=0, R=None):
+        """mode 0 bias, 1 bias+gelu, 2 residual (Y = R + bias + X.W^T), 3 logits + argmax."""
         X, W = _f32(X), _f32(W)
         B, K = X.shape
         N = W.shape[0]
         bias = _f32(bias) if bias is not None else np.zeros(N, np.float32)
-        Y = np.zeros((ksplit if mode == 2 else 1, B, N), np.float32)
+        R = _f32(R) if R is not None else None
+        Y = np.zeros((B, N), np.float32)
         am = np.zeros(B, np.int64)
-        self._check(lib().wt_dbg_dec_gemm(self._h, mode, B, N, K, ksplit, _fp(X), _fp(W), _fp(bias), _fp(Y),
+        self._check(lib().wt_dbg_dec_gemm(self._h, mode, B, N, K, _fp(X), _fp(W), _fp(bias), _fp(R), _fp(Y),
                                           am.ctypes.data_as(POINTER(c_int64))))
-        if mode == 2:
-            return Y
-        return (Y[0], am) if mode == 3 else Y[0]
+        return (Y, am) if mode == 3 else Y
 
-    def dbg_dec_ln_gemm(self, W, bias, ln_g, ln_b, xin=None, slabs=None, bias_in=None, ids=None, pos=0,
-                        tok_emb=None, pos_emb=None, gelu=False):
+    def dbg_dec_ln_gemm(self, W, bias, ln_g, ln_b, xin=None, ids=None, pos=0, tok_emb=None, pos_emb=None,
+                        gelu=False):
         W, bias, ln_g, ln_b = _f32(W), _f32(bias), _f32(ln_g), _f32(ln_b)
         N, K = W.shape
         xin = _f32(xin) if xin is not None else None
-        slabs = _f32(slabs) if slabs is not None else None
-        bias_in = _f32(bias_in) if bias_in is not None else None
         ids_a = np.ascontiguousarray(ids, dtype=np.int64) if ids is not None else None
         tok_emb = _f32(tok_emb) if tok_emb is not None else None
         pos_emb = _f32(pos_emb) if pos_emb is not None else None
@@ -372,7 +369,7 @@ class Engine:
         Y = np.zeros((B, N), np.float32)
         xout = np.zeros((B, K), np.float32)
         self._check(lib().wt_dbg_dec_ln_gemm(
-            self._h, B, N, K, _fp(xin), _fp(slabs), slabs.shape[0] if slabs is not None else 0, _fp(bias_in),
+            self._h, B, N, K, _fp(xin),
             ids_a.ctypes.data_as(POINTER(c_int64)) if ids_a is not None else None, pos, _fp(tok_emb), _fp(pos_emb),
             tok_emb.shape[0] if tok_emb is not None else 0, pos_emb.shape[0] if pos_emb is not None else 0,
             _fp(ln_g), _fp(ln_b), _fp(W), _fp(bias), int(gelu), _fp(Y), _fp(xout)))

@@ -381,27 +381,26 @@ int wt_dbg_gemm(wt_engine* h, int M, int N, int K, const float* A, const float* 
   });
 }
 
-int wt_dbg_dec_gemm(wt_engine* h, int mode, int B, int N, int K, int ksplit, const float* X,
-                    const float* W, const float* bias, float* Y, int64_t* argmax_out) {
-  if (!h || mode < 0 || mode > 3 || B < 1 || B > 64 || ksplit < 1 || K % (32 * ksplit) != 0 ||
-      (mode != 2 && ksplit != 1)) {
+int wt_dbg_dec_gemm(wt_engine* h, int mode, int B, int N, int K, const float* X, const float* W,
+                    const float* bias, const float* R, float* Y, int64_t* argmax_out) {
+  if (!h || mode < 0 || mode > 3 || B < 1 || B > 64 || K % 32 != 0 || (mode == 2 && !R)) {
     return WT_ERR_INVALID_ARG;
   }
   return guarded(h, [&] {
     const std::vector<float> tiled = wt::tile_weights(W, N, K);
-    const size_t out_n = size_t(mode == 2 ? ksplit : 1) * B * N;
     const int n_tiles = (N + 31) / 32;
-    DevBuf dX(X, size_t(B) * K), dW(tiled.data(), tiled.size()), dB(bias, N), dY(out_n);
+    DevBuf dX(X, size_t(B) * K), dW(tiled.data(), tiled.size()), dB(bias, N);
+    DevBuf dY(mode == 2 ? R : nullptr, size_t(B) * N);
     DevBuf dBest(size_t(B) * 2 * n_tiles);
     hipchk(hipMemset(dBest.p, 0, size_t(B) * 8 * n_tiles), "memset");
     wt::DecGemmArgs g;
-    g.Wt = dW.p; g.N = N; g.K = K; g.B = B; g.ksplit = ksplit; g.X = dX.p; g.ldx = K;
-    g.bias = dB.p; g.Y = dY.p; g.ldy = N; g.slab_out = dY.p;
+    g.Wt = dW.p; g.N = N; g.K = K; g.B = B; g.X = dX.p; g.ldx = K;
+    g.bias = dB.p; g.R = dY.p; g.Y = dY.p; g.ldy = N;  // residual in place, as the engine does
     g.best = reinterpret_cast<unsigned long long*>(dBest.p);
-    const int epi = mode == 0 ? wt::kDecBias : mode == 1 ? wt::kDecBiasGelu : mode == 2 ? wt::kDecSlab : wt::kDecLogits;
+    const int epi = mode == 0 ? wt::kDecBias : mode == 1 ? wt::kDecBiasGelu : mode == 2 ? wt::kDecResid : wt::kDecLogits;
     wt::launch_dec_gemm(g, wt::kProNone, epi, h->impl->stream());
     h->impl->sync();
-    dY.to_host(Y, out_n);
+    dY.to_host(Y, size_t(B) * N);
     if (argmax_out && mode == 3) {
       // reduce the per-tile records exactly as select_token does (max of the packed keys)
       std::vector<unsigned long long> best(size_t(B) * n_tiles);
@@ -415,23 +414,22 @@ int wt_dbg_dec_gemm(wt_engine* h, int mode, int B, int N, int K, int ksplit, con
   });
 }
 
-int wt_dbg_dec_ln_gemm(wt_engine* h, int B, int N, int K, const float* xin, const float* slabs_in,
-                       int n_slabs, const float* bias_in, const int64_t* ids, int pos,
+int wt_dbg_dec_ln_gemm(wt_engine* h, int B, int N, int K, const float* xin, const int64_t* ids, int pos,
                        const float* tok_emb, const float* pos_emb, int n_vocab, int n_pos,
                        const float* ln_g, const float* ln_b, const float* W, const float* bias,
                        int gelu, float* Y, float* xout) {
-  if (!h || B < 1 || B > 64 || K > 512 || K % 32 != 0) return WT_ERR_INVALID_ARG;
+  if (!h || B < 1 || B > 64 || (K != 128 && K != 384 && K != 512) || (!xin && !ids)) return WT_ERR_INVALID_ARG;
   return guarded(h, [&] {
     const std::vector<float> tiled = wt::tile_weights(W, N, K);
-    DevBuf dxin(xin, xin ? size_t(B) * K : 0), dsl(slabs_in, size_t(n_slabs) * B * K), dbi(bias_in, bias_in ? K : 0);
+    DevBuf dxin(xin, xin ? size_t(B) * K : 0);
     DevBuf dtok(tok_emb, ids ? size_t(n_vocab) * K : 0), dpos(pos_emb, ids ? size_t(n_pos) * K : 0);
     DevBuf dg(ln_g, K), db(ln_b, K), dW(tiled.data(), tiled.size()), dB(bias, N), dY(size_t(B) * N), dxo(size_t(B) * K);
     DevBuf dids(size_t(B) * 2);
     if (ids) hipchk(hipMemcpy(dids.p, ids, size_t(B) * 8, hipMemcpyHostToDevice), "H2D ids");
+    hipchk(hipMemset(dxo.p, 0, size_t(B) * K * 4), "memset");
     wt::DecGemmArgs g;
     g.Wt = dW.p; g.N = N; g.K = K; g.B = B;
-    g.xin = dxin.p; g.slabs_in = dsl.p; g.n_slabs_in = n_slabs; g.bias_in = bias_in ? dbi.p : nullptr;
-    g.xout = dxo.p; g.ln_g = dg.p; g.ln_b = db.p;
+    g.xin = dxin.p; g.xout = dxo.p; g.ln_g = dg.p; g.ln_b = db.p;
     if (ids) {
       g.ids = reinterpret_cast<const long long*>(dids.p); g.ids_stride = 1; g.pos = 0;
       g.tok_emb = dtok.p; g.pos_emb = dpos.p + size_t(pos) * K; g.n_vocab = n_vocab;
@@ -467,32 +465,27 @@ int wt_dbg_encoder_attention(wt_engine* h, int batch, int T, int heads, const fl
 
 int wt_dbg_cross_attention(wt_engine* h, int batch, int heads, int T, int chunks, const float* q,
                            const float* kc, const float* vc, float* out) {
-  if (!h || chunks < 1 || chunks > 64 || batch > 64) return WT_ERR_INVALID_ARG;
+  if (!h || chunks < 1 || chunks > 64 || batch > 64 || heads * 64 > 384) return WT_ERR_INVALID_ARG;
   return guarded(h, [&] {
     const size_t d = size_t(heads) * 64;
     DevBuf dq(q, size_t(batch) * d), dk(kc, size_t(batch) * T * d), dv(vc, size_t(batch) * T * d);
-    const int ks = (d % 128 == 0) ? 4 : 1;
-    DevBuf dws(size_t(batch) * heads * chunks * 68), dout(size_t(ks) * batch * d);
+    DevBuf dws(size_t(batch) * heads * chunks * 68), dout(size_t(batch) * d), dzero(d);
+    hipchk(hipMemset(dout.p, 0, size_t(batch) * d * 4), "memset");
+    hipchk(hipMemset(dzero.p, 0, d * 4), "memset");
     // the product combines the chunk partials in the out-projection's prologue; an identity
-    // projection exposes exactly that combined row
+    // projection onto a zero residual exposes exactly that combined row
     std::vector<float> eye(d * d, 0.0f);
     for (size_t i = 0; i < d; ++i) eye[i * d + i] = 1.0f;
     const std::vector<float> tiled = wt::tile_weights(eye.data(), int(d), int(d));
     DevBuf dW(tiled.data(), tiled.size());
     wt::launch_cross_attention(dq.p, dk.p, dv.p, dws.p, batch, heads, T, chunks, h->impl->stream());
     wt::DecGemmArgs g;
-    g.Wt = dW.p; g.N = int(d); g.K = int(d); g.B = batch; g.ksplit = ks;
-    g.cross_ws = dws.p; g.heads = heads; g.chunks = chunks; g.slab_out = dout.p;
-    wt::launch_dec_gemm(g, wt::kProCombine, wt::kDecSlab, h->impl->stream());
+    g.Wt = dW.p; g.N = int(d); g.K = int(d); g.B = batch;
+    g.cross_ws = dws.p; g.heads = heads; g.chunks = chunks;
+    g.bias = dzero.p; g.R = dout.p; g.Y = dout.p; g.ldy = int(d);
+    wt::launch_dec_gemm(g, wt::kProCombine, wt::kDecResid, h->impl->stream());
     h->impl->sync();
-    // with an identity projection slab ky holds exactly the columns of its K range
-    std::vector<float> slabs(size_t(ks) * batch * d);
-    dout.to_host(slabs.data(), slabs.size());
-    for (size_t i = 0; i < size_t(batch) * d; ++i) {
-      float v = 0.0f;
-      for (int k = 0; k < ks; ++k) v += slabs[size_t(k) * batch * d + i];
-      out[i] = v;
-    }
+    dout.to_host(out, size_t(batch) * d);
   });
 }
 

@@ -397,8 +397,6 @@ void Engine::ensure_batch(int batch) {
     sl.used = false;
   }
   ws_.xd = alloc(B * d, false);
-  ws_.xd2 = alloc(B * d, false);
-  ws_.slabs = alloc(size_t(3) * dec_ksplit_ * B * d, false);
   ws_.lnd = alloc(B * d, false);
   ws_.qkvd = alloc(B * 3 * d, false);
   ws_.attd = alloc(B * d, false);
@@ -692,75 +690,56 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
   const int chunks = int(std::min<long>(std::max<long>(cross_chunks, 1), 64));
   const size_t kv_slab = size_t(batch) * T * d;  // one (layer, k|v) slab of the cross cache
   const size_t self_slab = size_t(batch) * self_cap_ * d;
-  const int ks = dec_ksplit_;                    // split-K blocks of the narrow (N = d) GEMMs
-  float* const slab1 = ws_.slabs;                           // self out-proj partials
-  float* const slab2 = ws_.slabs + size_t(ks) * batch * d;  // cross out-proj partials
-  float* const slab3 = ws_.slabs + size_t(2 * ks) * batch * d;  // fc2 partials
   int steps = 0;
+  float* const x = ws_.xd;  // residual stream [B][d], updated in place by the residual GEMMs
   for (int pos = 0; pos < max_pos; ++pos) {
-    // residual stream ping-pongs between xa/xb: every LN-fused GEMM reads the old stream
-    // plus the pending Linear's (bias, slabs) and writes the updated stream once
-    float* xin = ws_.xd;
-    float* xout = ws_.xd2;
-    const float* pend_slabs = nullptr;
-    const float* pend_bias = nullptr;
-    int pend_n = 0;
     for (int l = 0; l < c.n_text_layer; ++l) {
       const BlockWeights& w = dec_blocks_[l];
-      DecGemmArgs q;  // LN + fused q|k|v projection (+ embedding at layer 0)
+      DecGemmArgs q;  // LN + fused q|k|v projection (+ token/positional embedding at layer 0)
       q.Wt = w.attn.wqkv; q.N = 3 * d; q.K = d; q.B = batch;
-      q.xin = xin; q.xout = xout; q.slabs_in = pend_slabs; q.n_slabs_in = pend_n; q.bias_in = pend_bias;
-      q.ln_g = w.attn_ln_g; q.ln_b = w.attn_ln_b;
+      q.xin = x; q.ln_g = w.attn_ln_g; q.ln_b = w.attn_ln_b;
       if (l == 0) {
         q.ids = ws_.ids; q.ids_stride = stride; q.pos = pos; q.tok_emb = tok_emb; q.pos_emb = dec_pos;
-        q.n_vocab = V;
+        q.n_vocab = V; q.xout = x;
       }
       q.bias = w.attn.bqkv; q.Y = ws_.qkvd; q.ldy = 3 * d;
       launch_dec_gemm(q, kProLn, kDecBias, stream_);
-      std::swap(xin, xout);
       launch_self_attention(ws_.qkvd, ws_.self_kv + (size_t(l) * 2 + 0) * self_slab,
                             ws_.self_kv + (size_t(l) * 2 + 1) * self_slab, self_cap_, pos, ws_.attd,
                             batch, H, stream_);
-      DecGemmArgs o;  // self-attention out-projection -> split-K slabs
-      o.Wt = w.attn.wo; o.N = d; o.K = d; o.B = batch; o.ksplit = ks; o.X = ws_.attd; o.ldx = d;
-      o.slab_out = slab1;
-      launch_dec_gemm(o, kProNone, kDecSlab, stream_);
+      DecGemmArgs o;  // x += attn . Wo^T + bo
+      o.Wt = w.attn.wo; o.N = d; o.K = d; o.B = batch; o.X = ws_.attd; o.ldx = d;
+      o.bias = w.attn.bo; o.R = x; o.Y = x; o.ldy = d;
+      launch_dec_gemm(o, kProNone, kDecResid, stream_);
 
-      DecGemmArgs cq;  // residual + LN + cross-attention query projection
+      DecGemmArgs cq;  // LN + cross-attention query projection
       cq.Wt = w.cross.wq; cq.N = d; cq.K = d; cq.B = batch;
-      cq.xin = xin; cq.xout = xout; cq.slabs_in = slab1; cq.n_slabs_in = ks; cq.bias_in = w.attn.bo;
-      cq.ln_g = w.cross_ln_g; cq.ln_b = w.cross_ln_b;
+      cq.xin = x; cq.ln_g = w.cross_ln_g; cq.ln_b = w.cross_ln_b;
       cq.bias = w.cross.bq; cq.Y = ws_.qd; cq.ldy = d;
       launch_dec_gemm(cq, kProLn, kDecBias, stream_);
-      std::swap(xin, xout);
       launch_cross_attention(ws_.qd, slot.cross_kv + (size_t(l) * 2 + 0) * kv_slab,
                              slot.cross_kv + (size_t(l) * 2 + 1) * kv_slab, ws_.cross_ws, batch, H, T,
                              chunks, stream_);
-      DecGemmArgs co;  // chunk combine + cross out-projection -> slabs
-      co.Wt = w.cross.wo; co.N = d; co.K = d; co.B = batch; co.ksplit = ks;
-      co.cross_ws = ws_.cross_ws; co.heads = H; co.chunks = chunks; co.slab_out = slab2;
-      launch_dec_gemm(co, kProCombine, kDecSlab, stream_);
+      DecGemmArgs co;  // x += combine(chunks) . Wco^T + bco
+      co.Wt = w.cross.wo; co.N = d; co.K = d; co.B = batch;
+      co.cross_ws = ws_.cross_ws; co.heads = H; co.chunks = chunks;
+      co.bias = w.cross.bo; co.R = x; co.Y = x; co.ldy = d;
+      launch_dec_gemm(co, kProCombine, kDecResid, stream_);
 
-      DecGemmArgs f1;  // residual + LN + fc1 + GELU
+      DecGemmArgs f1;  // LN + fc1 + GELU
       f1.Wt = w.w1; f1.N = 4 * d; f1.K = d; f1.B = batch;
-      f1.xin = xin; f1.xout = xout; f1.slabs_in = slab2; f1.n_slabs_in = ks; f1.bias_in = w.cross.bo;
-      f1.ln_g = w.mlp_ln_g; f1.ln_b = w.mlp_ln_b;
+      f1.xin = x; f1.ln_g = w.mlp_ln_g; f1.ln_b = w.mlp_ln_b;
       f1.bias = w.b1; f1.Y = ws_.hd; f1.ldy = 4 * d;
       launch_dec_gemm(f1, kProLn, kDecBiasGelu, stream_);
-      std::swap(xin, xout);
-      DecGemmArgs f2;  // fc2 -> slabs
-      f2.Wt = w.w2; f2.N = d; f2.K = 4 * d; f2.B = batch; f2.ksplit = ks; f2.X = ws_.hd; f2.ldx = 4 * d;
-      f2.slab_out = slab3;
-      launch_dec_gemm(f2, kProNone, kDecSlab, stream_);
-      pend_slabs = slab3;
-      pend_n = ks;
-      pend_bias = w.b2;
+      DecGemmArgs f2;  // x += h . W2^T + b2
+      f2.Wt = w.w2; f2.N = d; f2.K = 4 * d; f2.B = batch; f2.X = ws_.hd; f2.ldx = 4 * d;
+      f2.bias = w.b2; f2.R = x; f2.Y = x; f2.ldy = d;
+      launch_dec_gemm(f2, kProNone, kDecResid, stream_);
     }
     if (pos >= n_prompt - 1) {
       // logits against the tied embedding + greedy argmax (whisper.cpp:379-399); only the
       // last position's row exists here, the reference computes and drops the others
-      launch_dec_finalize_ln(xin, pend_slabs, pend_n, pend_bias, dec_ln_g, dec_ln_b, ws_.lnd, batch, d,
-                             stream_);
+      launch_dec_finalize_ln(x, dec_ln_g, dec_ln_b, ws_.lnd, batch, d, stream_);
       DecGemmArgs lg;
       lg.Wt = tok_emb_tiled; lg.N = V; lg.K = d; lg.B = batch; lg.X = ws_.lnd; lg.ldx = d;
       lg.Y = logits_host ? ws_.logits : nullptr; lg.ldy = V; lg.best = ws_.best;

@@ -161,7 +161,7 @@ class Engine {
     float *melT = nullptr, *h1p = nullptr, *x = nullptr, *ln = nullptr, *qkv = nullptr,
           *att = nullptr, *hid = nullptr, *enc_out = nullptr;
     // decoder
-    float *xd = nullptr, *xd2 = nullptr, *slabs = nullptr, *lnd = nullptr, *qkvd = nullptr, *attd = nullptr, *qd = nullptr,
+    float *xd = nullptr, *lnd = nullptr, *qkvd = nullptr, *attd = nullptr, *qd = nullptr,
           *hd = nullptr, *cross_ws = nullptr, *self_kv = nullptr, *logits = nullptr;
     unsigned long long* best = nullptr;
     long long* ids = nullptr;
@@ -181,7 +181,6 @@ class Engine {
                                   {"layernorm_rows", 0, 0, 0, 0},
                                   {"mel_transpose", 0, 0, 0, 0}};
   int self_cap_ = 32;
-  int dec_ksplit_ = 4;  // == kDecSlabs (kernels.h): split-K blocks of the decoder's N = d GEMMs
 };
 
 }  // namespace wt

@@ -8,11 +8,13 @@
 //   * weights are pre-tiled at load time into MFMA-fragment order ([tile][k/8][lane][4]), so
 //     one wave-instruction reads 1 KiB contiguous and a wave issues ALL its weight loads
 //     (<= 12 x 16 B per lane) before anything else — operand streamed once, straight to VGPRs;
-//   * every block = 4 wavefronts splitting K, combined through LDS; narrow outputs also split
-//     K over blockIdx.y into partial slabs that the NEXT kernel's prologue sums in a fixed
-//     order (deterministic, no atomics, no separate reduce launch);
-//   * prologues fuse what used to be separate launches: residual update + LayerNorm
-//     (+ token/positional embedding at layer 0), and the cross-attention chunk combine;
+//   * every block = 4 wavefronts splitting K, combined through LDS in a fixed order
+//     (deterministic, no atomics);
+//   * prologues/epilogues fuse what used to be separate launches: LayerNorm (+ token/positional
+//     embedding at layer 0) and the cross-attention chunk combine in front of the GEMM, bias /
+//     GELU / residual add / argmax behind it.  A prologue reads ONE array (the residual
+//     stream): a first version folded 4 split-K slabs + bias there and was latency-bound on
+//     the 6x larger read (26 us per launch instead of ~8);
 //   * every trip count that guards a load is a template constant: a runtime-predicated load
 //     makes hipcc branch around it and wait vmcnt(0) per element (measured: 6x slower).
 #include <hip/hip_runtime.h>
@@ -38,12 +40,10 @@ __device__ __forceinline__ unsigned ordered_bits(float v) {
 
 struct DecGemmDev {
   const float* Wt;
-  int N, K, B, ksplit;
+  int N, K, B;
   const float* X;
   int ldx;
   const float* xin;
-  const float* slabs_in;
-  const float* bias_in;
   float* xout;
   const float* ln_g;
   const float* ln_b;
@@ -56,18 +56,15 @@ struct DecGemmDev {
   int heads, chunks;
   const float* bias;
   int gelu;
+  const float* R;
   float* Y;
   int ldy;
-  float* slab_out;
   unsigned long long* best;
 };
 
-// Row sources of the residual stream.  LNMODE 0: x = xin;  1: x = xin + bias_in + the
-// kDecSlabs split-K slabs of the pending Linear (fixed order);  2: x = tok_emb[id] + pos_emb.
+// Row sources of the residual stream.  LNMODE 0: x = xin;  2: x = tok_emb[id] + pos_emb.
 struct RowSrc {
   const float* xin;
-  const float* bias_in;
-  const float* slabs_in;
   const long long* ids;
   int ids_stride, pos;
   const float* tok_emb;
@@ -75,8 +72,8 @@ struct RowSrc {
   int n_vocab;
 };
 
-// 8 lanes own one row (16-byte columns sub, sub + 8, ...); all NF4 * (1 + 1 + kDecSlabs) loads
-// of the row are independent and issued before the first use.
+// 8 lanes own one row (16-byte columns sub, sub + 8, ...); the NF4 loads of the row are
+// independent and issued before the first use.
 template <int NF4, int LNMODE>
 __device__ __forceinline__ void load_row(f32x4 (&v)[NF4], const RowSrc& r, int row, int sub, int B,
                                          int K) {
@@ -92,16 +89,6 @@ __device__ __forceinline__ void load_row(f32x4 (&v)[NF4], const RowSrc& r, int r
     const float* pe = r.pos_emb + (long)r.pos * K;
 #pragma unroll
     for (int j = 0; j < NF4; ++j) v[j] += *reinterpret_cast<const f32x4*>(pe + (sub + 8 * j) * 4);
-  }
-  if (LNMODE == 1) {
-#pragma unroll
-    for (int j = 0; j < NF4; ++j) v[j] += *reinterpret_cast<const f32x4*>(r.bias_in + (sub + 8 * j) * 4);
-#pragma unroll
-    for (int sl = 0; sl < kDecSlabs; ++sl) {
-      const float* sp = r.slabs_in + ((long)sl * B + row) * K;
-#pragma unroll
-      for (int j = 0; j < NF4; ++j) v[j] += *reinterpret_cast<const f32x4*>(sp + (sub + 8 * j) * 4);
-    }
   }
 }
 
@@ -138,11 +125,11 @@ __global__ __launch_bounds__(256) void dec_gemm(DecGemmDev g) {
   float* xs = smem + 3 * MT * 16 * 64;  // [MT*32][K + 4] LayerNorm rows (kProLn)
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
-  const int tile = blockIdx.x, ky = blockIdx.y;
+  const int tile = blockIdx.x;
   const int K = g.K, B = g.B, xld = K + 4;
 
-  const int kblock = K / g.ksplit, kwave = kblock >> 2;
-  const int k0 = ky * kblock + wid * kwave;
+  const int kwave = K >> 2;
+  const int k0 = wid * kwave;
   const int nchunks = kwave >> 3;
   const float* wp = g.Wt + ((long)tile * (K >> 3) + (k0 >> 3)) * 256 + lane * 4;
   // the weight stream does not depend on the prologue: its first group goes in flight now so
@@ -156,10 +143,11 @@ __global__ __launch_bounds__(256) void dec_gemm(DecGemmDev g) {
   }
 
   if (PRO == kProLn) {
-    // residual update + LayerNorm; a wavefront handles 8 rows at once, one round trip per pass
-    const bool writer = blockIdx.x == 0 && blockIdx.y == 0 && g.xout != nullptr;
+    // LayerNorm of the residual stream; a wavefront handles 8 rows at once, one memory round
+    // trip per pass.  With the embedding source the rows are also materialised once (block 0).
+    const bool writer = LNMODE == 2 && blockIdx.x == 0 && g.xout != nullptr;
     const int r8 = lane >> 3, sub = lane & 7;
-    const RowSrc src{g.xin, g.bias_in, g.slabs_in, g.ids, g.ids_stride, g.pos, g.tok_emb, g.pos_emb, g.n_vocab};
+    const RowSrc src{g.xin, g.ids, g.ids_stride, g.pos, g.tok_emb, g.pos_emb, g.n_vocab};
     constexpr int NV = NF4 > 0 ? NF4 : 1;
 #pragma unroll 1
     for (int pass = 0; pass < MT; ++pass) {
@@ -299,7 +287,7 @@ __global__ __launch_bounds__(256) void dec_gemm(DecGemmDev g) {
 
   const int n = tile * 32 + l31;
   const bool n_ok = n < g.N;
-  const float bias = (EPI == kDecBias && n_ok) ? g.bias[n] : 0.0f;
+  const float bias = ((EPI == kDecBias || EPI == kDecResid) && n_ok) ? g.bias[n] : 0.0f;
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
 #pragma unroll
@@ -308,11 +296,8 @@ __global__ __launch_bounds__(256) void dec_gemm(DecGemmDev g) {
       float v = acc[t][r] + bias;
       if (EPI == kDecBias && g.gelu) v = gelu_erf(v);
       const bool ok = n_ok && b < B;
-      if (EPI == kDecSlab) {
-        if (ok) g.slab_out[((long)ky * B + b) * g.N + n] = v;
-      } else {
-        if (ok && g.Y) g.Y[(long)b * g.ldy + n] = v;
-      }
+      if (EPI == kDecResid && ok) v += g.R[(long)b * g.ldy + n];  // R may alias Y: same thread
+      if (ok && g.Y) g.Y[(long)b * g.ldy + n] = v;
       if (EPI == kDecLogits) {
         // fold (value, column): larger value wins, then the larger column — the reference's
         // `>=` scan keeps the LAST maximal index (whisper.cpp:353)
@@ -329,7 +314,7 @@ __global__ __launch_bounds__(256) void dec_gemm(DecGemmDev g) {
   }
 }
 
-// x = xin + bias + sum(slabs) -> LayerNorm -> y   (input rows of the logits GEMM).
+// y = LayerNorm(x)   (input rows of the logits GEMM).
 template <int NF4>
 __global__ __launch_bounds__(256) void dec_finalize_ln(RowSrc src, const float* __restrict__ g,
                                                        const float* __restrict__ b,
@@ -339,7 +324,7 @@ __global__ __launch_bounds__(256) void dec_finalize_ln(RowSrc src, const float* 
   const int row = blockIdx.x * 32 + wid * 8 + r8;
   if (row >= B) return;  // whole 8-lane groups leave together; the shuffles stay inside a group
   f32x4 v[NF4];
-  load_row<NF4, 1>(v, src, row, sub, B, K);
+  load_row<NF4, 0>(v, src, row, sub, B, K);
   float mean, rstd;
   row_stats<NF4>(v, K, &mean, &rstd);
 #pragma unroll
@@ -359,7 +344,7 @@ void launch_mt(const DecGemmDev& g, hipStream_t s) {
   const int n_tiles = (g.N + 31) / 32;
   const int MT = g.B <= 32 ? 1 : 2;
   const size_t smem = (size_t)(3 * MT * 16 * 64 + (PRO == kProLn ? MT * 32 * (g.K + 4) : 0)) * sizeof(float);
-  const dim3 grid(n_tiles, g.ksplit);
+  const dim3 grid(n_tiles);
   // dynamic LDS beyond the 64 KiB default needs an opt-in, once per kernel
   static const bool raised = [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_gemm<PRO, EPI, 1, NF4, LNMODE>),
@@ -391,22 +376,18 @@ void launch_ln(const DecGemmDev& g, hipStream_t s) {
 void launch_dec_gemm(const DecGemmArgs& a, int pro, int epi, hipStream_t s) {
   const int gelu = epi == kDecBiasGelu ? 1 : 0;
   if (epi == kDecBiasGelu) epi = kDecBias;
-  DecGemmDev g{a.Wt,      a.N,       a.K,       a.B,        a.ksplit, a.X,      a.ldx,        a.xin,
-               a.slabs_in, a.bias_in, a.xout,   a.ln_g,     a.ln_b,   a.ids,    a.ids_stride, a.pos,
-               a.tok_emb, a.pos_emb, a.n_vocab, a.cross_ws, a.heads,  a.chunks, a.bias,       gelu,
-               a.Y,       a.ldy,     a.slab_out, a.best};
+  DecGemmDev g{a.Wt,      a.N,       a.K,       a.B,        a.X,     a.ldx,    a.xin,  a.xout, a.ln_g,
+               a.ln_b,    a.ids,     a.ids_stride, a.pos,   a.tok_emb, a.pos_emb, a.n_vocab,
+               a.cross_ws, a.heads,  a.chunks,  a.bias,     gelu,    a.R,      a.Y,    a.ldy,  a.best};
   // host-side shape contract: operands must match what the kernel indexes
-  if (a.B < 1 || a.B > 64 || a.K > 2048 || a.ksplit < 1 || a.K % (32 * a.ksplit) != 0 ||
-      (epi != kDecSlab && a.ksplit != 1) || (pro == kProCombine && a.K / (32 * a.ksplit) > kGroup) ||
-      (a.n_slabs_in != 0 && a.n_slabs_in != kDecSlabs) || (a.n_slabs_in != 0 && !a.bias_in)) {
+  if (a.B < 1 || a.B > 64 || a.K > 2048 || a.K % 32 != 0 || (pro == kProCombine && a.K / 32 > kGroup) ||
+      (epi == kDecResid && (!a.R || !a.Y))) {
     abort();
   }
   if (pro == kProLn) {
     if (epi != kDecBias) abort();
     if (a.ids) {
       launch_ln<2>(g, s);
-    } else if (a.n_slabs_in) {
-      launch_ln<1>(g, s);
     } else {
       launch_ln<0>(g, s);
     }
@@ -414,18 +395,17 @@ void launch_dec_gemm(const DecGemmArgs& a, int pro, int epi, hipStream_t s) {
   }
   const int key = pro * 8 + epi;
   switch (key) {
-    case kProNone * 8 + kDecSlab: launch_mt<kProNone, kDecSlab, 0, 0>(g, s); break;
+    case kProNone * 8 + kDecResid: launch_mt<kProNone, kDecResid, 0, 0>(g, s); break;
     case kProNone * 8 + kDecBias: launch_mt<kProNone, kDecBias, 0, 0>(g, s); break;
     case kProNone * 8 + kDecLogits: launch_mt<kProNone, kDecLogits, 0, 0>(g, s); break;
-    case kProCombine * 8 + kDecSlab: launch_mt<kProCombine, kDecSlab, 0, 0>(g, s); break;
+    case kProCombine * 8 + kDecResid: launch_mt<kProCombine, kDecResid, 0, 0>(g, s); break;
     default: abort();
   }
 }
 
-void launch_dec_finalize_ln(const float* xin, const float* slabs, int n_slabs, const float* bias,
-                            const float* g, const float* b, float* y, int B, int K, hipStream_t s) {
-  if (n_slabs != kDecSlabs || !bias) abort();  // shape contract of the kernel
-  const RowSrc src{xin, bias, slabs, nullptr, 0, 0, nullptr, nullptr, 0};
+void launch_dec_finalize_ln(const float* xin, const float* g, const float* b, float* y, int B, int K,
+                            hipStream_t s) {
+  const RowSrc src{xin, nullptr, 0, 0, nullptr, nullptr, 0};
   const dim3 grid((B + 31) / 32);
   switch (K) {
     case 128: hipLaunchKernelGGL(dec_finalize_ln<4>, grid, dim3(256), 0, s, src, g, b, y, B, K); break;

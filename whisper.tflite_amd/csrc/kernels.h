@@ -45,28 +45,24 @@ void launch_gemm(const GemmArgs& a, int epi, hipStream_t s);
 
 // Decoder-step GEMM: out[B][N] = epi(pro(x)[B][K] . W[N][K]^T), B <= 64 (k_decoder.hip).
 // Wt is W pre-tiled by tile_weights(): [ceil(N/32)][K/8][64 lanes][4].
-constexpr int kDecSlabs = 4;  // split-K slabs of the decoder's N = d_model GEMMs (ksplit)
 enum DecPro : int {
   kProNone = 0,    // A operand = X [B][K] (ldx) from global memory
-  kProLn = 1,      // x = xin (+ bias_in + kDecSlabs slabs_in when n_slabs_in != 0) [or embedding when
-                   // ids != nullptr]; block (0,0) stores x to xout; A = LayerNorm(x) * ln_g + ln_b
+  kProLn = 1,      // A = LayerNorm(x) * ln_g + ln_b with x = xin, or (ids != nullptr) the token +
+                   // positional embedding, which block 0 also stores to xout
   kProCombine = 2  // A = combine of the cross-attention key-chunk partials cross_ws
 };
 enum DecEpi : int {
-  kDecSlab = 0,      // raw split-K partials -> slab_out[blockIdx.y][B][N]   (ksplit >= 1)
-  kDecBias = 1,      // Y = acc + bias                                       (ksplit == 1)
+  kDecResid = 0,     // Y = R + bias + acc   (R may alias Y: the residual stream, in place)
+  kDecBias = 1,      // Y = acc + bias
   kDecBiasGelu = 2,  // Y = gelu(acc + bias)
   kDecLogits = 3     // (optional Y = acc) + per-tile argmax records best[b][tile], reference tie rule
 };
 struct DecGemmArgs {
   const float* Wt = nullptr;
-  int N = 0, K = 0, B = 0, ksplit = 1;
+  int N = 0, K = 0, B = 0;
   const float* X = nullptr;
   int ldx = 0;
   const float* xin = nullptr;
-  const float* slabs_in = nullptr;
-  int n_slabs_in = 0;
-  const float* bias_in = nullptr;
   float* xout = nullptr;
   const float* ln_g = nullptr;
   const float* ln_b = nullptr;
@@ -78,15 +74,15 @@ struct DecGemmArgs {
   const float* cross_ws = nullptr;
   int heads = 0, chunks = 0;
   const float* bias = nullptr;
+  const float* R = nullptr;
   float* Y = nullptr;
   int ldy = 0;
-  float* slab_out = nullptr;
   unsigned long long* best = nullptr;
 };
 void launch_dec_gemm(const DecGemmArgs& a, int pro, int epi, hipStream_t s);
-// y = LayerNorm(xin + bias + sum(slabs)) : input rows of the logits GEMM
-void launch_dec_finalize_ln(const float* xin, const float* slabs, int n_slabs, const float* bias,
-                            const float* g, const float* b, float* y, int B, int K, hipStream_t s);
+// y = LayerNorm(x) * g + b : input rows of the logits GEMM
+void launch_dec_finalize_ln(const float* xin, const float* g, const float* b, float* y, int B, int K,
+                            hipStream_t s);
 
 // ------------------------------------------------------------- LayerNorm ---
 // y[m][:] = (x[m][:] - mean) * rstd * g + b, eps 1e-5, one wavefront per row.
