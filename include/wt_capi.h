@@ -69,7 +69,7 @@ int wt_engine_dims(const wt_engine* h, wt_dims* out);
 /* Options (reference hard-codes them): "language" (prompt language id, whisper.cpp:327,
  * default language_id("de") = 2), "max_tokens" (max decoder positions, whisper.cpp:364,
  * default 30), "stop_at_eot" (whisper.cpp:397-399, default 1), "verbose" (default 0),
- * "cross_chunks" (key chunks per (clip, head) in the decoder cross attention). */
+ * "cross_chunks" (key chunks per (clip, head) in the decoder cross attention: 1, 2, 4 or 8). */
 int wt_engine_set_option(wt_engine* h, const char* key, long value);
 int wt_engine_get_option(const wt_engine* h, const char* key, long* value);
 /* Replaces the reference's hard-coded prompt [sot, 50259+language, transcribe, notimestamps]

@@ -113,7 +113,7 @@ int wt_engine_set_option(wt_engine* h, const char* key, long value) {
   } else if (k == "verbose") {
     e.verbose = value;
   } else if (k == "cross_chunks") {
-    if (value < 1 || value > 64) return fail(h, WT_ERR_INVALID_ARG, "cross_chunks must be in [1, 64]");
+    if (value != 1 && value != 2 && value != 4 && value != 8) return fail(h, WT_ERR_INVALID_ARG, "cross_chunks must be 1, 2, 4 or 8");
     e.cross_chunks = value;
   } else {
     return fail(h, WT_ERR_INVALID_ARG, "unknown option: " + k);
@@ -465,7 +465,7 @@ int wt_dbg_encoder_attention(wt_engine* h, int batch, int T, int heads, const fl
 
 int wt_dbg_cross_attention(wt_engine* h, int batch, int heads, int T, int chunks, const float* q,
                            const float* kc, const float* vc, float* out) {
-  if (!h || chunks < 1 || chunks > 64 || batch > 64 || heads * 64 > 384) return WT_ERR_INVALID_ARG;
+  if (!h || (chunks != 1 && chunks != 2 && chunks != 4 && chunks != 8) || batch > 64 || heads % 2 != 0) return WT_ERR_INVALID_ARG;
   return guarded(h, [&] {
     const size_t d = size_t(heads) * 64;
     DevBuf dq(q, size_t(batch) * d), dk(kc, size_t(batch) * T * d), dv(vc, size_t(batch) * T * d);

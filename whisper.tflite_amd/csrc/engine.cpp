@@ -687,7 +687,7 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
   HIPCHK(hipMemcpyAsync(ws_.n_ids, h_n_, size_t(batch) * sizeof(int), hipMemcpyHostToDevice, stream_));
   HIPCHK(hipMemsetAsync(ws_.finished, 0, size_t(batch) * sizeof(int), stream_));
 
-  const int chunks = int(std::min<long>(std::max<long>(cross_chunks, 1), 64));
+  const int chunks = int(cross_chunks);  // 1, 2, 4 or 8 (wt_engine_set_option)
   const size_t kv_slab = size_t(batch) * T * d;  // one (layer, k|v) slab of the cross cache
   const size_t self_slab = size_t(batch) * self_cap_ * d;
   int steps = 0;

@@ -117,18 +117,21 @@ __device__ __forceinline__ void row_stats(const f32x4 (&v)[NF4], int K, float* m
   *rstd = rsqrtf(q / (float)K + 1e-5f);
 }
 
-// PRO: kProNone / kProLn / kProCombine; LNMODE as above (kProLn only); NF4 = K / 32 (kProLn only).
-template <int PRO, int EPI, int MT, int NF4, int LNMODE>
-__global__ __launch_bounds__(256) void dec_gemm(DecGemmDev g) {
+// PRO: kProNone / kProLn / kProCombine; LNMODE as above (kProLn only); NF4 = K / 32 (kProLn
+// only); WAVES = wavefronts per block, all splitting K (16 for the narrow N = d_model GEMMs,
+// which have only N/32 = 12 column tiles: parallelism has to come from K); CH = compile-time
+// key-chunk count of the combine prologue.
+template <int PRO, int EPI, int MT, int NF4, int LNMODE, int WAVES, int CH>
+__global__ __launch_bounds__(WAVES * 64) void dec_gemm(DecGemmDev g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* red = smem;                    // [3][MT][16][64] split-K partials of waves 1..3
-  float* xs = smem + 3 * MT * 16 * 64;  // [MT*32][K + 4] LayerNorm rows (kProLn)
+  float* red = smem;                              // [WAVES-1][MT][16][64] split-K partials
+  float* xs = smem + (WAVES - 1) * MT * 16 * 64;  // [MT*32][K + 4] LayerNorm rows (kProLn)
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
   const int tile = blockIdx.x;
   const int K = g.K, B = g.B, xld = K + 4;
 
-  const int kwave = K >> 2;
+  const int kwave = K / WAVES;
   const int k0 = wid * kwave;
   const int nchunks = kwave >> 3;
   const float* wp = g.Wt + ((long)tile * (K >> 3) + (k0 >> 3)) * 256 + lane * 4;
@@ -149,6 +152,7 @@ __global__ __launch_bounds__(256) void dec_gemm(DecGemmDev g) {
     const int r8 = lane >> 3, sub = lane & 7;
     const RowSrc src{g.xin, g.ids, g.ids_stride, g.pos, g.tok_emb, g.pos_emb, g.n_vocab};
     constexpr int NV = NF4 > 0 ? NF4 : 1;
+    static_assert(PRO != kProLn || WAVES == 4, "the LayerNorm prologue maps 4 waves x 8 rows");
 #pragma unroll 1
     for (int pass = 0; pass < MT; ++pass) {
       const int row = pass * 32 + wid * 8 + r8;
@@ -203,15 +207,24 @@ __global__ __launch_bounds__(256) void dec_gemm(DecGemmDev g) {
           const int rowb = t * 32 + l31;
           f32x4 o = {0, 0, 0, 0};
           if (rowb < B) {
-            const float* p = g.cross_ws + ((long)(rowb * g.heads + hh) * g.chunks) * 68;
-            float mx = -1e30f;
-            for (int c = 0; c < g.chunks; ++c) mx = fmaxf(mx, p[c * 68 + 64]);
+            const float* p = g.cross_ws + ((long)(rowb * g.heads + hh) * CH) * 68;
+            float mc[CH], lc[CH];
+            f32x4 pv[CH];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {  // all loads first: CH is a compile-time constant
+              mc[c] = p[c * 68 + 64];
+              lc[c] = p[c * 68 + 65];
+              pv[c] = *reinterpret_cast<const f32x4*>(p + c * 68 + dd);
+            }
+            float mx = mc[0];
+#pragma unroll
+            for (int c = 1; c < CH; ++c) mx = fmaxf(mx, mc[c]);
             float l = 0.0f;
-            for (int c = 0; c < g.chunks; ++c) {
-              const float wgt = __expf(p[c * 68 + 64] - mx);
-              const f32x4 pv = *reinterpret_cast<const f32x4*>(p + c * 68 + dd);
-              o += wgt * pv;
-              l += wgt * p[c * 68 + 65];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+              const float wgt = __expf(mc[c] - mx);
+              o += wgt * pv[c];
+              l += wgt * lc[c];
             }
             const float inv = 1.0f / l;
             o *= inv;
@@ -279,7 +292,7 @@ __global__ __launch_bounds__(256) void dec_gemm(DecGemmDev g) {
   __syncthreads();
   if (wid > 0) return;
 #pragma unroll
-  for (int wv = 0; wv < 3; ++wv)  // fixed order: wave 1, 2, 3
+  for (int wv = 0; wv < WAVES - 1; ++wv)  // fixed order: wave 1, 2, 3, ...
 #pragma unroll
     for (int t = 0; t < MT; ++t)
 #pragma unroll
@@ -339,34 +352,35 @@ __global__ __launch_bounds__(256) void dec_finalize_ln(RowSrc src, const float* 
   }
 }
 
-template <int PRO, int EPI, int NF4, int LNMODE>
+template <int PRO, int EPI, int NF4, int LNMODE, int WAVES, int CH>
 void launch_mt(const DecGemmDev& g, hipStream_t s) {
   const int n_tiles = (g.N + 31) / 32;
   const int MT = g.B <= 32 ? 1 : 2;
-  const size_t smem = (size_t)(3 * MT * 16 * 64 + (PRO == kProLn ? MT * 32 * (g.K + 4) : 0)) * sizeof(float);
+  const size_t smem =
+      (size_t)((WAVES - 1) * MT * 16 * 64 + (PRO == kProLn ? MT * 32 * (g.K + 4) : 0)) * sizeof(float);
   const dim3 grid(n_tiles);
   // dynamic LDS beyond the 64 KiB default needs an opt-in, once per kernel
   static const bool raised = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_gemm<PRO, EPI, 1, NF4, LNMODE>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_gemm<PRO, EPI, 1, NF4, LNMODE, WAVES, CH>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_gemm<PRO, EPI, 2, NF4, LNMODE>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_gemm<PRO, EPI, 2, NF4, LNMODE, WAVES, CH>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return true;
   }();
   (void)raised;
   if (MT == 1) {
-    hipLaunchKernelGGL((dec_gemm<PRO, EPI, 1, NF4, LNMODE>), grid, dim3(256), smem, s, g);
+    hipLaunchKernelGGL((dec_gemm<PRO, EPI, 1, NF4, LNMODE, WAVES, CH>), grid, dim3(WAVES * 64), smem, s, g);
   } else {
-    hipLaunchKernelGGL((dec_gemm<PRO, EPI, 2, NF4, LNMODE>), grid, dim3(256), smem, s, g);
+    hipLaunchKernelGGL((dec_gemm<PRO, EPI, 2, NF4, LNMODE, WAVES, CH>), grid, dim3(WAVES * 64), smem, s, g);
   }
 }
 
 template <int LNMODE>
 void launch_ln(const DecGemmDev& g, hipStream_t s) {
   switch (g.K) {
-    case 128: launch_mt<kProLn, kDecBias, 4, LNMODE>(g, s); break;
-    case 384: launch_mt<kProLn, kDecBias, 12, LNMODE>(g, s); break;
-    case 512: launch_mt<kProLn, kDecBias, 16, LNMODE>(g, s); break;
+    case 128: launch_mt<kProLn, kDecBias, 4, LNMODE, 4, 1>(g, s); break;
+    case 384: launch_mt<kProLn, kDecBias, 12, LNMODE, 4, 1>(g, s); break;
+    case 512: launch_mt<kProLn, kDecBias, 16, LNMODE, 4, 1>(g, s); break;
     default: abort();  // d_model of the supported architectures (micro / tiny / base)
   }
 }
@@ -380,8 +394,9 @@ void launch_dec_gemm(const DecGemmArgs& a, int pro, int epi, hipStream_t s) {
                a.ln_b,    a.ids,     a.ids_stride, a.pos,   a.tok_emb, a.pos_emb, a.n_vocab,
                a.cross_ws, a.heads,  a.chunks,  a.bias,     gelu,    a.R,      a.Y,    a.ldy,  a.best};
   // host-side shape contract: operands must match what the kernel indexes
-  if (a.B < 1 || a.B > 64 || a.K > 2048 || a.K % 32 != 0 || (pro == kProCombine && a.K / 32 > kGroup) ||
-      (epi == kDecResid && (!a.R || !a.Y))) {
+  const bool wide = epi == kDecResid;  // N = d_model: 16 wavefronts split K
+  if (a.B < 1 || a.B > 64 || a.K > 2048 || a.K % (wide ? 128 : 32) != 0 ||
+      (pro == kProCombine && (a.K / 128 > kGroup || a.K != a.heads * 64)) || (wide && (!a.R || !a.Y))) {
     abort();
   }
   if (pro == kProLn) {
@@ -395,10 +410,18 @@ void launch_dec_gemm(const DecGemmArgs& a, int pro, int epi, hipStream_t s) {
   }
   const int key = pro * 8 + epi;
   switch (key) {
-    case kProNone * 8 + kDecResid: launch_mt<kProNone, kDecResid, 0, 0>(g, s); break;
-    case kProNone * 8 + kDecBias: launch_mt<kProNone, kDecBias, 0, 0>(g, s); break;
-    case kProNone * 8 + kDecLogits: launch_mt<kProNone, kDecLogits, 0, 0>(g, s); break;
-    case kProCombine * 8 + kDecResid: launch_mt<kProCombine, kDecResid, 0, 0>(g, s); break;
+    case kProNone * 8 + kDecResid: launch_mt<kProNone, kDecResid, 0, 0, 16, 1>(g, s); break;
+    case kProNone * 8 + kDecBias: launch_mt<kProNone, kDecBias, 0, 0, 4, 1>(g, s); break;
+    case kProNone * 8 + kDecLogits: launch_mt<kProNone, kDecLogits, 0, 0, 4, 1>(g, s); break;
+    case kProCombine * 8 + kDecResid:
+      switch (a.chunks) {  // compile-time chunk count keeps the partial loads independent
+        case 1: launch_mt<kProCombine, kDecResid, 0, 0, 16, 1>(g, s); break;
+        case 2: launch_mt<kProCombine, kDecResid, 0, 0, 16, 2>(g, s); break;
+        case 4: launch_mt<kProCombine, kDecResid, 0, 0, 16, 4>(g, s); break;
+        case 8: launch_mt<kProCombine, kDecResid, 0, 0, 16, 8>(g, s); break;
+        default: abort();
+      }
+      break;
     default: abort();
   }
 }
