@@ -226,75 +226,82 @@ __global__ void self_attention_step(const float* __restrict__ qkv, float* __rest
 }
 
 // ------------------------------------------------ decoder cross attention ---
-// One block per (clip, head, key chunk): streams its contiguous K then V slab
-// ([keys][64] floats, 256 B per key) with 16-byte loads, 16 lanes per key.
+// One block per (clip, head, key chunk).  The chunk's K and V slabs ([keys][64] floats,
+// 256 B per key, contiguous) are streamed ONCE in a single pass: 16 lanes own a key row
+// (16-byte loads), each 16-lane group runs an online softmax over its keys (4 keys = 8 loads of
+// 16 B per lane in flight), and the 16 group partials are merged through LDS at the end.
+// Output per block: o[64] (unnormalised), m (running max, natural-log units), l (sum).
 __global__ __launch_bounds__(256) void cross_attention_step(const float* __restrict__ q,
                                                             const float* __restrict__ kc,
                                                             const float* __restrict__ vc,
                                                             float* __restrict__ ws, int heads,
                                                             int T, int chunks) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ __attribute__((aligned(16))) float go[16 * 64];
+  __shared__ float gm[16], gl[16];
   const int chunk = blockIdx.x % chunks, bh = blockIdx.x / chunks;
   const int b = bh / heads, h = bh % heads;
   const int per = (T + chunks - 1) / chunks;
   const int k_begin = chunk * per, k_end = min(T, k_begin + per), nk = k_end - k_begin;
-  const int tid = threadIdx.x, grp = tid >> 4, gl = tid & 15;
-  const int per4 = (per + 3) & ~3;
-  float* sc = smem;               // [per4] scores -> probabilities
-  float* red = smem + per4;       // [16][64] partial outputs (16-byte aligned)
-  float* wred = red + 16 * 64;    // [8] per-wavefront max / sum
+  const int tid = threadIdx.x, grp = tid >> 4, gl16 = tid & 15;
+  constexpr float kLog2e = 1.44269504088896340736f;
+  constexpr int U = 4;
 
-  const f32x4 qv = *reinterpret_cast<const f32x4*>(q + ((long)b * heads + h) * 64 + gl * 4);
-  const float* kb = kc + ((long)bh * T + k_begin) * 64 + gl * 4;
-  const float* vb = vc + ((long)bh * T + k_begin) * 64 + gl * 4;
+  f32x4 qv = *reinterpret_cast<const f32x4*>(q + ((long)b * heads + h) * 64 + gl16 * 4);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) qv[j] *= 0.125f * kLog2e;  // scores in log2 units: p = exp2(s - m)
+  const float* kb = kc + ((long)bh * T + k_begin) * 64 + gl16 * 4;
+  const float* vb = vc + ((long)bh * T + k_begin) * 64 + gl16 * 4;
 
-  float lmax = -1e30f;
-  for (int k = grp; k < nk; k += 16) {
-    const f32x4 kv = *reinterpret_cast<const f32x4*>(kb + (long)k * 64);
-    float s = kv[0] * qv[0] + kv[1] * qv[1] + kv[2] * qv[2] + kv[3] * qv[3];
+  float m = -1e30f, l = 0.0f;
+  f32x4 o = {0, 0, 0, 0};
+  for (int k0 = grp; k0 < nk; k0 += 16 * U) {
+    f32x4 kv[U], vv[U];
 #pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
-    s *= 0.125f;
-    if (gl == 0) sc[k] = s;
-    lmax = fmaxf(lmax, s);
+    for (int u = 0; u < U; ++u) {  // unguarded loads: keys past the chunk re-read its last row
+      const int k = k0 + 16 * u;
+      const int kk = k < nk ? k : nk - 1;
+      kv[u] = *reinterpret_cast<const f32x4*>(kb + (long)kk * 64);
+      vv[u] = *reinterpret_cast<const f32x4*>(vb + (long)kk * 64);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float s = kv[u][0] * qv[0] + kv[u][1] * qv[1] + kv[u][2] * qv[2] + kv[u][3] * qv[3];
+      s += __shfl_xor(s, 8, 64);
+      s += __shfl_xor(s, 4, 64);
+      s += __shfl_xor(s, 2, 64);
+      s += __shfl_xor(s, 1, 64);
+      if (k0 + 16 * u >= nk) s = -1e30f;
+      const float mn = fmaxf(m, s);
+      const float a = exp2f(m - mn), p = exp2f(s - mn);
+      l = l * a + p;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = o[j] * a + p * vv[u][j];
+      m = mn;
+    }
   }
-  // block max
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, off, 64));
-  if ((tid & 63) == 0) wred[tid >> 6] = lmax;
-  __syncthreads();
-  const float mx = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
-  float lsum = 0.0f;
-  for (int k = tid; k < nk; k += 256) {
-    const float p = __expf(sc[k] - mx);
-    sc[k] = p;
-    lsum += p;
+  *reinterpret_cast<f32x4*>(&go[grp * 64 + gl16 * 4]) = o;
+  if (gl16 == 0) {
+    gm[grp] = m;
+    gl[grp] = l;
   }
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) lsum += __shfl_xor(lsum, off, 64);
-  if ((tid & 63) == 0) wred[4 + (tid >> 6)] = lsum;
   __syncthreads();
-  const float total = wred[4] + wred[5] + wred[6] + wred[7];
-
-  f32x4 acc = {0, 0, 0, 0};
-  for (int k = grp; k < nk; k += 16) {
-    const f32x4 vv = *reinterpret_cast<const f32x4*>(vb + (long)k * 64);
-    const float p = sc[k];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] += p * vv[j];
-  }
-  *reinterpret_cast<f32x4*>(&red[grp * 64 + gl * 4]) = acc;
-  __syncthreads();
-  float* dst = ws + ((long)bh * chunks + chunk) * 68;
   if (tid < 64) {
-    float o = 0.0f;
+    float mx = gm[0];
 #pragma unroll
-    for (int gI = 0; gI < 16; ++gI) o += red[gI * 64 + tid];
-    dst[tid] = o;
-  }
-  if (tid == 0) {
-    dst[64] = mx;
-    dst[65] = total;
+    for (int gI = 1; gI < 16; ++gI) mx = fmaxf(mx, gm[gI]);
+    float acc = 0.0f, lsum = 0.0f;
+#pragma unroll
+    for (int gI = 0; gI < 16; ++gI) {
+      const float w = exp2f(gm[gI] - mx);
+      acc += w * go[gI * 64 + tid];
+      lsum += w * gl[gI];
+    }
+    float* dst = ws + ((long)bh * chunks + chunk) * 68;
+    dst[tid] = acc;
+    if (tid == 0) {
+      dst[64] = mx * (1.0f / kLog2e);  // natural-log units for the combine prologue
+      dst[65] = lsum;
+    }
   }
 }
 
@@ -315,10 +322,8 @@ void launch_self_attention(const float* qkv, float* kcache, float* vcache, int c
 
 void launch_cross_attention(const float* q, const float* kc, const float* vc, float* ws, int batch,
                             int heads, int T, int chunks, hipStream_t s) {
-  const int per = (T + chunks - 1) / chunks;
-  const size_t smem = (size_t)(((per + 3) & ~3) + 16 * 64 + 8) * sizeof(float);
-  hipLaunchKernelGGL(cross_attention_step, dim3(batch * heads * chunks), dim3(256), smem, s, q, kc,
-                     vc, ws, heads, T, chunks);
+  hipLaunchKernelGGL(cross_attention_step, dim3(batch * heads * chunks), dim3(256), 0, s, q, kc, vc,
+                     ws, heads, T, chunks);
 }
 
 }  // namespace wt

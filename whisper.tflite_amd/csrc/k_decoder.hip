@@ -27,7 +27,7 @@ namespace {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int kGroup = 12;  // weight chunks (8 k each) a wave keeps in flight
+constexpr int kGroupMax = 12;  // weight chunks (8 k each) a wave keeps in flight (4-wave blocks)
 
 __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
@@ -123,6 +123,8 @@ __device__ __forceinline__ void row_stats(const f32x4 (&v)[NF4], int K, float* m
 // key-chunk count of the combine prologue.
 template <int PRO, int EPI, int MT, int NF4, int LNMODE, int WAVES, int CH>
 __global__ __launch_bounds__(WAVES * 64) void dec_gemm(DecGemmDev g) {
+  // 1024-thread blocks are capped at 128 VGPRs: keep 6 chunks (not 12) in flight there
+  constexpr int kGroup = WAVES > 4 ? 6 : kGroupMax;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* red = smem;                              // [WAVES-1][MT][16][64] split-K partials
   float* xs = smem + (WAVES - 1) * MT * 16 * 64;  // [MT*32][K + 4] LayerNorm rows (kProLn)
@@ -291,8 +293,8 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm(DecGemmDev g) {
   }
   __syncthreads();
   if (wid > 0) return;
-#pragma unroll
-  for (int wv = 0; wv < WAVES - 1; ++wv)  // fixed order: wave 1, 2, 3, ...
+#pragma unroll 1
+  for (int wv = 0; wv < WAVES - 1; ++wv)  // fixed order: wave 1, 2, 3, ... (rolled: 16 loads live)
 #pragma unroll
     for (int t = 0; t < MT; ++t)
 #pragma unroll
@@ -396,7 +398,7 @@ void launch_dec_gemm(const DecGemmArgs& a, int pro, int epi, hipStream_t s) {
   // host-side shape contract: operands must match what the kernel indexes
   const bool wide = epi == kDecResid;  // N = d_model: 16 wavefronts split K
   if (a.B < 1 || a.B > 64 || a.K > 2048 || a.K % (wide ? 128 : 32) != 0 ||
-      (pro == kProCombine && (a.K / 128 > kGroup || a.K != a.heads * 64)) || (wide && (!a.R || !a.Y))) {
+      (pro == kProCombine && (a.K / 128 > 6 || a.K != a.heads * 64)) || (wide && (!a.R || !a.Y))) {
     abort();
   }
   if (pro == kProLn) {
