@@ -19,7 +19,7 @@ namespace {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int BM = 128, BN = 128, BK = 32, LDS_LD = BK + 4;
+constexpr int BM = 128, BN = 128;
 
 __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
@@ -43,8 +43,13 @@ struct GemmDev {
   int kv_batch, kv_heads, kv_dmodel;
 };
 
-template <int EPI>
+// BK = 64 (69.6 KB of LDS, 2 blocks per CU) halves the barriers per k and leaves half of each
+// SIMD's registers and 90 KB of LDS free, so the decoder's small kernels of the previous batch
+// can co-reside with the encoder (two-stream pipeline); BK = 32 serves K % 64 != 0.
+template <int EPI, int BK>
 __global__ __launch_bounds__(256) void gemm_f32_128x128(GemmDev g) {
+  constexpr int LDS_LD = BK + 4;  // odd multiple of 16 B: conflict-free ds_read_b128
+  constexpr int NLD = BK / 8;     // float4 per thread per operand per k-tile
   __shared__ __attribute__((aligned(16))) float As[BM * LDS_LD];
   __shared__ __attribute__((aligned(16))) float Bs[BN * LDS_LD];
 
@@ -61,16 +66,19 @@ __global__ __launch_bounds__(256) void gemm_f32_128x128(GemmDev g) {
   const int wm = wid >> 1, wn = wid & 1;
   const int l31 = lane & 31, lh = lane >> 5;
 
-  // staging map: 128 rows x 8 float4 per operand tile, 4 float4 per thread per operand
-  const int srow = tid >> 3, scol = (tid & 7) * 4;
-  const float* a_ptr[4];
-  const float* w_ptr[4];
+  // staging map: 128 rows x BK/4 float4 per operand tile, NLD float4 per thread per operand;
+  // BK/4 consecutive threads cover one row's k-tile (128 or 256 contiguous bytes)
+  constexpr int TPR = BK / 4;       // threads per row
+  constexpr int RPP = 256 / TPR;    // rows per pass
+  const int srow = tid / TPR, scol = (tid % TPR) * 4;
+  const float* a_ptr[NLD];
+  const float* w_ptr[NLD];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int m = m0 + srow + 32 * i;
+  for (int i = 0; i < NLD; ++i) {
+    int m = m0 + srow + RPP * i;
     m = m < g.M ? m : g.M - 1;  // clamp: rows past M are computed and discarded
     a_ptr[i] = g.A + (long)(m / g.a_rpb) * g.a_bs + (long)(m % g.a_rpb) * g.lda + scol;
-    w_ptr[i] = g.W + (long)(n0 + srow + 32 * i) * g.K + scol;
+    w_ptr[i] = g.W + (long)(n0 + srow + RPP * i) * g.K + scol;
   }
 
   f32x16 acc[2][2];
@@ -81,9 +89,9 @@ __global__ __launch_bounds__(256) void gemm_f32_128x128(GemmDev g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  f32x4 ra[4], rb[4];
+  f32x4 ra[NLD], rb[NLD];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NLD; ++i) {
     ra[i] = *reinterpret_cast<const f32x4*>(a_ptr[i]);
     rb[i] = *reinterpret_cast<const f32x4*>(w_ptr[i]);
   }
@@ -91,14 +99,14 @@ __global__ __launch_bounds__(256) void gemm_f32_128x128(GemmDev g) {
   const int nkt = g.K / BK;
   for (int kt = 0; kt < nkt; ++kt) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<f32x4*>(&As[(srow + 32 * i) * LDS_LD + scol]) = ra[i];
-      *reinterpret_cast<f32x4*>(&Bs[(srow + 32 * i) * LDS_LD + scol]) = rb[i];
+    for (int i = 0; i < NLD; ++i) {
+      *reinterpret_cast<f32x4*>(&As[(srow + RPP * i) * LDS_LD + scol]) = ra[i];
+      *reinterpret_cast<f32x4*>(&Bs[(srow + RPP * i) * LDS_LD + scol]) = rb[i];
     }
     __syncthreads();
     if (kt + 1 < nkt) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NLD; ++i) {
         ra[i] = *reinterpret_cast<const f32x4*>(a_ptr[i] + (kt + 1) * BK);
         rb[i] = *reinterpret_cast<const f32x4*>(w_ptr[i] + (kt + 1) * BK);
       }
@@ -156,7 +164,11 @@ __global__ __launch_bounds__(256) void gemm_f32_128x128(GemmDev g) {
 
 template <int EPI>
 void launch_gemm_t(const GemmDev& g, int blocks, hipStream_t s) {
-  hipLaunchKernelGGL(gemm_f32_128x128<EPI>, dim3(blocks), dim3(256), 0, s, g);
+  if (g.K % 64 == 0) {
+    hipLaunchKernelGGL((gemm_f32_128x128<EPI, 64>), dim3(blocks), dim3(256), 0, s, g);
+  } else {
+    hipLaunchKernelGGL((gemm_f32_128x128<EPI, 32>), dim3(blocks), dim3(256), 0, s, g);
+  }
 }
 
 }  // namespace
