@@ -115,6 +115,9 @@ int wt_engine_set_option(wt_engine* h, const char* key, long value) {
   } else if (k == "cross_chunks") {
     if (value != 1 && value != 2 && value != 4 && value != 8) return fail(h, WT_ERR_INVALID_ARG, "cross_chunks must be 1, 2, 4 or 8");
     e.cross_chunks = value;
+  } else if (k == "gemm_bk") {
+    if (value != 32 && value != 64) return fail(h, WT_ERR_INVALID_ARG, "gemm_bk must be 32 or 64");
+    e.gemm_bk = value;
   } else {
     return fail(h, WT_ERR_INVALID_ARG, "unknown option: " + k);
   }
@@ -136,6 +139,7 @@ int wt_engine_get_option(const wt_engine* h, const char* key, long* value) {
   else if (k == "stop_at_eot") *value = e.stop_at_eot;
   else if (k == "verbose") *value = e.verbose;
   else if (k == "cross_chunks") *value = e.cross_chunks;
+  else if (k == "gemm_bk") *value = e.gemm_bk;
   else return WT_ERR_INVALID_ARG;
   return WT_OK;
 }

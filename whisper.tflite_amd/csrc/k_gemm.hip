@@ -163,8 +163,8 @@ __global__ __launch_bounds__(256) void gemm_f32_128x128(GemmDev g) {
 }
 
 template <int EPI>
-void launch_gemm_t(const GemmDev& g, int blocks, hipStream_t s) {
-  if (g.K % 64 == 0) {
+void launch_gemm_t(const GemmDev& g, int blocks, int bk, hipStream_t s) {
+  if (bk == 64 && g.K % 64 == 0) {
     hipLaunchKernelGGL((gemm_f32_128x128<EPI, 64>), dim3(blocks), dim3(256), 0, s, g);
   } else {
     hipLaunchKernelGGL((gemm_f32_128x128<EPI, 32>), dim3(blocks), dim3(256), 0, s, g);
@@ -179,12 +179,12 @@ void launch_gemm(const GemmArgs& a, int epi, hipStream_t s) {
             a.kv_dmodel};
   const int blocks = ((a.M + BM - 1) / BM) * (a.N / BN);
   switch (epi) {
-    case 0: launch_gemm_t<0>(g, blocks, s); break;
-    case kEpiBias: launch_gemm_t<kEpiBias>(g, blocks, s); break;
-    case kEpiBias | kEpiGelu: launch_gemm_t<kEpiBias | kEpiGelu>(g, blocks, s); break;
-    case kEpiBias | kEpiResidual: launch_gemm_t<kEpiBias | kEpiResidual>(g, blocks, s); break;
-    case kEpiBias | kEpiGelu | kEpiPos: launch_gemm_t<kEpiBias | kEpiGelu | kEpiPos>(g, blocks, s); break;
-    case kEpiBias | kEpiKvLayout: launch_gemm_t<kEpiBias | kEpiKvLayout>(g, blocks, s); break;
+    case 0: launch_gemm_t<0>(g, blocks, a.bk, s); break;
+    case kEpiBias: launch_gemm_t<kEpiBias>(g, blocks, a.bk, s); break;
+    case kEpiBias | kEpiGelu: launch_gemm_t<kEpiBias | kEpiGelu>(g, blocks, a.bk, s); break;
+    case kEpiBias | kEpiResidual: launch_gemm_t<kEpiBias | kEpiResidual>(g, blocks, a.bk, s); break;
+    case kEpiBias | kEpiGelu | kEpiPos: launch_gemm_t<kEpiBias | kEpiGelu | kEpiPos>(g, blocks, a.bk, s); break;
+    case kEpiBias | kEpiKvLayout: launch_gemm_t<kEpiBias | kEpiKvLayout>(g, blocks, a.bk, s); break;
     default: abort();
   }
 }
