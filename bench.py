@@ -153,7 +153,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="synchronous steps (encoder then decoder) instead of the two-deep pipeline")
-    ap.add_argument("--gemm-bk", type=int, default=None, help="encoder GEMM k-tile (32 or 64)")
+    ap.add_argument("--gemm-variant", type=int, default=None, help="encoder GEMM tile variant (k_gemm.hip)")
     ap.add_argument("--dry-run-gloo", action="store_true")
     args = ap.parse_args()
     if args.dry_run_gloo:
@@ -179,8 +179,8 @@ def main() -> None:
     tmp = tempfile.mkdtemp(prefix=f"wt_bench_r{rank}_")
     prefix, vocab = ge._assets(tmp, args.arch, 0)
     eng = pkg.Engine(prefix, vocab, True, device_id=local_rank)
-    if args.gemm_bk:
-        eng.set_option("gemm_bk", args.gemm_bk)
+    if args.gemm_variant is not None:
+        eng.set_option("gemm_variant", args.gemm_variant)
     eng.set_option("stop_at_eot", 0)  # full-length decode: 30 positions, 27 argmax steps
     B = args.batch
     lo, hi = shard_range(rank, world, world * B)

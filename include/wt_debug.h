@@ -11,6 +11,9 @@ extern "C" {
 /* C[M][N] = epi(A[M][K] . W[N][K]^T); needs N % 128 == 0, K % 32 == 0 */
 int wt_dbg_gemm(wt_engine* h, int M, int N, int K, const float* A, const float* W, const float* bias,
                 const float* R, const float* pos, int pos_period, int epi, float* C);
+/* times `iters` back-to-back launches of the encoder GEMM on random operands (HIP events on the
+ * engine's stream); variant selects the tile shape (k_gemm.hip) */
+int wt_dbg_gemm_bench(wt_engine* h, int M, int N, int K, int epi, int variant, int iters, float* avg_ms);
 /* decoder-step GEMM (k_decoder.hip), plain input X[B][K], W[N][K] (tiled internally):
  * mode 0: Y = X.W^T + bias   1: gelu(...)   2: Y = R + bias + X.W^T (in-place residual form)
  * mode 3: Y = X.W^T and argmax_out[B] = last maximal column (reference tie rule) */

@@ -255,3 +255,50 @@ def test_pipeline_submit_collect_matches_sync(tiny):
     a = e.pipeline_collect()
     b = e.pipeline_collect()
     assert np.array_equal(a[0], want[0][0]) and np.array_equal(b[0], want[1][0])
+
+
+def test_config3_second_weight_set_multilingual_prompt(pkg, assets, orc):
+    """BASELINE configs[2] (whisper-tiny-german): same graph, a different weight set (seed 1
+    stands in for the fine-tune) and the multilingual vocab path (sot 50258, <|de|> 50261,
+    transcribe 50359, notimestamps 50363).  Ids exact and logits within tolerance vs the oracle."""
+    prefix, vocab = assets("tiny", 1)
+    e = pkg.Engine(prefix, vocab, True)
+    e.set_option("stop_at_eot", 0)
+    assert prompt_of(e) == [50258, 50261, 50359, 50363]
+    rng = np.random.default_rng(31)
+    mel = rng.uniform(-1.0, 1.5, size=(3, 80, 3000)).astype(np.float32)
+    ids, n, enc, logits = e.encdec_debug_batch(mel)
+    m = orc.Model(prefix + ".wtw")
+    ids_ref, n_ref = m.encdec_batch(mel, prompt_of(e), 30, -1, False, True, n_threads=16)
+    assert np.array_equal(ids[:, :31], ids_ref) and list(n) == list(n_ref)
+    enc0 = m.encode(mel[2], 16)
+    assert np.abs(enc[2] - enc0).max() < ENC_TOL
+    _, lg = m.decode_greedy(enc0, prompt_of(e), 30, -1, False, True, 16, True)
+    assert np.abs(logits[2] - lg).max() < LOGIT_TOL
+    # another language id only changes the second prompt token
+    e.set_option("language", pkg.language_id("fr"))
+    ids_fr, _ = e.encdec_tokens_batch(mel[:1])
+    assert ids_fr[0, 1] == 50259 + 6 and ids_fr[0, 0] == 50258
+    m.close()
+    e.close()
+
+
+def test_config4_base_dims_fp32(pkg, assets, orc):
+    """BASELINE configs[3] shape (whisper-base: d 512, 8 heads, 6+6 layers) through the fp32
+    kernels against the oracle.  The bf16-MFMA variant named by that config is not built yet
+    (DESIGN.md §9): this pins the architecture generality of the fp32 path."""
+    prefix, vocab = assets("base", 0)
+    e = pkg.Engine(prefix, vocab, True)
+    e.set_option("stop_at_eot", 0)
+    assert e.dims.n_audio_state == 512 and e.dims.n_text_layer == 6
+    rng = np.random.default_rng(41)
+    mel = rng.uniform(-1.0, 1.5, size=(2, 80, 3000)).astype(np.float32)
+    ids, n, enc, logits = e.encdec_debug_batch(mel)
+    m = orc.Model(prefix + ".wtw")
+    enc0 = m.encode(mel[0], 16)
+    assert np.abs(enc[0] - enc0).max() < ENC_TOL
+    ids_ref, lg = m.decode_greedy(enc0, prompt_of(e), 30, -1, False, True, 16, True)
+    assert np.abs(logits[0] - lg).max() < LOGIT_TOL
+    assert list(ids[0, :31]) == list(ids_ref)
+    m.close()
+    e.close()

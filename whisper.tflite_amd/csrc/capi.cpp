@@ -115,9 +115,9 @@ int wt_engine_set_option(wt_engine* h, const char* key, long value) {
   } else if (k == "cross_chunks") {
     if (value != 1 && value != 2 && value != 4 && value != 8) return fail(h, WT_ERR_INVALID_ARG, "cross_chunks must be 1, 2, 4 or 8");
     e.cross_chunks = value;
-  } else if (k == "gemm_bk") {
-    if (value != 32 && value != 64) return fail(h, WT_ERR_INVALID_ARG, "gemm_bk must be 32 or 64");
-    e.gemm_bk = value;
+  } else if (k == "gemm_variant") {
+    if (value < 0 || value > 6) return fail(h, WT_ERR_INVALID_ARG, "gemm_variant must be in [0, 6]");
+    e.gemm_variant = value;
   } else {
     return fail(h, WT_ERR_INVALID_ARG, "unknown option: " + k);
   }
@@ -139,7 +139,7 @@ int wt_engine_get_option(const wt_engine* h, const char* key, long* value) {
   else if (k == "stop_at_eot") *value = e.stop_at_eot;
   else if (k == "verbose") *value = e.verbose;
   else if (k == "cross_chunks") *value = e.cross_chunks;
-  else if (k == "gemm_bk") *value = e.gemm_bk;
+  else if (k == "gemm_variant") *value = e.gemm_variant;
   else return WT_ERR_INVALID_ARG;
   return WT_OK;
 }
@@ -382,6 +382,38 @@ int wt_dbg_gemm(wt_engine* h, int M, int N, int K, const float* A, const float* 
     wt::launch_gemm(g, epi, h->impl->stream());
     h->impl->sync();
     dC.to_host(C, size_t(M) * N);
+  });
+}
+
+int wt_dbg_gemm_bench(wt_engine* h, int M, int N, int K, int epi, int variant, int iters, float* avg_ms) {
+  if (!h || N % 128 || K % 32 || iters < 1 || !avg_ms) return WT_ERR_INVALID_ARG;
+  return guarded(h, [&] {
+    // random operands (zero-filled ones would run at a higher clock and flatter the kernel)
+    std::vector<float> hostA(size_t(M) * K), hostW(size_t(N) * K), hostB(N);
+    uint64_t x = 88172645463325252ull;
+    auto rnd = [&x] { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return float(int64_t(x % 2000001) - 1000000) * 1e-6f; };
+    for (auto& v : hostA) v = rnd();
+    for (auto& v : hostW) v = rnd() * 0.05f;
+    for (auto& v : hostB) v = rnd();
+    DevBuf dA(hostA.data(), hostA.size()), dW(hostW.data(), hostW.size()), dB(hostB.data(), N), dC(size_t(M) * N);
+    hipchk(hipMemset(dC.p, 0, size_t(M) * N * 4), "memset");
+    wt::GemmArgs g;
+    g.A = dA.p; g.lda = K; g.W = dW.p; g.bias = dB.p; g.C = dC.p; g.R = dC.p; g.ldc = N;
+    g.M = M; g.N = N; g.K = K; g.variant = variant;
+    hipStream_t st = h->impl->stream();
+    hipEvent_t e0, e1;
+    hipchk(hipEventCreate(&e0), "event");
+    hipchk(hipEventCreate(&e1), "event");
+    for (int i = 0; i < 3; ++i) wt::launch_gemm(g, epi, st);
+    hipchk(hipEventRecord(e0, st), "record");
+    for (int i = 0; i < iters; ++i) wt::launch_gemm(g, epi, st);
+    hipchk(hipEventRecord(e1, st), "record");
+    hipchk(hipEventSynchronize(e1), "sync");
+    float ms = 0;
+    hipchk(hipEventElapsedTime(&ms, e0, e1), "elapsed");
+    *avg_ms = ms / iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
   });
 }
 

@@ -19,7 +19,6 @@ namespace {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int BM = 128, BN = 128;
 
 __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
@@ -43,15 +42,19 @@ struct GemmDev {
   int kv_batch, kv_heads, kv_dmodel;
 };
 
-// BK = 64 (69.6 KB of LDS, 2 blocks per CU) halves the barriers per k and leaves half of each
-// SIMD's registers and 90 KB of LDS free, so the decoder's small kernels of the previous batch
-// can co-reside with the encoder (two-stream pipeline); BK = 32 serves K % 64 != 0.
-template <int EPI, int BK>
-__global__ __launch_bounds__(256) void gemm_f32_128x128(GemmDev g) {
+// Tile template: BM x BN output tile (64 or 128 each), 4 wavefronts as 2 x 2, each owning
+// (BM/2) x (BN/2) = MI x NI MFMA tiles of 32 x 32; k-tile BK (32 or 64); DBUF = two LDS
+// buffers and one barrier per k-tile instead of two.
+template <int EPI, int BM, int BN, int BK, bool DBUF>
+__global__ __launch_bounds__(256) void gemm_f32_tile(GemmDev g) {
   constexpr int LDS_LD = BK + 4;  // odd multiple of 16 B: conflict-free ds_read_b128
-  constexpr int NLD = BK / 8;     // float4 per thread per operand per k-tile
-  __shared__ __attribute__((aligned(16))) float As[BM * LDS_LD];
-  __shared__ __attribute__((aligned(16))) float Bs[BN * LDS_LD];
+  constexpr int MI = BM / 64, NI = BN / 64;
+  constexpr int TPR = BK / 4;     // threads covering one row's k-tile (128 or 256 contiguous B)
+  constexpr int RPP = 256 / TPR;  // rows staged per pass
+  constexpr int NA = BM / RPP, NB = BN / RPP;  // float4 per thread per k-tile (A, W)
+  constexpr int NBUF = DBUF ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) float As[NBUF * BM * LDS_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[NBUF * BN * LDS_LD];
 
   // XCD-aware bijective remap: blocks with equal blockIdx % 8 share an XCD (speed only).
   const int nb = gridDim.x, bid = blockIdx.x;
@@ -66,82 +69,96 @@ __global__ __launch_bounds__(256) void gemm_f32_128x128(GemmDev g) {
   const int wm = wid >> 1, wn = wid & 1;
   const int l31 = lane & 31, lh = lane >> 5;
 
-  // staging map: 128 rows x BK/4 float4 per operand tile, NLD float4 per thread per operand;
-  // BK/4 consecutive threads cover one row's k-tile (128 or 256 contiguous bytes)
-  constexpr int TPR = BK / 4;       // threads per row
-  constexpr int RPP = 256 / TPR;    // rows per pass
   const int srow = tid / TPR, scol = (tid % TPR) * 4;
-  const float* a_ptr[NLD];
-  const float* w_ptr[NLD];
+  const float* a_ptr[NA];
+  const float* w_ptr[NB];
 #pragma unroll
-  for (int i = 0; i < NLD; ++i) {
+  for (int i = 0; i < NA; ++i) {
     int m = m0 + srow + RPP * i;
     m = m < g.M ? m : g.M - 1;  // clamp: rows past M are computed and discarded
     a_ptr[i] = g.A + (long)(m / g.a_rpb) * g.a_bs + (long)(m % g.a_rpb) * g.lda + scol;
-    w_ptr[i] = g.W + (long)(n0 + srow + RPP * i) * g.K + scol;
   }
+#pragma unroll
+  for (int i = 0; i < NB; ++i) w_ptr[i] = g.W + (long)(n0 + srow + RPP * i) * g.K + scol;
 
-  f32x16 acc[2][2];
+  f32x16 acc[MI][NI];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NI; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  f32x4 ra[NLD], rb[NLD];
+  f32x4 ra[NA], rb[NB];
+  auto load_tile = [&](int kt) {
 #pragma unroll
-  for (int i = 0; i < NLD; ++i) {
-    ra[i] = *reinterpret_cast<const f32x4*>(a_ptr[i]);
-    rb[i] = *reinterpret_cast<const f32x4*>(w_ptr[i]);
-  }
-
-  const int nkt = g.K / BK;
-  for (int kt = 0; kt < nkt; ++kt) {
+    for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(a_ptr[i] + kt * BK);
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      *reinterpret_cast<f32x4*>(&As[(srow + RPP * i) * LDS_LD + scol]) = ra[i];
-      *reinterpret_cast<f32x4*>(&Bs[(srow + RPP * i) * LDS_LD + scol]) = rb[i];
-    }
-    __syncthreads();
-    if (kt + 1 < nkt) {
+    for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const f32x4*>(w_ptr[i] + kt * BK);
+  };
+  auto store_tile = [&](int buf) {
 #pragma unroll
-      for (int i = 0; i < NLD; ++i) {
-        ra[i] = *reinterpret_cast<const f32x4*>(a_ptr[i] + (kt + 1) * BK);
-        rb[i] = *reinterpret_cast<const f32x4*>(w_ptr[i] + (kt + 1) * BK);
-      }
-    }
+    for (int i = 0; i < NA; ++i)
+      *reinterpret_cast<f32x4*>(&As[buf * BM * LDS_LD + (srow + RPP * i) * LDS_LD + scol]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      *reinterpret_cast<f32x4*>(&Bs[buf * BN * LDS_LD + (srow + RPP * i) * LDS_LD + scol]) = rb[i];
+  };
+  auto compute = [&](int buf) {
+    const float* Ab = As + buf * BM * LDS_LD + (wm * (BM / 2) + l31) * LDS_LD + 4 * lh;
+    const float* Bb = Bs + buf * BN * LDS_LD + (wn * (BN / 2) + l31) * LDS_LD + 4 * lh;
 #pragma unroll
     for (int kq = 0; kq < BK / 8; ++kq) {
-      // lane (row l31, half lh) takes k = 8*kq + 4*lh + j for MFMA step j: A and B use
-      // the same k permutation, so the contraction is complete and exact.
-      const int kof = kq * 8 + 4 * lh;
-      const f32x4 a0 = *reinterpret_cast<const f32x4*>(&As[(wm * 64 + l31) * LDS_LD + kof]);
-      const f32x4 a1 = *reinterpret_cast<const f32x4*>(&As[(wm * 64 + 32 + l31) * LDS_LD + kof]);
-      const f32x4 b0 = *reinterpret_cast<const f32x4*>(&Bs[(wn * 64 + l31) * LDS_LD + kof]);
-      const f32x4 b1 = *reinterpret_cast<const f32x4*>(&Bs[(wn * 64 + 32 + l31) * LDS_LD + kof]);
+      // lane (row l31, half lh) takes k = 8*kq + 4*lh + j for MFMA step j: A and B use the
+      // same k permutation, so the contraction is complete and exact.
+      f32x4 af[MI], bf[NI];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc[1][1], 0, 0, 0);
-      }
+      for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDS_LD + kq * 8);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDS_LD + kq * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
     }
+  };
+
+  const int nkt = g.K / BK;
+  load_tile(0);
+  if (DBUF) {
+    store_tile(0);
     __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < nkt) load_tile(kt + 1);
+      compute(cur);
+      if (kt + 1 < nkt) store_tile(cur ^ 1);
+      __syncthreads();
+    }
+  } else {
+    for (int kt = 0; kt < nkt; ++kt) {
+      store_tile(0);
+      __syncthreads();
+      if (kt + 1 < nkt) load_tile(kt + 1);
+      compute(0);
+      __syncthreads();
+    }
   }
 
   // epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
+  for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int m = m0 + wm * (BM / 2) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
       if (m >= g.M) continue;
       const int mb = m / g.c_rpb, mt = m % g.c_rpb;
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        const int n = n0 + wn * 64 + ni * 32 + l31;
+      for (int ni = 0; ni < NI; ++ni) {
+        const int n = n0 + wn * (BN / 2) + ni * 32 + l31;
         float v = acc[mi][ni][r];
         if (EPI & kEpiBias) v += g.bias[n];
         if (EPI & kEpiGelu) v = gelu_erf(v);
@@ -162,12 +179,26 @@ __global__ __launch_bounds__(256) void gemm_f32_128x128(GemmDev g) {
   }
 }
 
+template <int EPI, int BM, int BN, int BK, bool DBUF>
+void launch_tile(const GemmDev& g, hipStream_t s) {
+  const int blocks = ((g.M + BM - 1) / BM) * (g.N / BN);
+  hipLaunchKernelGGL((gemm_f32_tile<EPI, BM, BN, BK, DBUF>), dim3(blocks), dim3(256), 0, s, g);
+}
+
+// variant: 0 = 128x128x32 (3 blocks/CU), 1 = 128x128x64, 2 = 128x128x32 double-buffered,
+//          3 = 128x64x32, 4 = 64x128x32, 5 = 128x64x32 double-buffered, 6 = 64x64x32
 template <int EPI>
-void launch_gemm_t(const GemmDev& g, int blocks, int bk, hipStream_t s) {
-  if (bk == 64 && g.K % 64 == 0) {
-    hipLaunchKernelGGL((gemm_f32_128x128<EPI, 64>), dim3(blocks), dim3(256), 0, s, g);
-  } else {
-    hipLaunchKernelGGL((gemm_f32_128x128<EPI, 32>), dim3(blocks), dim3(256), 0, s, g);
+void launch_gemm_t(const GemmDev& g, int variant, hipStream_t s) {
+  if (variant == 1 && g.K % 64 != 0) variant = 0;
+  switch (variant) {
+    case 0: launch_tile<EPI, 128, 128, 32, false>(g, s); break;
+    case 1: launch_tile<EPI, 128, 128, 64, false>(g, s); break;
+    case 2: launch_tile<EPI, 128, 128, 32, true>(g, s); break;
+    case 3: launch_tile<EPI, 128, 64, 32, false>(g, s); break;
+    case 4: launch_tile<EPI, 64, 128, 32, false>(g, s); break;
+    case 5: launch_tile<EPI, 128, 64, 32, true>(g, s); break;
+    case 6: launch_tile<EPI, 64, 64, 32, false>(g, s); break;
+    default: abort();
   }
 }
 
@@ -177,14 +208,15 @@ void launch_gemm(const GemmArgs& a, int epi, hipStream_t s) {
   GemmDev g{a.A,   a.W,   a.C,    a.bias, a.R,   a.pos,        a.M,        a.N,        a.K,
             a.a_rpb, a.a_bs, a.lda, a.c_rpb, a.c_bs, a.ldc, a.pos_period, a.kv_batch, a.kv_heads,
             a.kv_dmodel};
-  const int blocks = ((a.M + BM - 1) / BM) * (a.N / BN);
+  if (a.N % 128 != 0 || a.K % 32 != 0 || a.M < 1) abort();  // shape contract of the kernels
+  const int v = a.variant;
   switch (epi) {
-    case 0: launch_gemm_t<0>(g, blocks, a.bk, s); break;
-    case kEpiBias: launch_gemm_t<kEpiBias>(g, blocks, a.bk, s); break;
-    case kEpiBias | kEpiGelu: launch_gemm_t<kEpiBias | kEpiGelu>(g, blocks, a.bk, s); break;
-    case kEpiBias | kEpiResidual: launch_gemm_t<kEpiBias | kEpiResidual>(g, blocks, a.bk, s); break;
-    case kEpiBias | kEpiGelu | kEpiPos: launch_gemm_t<kEpiBias | kEpiGelu | kEpiPos>(g, blocks, a.bk, s); break;
-    case kEpiBias | kEpiKvLayout: launch_gemm_t<kEpiBias | kEpiKvLayout>(g, blocks, a.bk, s); break;
+    case 0: launch_gemm_t<0>(g, v, s); break;
+    case kEpiBias: launch_gemm_t<kEpiBias>(g, v, s); break;
+    case kEpiBias | kEpiGelu: launch_gemm_t<kEpiBias | kEpiGelu>(g, v, s); break;
+    case kEpiBias | kEpiResidual: launch_gemm_t<kEpiBias | kEpiResidual>(g, v, s); break;
+    case kEpiBias | kEpiGelu | kEpiPos: launch_gemm_t<kEpiBias | kEpiGelu | kEpiPos>(g, v, s); break;
+    case kEpiBias | kEpiKvLayout: launch_gemm_t<kEpiBias | kEpiKvLayout>(g, v, s); break;
     default: abort();
   }
 }
