@@ -6,7 +6,8 @@
 //   1 + LDS fragment reads (4 x ds_read_b128 per 16 MFMA), no barrier
 //   2 + __syncthreads every 64 MFMA
 //   3 + ds_write_b128 of a fresh tile (8 per thread) every 64 MFMA
-//   4 + global loads feeding those writes (the whole staging path)
+//   4 + global loads feeding those writes (the whole staging path), L2-resident source
+//   5 same, but every block streams its own fresh 16 KB per k-tile (HBM-resident source)
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -42,8 +43,10 @@ __global__ __launch_bounds__(256) void probe(const float* __restrict__ src, floa
     if (MODE >= 4) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        ra[i] = *reinterpret_cast<const f32x4*>(gp + (long)(i * 32) * 32 + ((it & 15) * 4096));
-        rb[i] = *reinterpret_cast<const f32x4*>(gp + (long)(i * 32) * 32 + ((it & 15) * 4096) + 2048);
+        const long off = MODE == 5 ? ((long)blockIdx.x * iters + it) * 8192 - (long)blockIdx.x * 4096
+                                   : (long)((it & 15) * 4096);
+        ra[i] = *reinterpret_cast<const f32x4*>(gp + (long)(i * 32) * 32 + off);
+        rb[i] = *reinterpret_cast<const f32x4*>(gp + (long)(i * 32) * 32 + off + 2048);
       }
     }
 #pragma unroll
@@ -100,7 +103,7 @@ void run(const float* src, float* dst, int blocks, int iters) {
 
 int main() {
   float *src, *dst;
-  const size_t n = 64u << 20;
+  const size_t n = 300u << 20;  // 1.2 GB: mode 5 streams 32 KB per block per k-tile
   hipMalloc(&src, n * 4);
   hipMalloc(&dst, 16u << 20);
   std::vector<float> h(n);
@@ -116,9 +119,12 @@ int main() {
     run<2>(src, dst, blocks, 48);
     run<3>(src, dst, blocks, 48);
     run<4>(src, dst, blocks, 48);
+    if (blocks <= 1024) run<5>(src, dst, blocks, 32);
   }
   run<0>(src, dst, 768, 12);
   run<4>(src, dst, 768, 12);
   run<4>(src, dst, 1125, 12);
+  run<5>(src, dst, 768, 12);
+  run<5>(src, dst, 1125, 12);
   return 0;
 }

@@ -45,7 +45,7 @@ struct GemmDev {
 // Tile template: BM x BN output tile (64 or 128 each), 4 wavefronts as 2 x 2, each owning
 // (BM/2) x (BN/2) = MI x NI MFMA tiles of 32 x 32; k-tile BK (32 or 64); DBUF = two LDS
 // buffers and one barrier per k-tile instead of two.
-template <int EPI, int BM, int BN, int BK, bool DBUF>
+template <int EPI, int BM, int BN, int BK, bool DBUF, bool PF2 = false>
 __global__ __launch_bounds__(256) void gemm_f32_tile(GemmDev g) {
   constexpr int LDS_LD = BK + 4;  // odd multiple of 16 B: conflict-free ds_read_b128
   constexpr int MI = BM / 64, NI = BN / 64;
@@ -90,20 +90,23 @@ __global__ __launch_bounds__(256) void gemm_f32_tile(GemmDev g) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
   f32x4 ra[NA], rb[NB];
-  auto load_tile = [&](int kt) {
+  f32x4 ra2[PF2 ? NA : 1], rb2[PF2 ? NB : 1];  // second register stage (prefetch depth 2)
+  auto load_into = [&](f32x4* xa, f32x4* xb, int kt) {
 #pragma unroll
-    for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(a_ptr[i] + kt * BK);
+    for (int i = 0; i < NA; ++i) xa[i] = *reinterpret_cast<const f32x4*>(a_ptr[i] + kt * BK);
 #pragma unroll
-    for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const f32x4*>(w_ptr[i] + kt * BK);
+    for (int i = 0; i < NB; ++i) xb[i] = *reinterpret_cast<const f32x4*>(w_ptr[i] + kt * BK);
   };
-  auto store_tile = [&](int buf) {
+  auto store_from = [&](const f32x4* xa, const f32x4* xb, int buf) {
 #pragma unroll
     for (int i = 0; i < NA; ++i)
-      *reinterpret_cast<f32x4*>(&As[buf * BM * LDS_LD + (srow + RPP * i) * LDS_LD + scol]) = ra[i];
+      *reinterpret_cast<f32x4*>(&As[buf * BM * LDS_LD + (srow + RPP * i) * LDS_LD + scol]) = xa[i];
 #pragma unroll
     for (int i = 0; i < NB; ++i)
-      *reinterpret_cast<f32x4*>(&Bs[buf * BN * LDS_LD + (srow + RPP * i) * LDS_LD + scol]) = rb[i];
+      *reinterpret_cast<f32x4*>(&Bs[buf * BN * LDS_LD + (srow + RPP * i) * LDS_LD + scol]) = xb[i];
   };
+  auto load_tile = [&](int kt) { load_into(ra, rb, kt); };
+  auto store_tile = [&](int buf) { store_from(ra, rb, buf); };
   auto compute = [&](int buf) {
     const float* Ab = As + buf * BM * LDS_LD + (wm * (BM / 2) + l31) * LDS_LD + 4 * lh;
     const float* Bb = Bs + buf * BN * LDS_LD + (wn * (BN / 2) + l31) * LDS_LD + 4 * lh;
@@ -128,7 +131,27 @@ __global__ __launch_bounds__(256) void gemm_f32_tile(GemmDev g) {
 
   const int nkt = g.K / BK;
   load_tile(0);
-  if (DBUF) {
+  if (PF2) {
+    // Two k-tiles of global loads in flight: HBM latency (~2-3 us under load) exceeds one
+    // k-tile of MFMA work (4096 cycles), so a tile is requested two iterations before its
+    // LDS write.  Register stages alternate (static names: the loop is unrolled by two).
+    static_assert(!PF2 || DBUF, "prefetch depth 2 uses both LDS buffers");
+    store_tile(0);
+    if (nkt > 1) load_into(ra, rb, 1);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; kt += 2) {
+      if (kt + 2 < nkt) load_into(ra2, rb2, kt + 2);
+      compute(0);
+      if (kt + 1 < nkt) store_from(ra, rb, 1);
+      __syncthreads();
+      if (kt + 1 < nkt) {
+        if (kt + 3 < nkt) load_into(ra, rb, kt + 3);
+        compute(1);
+        if (kt + 2 < nkt) store_from(ra2, rb2, 0);
+        __syncthreads();
+      }
+    }
+  } else if (DBUF) {
     store_tile(0);
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
@@ -179,14 +202,15 @@ __global__ __launch_bounds__(256) void gemm_f32_tile(GemmDev g) {
   }
 }
 
-template <int EPI, int BM, int BN, int BK, bool DBUF>
+template <int EPI, int BM, int BN, int BK, bool DBUF, bool PF2 = false>
 void launch_tile(const GemmDev& g, hipStream_t s) {
   const int blocks = ((g.M + BM - 1) / BM) * (g.N / BN);
-  hipLaunchKernelGGL((gemm_f32_tile<EPI, BM, BN, BK, DBUF>), dim3(blocks), dim3(256), 0, s, g);
+  hipLaunchKernelGGL((gemm_f32_tile<EPI, BM, BN, BK, DBUF, PF2>), dim3(blocks), dim3(256), 0, s, g);
 }
 
 // variant: 0 = 128x128x32 (3 blocks/CU), 1 = 128x128x64, 2 = 128x128x32 double-buffered,
-//          3 = 128x64x32, 4 = 64x128x32, 5 = 128x64x32 double-buffered, 6 = 64x64x32
+//          3 = 128x64x32, 4 = 64x128x32, 5 = 128x64x32 double-buffered, 6 = 64x64x32,
+//          7 = 128x128x32 double-buffered + global prefetch depth 2, 8 = 128x64x32 likewise
 template <int EPI>
 void launch_gemm_t(const GemmDev& g, int variant, hipStream_t s) {
   if (variant == 1 && g.K % 64 != 0) variant = 0;
@@ -198,6 +222,8 @@ void launch_gemm_t(const GemmDev& g, int variant, hipStream_t s) {
     case 4: launch_tile<EPI, 64, 128, 32, false>(g, s); break;
     case 5: launch_tile<EPI, 128, 64, 32, true>(g, s); break;
     case 6: launch_tile<EPI, 64, 64, 32, false>(g, s); break;
+    case 7: launch_tile<EPI, 128, 128, 32, true, true>(g, s); break;
+    case 8: launch_tile<EPI, 128, 64, 32, true, true>(g, s); break;
     default: abort();
   }
 }
