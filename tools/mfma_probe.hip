@@ -8,6 +8,8 @@
 //   3 + ds_write_b128 of a fresh tile (8 per thread) every 64 MFMA
 //   4 + global loads feeding those writes (the whole staging path), L2-resident source
 //   5 same, but every block streams its own fresh 16 KB per k-tile (HBM-resident source)
+//   6 = 5 + the GEMM's naive epilogue (64 dword stores per lane, bias + residual read)
+//   7 = 5 + LDS-transposed epilogue (16 float4 stores per lane, float4 residual reads)
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -43,7 +45,7 @@ __global__ __launch_bounds__(256) void probe(const float* __restrict__ src, floa
     if (MODE >= 4) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const long off = MODE == 5 ? ((long)blockIdx.x * iters + it) * 8192 - (long)blockIdx.x * 4096
+        const long off = MODE >= 5 ? ((long)blockIdx.x * iters + it) * 8192 - (long)blockIdx.x * 4096
                                    : (long)((it & 15) * 4096);
         ra[i] = *reinterpret_cast<const f32x4*>(gp + (long)(i * 32) * 32 + off);
         rb[i] = *reinterpret_cast<const f32x4*>(gp + (long)(i * 32) * 32 + off + 2048);
@@ -76,6 +78,44 @@ __global__ __launch_bounds__(256) void probe(const float* __restrict__ src, floa
       __syncthreads();
     }
   }
+  if (MODE == 6) {
+    // C/D layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); N = 384
+    const long m0 = (long)(blockIdx.x / 3) * 128, n0 = (blockIdx.x % 3) * 128;
+    for (int mi = 0; mi < 2; ++mi)
+      for (int r = 0; r < 16; ++r) {
+        const long m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        for (int ni = 0; ni < 2; ++ni) {
+          const long n = n0 + wn * 64 + ni * 32 + l31;
+          float v = acc[mi][ni][r] + src[n];
+          v += dst[m * 384 + n];
+          dst[m * 384 + n] = v;
+        }
+      }
+    return;
+  }
+  if (MODE == 7) {
+    const long m0 = (long)(blockIdx.x / 3) * 128, n0 = (blockIdx.x % 3) * 128;
+    __syncthreads();  // all waves are done with As/Bs
+    float* stage = As + wid * (32 * 68);  // per-wave [32 rows][64 cols + 4]; As+Bs = 9216 floats >= 4*2176
+    const int rr = lane >> 4, c4 = (lane & 15) * 4;
+    const f32x4 bias = *reinterpret_cast<const f32x4*>(src + n0 + wn * 64 + c4);
+    for (int mi = 0; mi < 2; ++mi) {
+      for (int ni = 0; ni < 2; ++ni)
+        for (int r = 0; r < 16; ++r)
+          stage[((r & 3) + 8 * (r >> 2) + 4 * lh) * 68 + ni * 32 + l31] = acc[mi][ni][r];
+      // wave-private staging: no block barrier needed, only LDS ordering inside the wave
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      for (int i = 0; i < 8; ++i) {
+        const int row = i * 4 + rr;
+        f32x4 v = *reinterpret_cast<const f32x4*>(&stage[row * 68 + c4]);
+        const long o = (m0 + wm * 64 + mi * 32 + row) * 384 + n0 + wn * 64 + c4;
+        const f32x4 res = *reinterpret_cast<const f32x4*>(dst + o);
+        v += bias + res;
+        *reinterpret_cast<f32x4*>(dst + o) = v;
+      }
+    }
+    return;
+  }
   float s = 0;
   for (int i = 0; i < 2; ++i)
     for (int j = 0; j < 2; ++j)
@@ -83,8 +123,20 @@ __global__ __launch_bounds__(256) void probe(const float* __restrict__ src, floa
   dst[(long)blockIdx.x * 256 + tid] = s;
 }
 
+static size_t g_src_floats = 0, g_dst_floats = 0;
+
 template <int MODE>
 void run(const float* src, float* dst, int blocks, int iters) {
+  // host-side bounds check of everything the kernel will index (a first version of this probe
+  // faulted the GPU by streaming past the source buffer)
+  if (MODE >= 5 && (size_t)blocks * iters * 8192 + 2 * 8192 > g_src_floats) {
+    printf("mode %d blocks %d iters %d: skipped (source buffer too small)\n", MODE, blocks, iters);
+    return;
+  }
+  if (MODE >= 6 && ((size_t)(blocks / 3 + 1) * 128 * 384 > g_dst_floats || blocks % 3 != 0)) {
+    printf("mode %d blocks %d: skipped (output buffer too small / blocks not a multiple of 3)\n", MODE, blocks);
+    return;
+  }
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
@@ -105,7 +157,9 @@ int main() {
   float *src, *dst;
   const size_t n = 300u << 20;  // 1.2 GB: mode 5 streams 32 KB per block per k-tile
   hipMalloc(&src, n * 4);
-  hipMalloc(&dst, 16u << 20);
+  hipMalloc(&dst, 256u << 20);
+  g_src_floats = n;
+  g_dst_floats = (256u << 20) / 4;  // modes 6/7 write a [blocks/3*128][384] fp32 output
   std::vector<float> h(n);
   unsigned x = 12345;
   for (auto& v : h) {
@@ -126,5 +180,13 @@ int main() {
   run<4>(src, dst, 1125, 12);
   run<5>(src, dst, 768, 12);
   run<5>(src, dst, 1125, 12);
+  for (int it : {12, 48}) {
+    run<5>(src, dst, 1125, it);
+    run<6>(src, dst, 1125, it);
+    run<7>(src, dst, 1125, it);
+  }
+  run<5>(src, dst, 3375, 12);
+  run<6>(src, dst, 3375, 12);
+  run<7>(src, dst, 3375, 12);
   return 0;
 }

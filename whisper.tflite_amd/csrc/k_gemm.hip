@@ -53,8 +53,11 @@ __global__ __launch_bounds__(256) void gemm_f32_tile(GemmDev g) {
   constexpr int RPP = 256 / TPR;  // rows staged per pass
   constexpr int NA = BM / RPP, NB = BN / RPP;  // float4 per thread per k-tile (A, W)
   constexpr int NBUF = DBUF ? 2 : 1;
-  __shared__ __attribute__((aligned(16))) float As[NBUF * BM * LDS_LD];
-  __shared__ __attribute__((aligned(16))) float Bs[NBUF * BN * LDS_LD];
+  constexpr int SLD = NI * 32 + 4;  // epilogue staging row stride (floats)
+  constexpr int kTileFloats = NBUF * (BM + BN) * LDS_LD, kStageFloats = 4 * 32 * SLD;
+  __shared__ __attribute__((aligned(16))) float smem[kTileFloats > kStageFloats ? kTileFloats : kStageFloats];
+  float* const As = smem;
+  float* const Bs = smem + NBUF * BM * LDS_LD;
 
   // XCD-aware bijective remap: blocks with equal blockIdx % 8 share an XCD (speed only).
   const int nb = gridDim.x, bid = blockIdx.x;
@@ -171,31 +174,51 @@ __global__ __launch_bounds__(256) void gemm_f32_tile(GemmDev g) {
     }
   }
 
-  // epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  // Epilogue.  The C/D layout (col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5))
+  // would make every lane issue 16 * MI * NI single-dword stores (and as many residual loads):
+  // measured on a probe of this loop, that costs +64 % on a K = 384 GEMM.  Each wavefront
+  // instead transposes 32-row slabs of its tile through a private LDS stage (the operand
+  // tiles are dead by now) and moves 16 bytes per lane: 4x fewer memory instructions, whole
+  // 128/256-byte row segments per 8/16 lanes.
+  __syncthreads();  // every wavefront is done reading the operand tiles
+  float* const stage = smem + wid * (32 * SLD);
+  constexpr int LPR = NI * 8;        // lanes per staged row (one float4 each)
+  constexpr int RPS = 64 / LPR;      // rows per pass
+  const int prow = lane / LPR, c4 = (lane % LPR) * 4;
+  const int n = n0 + wn * (BN / 2) + c4;
+  f32x4 bias4 = {0, 0, 0, 0};
+  if (EPI & kEpiBias) bias4 = *reinterpret_cast<const f32x4*>(g.bias + n);
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm * (BM / 2) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (m >= g.M) continue;
-      const int mb = m / g.c_rpb, mt = m % g.c_rpb;
+    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        const int n = n0 + wn * (BN / 2) + ni * 32 + l31;
-        float v = acc[mi][ni][r];
-        if (EPI & kEpiBias) v += g.bias[n];
-        if (EPI & kEpiGelu) v = gelu_erf(v);
-        if (EPI & kEpiPos) v += g.pos[(long)(m % g.pos_period) * g.N + n];
+      for (int r = 0; r < 16; ++r)
+        stage[((r & 3) + 8 * (r >> 2) + 4 * lh) * SLD + ni * 32 + l31] = acc[mi][ni][r];
+    // the stage is private to this wavefront and LDS executes a wave's operations in order
+#pragma unroll
+    for (int p = 0; p < 32 / RPS; ++p) {
+      const int row = p * RPS + prow;
+      const int m = m0 + wm * (BM / 2) + mi * 32 + row;
+      f32x4 v = *reinterpret_cast<const f32x4*>(&stage[row * SLD + c4]);
+      if (m < g.M) {
+        const int mb = m / g.c_rpb, mt = m % g.c_rpb;
+        v += bias4;
+        if (EPI & kEpiGelu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+        }
+        if (EPI & kEpiPos) v += *reinterpret_cast<const f32x4*>(g.pos + (long)(m % g.pos_period) * g.N + n);
         if (EPI & kEpiKvLayout) {
           const int slab = n / g.kv_dmodel, rem = n % g.kv_dmodel;
-          const int head = rem >> 6, dd = rem & 63;
+          const int head = rem >> 6, dd = rem & 63;  // 4 consecutive dd: c4 is a multiple of 4
           const long o = (((long)slab * g.kv_batch + mb) * g.kv_heads + head) * (long)g.c_rpb * 64 +
                          (long)mt * 64 + dd;
-          g.C[o] = v;
+          *reinterpret_cast<f32x4*>(g.C + o) = v;
         } else {
           const long o = (long)mb * g.c_bs + (long)mt * g.ldc + n;
-          if (EPI & kEpiResidual) v += g.R[o];
-          g.C[o] = v;
+          if (EPI & kEpiResidual) v += *reinterpret_cast<const f32x4*>(g.R + o);
+          *reinterpret_cast<f32x4*>(g.C + o) = v;
         }
       }
     }
