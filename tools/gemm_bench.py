@@ -11,7 +11,7 @@ pkg = ge.load_package()
 tmp = tempfile.mkdtemp()
 prefix, vocab = ge._assets(tmp, "micro", 0)
 eng = pkg.Engine(prefix, vocab, True)
-names = {0: "128x128x32", 1: "128x128x64", 2: "128x128x32db", 3: "128x64x32", 4: "64x128x32", 5: "128x64x32db", 6: "64x64x32", 7: "128x128pf2", 8: "128x64pf2"}
+names = {0: "128x128x32", 1: "128x128x64", 2: "128x128x32db", 3: "128x64x32", 4: "64x128x32", 5: "128x64x32db", 6: "64x64x32", 7: "128x128pf2", 8: "128x64pf2", 9: "192x128x32"}
 shapes = [(48000, 384, 384, 5, "out-proj"), (48000, 1152, 384, 1, "qkv"), (48000, 1536, 384, 3, "fc1"),
           (48000, 384, 1536, 5, "fc2"), (48000, 384, 1152, 3, "conv2"), (96000, 384, 256, 3, "conv1"),
           (48000, 3072, 384, 1, "cross-kv")]

@@ -116,7 +116,7 @@ int wt_engine_set_option(wt_engine* h, const char* key, long value) {
     if (value != 1 && value != 2 && value != 4 && value != 8) return fail(h, WT_ERR_INVALID_ARG, "cross_chunks must be 1, 2, 4 or 8");
     e.cross_chunks = value;
   } else if (k == "gemm_variant") {
-    if (value < 0 || value > 8) return fail(h, WT_ERR_INVALID_ARG, "gemm_variant must be in [0, 8]");
+    if (value < -1 || value > 9) return fail(h, WT_ERR_INVALID_ARG, "gemm_variant must be in [-1, 9]");
     e.gemm_variant = value;
   } else {
     return fail(h, WT_ERR_INVALID_ARG, "unknown option: " + k);

@@ -72,7 +72,7 @@ class Engine {
   long stop_at_eot = 1;
   long verbose = 0;
   long cross_chunks = 4;
-  long gemm_variant = 0;  // encoder GEMM tile variant (k_gemm.hip)
+  long gemm_variant = -1;  // encoder GEMM tile variant (k_gemm.hip); -1 = per-shape choice
   // non-empty: replaces the reference's hard-coded prompt (test-sized vocabularies)
   std::vector<long long> prompt_override;
 

@@ -233,7 +233,8 @@ void launch_tile(const GemmDev& g, hipStream_t s) {
 
 // variant: 0 = 128x128x32 (3 blocks/CU), 1 = 128x128x64, 2 = 128x128x32 double-buffered,
 //          3 = 128x64x32, 4 = 64x128x32, 5 = 128x64x32 double-buffered, 6 = 64x64x32,
-//          7 = 128x128x32 double-buffered + global prefetch depth 2, 8 = 128x64x32 likewise
+//          7 = 128x128x32 double-buffered + global prefetch depth 2, 8 = 128x64x32 likewise,
+//          9 = 192x128x32 (wave tile 96x64)
 template <int EPI>
 void launch_gemm_t(const GemmDev& g, int variant, hipStream_t s) {
   if (variant == 1 && g.K % 64 != 0) variant = 0;
@@ -247,6 +248,7 @@ void launch_gemm_t(const GemmDev& g, int variant, hipStream_t s) {
     case 6: launch_tile<EPI, 64, 64, 32, false>(g, s); break;
     case 7: launch_tile<EPI, 128, 128, 32, true, true>(g, s); break;
     case 8: launch_tile<EPI, 128, 64, 32, true, true>(g, s); break;
+    case 9: launch_tile<EPI, 192, 128, 32, false>(g, s); break;
     default: abort();
   }
 }
@@ -258,7 +260,13 @@ void launch_gemm(const GemmArgs& a, int epi, hipStream_t s) {
             a.a_rpb, a.a_bs, a.lda, a.c_rpb, a.c_bs, a.ldc, a.pos_period, a.kv_batch, a.kv_heads,
             a.kv_dmodel};
   if (a.N % 128 != 0 || a.K % 32 != 0 || a.M < 1) abort();  // shape contract of the kernels
-  const int v = a.variant;
+  int v = a.variant;
+  if (v < 0) {
+    // auto: 128x128 tiles unless they make fewer than three rounds of 3 blocks x 256 CUs, where
+    // the ragged last round costs 15-20 % (measured); 64x128 tiles halve the quantum
+    const long blocks128 = (long)((a.M + 127) / 128) * (a.N / 128);
+    v = blocks128 < 3 * 768 ? 4 : 0;
+  }
   switch (epi) {
     case 0: launch_gemm_t<0>(g, v, s); break;
     case kEpiBias: launch_gemm_t<kEpiBias>(g, v, s); break;

@@ -40,7 +40,7 @@ struct GemmArgs {
   //   -> C[((slab * kv_batch + b) * kv_heads + head) * T * 64 + t * 64 + dd]
   // where slab enumerates (layer, k|v); T = c_rpb.
   int kv_batch = 0, kv_heads = 0, kv_dmodel = 0;
-  int variant = 0;  // tile shape / pipelining variant, see k_gemm.hip launch_gemm_t
+  int variant = -1;  // tile shape / pipelining variant (k_gemm.hip launch_gemm_t); -1 = auto
 };
 void launch_gemm(const GemmArgs& a, int epi, hipStream_t s);
 
