@@ -153,6 +153,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="synchronous steps (encoder then decoder) instead of the two-deep pipeline")
+    ap.add_argument("--depth", type=int, default=3, choices=(1, 2, 3), help="batches in flight (pipelined mode)")
     ap.add_argument("--gemm-variant", type=int, default=None, help="encoder GEMM tile variant (k_gemm.hip)")
     ap.add_argument("--dry-run-gloo", action="store_true")
     args = ap.parse_args()
@@ -200,9 +201,9 @@ def main() -> None:
         return finish(*eng.encdec_tokens_batch_dev(d_mel.data_ptr(), B))
 
     def run_steps(k, on_step=None):
-        """k passes of the hot path.  Pipelined: batch i+1 is submitted (encoder on one HIP
-        stream) before batch i is collected (decoder on a second stream), all k batches start
-        and finish inside the call."""
+        """k passes of the hot path.  Pipelined: up to --depth batches are in flight (encoder on
+        one HIP stream, decoders alternating between two more); all k batches start and
+        finish inside the call."""
         out = None
         if not pipelined:
             for _ in range(k):
@@ -210,15 +211,20 @@ def main() -> None:
                 if on_step:
                     on_step()
             return out
-        eng.pipeline_submit_dev(d_mel.data_ptr(), B)
-        for _ in range(k - 1):
+        in_flight = 0
+        for _ in range(k):
             eng.pipeline_submit_dev(d_mel.data_ptr(), B)
+            in_flight += 1
+            if in_flight == args.depth:
+                out = finish(*eng.pipeline_collect())
+                in_flight -= 1
+                if on_step:
+                    on_step()
+        while in_flight:
             out = finish(*eng.pipeline_collect())
+            in_flight -= 1
             if on_step:
                 on_step()
-        out = finish(*eng.pipeline_collect())
-        if on_step:
-            on_step()
         return out
 
     if args.warmup:
@@ -305,7 +311,7 @@ def main() -> None:
                                    "weights (BASELINE.json configs[1]); mel resident in HBM -> token ids on host",
                        "clips_per_gpu": B, "global_batch": world * B, "decoder_positions": 30,
                        "argmax_steps": 27, "parallelism": f"clip-parallel dp{world}, RCCL all_gather of id records",
-                       "pipelined": pipelined},
+                       "pipelined": pipelined, "batches_in_flight": args.depth if pipelined else 1},
             "roofline": roof,
             "roofline_detail": detail,
             "decoder_roofline": {"bound": "hbm", "achieved": round(dec_ach, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",

@@ -104,12 +104,12 @@ int wt_encdec_tokens_batch_dev(wt_engine* h, const float* d_mel, int batch, int6
 int wt_transcribe_tokens_batch_dev(wt_engine* h, const float* d_pcm, int batch, int64_t* ids,
                                    int32_t* n_ids);
 
-/* Two-deep pipeline over the same path: submit enqueues encoder (one HIP stream) and decoder
- * (a second, higher-priority stream) for one device-resident batch and returns at once;
- * collect blocks until the OLDEST submitted batch has its ids on the host.  With two batches
- * in flight the MFMA-bound encoder of batch i+1 overlaps the latency/HBM-bound decoder of
- * batch i.  d_mel must stay valid until that batch is collected.  At most 2 uncollected
- * submits; batch <= 64. */
+/* Three-deep pipeline over the same path: submit enqueues encoder (one HIP stream) and decoder
+ * (one of two further streams, alternating between batches) for one device-resident batch and
+ * returns at once; collect blocks until the OLDEST submitted batch has its ids on the host.
+ * In steady state the MFMA-bound encoder of batch i+2 shares the chip with the two
+ * latency/HBM-bound decoder chains of batches i+1 and i.  d_mel must stay valid until that
+ * batch is collected.  At most 3 uncollected submits; batch <= 64. */
 int wt_pipeline_submit_dev(wt_engine* h, const float* d_mel, int batch);
 int wt_pipeline_collect(wt_engine* h, int64_t* ids, int32_t* n_ids);
 

@@ -323,7 +323,7 @@ Engine::Engine(const std::string& model_prefix, const std::string& vocab_path, b
   HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
   HIPCHK(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, prio_lo));
   // the decoder's tiny dependent launches go ahead of the encoder's big grids
-  HIPCHK(hipStreamCreateWithPriority(&dstream_, hipStreamNonBlocking, prio_hi));
+  for (auto& ds : dstream_) HIPCHK(hipStreamCreateWithPriority(&ds, hipStreamNonBlocking, prio_hi));
   for (auto& e : ev_) HIPCHK(hipEventCreate(&e));
   for (Slot& sl : slots_) {
     for (hipEvent_t* e : {&sl.enc_begin, &sl.enc_mid, &sl.enc_done, &sl.dec_begin, &sl.dec_done}) {
@@ -343,7 +343,8 @@ Engine::Engine(const std::string& model_prefix, const std::string& vocab_path, b
 Engine::~Engine() {
   (void)hipSetDevice(device_);
   if (stream_) (void)hipStreamSynchronize(stream_);
-  if (dstream_) (void)hipStreamSynchronize(dstream_);
+  for (auto& ds : dstream_)
+    if (ds) (void)hipStreamSynchronize(ds);
   for (void* p : ws_.owned) (void)hipFree(p);
   for (void* p : allocations_) (void)hipFree(p);
   for (auto& e : ev_)
@@ -356,12 +357,13 @@ Engine::~Engine() {
     if (sl.h_n) (void)hipHostFree(sl.h_n);
   }
   if (stream_) (void)hipStreamDestroy(stream_);
-  if (dstream_) (void)hipStreamDestroy(dstream_);
+  for (auto& ds : dstream_)
+    if (ds) (void)hipStreamDestroy(ds);
 }
 
 void Engine::sync() {
   HIPCHK(hipStreamSynchronize(stream_));
-  HIPCHK(hipStreamSynchronize(dstream_));
+  for (auto& ds : dstream_) HIPCHK(hipStreamSynchronize(ds));
 }
 
 void Engine::ensure_batch(int batch) {
@@ -370,7 +372,7 @@ void Engine::ensure_batch(int batch) {
   if (batch <= ws_.batch) return;
   if (!inflight_.empty()) throw Error(1, "cannot grow the workspace while batches are in flight");
   HIPCHK(hipStreamSynchronize(stream_));
-  HIPCHK(hipStreamSynchronize(dstream_));
+  for (auto& ds : dstream_) HIPCHK(hipStreamSynchronize(ds));
   for (void* p : ws_.owned) (void)hipFree(p);
   ws_ = Workspace();
   const wtw::Dims& c = dims_;
@@ -396,19 +398,21 @@ void Engine::ensure_batch(int batch) {
     sl.cross_kv = alloc(size_t(c.n_text_layer) * 2 * B * T * d, false);
     sl.used = false;
   }
-  ws_.xd = alloc(B * d, false);
-  ws_.lnd = alloc(B * d, false);
-  ws_.qkvd = alloc(B * 3 * d, false);
-  ws_.attd = alloc(B * d, false);
-  ws_.qd = alloc(B * d, false);
-  ws_.hd = alloc(B * 4 * d, false);
-  ws_.cross_ws = alloc(B * c.n_text_head * 64 * 68, false);
-  ws_.self_kv = alloc(size_t(c.n_text_layer) * 2 * B * self_cap_ * d, true);
-  ws_.logits = alloc(B * c.n_vocab, false);
-  ws_.best = reinterpret_cast<unsigned long long*>(alloc(B * 2 * size_t((c.n_vocab + 31) / 32), true));
-  ws_.ids = reinterpret_cast<long long*>(alloc(B * 32 * 2, true));
-  ws_.n_ids = reinterpret_cast<int*>(alloc(B, true));
-  ws_.finished = reinterpret_cast<int*>(alloc(B, true));
+  for (DecWorkspace& dw : dws_) {
+    dw.xd = alloc(B * d, false);
+    dw.lnd = alloc(B * d, false);
+    dw.qkvd = alloc(B * 3 * d, false);
+    dw.attd = alloc(B * d, false);
+    dw.qd = alloc(B * d, false);
+    dw.hd = alloc(B * 4 * d, false);
+    dw.cross_ws = alloc(B * c.n_text_head * 64 * 68, false);
+    dw.self_kv = alloc(size_t(c.n_text_layer) * 2 * B * self_cap_ * d, true);
+    dw.logits = alloc(B * c.n_vocab, false);
+    dw.best = reinterpret_cast<unsigned long long*>(alloc(B * 2 * size_t((c.n_vocab + 31) / 32), true));
+    dw.ids = reinterpret_cast<long long*>(alloc(B * 32 * 2, true));
+    dw.n_ids = reinterpret_cast<int*>(alloc(B, true));
+    dw.finished = reinterpret_cast<int*>(alloc(B, true));
+  }
   ws_.mel_stage = alloc(B * mel_elems(), false);
   ws_.batch = batch;
   HIPCHK(hipStreamSynchronize(stream_));
@@ -631,7 +635,7 @@ void Engine::encode(const float* d_mel, int batch) {
   HIPCHK(hipEventRecord(slot.enc_done, stream_));
   slot.used = true;
   last_enc_slot_ = enc_slot_;
-  enc_slot_ ^= 1;
+  enc_slot_ = (enc_slot_ + 1) % kSlots;
 }
 
 // ------------------------------------------------------------ decoder ---
@@ -644,7 +648,7 @@ void Engine::decode(int batch, int64_t* ids, int32_t* n_ids, float* logits_host,
 }
 
 void Engine::submit(const float* d_mel, int batch) {
-  if (inflight_.size() >= 2) throw Error(1, "pipeline is two batches deep: collect() first");
+  if (int(inflight_.size()) >= kSlots) throw Error(1, "pipeline is three batches deep: collect() first");
   if (batch > 64) throw Error(1, "decoder batches are limited to 64 clips per call");
   encode(d_mel, batch);
   decode_enqueue(batch, last_enc_slot_, nullptr, 0);
@@ -661,7 +665,10 @@ void Engine::collect(int64_t* ids, int32_t* n_ids) {
 void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int logits_steps_cap) {
   ensure_batch(batch);
   Slot& slot = slots_[slot_idx];
-  hipStream_t const stream_ = dstream_;  // everything below runs on the decoder stream
+  slot.dec = next_dec_;
+  next_dec_ = (next_dec_ + 1) % kDecStreams;
+  DecWorkspace& dw = dws_[slot.dec];
+  hipStream_t const stream_ = dstream_[slot.dec];  // everything below runs on this decoder stream
   HIPCHK(hipStreamWaitEvent(stream_, slot.enc_done, 0));
   HIPCHK(hipEventRecord(slot.dec_begin, stream_));
   long long* const h_ids_ = slot.h_ids;
@@ -682,16 +689,16 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
     for (int i = 0; i < stride; ++i) h_ids_[size_t(b) * stride + i] = i < n_prompt ? prompt[i] : 0;
     h_n_[b] = n_prompt;
   }
-  HIPCHK(hipMemcpyAsync(ws_.ids, h_ids_, size_t(batch) * stride * sizeof(long long),
+  HIPCHK(hipMemcpyAsync(dw.ids, h_ids_, size_t(batch) * stride * sizeof(long long),
                         hipMemcpyHostToDevice, stream_));
-  HIPCHK(hipMemcpyAsync(ws_.n_ids, h_n_, size_t(batch) * sizeof(int), hipMemcpyHostToDevice, stream_));
-  HIPCHK(hipMemsetAsync(ws_.finished, 0, size_t(batch) * sizeof(int), stream_));
+  HIPCHK(hipMemcpyAsync(dw.n_ids, h_n_, size_t(batch) * sizeof(int), hipMemcpyHostToDevice, stream_));
+  HIPCHK(hipMemsetAsync(dw.finished, 0, size_t(batch) * sizeof(int), stream_));
 
   const int chunks = int(cross_chunks);  // 1, 2, 4 or 8 (wt_engine_set_option)
   const size_t kv_slab = size_t(batch) * T * d;  // one (layer, k|v) slab of the cross cache
   const size_t self_slab = size_t(batch) * self_cap_ * d;
   int steps = 0;
-  float* const x = ws_.xd;  // residual stream [B][d], updated in place by the residual GEMMs
+  float* const x = dw.xd;  // residual stream [B][d], updated in place by the residual GEMMs
   for (int pos = 0; pos < max_pos; ++pos) {
     for (int l = 0; l < c.n_text_layer; ++l) {
       const BlockWeights& w = dec_blocks_[l];
@@ -699,64 +706,64 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
       q.Wt = w.attn.wqkv; q.N = 3 * d; q.K = d; q.B = batch;
       q.xin = x; q.ln_g = w.attn_ln_g; q.ln_b = w.attn_ln_b;
       if (l == 0) {
-        q.ids = ws_.ids; q.ids_stride = stride; q.pos = pos; q.tok_emb = tok_emb; q.pos_emb = dec_pos;
+        q.ids = dw.ids; q.ids_stride = stride; q.pos = pos; q.tok_emb = tok_emb; q.pos_emb = dec_pos;
         q.n_vocab = V; q.xout = x;
       }
-      q.bias = w.attn.bqkv; q.Y = ws_.qkvd; q.ldy = 3 * d;
+      q.bias = w.attn.bqkv; q.Y = dw.qkvd; q.ldy = 3 * d;
       launch_dec_gemm(q, kProLn, kDecBias, stream_);
-      launch_self_attention(ws_.qkvd, ws_.self_kv + (size_t(l) * 2 + 0) * self_slab,
-                            ws_.self_kv + (size_t(l) * 2 + 1) * self_slab, self_cap_, pos, ws_.attd,
+      launch_self_attention(dw.qkvd, dw.self_kv + (size_t(l) * 2 + 0) * self_slab,
+                            dw.self_kv + (size_t(l) * 2 + 1) * self_slab, self_cap_, pos, dw.attd,
                             batch, H, stream_);
       DecGemmArgs o;  // x += attn . Wo^T + bo
-      o.Wt = w.attn.wo; o.N = d; o.K = d; o.B = batch; o.X = ws_.attd; o.ldx = d;
+      o.Wt = w.attn.wo; o.N = d; o.K = d; o.B = batch; o.X = dw.attd; o.ldx = d;
       o.bias = w.attn.bo; o.R = x; o.Y = x; o.ldy = d;
       launch_dec_gemm(o, kProNone, kDecResid, stream_);
 
       DecGemmArgs cq;  // LN + cross-attention query projection
       cq.Wt = w.cross.wq; cq.N = d; cq.K = d; cq.B = batch;
       cq.xin = x; cq.ln_g = w.cross_ln_g; cq.ln_b = w.cross_ln_b;
-      cq.bias = w.cross.bq; cq.Y = ws_.qd; cq.ldy = d;
+      cq.bias = w.cross.bq; cq.Y = dw.qd; cq.ldy = d;
       launch_dec_gemm(cq, kProLn, kDecBias, stream_);
-      launch_cross_attention(ws_.qd, slot.cross_kv + (size_t(l) * 2 + 0) * kv_slab,
-                             slot.cross_kv + (size_t(l) * 2 + 1) * kv_slab, ws_.cross_ws, batch, H, T,
+      launch_cross_attention(dw.qd, slot.cross_kv + (size_t(l) * 2 + 0) * kv_slab,
+                             slot.cross_kv + (size_t(l) * 2 + 1) * kv_slab, dw.cross_ws, batch, H, T,
                              chunks, stream_);
       DecGemmArgs co;  // x += combine(chunks) . Wco^T + bco
       co.Wt = w.cross.wo; co.N = d; co.K = d; co.B = batch;
-      co.cross_ws = ws_.cross_ws; co.heads = H; co.chunks = chunks;
+      co.cross_ws = dw.cross_ws; co.heads = H; co.chunks = chunks;
       co.bias = w.cross.bo; co.R = x; co.Y = x; co.ldy = d;
       launch_dec_gemm(co, kProCombine, kDecResid, stream_);
 
       DecGemmArgs f1;  // LN + fc1 + GELU
       f1.Wt = w.w1; f1.N = 4 * d; f1.K = d; f1.B = batch;
       f1.xin = x; f1.ln_g = w.mlp_ln_g; f1.ln_b = w.mlp_ln_b;
-      f1.bias = w.b1; f1.Y = ws_.hd; f1.ldy = 4 * d;
+      f1.bias = w.b1; f1.Y = dw.hd; f1.ldy = 4 * d;
       launch_dec_gemm(f1, kProLn, kDecBiasGelu, stream_);
       DecGemmArgs f2;  // x += h . W2^T + b2
-      f2.Wt = w.w2; f2.N = d; f2.K = 4 * d; f2.B = batch; f2.X = ws_.hd; f2.ldx = 4 * d;
+      f2.Wt = w.w2; f2.N = d; f2.K = 4 * d; f2.B = batch; f2.X = dw.hd; f2.ldx = 4 * d;
       f2.bias = w.b2; f2.R = x; f2.Y = x; f2.ldy = d;
       launch_dec_gemm(f2, kProNone, kDecResid, stream_);
     }
     if (pos >= n_prompt - 1) {
       // logits against the tied embedding + greedy argmax (whisper.cpp:379-399); only the
       // last position's row exists here, the reference computes and drops the others
-      launch_dec_finalize_ln(x, dec_ln_g, dec_ln_b, ws_.lnd, batch, d, stream_);
+      launch_dec_finalize_ln(x, dec_ln_g, dec_ln_b, dw.lnd, batch, d, stream_);
       DecGemmArgs lg;
-      lg.Wt = tok_emb_tiled; lg.N = V; lg.K = d; lg.B = batch; lg.X = ws_.lnd; lg.ldx = d;
-      lg.Y = logits_host ? ws_.logits : nullptr; lg.ldy = V; lg.best = ws_.best;
+      lg.Wt = tok_emb_tiled; lg.N = V; lg.K = d; lg.B = batch; lg.X = dw.lnd; lg.ldx = d;
+      lg.Y = logits_host ? dw.logits : nullptr; lg.ldy = V; lg.best = dw.best;
       launch_dec_gemm(lg, kProNone, kDecLogits, stream_);
       if (logits_host && steps < logits_steps_cap) {
         HIPCHK(hipMemcpy2DAsync(logits_host + size_t(steps) * V, size_t(logits_steps_cap) * V * sizeof(float),
-                                ws_.logits, size_t(V) * sizeof(float), size_t(V) * sizeof(float), batch,
+                                dw.logits, size_t(V) * sizeof(float), size_t(V) * sizeof(float), batch,
                                 hipMemcpyDeviceToHost, stream_));
       }
-      launch_select_token(ws_.best, (V + 31) / 32, ws_.ids, stride, pos, ws_.n_ids, ws_.finished,
+      launch_select_token(dw.best, (V + 31) / 32, dw.ids, stride, pos, dw.n_ids, dw.finished,
                           vocab_.token_eot, int(stop_at_eot), batch, stream_);
       ++steps;
     }
   }
-  HIPCHK(hipMemcpyAsync(h_ids_, ws_.ids, size_t(batch) * stride * sizeof(long long),
+  HIPCHK(hipMemcpyAsync(h_ids_, dw.ids, size_t(batch) * stride * sizeof(long long),
                         hipMemcpyDeviceToHost, stream_));
-  HIPCHK(hipMemcpyAsync(h_n_, ws_.n_ids, size_t(batch) * sizeof(int), hipMemcpyDeviceToHost, stream_));
+  HIPCHK(hipMemcpyAsync(h_n_, dw.n_ids, size_t(batch) * sizeof(int), hipMemcpyDeviceToHost, stream_));
   HIPCHK(hipEventRecord(slot.dec_done, stream_));
   slot.steps = steps;
 }

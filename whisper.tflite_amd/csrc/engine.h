@@ -88,9 +88,11 @@ class Engine {
   // greedy loop over the slot encode() just filled, on the decoder stream; synchronises and
   // returns ids [B][32], n [B].
   void decode(int batch, int64_t* ids, int32_t* n_ids, float* logits_host, int logits_steps_cap);
-  // Two-deep pipeline: submit() enqueues encoder (stream E) + decoder (stream D, higher
-  // priority) for one batch and returns; the encoder of batch i+1 then overlaps the
-  // latency-bound decoder of batch i.  collect() waits for the OLDEST submitted batch.
+  // Three-deep pipeline: submit() enqueues encoder (stream E) + decoder (one of two decoder
+  // streams, alternating) for one batch and returns.  In steady state the MFMA-bound encoder
+  // of batch i+2 and the two latency-bound decoder chains of batches i+1 and i share the
+  // chip: the decoders' ~1000 tiny dependent launches leave most of it idle on their own.
+  // collect() waits for the OLDEST submitted batch.
   void submit(const float* d_mel, int batch);
   void collect(int64_t* ids, int32_t* n_ids);
   int in_flight() const { return int(inflight_.size()); }
@@ -118,7 +120,8 @@ class Engine {
 
   int device_ = 0;
   hipStream_t stream_ = nullptr;   // encoder + front end
-  hipStream_t dstream_ = nullptr;  // decoder
+  static constexpr int kSlots = 3, kDecStreams = 2;
+  hipStream_t dstream_[kDecStreams] = {nullptr, nullptr};  // decoders (alternating batches)
   hipEvent_t ev_[2] = {nullptr, nullptr};  // front end begin / end
   struct Slot {
     float* cross_kv = nullptr;  // [layer][k|v][clip][head][t][64]
@@ -126,12 +129,13 @@ class Engine {
     hipEvent_t dec_begin = nullptr, dec_done = nullptr;
     long long* h_ids = nullptr;  // pinned [4096][32]
     int* h_n = nullptr;          // pinned [4096]
-    int batch = 0, steps = 0;
+    int batch = 0, steps = 0, dec = 0;  // dec: decoder stream / workspace of this batch
     bool used = false;
     std::vector<hipEvent_t> kt_events;
     std::vector<int> kt_cls;
     std::vector<double> kt_flops, kt_bytes;
-  } slots_[2];
+  } slots_[kSlots];
+  int next_dec_ = 0;
   int enc_slot_ = 0;        // slot the next encode() fills
   int last_enc_slot_ = 0;   // slot the last encode() filled
   std::vector<int> inflight_;
@@ -157,16 +161,17 @@ class Engine {
   const float* mel_w = nullptr;      // [mel_n][mel_k]
   int dft_n = 0, dft_k = 0, dft_im_off = 0, mel_n = 0, mel_k = 0;
 
-  struct Workspace {
-    int batch = 0;
-    float *melT = nullptr, *h1p = nullptr, *x = nullptr, *ln = nullptr, *qkv = nullptr,
-          *att = nullptr, *hid = nullptr, *enc_out = nullptr;
-    // decoder
+  struct DecWorkspace {  // one per decoder stream
     float *xd = nullptr, *lnd = nullptr, *qkvd = nullptr, *attd = nullptr, *qd = nullptr,
           *hd = nullptr, *cross_ws = nullptr, *self_kv = nullptr, *logits = nullptr;
     unsigned long long* best = nullptr;
     long long* ids = nullptr;
     int *n_ids = nullptr, *finished = nullptr;
+  } dws_[kDecStreams];
+  struct Workspace {
+    int batch = 0;
+    float *melT = nullptr, *h1p = nullptr, *x = nullptr, *ln = nullptr, *qkv = nullptr,
+          *att = nullptr, *hid = nullptr, *enc_out = nullptr;
     // front end
     float *pcm_pad = nullptr, *spec = nullptr, *pw = nullptr, *melacc = nullptr;
     unsigned* clip_max = nullptr;
