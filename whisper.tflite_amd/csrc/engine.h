@@ -88,11 +88,11 @@ class Engine {
   // greedy loop over the slot encode() just filled, on the decoder stream; synchronises and
   // returns ids [B][32], n [B].
   void decode(int batch, int64_t* ids, int32_t* n_ids, float* logits_host, int logits_steps_cap);
-  // Three-deep pipeline: submit() enqueues encoder (stream E) + decoder (one of two decoder
-  // streams, alternating) for one batch and returns.  In steady state the MFMA-bound encoder
-  // of batch i+2 and the two latency-bound decoder chains of batches i+1 and i share the
-  // chip: the decoders' ~1000 tiny dependent launches leave most of it idle on their own.
-  // collect() waits for the OLDEST submitted batch.
+  // Pipeline, kSlots deep: submit() enqueues encoder (stream E) + decoder (one of kDecStreams
+  // decoder streams, in rotation) for one batch and returns.  In steady state the MFMA-bound
+  // encoder of the newest batch shares the chip with the latency-bound decoder chains of the
+  // previous ones: a decoder's ~1000 tiny dependent launches leave most of the chip idle on
+  // their own.  collect() waits for the OLDEST submitted batch.
   void submit(const float* d_mel, int batch);
   void collect(int64_t* ids, int32_t* n_ids);
   int in_flight() const { return int(inflight_.size()); }
@@ -120,8 +120,8 @@ class Engine {
 
   int device_ = 0;
   hipStream_t stream_ = nullptr;   // encoder + front end
-  static constexpr int kSlots = 3, kDecStreams = 2;
-  hipStream_t dstream_[kDecStreams] = {nullptr, nullptr};  // decoders (alternating batches)
+  static constexpr int kDecStreams = 4, kSlots = kDecStreams + 1;
+  hipStream_t dstream_[kDecStreams] = {};  // decoders (batches rotate over them)
   hipEvent_t ev_[2] = {nullptr, nullptr};  // front end begin / end
   struct Slot {
     float* cross_kv = nullptr;  // [layer][k|v][clip][head][t][64]
