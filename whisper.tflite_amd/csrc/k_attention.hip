@@ -128,22 +128,28 @@ __global__ __launch_bounds__(256) void encoder_attention_f32(const float* __rest
     for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s1[r]);
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
     const float m_new = fmaxf(m_run, tmax);
-    const float alpha = exp2f(m_run - m_new);
     float psum = 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      s0[r] = exp2f(s0[r] - m_new);
-      s1[r] = exp2f(s1[r] - m_new);
+      // raw v_exp_f32: arguments are <= 0 and far from the denormal range that exp2f() guards
+      s0[r] = __builtin_amdgcn_exp2f(s0[r] - m_new);
+      s1[r] = __builtin_amdgcn_exp2f(s1[r] - m_new);
       psum += s0[r] + s1[r];
     }
     psum += __shfl_xor(psum, 32, 64);
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
+    // rescale only when some row's running max moved (wave-uniform branch; after the first
+    // tiles it rarely does): alpha == 1 exactly otherwise, so skipping is bit-identical
+    if (__any(m_new != m_run)) {
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      o0[r] *= alpha;
-      o1[r] *= alpha;
+      for (int r = 0; r < 16; ++r) {
+        o0[r] *= alpha;
+        o1[r] *= alpha;
+      }
+      m_run = m_new;
     }
+    l_run += psum;
     // O^T += V^T . P^T : step r contracts key crow(r, lh) (+32 for the second half)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
