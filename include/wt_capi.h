@@ -88,6 +88,13 @@ int wt_transcribe_pcm(wt_engine* h, const float* pcm, size_t n_samples, char* ou
                       size_t* len);
 int wt_transcribe_file(wt_engine* h, const char* wav_path, char* out, size_t cap, size_t* len);
 
+/* Long audio (the reference truncates to one 30 s window, whisper.cpp:753,773):
+ * pcm is cut into consecutive 30 s windows (the last one zero-padded), the windows are
+ * transcribed as batches of up to 32 clips, and the per-window texts — each exactly what
+ * wt_transcribe_pcm returns for that window — are joined with '\n'. */
+int wt_transcribe_long_pcm(wt_engine* h, const float* pcm, size_t n_samples, char* out, size_t cap,
+                           size_t* len);
+
 /* ---- batch entry points (the reference is batch 1; clips are independent) ---------------
  * Host-pointer forms copy over PCIe; *_dev forms take device pointers already in HBM (the
  * form bench.py times).  All are synchronous on return.

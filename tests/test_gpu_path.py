@@ -309,3 +309,18 @@ def test_config4_base_dims_fp32(pkg, assets, orc):
     assert list(ids[0, :31]) == list(ids_ref)
     m.close()
     e.close()
+
+
+def test_long_audio_windows_and_language(tiny):
+    """SURVEY §8 f2: audio longer than 30 s is cut into windows that are transcribed as one batch;
+    every window's text equals the single-clip call on that window."""
+    e, _ = tiny
+    e.set_option("stop_at_eot", 1)
+    pcm = synth_pcm("speechlike", 480000 * 2 + 123456, 51)
+    text = e.transcribe_long(pcm)
+    parts = text.split("\n")
+    assert len(parts) == 3
+    for i, part in enumerate(parts):
+        assert part == e.transcribe(pcm[i * 480000:(i + 1) * 480000])
+    assert e.transcribe_long(pcm[:1000]) == e.transcribe(pcm[:1000])
+    e.set_option("stop_at_eot", 0)

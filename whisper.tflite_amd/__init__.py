@@ -36,7 +36,7 @@ STATUS_NAMES = {0: "WT_OK", 1: "WT_ERR_INVALID_ARG", 2: "WT_ERR_IO", 3: "WT_ERR_
 # Every symbol include/wt_capi.h and include/wt_debug.h declare.
 CAPI_SYMBOLS = [
     "wt_engine_create", "wt_engine_destroy", "wt_last_error", "wt_engine_dims",
-    "wt_engine_set_option", "wt_engine_get_option", "wt_engine_set_prompt", "wt_transcribe_pcm", "wt_transcribe_file",
+    "wt_engine_set_option", "wt_engine_get_option", "wt_engine_set_prompt", "wt_transcribe_pcm", "wt_transcribe_long_pcm", "wt_transcribe_file",
     "wt_logmel_batch", "wt_logmel_batch_dev", "wt_encdec_tokens_batch",
     "wt_encdec_tokens_batch_dev", "wt_transcribe_tokens_batch_dev", "wt_pipeline_submit_dev", "wt_pipeline_collect",
     "wt_encdec_debug_batch",
@@ -100,6 +100,7 @@ def lib() -> ctypes.CDLL:
         L.wt_engine_get_option.argtypes = [c_void_p, c_char_p, POINTER(c_long)]
         L.wt_engine_set_prompt.argtypes = [c_void_p, ip64, c_int]
         L.wt_transcribe_pcm.argtypes = [c_void_p, fp, c_size_t, c_char_p, c_size_t, POINTER(c_size_t)]
+        L.wt_transcribe_long_pcm.argtypes = [c_void_p, fp, c_size_t, c_char_p, c_size_t, POINTER(c_size_t)]
         L.wt_transcribe_file.argtypes = [c_void_p, c_char_p, c_char_p, c_size_t, POINTER(c_size_t)]
         L.wt_logmel_batch.argtypes = [c_void_p, fp, c_int, fp]
         L.wt_logmel_batch_dev.argtypes = [c_void_p, c_void_p, c_int, c_void_p]
@@ -237,6 +238,14 @@ class Engine:
         else:
             pcm = _f32(samples_or_path).reshape(-1)
             self._check(lib().wt_transcribe_pcm(self._h, _fp(pcm), pcm.size, buf, len(buf), byref(n)))
+        return buf.raw[: n.value].decode("utf-8", errors="replace")
+
+    def transcribe_long(self, samples) -> str:
+        """Long audio: consecutive 30 s windows, batched; per-window texts joined with '\\n'."""
+        pcm = _f32(samples).reshape(-1)
+        buf = ctypes.create_string_buffer(1 << 20)
+        n = c_size_t(0)
+        self._check(lib().wt_transcribe_long_pcm(self._h, _fp(pcm), pcm.size, buf, len(buf), byref(n)))
         return buf.raw[: n.value].decode("utf-8", errors="replace")
 
     # -- batch entry points ----------------------------------------------------------

@@ -8,24 +8,34 @@
 #include <iostream>
 #include <string>
 
+#include <vector>
+
 #include "whisper.tflite/whisper.h"
+#include "wt_capi.h"
 
 namespace {
 void usage(const char* argv0) {
   std::cerr << "Usage: " << argv0 << " --model-prefix <prefix> --vocab <vocab.bin> --input <wav>\n"
             << "  --model-prefix  Model prefix (loads <prefix>.wtw)   REQUIRED\n"
             << "  --vocab         Path to vocabulary                 REQUIRED\n"
-            << "  --input         Path to the 16 kHz mono WAV        REQUIRED\n";
+            << "  --input         Path to the 16 kHz mono WAV        REQUIRED\n"
+            << "  --lang          language code of the prompt (default de, as the reference hard-codes)\n"
+            << "  --long          transcribe every 30 s window of the file, not only the first\n";
 }
 }  // namespace
 
 int main(int argc, char* argv[]) {
-  std::string model_prefix, vocab, input;
+  std::string model_prefix, vocab, input, lang;
+  bool long_audio = false;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i], v;
     if (a == "-h" || a == "--help") {
       usage(argv[0]);
       return 0;
+    }
+    if (a == "--long") {
+      long_audio = true;
+      continue;
     }
     const size_t eq = a.find('=');
     if (eq != std::string::npos) {
@@ -40,6 +50,7 @@ int main(int argc, char* argv[]) {
     if (a == "--model-prefix") model_prefix = v;
     else if (a == "--vocab") vocab = v;
     else if (a == "--input") input = v;
+    else if (a == "--lang") lang = v;
     else {
       std::cerr << "The following argument was not expected: " << a << "\n";
       usage(argv[0]);
@@ -55,7 +66,26 @@ int main(int argc, char* argv[]) {
   using namespace whisper;  // NOLINT
   const bool multilingual = true;  // hard-coded in the reference (app/encdec.cpp:47)
   EncDec encdec(model_prefix, vocab, multilingual);
-  const std::string text = encdec.transcribe(input.c_str());
+  if (!lang.empty()) {
+    const int id = language_id(lang);
+    if (wt_engine_set_option(encdec.handle(), "language", id) != WT_OK) {
+      std::cerr << "--lang: unknown language code " << lang << "\n";
+      return 105;
+    }
+  }
+  std::string text;
+  if (long_audio) {
+    std::vector<float> pcm = wav_read_legacy(input.c_str());
+    std::vector<char> buf(1 << 20);
+    size_t len = 0;
+    if (wt_transcribe_long_pcm(encdec.handle(), pcm.data(), pcm.size(), buf.data(), buf.size(), &len) != WT_OK) {
+      std::cerr << "transcribe failed: " << wt_last_error(encdec.handle()) << "\n";
+      return 1;
+    }
+    text.assign(buf.data(), len);
+  } else {
+    text = encdec.transcribe(input.c_str());
+  }
   std::cout << text << "\n";
   return 0;
 }

@@ -278,6 +278,45 @@ int wt_transcribe_pcm(wt_engine* h, const float* pcm, size_t n_samples, char* ou
   return copy_text(text, out, cap, len);
 }
 
+int wt_transcribe_long_pcm(wt_engine* h, const float* pcm, size_t n_samples, char* out, size_t cap,
+                           size_t* len) {
+  if (!h || (!pcm && n_samples)) return WT_ERR_INVALID_ARG;
+  std::string text;
+  const int rc = guarded(h, [&] {
+    wt::Engine& e = *h->impl;
+    const size_t win = e.pcm_elems();
+    const size_t n_win = std::max<size_t>(1, (n_samples + win - 1) / win);
+    for (size_t w0 = 0; w0 < n_win; w0 += 32) {
+      const int B = int(std::min<size_t>(32, n_win - w0));
+      std::vector<float> clips(size_t(B) * win, 0.0f);
+      for (int b = 0; b < B; ++b) {
+        const size_t off = (w0 + b) * win;
+        if (off < n_samples) std::memcpy(&clips[size_t(b) * win], pcm + off, std::min(win, n_samples - off) * sizeof(float));
+      }
+      float* d_pcm = e.staging_pcm(B);
+      float* d_mel = e.staging_mel(B);
+      hipchk(hipMemcpyAsync(d_pcm, clips.data(), clips.size() * sizeof(float), hipMemcpyHostToDevice, e.stream()), "H2D pcm");
+      e.logmel(d_pcm, B, d_mel);
+      e.encode(d_mel, B);
+      std::vector<int64_t> ids(size_t(B) * WT_MAX_IDS);
+      std::vector<int32_t> n(B);
+      e.decode(B, ids.data(), n.data(), nullptr, 0);
+      e.sync();  // clips[] is read by the H2D copy on the encoder stream
+      for (int b = 0; b < B; ++b) {
+        if (w0 + b) text += '\n';
+        bool missing = false;
+        text += wt::decode_tokens(e.vocab(), &ids[size_t(b) * WT_MAX_IDS], n[b], false, &missing);
+      }
+    }
+  });
+  if (rc != WT_OK) {
+    if (len) *len = 0;
+    if (out && cap) out[0] = 0;
+    return rc;
+  }
+  return copy_text(text, out, cap, len);
+}
+
 int wt_transcribe_file(wt_engine* h, const char* wav_path, char* out, size_t cap, size_t* len) {
   if (!h || !wav_path) return WT_ERR_INVALID_ARG;
   std::vector<float> pcm;
