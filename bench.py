@@ -295,8 +295,20 @@ def main() -> None:
         roof = None
         if dom:
             d = detail[dom]
+            # HBM-side bytes per launch of this kernel class come from separate rocprofv3 --pmc
+            # passes (FETCH_SIZE, WRITE_SIZE) whose summary is committed under profiles/
+            traffic, traffic_src = None, None
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                    t = json.load(f)
+                if t["kernel_class"].startswith(dom):
+                    traffic, traffic_src = int(t["traffic_bytes_per_launch"]), "profiles/r01_pmc_traffic.json"
+            except (OSError, KeyError, ValueError):
+                pass
             roof = {"kernel": dom, "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"],
-                    "unit": d["unit"], "frac": d["frac"], "traffic": None, "avg_launch_us": d["avg_launch_us"]}
+                    "unit": d["unit"], "frac": d["frac"], "traffic": traffic, "traffic_source": traffic_src,
+                    "algorithmic_flops_per_launch": int(kstats[dom]["flops"] / max(1, kstats[dom]["launches"])),
+                    "avg_launch_us": d["avg_launch_us"]}
         # decoder phase against HBM: algorithmic bytes per step of this batch
         dm = eng.dims
         dstate, L, T, V = dm.n_text_state, dm.n_text_layer, dm.n_audio_ctx, dm.n_vocab

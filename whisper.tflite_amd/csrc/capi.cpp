@@ -34,6 +34,7 @@ int fail(wt_engine* h, int code, const std::string& msg) {
 template <class F>
 int guarded(wt_engine* h, F&& fn) {
   try {
+    if (h && h->impl) h->impl->bind_device();  // one handle per GPU: launches go to its device
     fn();
     if (h) h->last_error.clear();
     return WT_OK;

@@ -361,6 +361,8 @@ Engine::~Engine() {
     if (ds) (void)hipStreamDestroy(ds);
 }
 
+void Engine::bind_device() { HIPCHK(hipSetDevice(device_)); }
+
 void Engine::sync() {
   HIPCHK(hipStreamSynchronize(stream_));
   for (auto& ds : dstream_) HIPCHK(hipStreamSynchronize(ds));

@@ -97,6 +97,8 @@ class Engine {
   void collect(int64_t* ids, int32_t* n_ids);
   int in_flight() const { return int(inflight_.size()); }
   void sync();
+  // makes this engine's GPU the calling thread's current device (every C-ABI entry does it)
+  void bind_device();
 
   const float* enc_out() const { return ws_.enc_out; }
   void ensure_batch(int batch);
