@@ -14,6 +14,9 @@ int wt_dbg_gemm(wt_engine* h, int M, int N, int K, const float* A, const float* 
 /* times `iters` back-to-back launches of the encoder GEMM on random operands (HIP events on the
  * engine's stream); variant selects the tile shape (k_gemm.hip) */
 int wt_dbg_gemm_bench(wt_engine* h, int M, int N, int K, int epi, int variant, int iters, float* avg_ms);
+/* times back-to-back launches of a decoder GEMM: kind 0 residual, 1 LayerNorm-fused, 2 combine +
+ * residual; waves = wavefronts per block of the residual forms (4, 8, 16) */
+int wt_dbg_dec_gemm_bench(wt_engine* h, int kind, int B, int N, int K, int waves, int iters, float* avg_us);
 /* decoder-step GEMM (k_decoder.hip), plain input X[B][K], W[N][K] (tiled internally):
  * mode 0: Y = X.W^T + bias   1: gelu(...)   2: Y = R + bias + X.W^T (in-place residual form)
  * mode 3: Y = X.W^T and argmax_out[B] = last maximal column (reference tie rule) */

@@ -44,7 +44,7 @@ CAPI_SYMBOLS = [
     "wt_vocab_info", "wt_filters", "wt_write_synthetic_weights", "wt_write_synthetic_vocab",
 ]
 DEBUG_SYMBOLS = [
-    "wt_dbg_gemm", "wt_dbg_gemm_bench", "wt_dbg_dec_gemm", "wt_dbg_dec_ln_gemm", "wt_dbg_layernorm", "wt_dbg_encoder_attention",
+    "wt_dbg_gemm", "wt_dbg_gemm_bench", "wt_dbg_dec_gemm_bench", "wt_dbg_dec_gemm", "wt_dbg_dec_ln_gemm", "wt_dbg_layernorm", "wt_dbg_encoder_attention",
     "wt_dbg_cross_attention", "wt_dbg_self_attention",
 ]
 
@@ -123,6 +123,7 @@ def lib() -> ctypes.CDLL:
         L.wt_write_synthetic_vocab.argtypes = [c_char_p, c_int]
         L.wt_dbg_gemm.argtypes = [c_void_p, c_int, c_int, c_int, fp, fp, fp, fp, fp, c_int, c_int, fp]
         L.wt_dbg_gemm_bench.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_float)]
+        L.wt_dbg_dec_gemm_bench.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_float)]
         L.wt_dbg_dec_gemm.argtypes = [c_void_p, c_int, c_int, c_int, c_int, fp, fp, fp, fp, fp, ip64]
         L.wt_dbg_dec_ln_gemm.argtypes = [c_void_p, c_int, c_int, c_int, fp, ip64, c_int, fp, fp,
                                          c_int, c_int, fp, fp, fp, fp, c_int, fp, fp]
@@ -358,6 +359,11 @@ class Engine:
         ms = c_float(0)
         self._check(lib().wt_dbg_gemm_bench(self._h, M, N, K, epi, variant, iters, byref(ms)))
         return ms.value
+
+    def dbg_dec_gemm_bench(self, kind, B, N, K, waves=16, iters=200) -> float:
+        us = c_float(0)
+        self._check(lib().wt_dbg_dec_gemm_bench(self._h, kind, B, N, K, waves, iters, byref(us)))
+        return us.value
 
     def dbg_dec_gemm(self, X, W, bias=None, mode=0, R=None):
         """mode 0 bias, 1 bias+gelu, 2 residual (Y = R + bias + X.W^T), 3 logits + argmax."""

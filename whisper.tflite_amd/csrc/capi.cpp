@@ -457,6 +457,45 @@ int wt_dbg_gemm_bench(wt_engine* h, int M, int N, int K, int epi, int variant, i
   });
 }
 
+int wt_dbg_dec_gemm_bench(wt_engine* h, int kind, int B, int N, int K, int waves, int iters, float* avg_us) {
+  if (!h || !avg_us || B < 1 || B > 64 || iters < 1) return WT_ERR_INVALID_ARG;
+  return guarded(h, [&] {
+    // kind 0: residual GEMM, 1: LayerNorm-fused GEMM (+bias), 2: combine + residual GEMM
+    std::vector<float> hostW(size_t(N) * K), hostX(size_t(B) * std::max(K, N));
+    uint64_t x = 88172645463325252ull;
+    auto rnd = [&x] { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return float(int64_t(x % 2000001) - 1000000) * 1e-6f; };
+    for (auto& v : hostW) v = rnd() * 0.05f;
+    for (auto& v : hostX) v = rnd();
+    const std::vector<float> tiled = wt::tile_weights(hostW.data(), N, K);
+    const int heads = K / 64, chunks = 4;
+    DevBuf dW(tiled.data(), tiled.size()), dX(hostX.data(), size_t(B) * K), dB(hostX.data(), N), dG(hostX.data(), K);
+    DevBuf dY(hostX.data(), size_t(B) * N), dWs(size_t(B) * heads * chunks * 68);
+    std::vector<float> ws(size_t(B) * heads * chunks * 68);
+    for (auto& v : ws) v = rnd();
+    hipchk(hipMemcpy(dWs.p, ws.data(), ws.size() * 4, hipMemcpyHostToDevice), "H2D");
+    wt::DecGemmArgs g;
+    g.Wt = dW.p; g.N = N; g.K = K; g.B = B; g.bias = dB.p; g.Y = dY.p; g.ldy = N; g.resid_waves = waves;
+    int pro = wt::kProNone, epi = wt::kDecResid;
+    if (kind == 0) { g.X = dX.p; g.ldx = K; g.R = dY.p; }
+    if (kind == 1) { pro = wt::kProLn; epi = wt::kDecBias; g.xin = dX.p; g.ln_g = dG.p; g.ln_b = dG.p; }
+    if (kind == 2) { pro = wt::kProCombine; g.cross_ws = dWs.p; g.heads = heads; g.chunks = chunks; g.R = dY.p; }
+    hipStream_t st = h->impl->stream();
+    hipEvent_t e0, e1;
+    hipchk(hipEventCreate(&e0), "event");
+    hipchk(hipEventCreate(&e1), "event");
+    for (int i = 0; i < 5; ++i) wt::launch_dec_gemm(g, pro, epi, st);
+    hipchk(hipEventRecord(e0, st), "record");
+    for (int i = 0; i < iters; ++i) wt::launch_dec_gemm(g, pro, epi, st);
+    hipchk(hipEventRecord(e1, st), "record");
+    hipchk(hipEventSynchronize(e1), "sync");
+    float ms = 0;
+    hipchk(hipEventElapsedTime(&ms, e0, e1), "elapsed");
+    *avg_us = 1e3f * ms / iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+  });
+}
+
 int wt_dbg_dec_gemm(wt_engine* h, int mode, int B, int N, int K, const float* X, const float* W,
                     const float* bias, const float* R, float* Y, int64_t* argmax_out) {
   if (!h || mode < 0 || mode > 3 || B < 1 || B > 64 || K % 32 != 0 || (mode == 2 && !R)) {

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm(DecGemmDev g) {
   // (two-stream pipeline) they must win issue arbitration
   __builtin_amdgcn_s_setprio(3);
   // 1024-thread blocks are capped at 128 VGPRs: keep 6 chunks (not 12) in flight there
-  constexpr int kGroup = WAVES > 4 ? 6 : kGroupMax;
+  constexpr int kGroup = WAVES > 8 ? 6 : kGroupMax;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* red = smem;                              // [WAVES-1][MT][16][64] split-K partials
   float* xs = smem + (WAVES - 1) * MT * 16 * 64;  // [MT*32][K + 4] LayerNorm rows (kProLn)
@@ -403,8 +403,8 @@ void launch_dec_gemm(const DecGemmArgs& a, int pro, int epi, hipStream_t s) {
                a.cross_ws, a.heads,  a.chunks,  a.bias,     gelu,    a.R,      a.Y,    a.ldy,  a.best};
   // host-side shape contract: operands must match what the kernel indexes
   const bool wide = epi == kDecResid;  // N = d_model: 16 wavefronts split K
-  if (a.B < 1 || a.B > 64 || a.K > 2048 || a.K % (wide ? 128 : 32) != 0 ||
-      (pro == kProCombine && (a.K / 128 > 6 || a.K != a.heads * 64)) || (wide && (!a.R || !a.Y))) {
+  if (a.B < 1 || a.B > 64 || a.K > 2048 || a.K % (wide ? 8 * a.resid_waves : 32) != 0 || (a.resid_waves != 4 && a.resid_waves != 8 && a.resid_waves != 16) ||
+      (pro == kProCombine && (a.K / (8 * a.resid_waves) > (a.resid_waves > 8 ? 6 : 12) || a.K != a.heads * 64)) || (wide && (!a.R || !a.Y))) {
     abort();
   }
   if (pro == kProLn) {
@@ -418,14 +418,28 @@ void launch_dec_gemm(const DecGemmArgs& a, int pro, int epi, hipStream_t s) {
   }
   const int key = pro * 8 + epi;
   switch (key) {
-    case kProNone * 8 + kDecResid: launch_mt<kProNone, kDecResid, 0, 0, 16, 1>(g, s); break;
+    case kProNone * 8 + kDecResid:
+      switch (a.resid_waves) {
+        case 4: launch_mt<kProNone, kDecResid, 0, 0, 4, 1>(g, s); break;
+        case 8: launch_mt<kProNone, kDecResid, 0, 0, 8, 1>(g, s); break;
+        default: launch_mt<kProNone, kDecResid, 0, 0, 16, 1>(g, s); break;
+      }
+      break;
     case kProNone * 8 + kDecBias: launch_mt<kProNone, kDecBias, 0, 0, 4, 1>(g, s); break;
     case kProNone * 8 + kDecLogits: launch_mt<kProNone, kDecLogits, 0, 0, 4, 1>(g, s); break;
     case kProCombine * 8 + kDecResid:
       switch (a.chunks) {  // compile-time chunk count keeps the partial loads independent
         case 1: launch_mt<kProCombine, kDecResid, 0, 0, 16, 1>(g, s); break;
         case 2: launch_mt<kProCombine, kDecResid, 0, 0, 16, 2>(g, s); break;
-        case 4: launch_mt<kProCombine, kDecResid, 0, 0, 16, 4>(g, s); break;
+        case 4:
+          if (a.resid_waves == 4) {
+            launch_mt<kProCombine, kDecResid, 0, 0, 4, 4>(g, s);
+          } else if (a.resid_waves == 8) {
+            launch_mt<kProCombine, kDecResid, 0, 0, 8, 4>(g, s);
+          } else {
+            launch_mt<kProCombine, kDecResid, 0, 0, 16, 4>(g, s);
+          }
+          break;
         case 8: launch_mt<kProCombine, kDecResid, 0, 0, 16, 8>(g, s); break;
         default: abort();
       }

@@ -79,6 +79,7 @@ struct DecGemmArgs {
   float* Y = nullptr;
   int ldy = 0;
   unsigned long long* best = nullptr;
+  int resid_waves = 16;  // wavefronts per block of the kDecResid GEMMs (4, 8 or 16)
 };
 void launch_dec_gemm(const DecGemmArgs& a, int pro, int epi, hipStream_t s);
 // y = LayerNorm(x) * g + b : input rows of the logits GEMM
