@@ -153,7 +153,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="synchronous steps (encoder then decoder) instead of the two-deep pipeline")
-    ap.add_argument("--depth", type=int, default=5, choices=(1, 2, 3, 4, 5), help="batches in flight (pipelined mode)")
+    ap.add_argument("--depth", type=int, default=5, choices=tuple(range(1, 9)), help="batches in flight (pipelined mode)")
     ap.add_argument("--gemm-variant", type=int, default=None, help="encoder GEMM tile variant (k_gemm.hip)")
     ap.add_argument("--dry-run-gloo", action="store_true")
     args = ap.parse_args()

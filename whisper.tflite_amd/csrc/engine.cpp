@@ -650,7 +650,7 @@ void Engine::decode(int batch, int64_t* ids, int32_t* n_ids, float* logits_host,
 }
 
 void Engine::submit(const float* d_mel, int batch) {
-  if (int(inflight_.size()) >= kSlots) throw Error(1, "pipeline is full (5 batches in flight): collect() first");
+  if (int(inflight_.size()) >= kSlots) throw Error(1, "pipeline is full (8 batches in flight): collect() first");
   if (batch > 64) throw Error(1, "decoder batches are limited to 64 clips per call");
   encode(d_mel, batch);
   decode_enqueue(batch, last_enc_slot_, nullptr, 0);

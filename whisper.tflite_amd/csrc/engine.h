@@ -122,7 +122,7 @@ class Engine {
 
   int device_ = 0;
   hipStream_t stream_ = nullptr;   // encoder + front end
-  static constexpr int kDecStreams = 4, kSlots = kDecStreams + 1;
+  static constexpr int kDecStreams = 6, kSlots = 8;
   hipStream_t dstream_[kDecStreams] = {};  // decoders (batches rotate over them)
   hipEvent_t ev_[2] = {nullptr, nullptr};  // front end begin / end
   struct Slot {

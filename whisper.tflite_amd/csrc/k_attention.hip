@@ -194,9 +194,6 @@ __global__ __launch_bounds__(256) void encoder_attention_f32(const float* __rest
 __global__ void self_attention_step(const float* __restrict__ qkv, float* __restrict__ kcache,
                                     float* __restrict__ vcache, int cap, int pos,
                                     float* __restrict__ out, int heads) {
-  // decoder launches are latency chains: when they share a SIMD with the encoder's MFMA waves
-  // (two-stream pipeline) they must win issue arbitration
-  __builtin_amdgcn_s_setprio(3);
   const int b = blockIdx.x, h = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int d = heads * 64;
   const float* row = qkv + (long)b * 3 * d;
@@ -245,9 +242,6 @@ __global__ __launch_bounds__(256) void cross_attention_step(const float* __restr
                                                             const float* __restrict__ vc,
                                                             float* __restrict__ ws, int heads,
                                                             int T, int chunks) {
-  // decoder launches are latency chains: when they share a SIMD with the encoder's MFMA waves
-  // (two-stream pipeline) they must win issue arbitration
-  __builtin_amdgcn_s_setprio(3);
   __shared__ __attribute__((aligned(16))) float go[16 * 64];
   __shared__ float gm[16], gl[16];
   const int chunk = blockIdx.x % chunks, bh = blockIdx.x / chunks;

@@ -123,9 +123,6 @@ __device__ __forceinline__ void row_stats(const f32x4 (&v)[NF4], int K, float* m
 // key-chunk count of the combine prologue.
 template <int PRO, int EPI, int MT, int NF4, int LNMODE, int WAVES, int CH>
 __global__ __launch_bounds__(WAVES * 64) void dec_gemm(DecGemmDev g) {
-  // decoder launches are latency chains: when they share a SIMD with the encoder's MFMA waves
-  // (two-stream pipeline) they must win issue arbitration
-  __builtin_amdgcn_s_setprio(3);
   // 1024-thread blocks are capped at 128 VGPRs: keep 6 chunks (not 12) in flight there
   constexpr int kGroup = WAVES > 8 ? 6 : kGroupMax;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -337,9 +334,6 @@ template <int NF4>
 __global__ __launch_bounds__(256) void dec_finalize_ln(RowSrc src, const float* __restrict__ g,
                                                        const float* __restrict__ b,
                                                        float* __restrict__ y, int B, int K) {
-  // decoder launches are latency chains: when they share a SIMD with the encoder's MFMA waves
-  // (two-stream pipeline) they must win issue arbitration
-  __builtin_amdgcn_s_setprio(3);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int r8 = lane >> 3, sub = lane & 7;
   const int row = blockIdx.x * 32 + wid * 8 + r8;
