@@ -190,6 +190,7 @@ def main() -> None:
     torch.cuda.synchronize()
 
     pipelined = not args.no_pipeline
+    host = {"submit_s": 0.0, "submits": 0}  # host time spent enqueueing (launch-bound check)
 
     def finish(ids, n):
         rec = torch.from_numpy(pack_records(ids, n))
@@ -213,7 +214,10 @@ def main() -> None:
             return out
         in_flight = 0
         for _ in range(k):
+            t_h = time.perf_counter()
             eng.pipeline_submit_dev(d_mel.data_ptr(), B)
+            host["submit_s"] += time.perf_counter() - t_h
+            host["submits"] += 1
             in_flight += 1
             if in_flight == args.depth:
                 out = finish(*eng.pipeline_collect())
@@ -341,6 +345,7 @@ def main() -> None:
                                  "frac": round(dec_ach / PEAK_HBM_GBPS, 4),
                                  "algorithmic_bytes_per_step": int(dec_bytes)},
             "stage_ms_per_step": stage,
+            "host_enqueue_ms_per_step": round(1e3 * host["submit_s"] / max(1, host["submits"]), 3) if pipelined else None,
         }
         if not args.no_cpu_baseline:
             info = eng.vocab_info()

@@ -324,3 +324,18 @@ def test_long_audio_windows_and_language(tiny):
         assert part == e.transcribe(pcm[i * 480000:(i + 1) * 480000])
     assert e.transcribe_long(pcm[:1000]) == e.transcribe(pcm[:1000])
     e.set_option("stop_at_eot", 0)
+
+
+def test_large_batch_runs_as_pipelined_sub_batches(tiny):
+    """A batch above 32 clips is split into sub-batches of 32 that go through the pipeline;
+    results equal the per-sub-batch synchronous calls (BASELINE configs[4] shape: many clips)."""
+    e, _ = tiny
+    rng = np.random.default_rng(909)
+    mel = rng.uniform(-1.0, 1.5, size=(70, 80, 3000)).astype(np.float32)
+    mel[40] = mel[3]  # the same clip in two sub-batches must give the same ids
+    ids, n = e.encdec_tokens_batch(mel)
+    assert ids.shape == (70, 32) and list(n) == [31] * 70
+    a, _ = e.encdec_tokens_batch(mel[:32])
+    b, _ = e.encdec_tokens_batch(mel[64:])
+    assert np.array_equal(ids[:32], a) and np.array_equal(ids[64:], b)
+    assert np.array_equal(ids[40], ids[3])

@@ -170,10 +170,30 @@ int wt_logmel_batch(wt_engine* h, const float* pcm, int batch, float* mel) {
 
 int wt_encdec_tokens_batch_dev(wt_engine* h, const float* d_mel, int batch, int64_t* ids,
                                int32_t* n_ids) {
-  if (!h || !d_mel || !ids || !n_ids) return WT_ERR_INVALID_ARG;
+  if (!h || !d_mel || !ids || !n_ids || batch < 1) return WT_ERR_INVALID_ARG;
   return guarded(h, [&] {
-    h->impl->encode(d_mel, batch);
-    h->impl->decode(batch, ids, n_ids, nullptr, 0);
+    wt::Engine& e = *h->impl;
+    if (batch <= 32) {
+      e.encode(d_mel, batch);
+      e.decode(batch, ids, n_ids, nullptr, 0);
+      return;
+    }
+    // larger batches run as pipelined sub-batches of 32 clips: the encoder of a later
+    // sub-batch overlaps the decoders of the earlier ones
+    if (e.in_flight()) throw wt::Error(WT_ERR_INVALID_ARG, "collect the submitted batches first");
+    const int n_sub = (batch + 31) / 32;
+    int submitted = 0, collected = 0;
+    auto collect_one = [&] {
+      e.collect(ids + size_t(collected) * 32 * WT_MAX_IDS, n_ids + size_t(collected) * 32);
+      ++collected;
+    };
+    while (submitted < n_sub) {
+      const int b0 = submitted * 32, nb = std::min(32, batch - b0);
+      e.submit(d_mel + size_t(b0) * e.mel_elems(), nb);
+      ++submitted;
+      if (submitted - collected == WT_PIPELINE_DEPTH) collect_one();
+    }
+    while (collected < submitted) collect_one();
   });
 }
 
@@ -188,7 +208,16 @@ int wt_pipeline_collect(wt_engine* h, int64_t* ids, int32_t* n_ids) {
 }
 
 int wt_encdec_tokens_batch(wt_engine* h, const float* mel, int batch, int64_t* ids, int32_t* n_ids) {
-  return wt_encdec_debug_batch(h, mel, batch, ids, n_ids, nullptr, nullptr, 0);
+  if (!h || !mel || !ids || !n_ids || batch < 1) return WT_ERR_INVALID_ARG;
+  if (batch <= 32) return wt_encdec_debug_batch(h, mel, batch, ids, n_ids, nullptr, nullptr, 0);
+  float* d_mel = nullptr;
+  const int rc = guarded(h, [&] {
+    wt::Engine& e = *h->impl;
+    d_mel = e.staging_mel(batch);
+    hipchk(hipMemcpyAsync(d_mel, mel, size_t(batch) * e.mel_elems() * sizeof(float), hipMemcpyHostToDevice, e.stream()), "H2D mel");
+  });
+  if (rc != WT_OK) return rc;
+  return wt_encdec_tokens_batch_dev(h, d_mel, batch, ids, n_ids);
 }
 
 int wt_transcribe_tokens_batch_dev(wt_engine* h, const float* d_pcm, int batch, int64_t* ids,
