@@ -155,6 +155,10 @@ def main() -> None:
                     help="synchronous steps (encoder then decoder) instead of the two-deep pipeline")
     ap.add_argument("--depth", type=int, default=5, choices=tuple(range(1, 9)), help="batches in flight (pipelined mode)")
     ap.add_argument("--gemm-variant", type=int, default=None, help="encoder GEMM tile variant (k_gemm.hip)")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="collective backend for N > 1 (gloo only to rehearse the multi-rank flow on a 1-GPU box)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--dry-run-gloo", action="store_true")
     args = ap.parse_args()
     if args.dry_run_gloo:
@@ -172,9 +176,14 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the engine")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     pkg = ge.load_package()
     tmp = tempfile.mkdtemp(prefix=f"wt_bench_r{rank}_")
@@ -195,7 +204,7 @@ def main() -> None:
     def finish(ids, n):
         rec = torch.from_numpy(pack_records(ids, n))
         if world > 1:
-            rec = gather_records(rec.cuda(), world)
+            rec = gather_records(rec.cuda() if args.backend == "nccl" else rec, world)
         return ids, n, rec
 
     def step():
@@ -256,7 +265,7 @@ def main() -> None:
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
