@@ -330,7 +330,7 @@ def main() -> None:
         dec_bytes = 30 * kv_bytes + 30 * (w_bytes - V * dstate * 4) + 27 * V * dstate * 4
         dec_ach = dec_bytes / (stage["decoder_ms"] * 1e-3) / 1e9 if stage["decoder_ms"] > 0 else 0.0
         out = {
-            "metric": "audio-sec/s (RTF) whisper-tiny 30s clips batch=32 per MI355X",
+            "metric": "audio-sec/s (RTF) whisper-tiny 30s clips batch=32 at 1/2/4/8 MI355X",
             "value": round(value, 1),
             "unit": "audio-sec/s",
             "n_gpus": world,
