@@ -3,12 +3,13 @@
 // inside tflite::Interpreter::Invoke() (whisper.tflite/whisper.cpp:295, :375) for
 // every Conv1D / Linear of the encoder and decoder graphs.
 //
-// gemm_f32_128x128: 256 threads = 4 wavefronts (2x2), each wavefront owns a 64x64
-// output sub-tile as 2x2 MFMA tiles (64 accumulator VGPRs).  A and W tiles are staged
-// global -> registers -> LDS (issue-early / write-late), LDS rows padded to 36 floats
-// so the ds_read_b128 fragment reads are bank-conflict-free.  blockIdx is remapped so
-// that the tiles of one XCD (blockIdx % 8) are consecutive in (m, n) order and share
-// their A panel through that XCD's L2.
+// gemm_f32_tile: 256 threads = 4 wavefronts (2x2), each wavefront owns MI x NI MFMA tiles
+// of 32x32 (64 accumulator registers for the 128x128 tile).  A and W tiles are staged
+// global -> registers -> LDS (issue-early / write-late), LDS rows padded to BK + 4 floats so
+// the ds_read_b128 fragment reads are bank-conflict-free.  blockIdx is remapped so that the
+// tiles of one XCD (blockIdx % 8) are consecutive in (m, n) order and share their A panel
+// through that XCD's L2.  The epilogue goes through a per-wavefront LDS transpose (16-byte
+// global accesses).  tools/mfma_probe.hip measures what bounds this loop.
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
