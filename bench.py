@@ -146,14 +146,16 @@ def cpu_baseline(prefix: str, mel: np.ndarray, prompt, eot: int) -> dict:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="clips per GPU")
     ap.add_argument("--arch", default="tiny")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="synchronous steps (encoder then decoder) instead of the two-deep pipeline")
     ap.add_argument("--depth", type=int, default=5, choices=tuple(range(1, 9)), help="batches in flight (pipelined mode)")
+    ap.add_argument("--resid-waves", type=int, default=None, choices=(4, 8, 16))
+    ap.add_argument("--no-graphs", action="store_true", help="launch the decoder eagerly instead of replaying its hipGraph")
     ap.add_argument("--gemm-variant", type=int, default=None, help="encoder GEMM tile variant (k_gemm.hip)")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="collective backend for N > 1 (gloo only to rehearse the multi-rank flow on a 1-GPU box)")
@@ -189,6 +191,10 @@ def main() -> None:
     tmp = tempfile.mkdtemp(prefix=f"wt_bench_r{rank}_")
     prefix, vocab = ge._assets(tmp, args.arch, 0)
     eng = pkg.Engine(prefix, vocab, True, device_id=local_rank)
+    if args.resid_waves:
+        eng.set_option("resid_waves", args.resid_waves)
+    if args.no_graphs:
+        eng.set_option("use_graphs", 0)
     if args.gemm_variant is not None:
         eng.set_option("gemm_variant", args.gemm_variant)
     eng.set_option("stop_at_eot", 0)  # full-length decode: 30 positions, 27 argmax steps

@@ -16,6 +16,11 @@ int wt_dbg_gemm(wt_engine* h, int M, int N, int K, const float* A, const float* 
 int wt_dbg_gemm_bench(wt_engine* h, int M, int N, int K, int epi, int variant, int iters, float* avg_ms);
 /* times back-to-back launches of a decoder GEMM: kind 0 residual, 1 LayerNorm-fused, 2 combine +
  * residual; waves = wavefronts per block of the residual forms (4, 8, 16) */
+/* Interference probe: enqueues `n_enc` encoder passes over d_mel [batch][80][3000] on the encoder
+ * stream and, concurrently, a chain of `chain_len` dependent trivial launches (`blocks` x 64
+ * threads) on a decoder stream; returns the device time of each. */
+int wt_dbg_interference(wt_engine* h, const float* d_mel, int batch, int n_enc, int chain_len, int blocks,
+                        float* enc_ms, float* chain_ms);
 int wt_dbg_dec_gemm_bench(wt_engine* h, int kind, int B, int N, int K, int waves, int iters, float* avg_us);
 /* decoder-step GEMM (k_decoder.hip), plain input X[B][K], W[N][K] (tiled internally):
  * mode 0: Y = X.W^T + bias   1: gelu(...)   2: Y = R + bias + X.W^T (in-place residual form)

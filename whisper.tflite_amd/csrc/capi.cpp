@@ -116,6 +116,11 @@ int wt_engine_set_option(wt_engine* h, const char* key, long value) {
   } else if (k == "cross_chunks") {
     if (value != 1 && value != 2 && value != 4 && value != 8) return fail(h, WT_ERR_INVALID_ARG, "cross_chunks must be 1, 2, 4 or 8");
     e.cross_chunks = value;
+  } else if (k == "resid_waves") {
+    if (value != 4 && value != 8 && value != 16) return fail(h, WT_ERR_INVALID_ARG, "resid_waves must be 4, 8 or 16");
+    e.resid_waves = value;
+  } else if (k == "use_graphs") {
+    e.use_graphs = value != 0;
   } else if (k == "gemm_variant") {
     if (value < -1 || value > 9) return fail(h, WT_ERR_INVALID_ARG, "gemm_variant must be in [-1, 9]");
     e.gemm_variant = value;
@@ -141,6 +146,8 @@ int wt_engine_get_option(const wt_engine* h, const char* key, long* value) {
   else if (k == "verbose") *value = e.verbose;
   else if (k == "cross_chunks") *value = e.cross_chunks;
   else if (k == "gemm_variant") *value = e.gemm_variant;
+  else if (k == "use_graphs") *value = e.use_graphs;
+  else if (k == "resid_waves") *value = e.resid_waves;
   else return WT_ERR_INVALID_ARG;
   return WT_OK;
 }
@@ -483,6 +490,32 @@ int wt_dbg_gemm_bench(wt_engine* h, int M, int N, int K, int epi, int variant, i
     *avg_ms = ms / iters;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+  });
+}
+
+int wt_dbg_interference(wt_engine* h, const float* d_mel, int batch, int n_enc, int chain_len, int blocks,
+                        float* enc_ms, float* chain_ms) {
+  if (!h || !d_mel || !enc_ms || !chain_ms || batch < 1 || batch > 64 || n_enc < 0 || n_enc > 8 ||
+      chain_len < 0 || blocks < 1 || blocks > 4096)
+    return WT_ERR_INVALID_ARG;
+  return guarded(h, [&] {
+    wt::Engine& e = *h->impl;
+    e.sync();
+    DevBuf buf(size_t(4096));
+    hipStream_t es = e.stream(), ds = e.decoder_stream(0);
+    hipEvent_t ev[4];
+    for (auto& x : ev) hipchk(hipEventCreate(&x), "event");
+    hipchk(hipEventRecord(ev[0], es), "record");
+    for (int i = 0; i < n_enc; ++i) e.encode(d_mel, batch);
+    hipchk(hipEventRecord(ev[1], es), "record");
+    hipchk(hipEventRecord(ev[2], ds), "record");
+    for (int i = 0; i < chain_len; ++i) wt::launch_chain_probe(buf.p, blocks, ds);
+    hipchk(hipEventRecord(ev[3], ds), "record");
+    hipchk(hipEventSynchronize(ev[1]), "sync");
+    hipchk(hipEventSynchronize(ev[3]), "sync");
+    hipchk(hipEventElapsedTime(enc_ms, ev[0], ev[1]), "elapsed");
+    hipchk(hipEventElapsedTime(chain_ms, ev[2], ev[3]), "elapsed");
+    for (auto& x : ev) (void)hipEventDestroy(x);
   });
 }
 

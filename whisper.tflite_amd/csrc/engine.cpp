@@ -8,6 +8,7 @@
 #include <cmath>
 #include <complex>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 
@@ -321,8 +322,23 @@ Engine::Engine(const std::string& model_prefix, const std::string& vocab_path, b
   }
   int prio_lo = 0, prio_hi = 0;
   HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-  HIPCHK(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, prio_lo));
-  // the decoder's tiny dependent launches go ahead of the encoder's big grids
+  HIPCHK(hipStreamCreateWithPriority(&stream_full_, hipStreamNonBlocking, prio_lo));
+  // Pipelined batches run the encoder on a stream that leaves `reserve` CUs of every XCD to the
+  // decoders (mask bit i = CU i/8 of XCD i%8): measured on MI355X, three decoder chains next
+  // to an encoder that owns every CU stretch it by 2.5 ms per batch, next to one that owns
+  // 224 of 256 CUs by 0.9 ms. Synchronous calls keep the whole chip.
+  int reserve = 4;
+  if (const char* v = getenv("WT_ENC_CU_RESERVE")) reserve = std::min(std::max(atoi(v), 0), 16);
+  const int n_cu = prop.multiProcessorCount;
+  if (reserve > 0 && n_cu >= 64 && n_cu % 8 == 0) {
+    const int keep = n_cu - 8 * reserve;
+    std::vector<uint32_t> mask((n_cu + 31) / 32, 0u);
+    for (int i = 0; i < keep; ++i) mask[i / 32] |= 1u << (i % 32);
+    HIPCHK(hipExtStreamCreateWithCUMask(&stream_masked_, uint32_t(mask.size()), mask.data()));
+  }
+  stream_ = stream_full_;
+  HIPCHK(hipEventCreate(&ev_switch_));
+  if (const char* v = getenv("WT_DEC_STREAMS")) n_dec_streams_ = std::min(std::max(atoi(v), 1), kDecStreams);
   for (auto& ds : dstream_) HIPCHK(hipStreamCreateWithPriority(&ds, hipStreamNonBlocking, prio_hi));
   for (auto& e : ev_) HIPCHK(hipEventCreate(&e));
   for (Slot& sl : slots_) {
@@ -342,9 +358,11 @@ Engine::Engine(const std::string& model_prefix, const std::string& vocab_path, b
 
 Engine::~Engine() {
   (void)hipSetDevice(device_);
-  if (stream_) (void)hipStreamSynchronize(stream_);
+  for (hipStream_t st : {stream_full_, stream_masked_})
+    if (st) (void)hipStreamSynchronize(st);
   for (auto& ds : dstream_)
     if (ds) (void)hipStreamSynchronize(ds);
+  for (auto& g : graphs_) (void)hipGraphExecDestroy(g.second.exec);
   for (void* p : ws_.owned) (void)hipFree(p);
   for (void* p : allocations_) (void)hipFree(p);
   for (auto& e : ev_)
@@ -356,15 +374,28 @@ Engine::~Engine() {
     if (sl.h_ids) (void)hipHostFree(sl.h_ids);
     if (sl.h_n) (void)hipHostFree(sl.h_n);
   }
-  if (stream_) (void)hipStreamDestroy(stream_);
+  if (ev_switch_) (void)hipEventDestroy(ev_switch_);
+  if (trace_base_) (void)hipEventDestroy(trace_base_);
+  for (hipStream_t st : {stream_full_, stream_masked_})
+    if (st) (void)hipStreamDestroy(st);
   for (auto& ds : dstream_)
     if (ds) (void)hipStreamDestroy(ds);
+}
+
+void Engine::select_stream(bool pipelined) {
+  hipStream_t target = pipelined && stream_masked_ ? stream_masked_ : stream_full_;
+  if (target == stream_) return;
+  // everything already enqueued on the old stream stays ahead of what follows on the new one
+  HIPCHK(hipEventRecord(ev_switch_, stream_));
+  HIPCHK(hipStreamWaitEvent(target, ev_switch_, 0));
+  stream_ = target;
 }
 
 void Engine::bind_device() { HIPCHK(hipSetDevice(device_)); }
 
 void Engine::sync() {
-  HIPCHK(hipStreamSynchronize(stream_));
+  HIPCHK(hipStreamSynchronize(stream_full_));
+  if (stream_masked_) HIPCHK(hipStreamSynchronize(stream_masked_));
   for (auto& ds : dstream_) HIPCHK(hipStreamSynchronize(ds));
 }
 
@@ -375,6 +406,8 @@ void Engine::ensure_batch(int batch) {
   if (!inflight_.empty()) throw Error(1, "cannot grow the workspace while batches are in flight");
   HIPCHK(hipStreamSynchronize(stream_));
   for (auto& ds : dstream_) HIPCHK(hipStreamSynchronize(ds));
+  for (auto& g : graphs_) (void)hipGraphExecDestroy(g.second.exec);  // captured pointers die with the workspace
+  graphs_.clear();
   for (void* p : ws_.owned) (void)hipFree(p);
   ws_ = Workspace();
   const wtw::Dims& c = dims_;
@@ -530,6 +563,11 @@ void Engine::resolve_kernel_stats(int slot) {
 // ------------------------------------------------------------ encoder ---
 
 void Engine::encode(const float* d_mel, int batch) {
+  select_stream(false);
+  encode_enqueue(d_mel, batch);
+}
+
+void Engine::encode_enqueue(const float* d_mel, int batch) {
   ensure_batch(batch);
   const wtw::Dims& c = dims_;
   const int T0 = mel_frames(), T = c.n_audio_ctx, d = c.n_audio_state, M = batch * T;
@@ -540,6 +578,10 @@ void Engine::encode(const float* d_mel, int batch) {
   slot.kt_flops.clear();
   slot.kt_bytes.clear();
   slot.batch = batch;
+  if (!trace_base_ && getenv("WT_TRACE_PIPELINE")) {
+    HIPCHK(hipEventCreate(&trace_base_));
+    HIPCHK(hipEventRecord(trace_base_, stream_));
+  }
   HIPCHK(hipEventRecord(slot.enc_begin, stream_));
   kt_begin(kKcTranspose, 0, 2.0 * batch * c.n_mels * T0 * 4);
   launch_mel_transpose(d_mel, ws_.melT, batch, c.n_mels, T0, stream_);
@@ -652,7 +694,8 @@ void Engine::decode(int batch, int64_t* ids, int32_t* n_ids, float* logits_host,
 void Engine::submit(const float* d_mel, int batch) {
   if (int(inflight_.size()) >= kSlots) throw Error(1, "pipeline is full (8 batches in flight): collect() first");
   if (batch > 64) throw Error(1, "decoder batches are limited to 64 clips per call");
-  encode(d_mel, batch);
+  select_stream(true);
+  encode_enqueue(d_mel, batch);
   decode_enqueue(batch, last_enc_slot_, nullptr, 0);
   inflight_.push_back(last_enc_slot_);
 }
@@ -667,8 +710,7 @@ void Engine::collect(int64_t* ids, int32_t* n_ids) {
 void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int logits_steps_cap) {
   ensure_batch(batch);
   Slot& slot = slots_[slot_idx];
-  slot.dec = next_dec_;
-  next_dec_ = (next_dec_ + 1) % kDecStreams;
+  slot.dec = slot_idx % n_dec_streams_;  // fixed pairing keeps the number of captured graphs small
   DecWorkspace& dw = dws_[slot.dec];
   hipStream_t const stream_ = dstream_[slot.dec];  // everything below runs on this decoder stream
   HIPCHK(hipStreamWaitEvent(stream_, slot.enc_done, 0));
@@ -691,81 +733,130 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
     for (int i = 0; i < stride; ++i) h_ids_[size_t(b) * stride + i] = i < n_prompt ? prompt[i] : 0;
     h_n_[b] = n_prompt;
   }
-  HIPCHK(hipMemcpyAsync(dw.ids, h_ids_, size_t(batch) * stride * sizeof(long long),
-                        hipMemcpyHostToDevice, stream_));
-  HIPCHK(hipMemcpyAsync(dw.n_ids, h_n_, size_t(batch) * sizeof(int), hipMemcpyHostToDevice, stream_));
-  HIPCHK(hipMemsetAsync(dw.finished, 0, size_t(batch) * sizeof(int), stream_));
-
   const int chunks = int(cross_chunks);  // 1, 2, 4 or 8 (wt_engine_set_option)
-  const size_t kv_slab = size_t(batch) * T * d;  // one (layer, k|v) slab of the cross cache
-  const size_t self_slab = size_t(batch) * self_cap_ * d;
   int steps = 0;
-  float* const x = dw.xd;  // residual stream [B][d], updated in place by the residual GEMMs
-  for (int pos = 0; pos < max_pos; ++pos) {
-    for (int l = 0; l < c.n_text_layer; ++l) {
-      const BlockWeights& w = dec_blocks_[l];
-      DecGemmArgs q;  // LN + fused q|k|v projection (+ token/positional embedding at layer 0)
-      q.Wt = w.attn.wqkv; q.N = 3 * d; q.K = d; q.B = batch;
-      q.xin = x; q.ln_g = w.attn_ln_g; q.ln_b = w.attn_ln_b;
-      if (l == 0) {
-        q.ids = dw.ids; q.ids_stride = stride; q.pos = pos; q.tok_emb = tok_emb; q.pos_emb = dec_pos;
-        q.n_vocab = V; q.xout = x;
+  auto enqueue_all = [&](int si) {
+    Slot& slot = slots_[si];
+    DecWorkspace& dw = dws_[si % n_dec_streams_];
+    hipStream_t const stream_ = dstream_[si % n_dec_streams_];
+    long long* const h_ids_ = slot.h_ids;
+    int* const h_n_ = slot.h_n;
+    steps = 0;
+    HIPCHK(hipMemcpyAsync(dw.ids, h_ids_, size_t(batch) * stride * sizeof(long long),
+                          hipMemcpyHostToDevice, stream_));
+    HIPCHK(hipMemcpyAsync(dw.n_ids, h_n_, size_t(batch) * sizeof(int), hipMemcpyHostToDevice, stream_));
+    HIPCHK(hipMemsetAsync(dw.finished, 0, size_t(batch) * sizeof(int), stream_));
+
+    const size_t kv_slab = size_t(batch) * T * d;  // one (layer, k|v) slab of the cross cache
+    const size_t self_slab = size_t(batch) * self_cap_ * d;
+    float* const x = dw.xd;  // residual stream [B][d], updated in place by the residual GEMMs
+    for (int pos = 0; pos < max_pos; ++pos) {
+      for (int l = 0; l < c.n_text_layer; ++l) {
+        const BlockWeights& w = dec_blocks_[l];
+        DecGemmArgs q;  // LN + fused q|k|v projection (+ token/positional embedding at layer 0)
+        q.Wt = w.attn.wqkv; q.N = 3 * d; q.K = d; q.B = batch;
+        q.xin = x; q.ln_g = w.attn_ln_g; q.ln_b = w.attn_ln_b;
+        if (l == 0) {
+          q.ids = dw.ids; q.ids_stride = stride; q.pos = pos; q.tok_emb = tok_emb; q.pos_emb = dec_pos;
+          q.n_vocab = V; q.xout = x;
+        }
+        q.bias = w.attn.bqkv; q.Y = dw.qkvd; q.ldy = 3 * d;
+        launch_dec_gemm(q, kProLn, kDecBias, stream_);
+        launch_self_attention(dw.qkvd, dw.self_kv + (size_t(l) * 2 + 0) * self_slab,
+                              dw.self_kv + (size_t(l) * 2 + 1) * self_slab, self_cap_, pos, dw.attd,
+                              batch, H, stream_);
+        DecGemmArgs o;  // x += attn . Wo^T + bo
+        o.Wt = w.attn.wo; o.N = d; o.K = d; o.B = batch; o.X = dw.attd; o.ldx = d;
+        o.bias = w.attn.bo; o.R = x; o.Y = x; o.ldy = d; o.resid_waves = int(resid_waves);
+        launch_dec_gemm(o, kProNone, kDecResid, stream_);
+
+        DecGemmArgs cq;  // LN + cross-attention query projection
+        cq.Wt = w.cross.wq; cq.N = d; cq.K = d; cq.B = batch;
+        cq.xin = x; cq.ln_g = w.cross_ln_g; cq.ln_b = w.cross_ln_b;
+        cq.bias = w.cross.bq; cq.Y = dw.qd; cq.ldy = d;
+        launch_dec_gemm(cq, kProLn, kDecBias, stream_);
+        launch_cross_attention(dw.qd, slot.cross_kv + (size_t(l) * 2 + 0) * kv_slab,
+                               slot.cross_kv + (size_t(l) * 2 + 1) * kv_slab, dw.cross_ws, batch, H, T,
+                               chunks, stream_);
+        DecGemmArgs co;  // x += combine(chunks) . Wco^T + bco
+        co.Wt = w.cross.wo; co.N = d; co.K = d; co.B = batch;
+        co.cross_ws = dw.cross_ws; co.heads = H; co.chunks = chunks;
+        co.bias = w.cross.bo; co.R = x; co.Y = x; co.ldy = d; co.resid_waves = int(resid_waves);
+        launch_dec_gemm(co, kProCombine, kDecResid, stream_);
+
+        DecGemmArgs f1;  // LN + fc1 + GELU
+        f1.Wt = w.w1; f1.N = 4 * d; f1.K = d; f1.B = batch;
+        f1.xin = x; f1.ln_g = w.mlp_ln_g; f1.ln_b = w.mlp_ln_b;
+        f1.bias = w.b1; f1.Y = dw.hd; f1.ldy = 4 * d;
+        launch_dec_gemm(f1, kProLn, kDecBiasGelu, stream_);
+        DecGemmArgs f2;  // x += h . W2^T + b2
+        f2.Wt = w.w2; f2.N = d; f2.K = 4 * d; f2.B = batch; f2.X = dw.hd; f2.ldx = 4 * d;
+        f2.bias = w.b2; f2.R = x; f2.Y = x; f2.ldy = d; f2.resid_waves = int(resid_waves);
+        launch_dec_gemm(f2, kProNone, kDecResid, stream_);
       }
-      q.bias = w.attn.bqkv; q.Y = dw.qkvd; q.ldy = 3 * d;
-      launch_dec_gemm(q, kProLn, kDecBias, stream_);
-      launch_self_attention(dw.qkvd, dw.self_kv + (size_t(l) * 2 + 0) * self_slab,
-                            dw.self_kv + (size_t(l) * 2 + 1) * self_slab, self_cap_, pos, dw.attd,
-                            batch, H, stream_);
-      DecGemmArgs o;  // x += attn . Wo^T + bo
-      o.Wt = w.attn.wo; o.N = d; o.K = d; o.B = batch; o.X = dw.attd; o.ldx = d;
-      o.bias = w.attn.bo; o.R = x; o.Y = x; o.ldy = d;
-      launch_dec_gemm(o, kProNone, kDecResid, stream_);
-
-      DecGemmArgs cq;  // LN + cross-attention query projection
-      cq.Wt = w.cross.wq; cq.N = d; cq.K = d; cq.B = batch;
-      cq.xin = x; cq.ln_g = w.cross_ln_g; cq.ln_b = w.cross_ln_b;
-      cq.bias = w.cross.bq; cq.Y = dw.qd; cq.ldy = d;
-      launch_dec_gemm(cq, kProLn, kDecBias, stream_);
-      launch_cross_attention(dw.qd, slot.cross_kv + (size_t(l) * 2 + 0) * kv_slab,
-                             slot.cross_kv + (size_t(l) * 2 + 1) * kv_slab, dw.cross_ws, batch, H, T,
-                             chunks, stream_);
-      DecGemmArgs co;  // x += combine(chunks) . Wco^T + bco
-      co.Wt = w.cross.wo; co.N = d; co.K = d; co.B = batch;
-      co.cross_ws = dw.cross_ws; co.heads = H; co.chunks = chunks;
-      co.bias = w.cross.bo; co.R = x; co.Y = x; co.ldy = d;
-      launch_dec_gemm(co, kProCombine, kDecResid, stream_);
-
-      DecGemmArgs f1;  // LN + fc1 + GELU
-      f1.Wt = w.w1; f1.N = 4 * d; f1.K = d; f1.B = batch;
-      f1.xin = x; f1.ln_g = w.mlp_ln_g; f1.ln_b = w.mlp_ln_b;
-      f1.bias = w.b1; f1.Y = dw.hd; f1.ldy = 4 * d;
-      launch_dec_gemm(f1, kProLn, kDecBiasGelu, stream_);
-      DecGemmArgs f2;  // x += h . W2^T + b2
-      f2.Wt = w.w2; f2.N = d; f2.K = 4 * d; f2.B = batch; f2.X = dw.hd; f2.ldx = 4 * d;
-      f2.bias = w.b2; f2.R = x; f2.Y = x; f2.ldy = d;
-      launch_dec_gemm(f2, kProNone, kDecResid, stream_);
+      if (pos >= n_prompt - 1) {
+        // logits against the tied embedding + greedy argmax (whisper.cpp:379-399); only the
+        // last position's row exists here, the reference computes and drops the others
+        launch_dec_finalize_ln(x, dec_ln_g, dec_ln_b, dw.lnd, batch, d, stream_);
+        DecGemmArgs lg;
+        lg.Wt = tok_emb_tiled; lg.N = V; lg.K = d; lg.B = batch; lg.X = dw.lnd; lg.ldx = d;
+        lg.Y = logits_host ? dw.logits : nullptr; lg.ldy = V; lg.best = dw.best;
+        launch_dec_gemm(lg, kProNone, kDecLogits, stream_);
+        if (logits_host && steps < logits_steps_cap) {
+          HIPCHK(hipMemcpy2DAsync(logits_host + size_t(steps) * V, size_t(logits_steps_cap) * V * sizeof(float),
+                                  dw.logits, size_t(V) * sizeof(float), size_t(V) * sizeof(float), batch,
+                                  hipMemcpyDeviceToHost, stream_));
+        }
+        launch_select_token(dw.best, (V + 31) / 32, dw.ids, stride, pos, dw.n_ids, dw.finished,
+                            vocab_.token_eot, int(stop_at_eot), batch, stream_);
+        ++steps;
+      }
     }
-    if (pos >= n_prompt - 1) {
-      // logits against the tied embedding + greedy argmax (whisper.cpp:379-399); only the
-      // last position's row exists here, the reference computes and drops the others
-      launch_dec_finalize_ln(x, dec_ln_g, dec_ln_b, dw.lnd, batch, d, stream_);
-      DecGemmArgs lg;
-      lg.Wt = tok_emb_tiled; lg.N = V; lg.K = d; lg.B = batch; lg.X = dw.lnd; lg.ldx = d;
-      lg.Y = logits_host ? dw.logits : nullptr; lg.ldy = V; lg.best = dw.best;
-      launch_dec_gemm(lg, kProNone, kDecLogits, stream_);
-      if (logits_host && steps < logits_steps_cap) {
-        HIPCHK(hipMemcpy2DAsync(logits_host + size_t(steps) * V, size_t(logits_steps_cap) * V * sizeof(float),
-                                dw.logits, size_t(V) * sizeof(float), size_t(V) * sizeof(float), batch,
-                                hipMemcpyDeviceToHost, stream_));
-      }
-      launch_select_token(dw.best, (V + 31) / 32, dw.ids, stride, pos, dw.n_ids, dw.finished,
-                          vocab_.token_eot, int(stop_at_eot), batch, stream_);
-      ++steps;
+    HIPCHK(hipMemcpyAsync(h_ids_, dw.ids, size_t(batch) * stride * sizeof(long long),
+                          hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipMemcpyAsync(h_n_, dw.n_ids, size_t(batch) * sizeof(int), hipMemcpyDeviceToHost, stream_));
+  };
+  // The ~1050 launches of a decode are identical from call to call for a given (slot, batch,
+  // options). The first call with a signature runs them eagerly (which also performs the
+  // kernels' one-time attribute set-up) and then captures one hipGraph per slot; later calls
+  // replay the slot's graph: one host call instead of ~1100. The logits tap stays eager.
+  auto key_of = [&](int si) {
+    return std::vector<long long>{si, batch, max_pos, n_prompt, chunks, long(stop_at_eot), resid_waves};
+  };
+  hipGraphExec_t exec = nullptr;
+  if (use_graphs && !logits_host) {
+    auto it = graphs_.find(key_of(slot_idx));
+    if (it != graphs_.end()) {
+      exec = it->second.exec;
+      steps = it->second.steps;
     }
   }
-  HIPCHK(hipMemcpyAsync(h_ids_, dw.ids, size_t(batch) * stride * sizeof(long long),
-                        hipMemcpyDeviceToHost, stream_));
-  HIPCHK(hipMemcpyAsync(h_n_, dw.n_ids, size_t(batch) * sizeof(int), hipMemcpyDeviceToHost, stream_));
+  if (exec) {
+    HIPCHK(hipGraphLaunch(exec, stream_));
+  } else {
+    enqueue_all(slot_idx);
+    const int eager_steps = steps;
+    if (use_graphs && !logits_host) {
+      for (int si = 0; si < kSlots; ++si) {
+        hipStream_t cs = dstream_[si % n_dec_streams_];
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t ge = nullptr;
+        HIPCHK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+        try {
+          enqueue_all(si);
+        } catch (...) {
+          (void)hipStreamEndCapture(cs, &graph);
+          if (graph) (void)hipGraphDestroy(graph);
+          throw;
+        }
+        HIPCHK(hipStreamEndCapture(cs, &graph));
+        HIPCHK(hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(graph);
+        graphs_[key_of(si)] = GraphEntry{ge, steps};
+      }
+    }
+    steps = eager_steps;
+  }
   HIPCHK(hipEventRecord(slot.dec_done, stream_));
   slot.steps = steps;
 }
@@ -788,6 +879,14 @@ void Engine::decode_collect(int slot_idx, int64_t* ids, int32_t* n_ids) {
   if (hipEventElapsedTime(&ms, slot.enc_mid, slot.enc_done) == hipSuccess) timings_.cross_kv_ms = ms;
   if (hipEventElapsedTime(&ms, slot.dec_begin, slot.dec_done) == hipSuccess) timings_.decoder_ms = ms;
   if (hipEventElapsedTime(&ms, slot.enc_begin, slot.dec_done) == hipSuccess) timings_.total_ms = ms;
+  static const bool trace = getenv("WT_TRACE_PIPELINE") != nullptr;
+  if (trace) {  // device timeline of the batch relative to the first traced batch, for pipeline analysis
+    hipEvent_t base = trace_base_;
+    float t[4] = {0, 0, 0, 0};
+    hipEvent_t evs[4] = {slot.enc_begin, slot.enc_done, slot.dec_begin, slot.dec_done};
+    for (int i = 0; i < 4; ++i) (void)hipEventElapsedTime(&t[i], base, evs[i]);
+    fprintf(stderr, "[wt-trace] slot %d enc %.3f..%.3f dec %.3f..%.3f\n", slot_idx, t[0], t[1], t[2], t[3]);
+  }
   if (timings_.logmel_ms < 0) {
     timings_.logmel_ms = 0;
     if (hipEventElapsedTime(&ms, ev_[0], ev_[1]) == hipSuccess) timings_.logmel_ms = ms;

@@ -65,6 +65,7 @@ class Engine {
   const FilterBank& filters() const { return filters_; }
   const Timings& timings() const { return timings_; }
   hipStream_t stream() const { return stream_; }
+  hipStream_t decoder_stream(int i) const { return dstream_[i % n_dec_streams_]; }
 
   // options (reference hard-codes them, see wt_capi.h)
   long language = 2;  // language_id("de")
@@ -72,6 +73,8 @@ class Engine {
   long stop_at_eot = 1;
   long verbose = 0;
   long cross_chunks = 4;
+  long resid_waves = 16;  // wavefronts per block of the decoder's residual GEMMs (4, 8, 16)
+  long use_graphs = 1;  // replay the decoder's launch sequence from a captured hipGraph
   long gemm_variant = -1;  // encoder GEMM tile variant (k_gemm.hip); -1 = per-shape choice
   // non-empty: replaces the reference's hard-coded prompt (test-sized vocabularies)
   std::vector<long long> prompt_override;
@@ -121,8 +124,14 @@ class Engine {
   void decode_collect(int slot, int64_t* ids, int32_t* n_ids);
 
   int device_ = 0;
-  hipStream_t stream_ = nullptr;   // encoder + front end
-  static constexpr int kDecStreams = 6, kSlots = 8;
+  hipStream_t stream_ = nullptr;   // encoder + front end: stream_full_ or stream_masked_ (select_stream)
+  hipStream_t stream_full_ = nullptr, stream_masked_ = nullptr;
+  hipEvent_t ev_switch_ = nullptr;
+  void select_stream(bool pipelined);
+  void encode_enqueue(const float* d_mel, int batch);
+  static constexpr int kDecStreams = 8, kSlots = 8;
+  int n_dec_streams_ = 3;  // decoder streams in use: one hardware queue each (the runtime multiplexes
+                           // streams onto 4 queues per priority; two decoders sharing one serialise)
   hipStream_t dstream_[kDecStreams] = {};  // decoders (batches rotate over them)
   hipEvent_t ev_[2] = {nullptr, nullptr};  // front end begin / end
   struct Slot {
@@ -137,7 +146,12 @@ class Engine {
     std::vector<int> kt_cls;
     std::vector<double> kt_flops, kt_bytes;
   } slots_[kSlots];
-  int next_dec_ = 0;
+  struct GraphEntry {
+    hipGraphExec_t exec;
+    int steps;
+  };
+  std::map<std::vector<long long>, GraphEntry> graphs_;
+  hipEvent_t trace_base_ = nullptr;  // WT_TRACE_PIPELINE=1: origin of the per-batch device timeline
   int enc_slot_ = 0;        // slot the next encode() fills
   int last_enc_slot_ = 0;   // slot the last encode() filled
   std::vector<int> inflight_;

@@ -196,6 +196,14 @@ void launch_layernorm(const float* x, float* y, const float* g, const float* b, 
   }
 }
 
+__global__ void chain_probe(float* p) {
+  if (threadIdx.x == 0) p[blockIdx.x] += 1.0f;
+}
+
+void launch_chain_probe(float* p, int blocks, hipStream_t stream) {
+  hipLaunchKernelGGL(chain_probe, dim3(blocks), dim3(64), 0, stream, p);
+}
+
 void launch_mel_transpose(const float* mel, float* melT, int batch, int n_mels, int T,
                           hipStream_t s) {
   hipLaunchKernelGGL(mel_transpose, dim3((T + 31) / 32, (n_mels + 31) / 32, batch), dim3(256), 0, s,

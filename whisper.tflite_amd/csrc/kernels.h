@@ -99,6 +99,8 @@ void launch_encoder_attention(const float* qkv, float* out, int batch, int T, in
 
 // ------------------------------------------------------------- front end ---
 // mel [B][n_mels][T] -> melT [B][T + 2][n_mels] rows 1..T (rows 0 and T+1 stay zero).
+// one dependent link of a launch-latency chain (test tap): blocks x 64 threads, p[block] += 1
+void launch_chain_probe(float* p, int blocks, hipStream_t stream);
 void launch_mel_transpose(const float* mel, float* melT, int batch, int n_mels, int T,
                           hipStream_t s);
 // spec [M][ld] holding re parts of all n_fft bins at columns [0,n_fft) and im parts at
