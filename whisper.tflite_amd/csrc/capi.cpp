@@ -122,7 +122,7 @@ int wt_engine_set_option(wt_engine* h, const char* key, long value) {
   } else if (k == "use_graphs") {
     e.use_graphs = value != 0;
   } else if (k == "gemm_variant") {
-    if (value < -1 || value > 9) return fail(h, WT_ERR_INVALID_ARG, "gemm_variant must be in [-1, 9]");
+    if (value < -1 || value > 11) return fail(h, WT_ERR_INVALID_ARG, "gemm_variant must be in [-1, 11]");
     e.gemm_variant = value;
   } else {
     return fail(h, WT_ERR_INVALID_ARG, "unknown option: " + k);
@@ -454,7 +454,7 @@ int wt_dbg_gemm(wt_engine* h, int M, int N, int K, const float* A, const float* 
     wt::GemmArgs g;
     g.A = dA.p; g.lda = K; g.W = dW.p; g.bias = dB.p; g.C = dC.p; g.R = dC.p; g.ldc = N;
     g.pos = dP.p; g.pos_period = pos_period > 0 ? pos_period : 1;
-    g.M = M; g.N = N; g.K = K;
+    g.M = M; g.N = N; g.K = K; g.variant = int(h->impl->gemm_variant);
     wt::launch_gemm(g, epi, h->impl->stream());
     h->impl->sync();
     dC.to_host(C, size_t(M) * N);

@@ -43,6 +43,64 @@ struct GemmDev {
   int kv_batch, kv_heads, kv_dmodel;
 };
 
+// Epilogue shared by the GEMM kernels.  The C/D layout (col = lane & 31, row = (r & 3) +
+// 8 * (r >> 2) + 4 * (lane >> 5)) would make every lane issue 16 * MI * NI single-dword stores
+// (and as many residual loads): measured on a probe of the fp32 loop, that costs +64 % on a
+// K = 384 GEMM.  Each wavefront instead transposes 32-row slabs of its tile through a private
+// LDS stage (the operand tiles are dead by now) and moves 16 bytes per lane: 4x fewer memory
+// instructions, whole 128/256-byte row segments per 8/16 lanes.
+template <int EPI, int BM, int BN, int MI, int NI>
+__device__ __forceinline__ void tile_epilogue(const GemmDev& g, f32x16 (&acc)[MI][NI], float* smem, int m0,
+                                              int n0) {
+  constexpr int SLD = NI * 32 + 4;  // staging row stride (floats)
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+  __syncthreads();  // every wavefront is done reading the operand tiles
+  float* const stage = smem + wid * (32 * SLD);
+  constexpr int LPR = NI * 8;        // lanes per staged row (one float4 each)
+  constexpr int RPS = 64 / LPR;      // rows per pass
+  const int prow = lane / LPR, c4 = (lane % LPR) * 4;
+  const int n = n0 + wn * (BN / 2) + c4;
+  f32x4 bias4 = {0, 0, 0, 0};
+  if (EPI & kEpiBias) bias4 = *reinterpret_cast<const f32x4*>(g.bias + n);
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        stage[((r & 3) + 8 * (r >> 2) + 4 * lh) * SLD + ni * 32 + l31] = acc[mi][ni][r];
+    // the stage is private to this wavefront and LDS executes a wave's operations in order
+#pragma unroll
+    for (int p = 0; p < 32 / RPS; ++p) {
+      const int row = p * RPS + prow;
+      const int m = m0 + wm * (BM / 2) + mi * 32 + row;
+      f32x4 v = *reinterpret_cast<const f32x4*>(&stage[row * SLD + c4]);
+      if (m < g.M) {
+        const int mb = m / g.c_rpb, mt = m % g.c_rpb;
+        v += bias4;
+        if (EPI & kEpiGelu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+        }
+        if (EPI & kEpiPos) v += *reinterpret_cast<const f32x4*>(g.pos + (long)(m % g.pos_period) * g.N + n);
+        if (EPI & kEpiKvLayout) {
+          const int slab = n / g.kv_dmodel, rem = n % g.kv_dmodel;
+          const int head = rem >> 6, dd = rem & 63;  // 4 consecutive dd: c4 is a multiple of 4
+          const long o = (((long)slab * g.kv_batch + mb) * g.kv_heads + head) * (long)g.c_rpb * 64 +
+                         (long)mt * 64 + dd;
+          *reinterpret_cast<f32x4*>(g.C + o) = v;
+        } else {
+          const long o = (long)mb * g.c_bs + (long)mt * g.ldc + n;
+          if (EPI & kEpiResidual) v += *reinterpret_cast<const f32x4*>(g.R + o);
+          *reinterpret_cast<f32x4*>(g.C + o) = v;
+        }
+      }
+    }
+  }
+}
+
 // Tile template: BM x BN output tile (64 or 128 each), 4 wavefronts as 2 x 2, each owning
 // (BM/2) x (BN/2) = MI x NI MFMA tiles of 32 x 32; k-tile BK (32 or 64); DBUF = two LDS
 // buffers and one barrier per k-tile instead of two.
@@ -175,55 +233,174 @@ __global__ __launch_bounds__(256) void gemm_f32_tile(GemmDev g) {
     }
   }
 
-  // Epilogue.  The C/D layout (col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5))
-  // would make every lane issue 16 * MI * NI single-dword stores (and as many residual loads):
-  // measured on a probe of this loop, that costs +64 % on a K = 384 GEMM.  Each wavefront
-  // instead transposes 32-row slabs of its tile through a private LDS stage (the operand
-  // tiles are dead by now) and moves 16 bytes per lane: 4x fewer memory instructions, whole
-  // 128/256-byte row segments per 8/16 lanes.
-  __syncthreads();  // every wavefront is done reading the operand tiles
-  float* const stage = smem + wid * (32 * SLD);
-  constexpr int LPR = NI * 8;        // lanes per staged row (one float4 each)
-  constexpr int RPS = 64 / LPR;      // rows per pass
-  const int prow = lane / LPR, c4 = (lane % LPR) * 4;
-  const int n = n0 + wn * (BN / 2) + c4;
-  f32x4 bias4 = {0, 0, 0, 0};
-  if (EPI & kEpiBias) bias4 = *reinterpret_cast<const f32x4*>(g.bias + n);
+  tile_epilogue<EPI, BM, BN, MI, NI>(g, acc, smem, m0, n0);
+}
+
+// gemm_split_tile: the same GEMM on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, 16x the
+// fp32 MFMA rate per k).  NS = 3: every fp32 operand element is split EXACTLY into three bf16
+// planes by truncation (x = h1 + h2 + h3, 8 significant bits each, the subtractions are exact),
+// and the six plane products with weight >= 2^-16 are accumulated in fp32:
+//   a.b = a1b1 + (a1b2 + a2b1) + (a2b2 + a1b3 + a3b1) + O(2^-24 |a||b|)
+// Each bf16 x bf16 product is exact in fp32, so the result carries fp32-level error (measured
+// against fp64 next to the fp32-MFMA kernel in tests/test_gpu_kernels.py) at 6/16 of the MFMA
+// cycles.  NS = 1 rounds the operands to bf16 (RNE) and is the bf16 compute mode of
+// BASELINE configs[3].  Operands stay fp32 in HBM; the split happens between the global load
+// and the LDS write (4 VALU ops + 1.5 v_perm per element, hidden behind the partner
+// wavefront's MFMAs at 2 blocks per CU).  128 x 128 x 32 tiles, 4 wavefronts as 2 x 2, two
+// k-tiles of global loads in flight (a k-tile is ~1500 MFMA cycles, shorter than HBM latency).
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+
+template <int NS>
+__device__ __forceinline__ void split_store8(const f32x4& lo, const f32x4& hi, unsigned short* dst, int plane_stride) {
+  float x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  if (NS == 1) {
+    u32x4 o;
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
+    for (int j = 0; j < 4; ++j) {
+      // round to nearest even on the upper 16 bits
+      unsigned a = __float_as_uint(x[2 * j]), b = __float_as_uint(x[2 * j + 1]);
+      a += 0x7FFFu + ((a >> 16) & 1u);
+      b += 0x7FFFu + ((b >> 16) & 1u);
+      o[j] = __builtin_amdgcn_perm(b, a, 0x07060302u);
+    }
+    *reinterpret_cast<u32x4*>(dst) = o;
+    return;
+  }
+  unsigned h[3][8];
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
+  for (int e = 0; e < 8; ++e) {
+    const unsigned u = __float_as_uint(x[e]);
+    h[0][e] = u;  // the pack below keeps the upper half only
+    const float r1 = x[e] - __uint_as_float(u & 0xFFFF0000u);
+    h[1][e] = __float_as_uint(r1);
+    const float r2 = r1 - __uint_as_float(h[1][e] & 0xFFFF0000u);
+    h[2][e] = __float_as_uint(r2);  // at most 8 significant bits are left: exact in bf16
+  }
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        stage[((r & 3) + 8 * (r >> 2) + 4 * lh) * SLD + ni * 32 + l31] = acc[mi][ni][r];
-    // the stage is private to this wavefront and LDS executes a wave's operations in order
+  for (int p = 0; p < 3; ++p) {
+    u32x4 o;
 #pragma unroll
-    for (int p = 0; p < 32 / RPS; ++p) {
-      const int row = p * RPS + prow;
-      const int m = m0 + wm * (BM / 2) + mi * 32 + row;
-      f32x4 v = *reinterpret_cast<const f32x4*>(&stage[row * SLD + c4]);
-      if (m < g.M) {
-        const int mb = m / g.c_rpb, mt = m % g.c_rpb;
-        v += bias4;
-        if (EPI & kEpiGelu) {
+    for (int j = 0; j < 4; ++j) o[j] = __builtin_amdgcn_perm(h[p][2 * j + 1], h[p][2 * j], 0x07060302u);
+    *reinterpret_cast<u32x4*>(dst + p * plane_stride) = o;
+  }
+}
+
+template <int EPI, int NS>
+__global__ __launch_bounds__(256, 2) void gemm_split_tile(GemmDev g) {
+  constexpr int BM = 128, BN = 128, BK = 32, MI = 2, NI = 2;
+  constexpr int LD = BK + 8;            // bf16 per LDS row: 80 B, an odd multiple of 16 B
+  constexpr int PLANE = BM * LD;        // bf16 per operand plane
+  constexpr int kTileBytes = 2 * NS * PLANE * 2, kStageBytes = 4 * 32 * (NI * 32 + 4) * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char smem_raw[kTileBytes > kStageBytes ? kTileBytes : kStageBytes];
+  unsigned short* const As = reinterpret_cast<unsigned short*>(smem_raw);
+  unsigned short* const Bs = As + NS * PLANE;
+
+  const int nb = gridDim.x, bid = blockIdx.x;
+  const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int n_tiles = g.N / BN;
+  const int m0 = (logical / n_tiles) * BM;
+  const int n0 = (logical % n_tiles) * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  // staging: 4 threads per row, 8 consecutive k each (two float4), 64 rows per pass
+  const int srow = tid >> 2, scol = (tid & 3) * 8;
+  const float* a_ptr[2];
+  const float* w_ptr[2];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-        }
-        if (EPI & kEpiPos) v += *reinterpret_cast<const f32x4*>(g.pos + (long)(m % g.pos_period) * g.N + n);
-        if (EPI & kEpiKvLayout) {
-          const int slab = n / g.kv_dmodel, rem = n % g.kv_dmodel;
-          const int head = rem >> 6, dd = rem & 63;  // 4 consecutive dd: c4 is a multiple of 4
-          const long o = (((long)slab * g.kv_batch + mb) * g.kv_heads + head) * (long)g.c_rpb * 64 +
-                         (long)mt * 64 + dd;
-          *reinterpret_cast<f32x4*>(g.C + o) = v;
-        } else {
-          const long o = (long)mb * g.c_bs + (long)mt * g.ldc + n;
-          if (EPI & kEpiResidual) v += *reinterpret_cast<const f32x4*>(g.R + o);
-          *reinterpret_cast<f32x4*>(g.C + o) = v;
-        }
+  for (int i = 0; i < 2; ++i) {
+    int m = m0 + srow + 64 * i;
+    m = m < g.M ? m : g.M - 1;  // clamp: rows past M are computed and discarded
+    a_ptr[i] = g.A + (long)(m / g.a_rpb) * g.a_bs + (long)(m % g.a_rpb) * g.lda + scol;
+    w_ptr[i] = g.W + (long)(n0 + srow + 64 * i) * g.K + scol;
+  }
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  f32x4 st0[8], st1[8];  // two register stages: {A pass 0, A pass 1, W pass 0, W pass 1} x 2 float4
+  auto load_into = [&](f32x4* st, int kt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      st[2 * i] = *reinterpret_cast<const f32x4*>(a_ptr[i] + kt * BK);
+      st[2 * i + 1] = *reinterpret_cast<const f32x4*>(a_ptr[i] + kt * BK + 4);
+      st[4 + 2 * i] = *reinterpret_cast<const f32x4*>(w_ptr[i] + kt * BK);
+      st[4 + 2 * i + 1] = *reinterpret_cast<const f32x4*>(w_ptr[i] + kt * BK + 4);
+    }
+  };
+  auto store_from = [&](const f32x4* st) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      split_store8<NS>(st[2 * i], st[2 * i + 1], As + (srow + 64 * i) * LD + scol, PLANE);
+      split_store8<NS>(st[4 + 2 * i], st[4 + 2 * i + 1], Bs + (srow + 64 * i) * LD + scol, PLANE);
+    }
+  };
+  auto compute = [&]() {
+    const unsigned short* Ab = As + (wm * 64 + l31) * LD + 8 * lh;
+    const unsigned short* Bb = Bs + (wn * 64 + l31) * LD + 8 * lh;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      // lane (row l31, half lh) holds k = 16*ks + 8*lh + 0..7 of its row, for A and W alike
+      bf16x8 af[MI][NS], bf[NI][NS];
+#pragma unroll
+      for (int p = 0; p < NS; ++p) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+          af[i][p] = *reinterpret_cast<const bf16x8*>(Ab + p * PLANE + i * 32 * LD + ks * 16);
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          bf[j][p] = *reinterpret_cast<const bf16x8*>(Bb + p * PLANE + j * 32 * LD + ks * 16);
       }
+      // smallest products first
+#pragma unroll
+      for (int w = 2 * (NS - 1) > 2 ? 2 : 2 * (NS - 1); w >= 0; --w)
+#pragma unroll
+        for (int pa = 0; pa < NS; ++pa) {
+          const int pb = w - pa;
+          if (pb < 0 || pb >= NS) continue;
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][pa], bf[j][pb], acc[i][j], 0, 0, 0);
+        }
+    }
+  };
+
+  const int nkt = g.K / BK;
+  load_into(st0, 0);
+  if (nkt > 1) load_into(st1, 1);
+  for (int kt = 0; kt < nkt; kt += 2) {
+    store_from(st0);
+    __syncthreads();
+    if (kt + 2 < nkt) load_into(st0, kt + 2);
+    compute();
+    __syncthreads();
+    if (kt + 1 < nkt) {
+      store_from(st1);
+      __syncthreads();
+      if (kt + 3 < nkt) load_into(st1, kt + 3);
+      compute();
+      __syncthreads();
     }
   }
+  tile_epilogue<EPI, BM, BN, MI, NI>(g, acc, reinterpret_cast<float*>(smem_raw), m0, n0);
+}
+
+template <int EPI, int NS>
+void launch_split(const GemmDev& g, hipStream_t s) {
+  const int blocks = ((g.M + 127) / 128) * (g.N / 128);
+  hipLaunchKernelGGL((gemm_split_tile<EPI, NS>), dim3(blocks), dim3(256), 0, s, g);
 }
 
 template <int EPI, int BM, int BN, int BK, bool DBUF, bool PF2 = false>
@@ -236,6 +413,8 @@ void launch_tile(const GemmDev& g, hipStream_t s) {
 //          3 = 128x64x32, 4 = 64x128x32, 5 = 128x64x32 double-buffered, 6 = 64x64x32,
 //          7 = 128x128x32 double-buffered + global prefetch depth 2, 8 = 128x64x32 likewise,
 //          9 = 192x128x32 (wave tile 96x64)
+//          10 = 128x128x32 on the bf16 matrix cores, exact 3-plane operand split (fp32 result)
+//          11 = 128x128x32 on the bf16 matrix cores, operands rounded to bf16
 template <int EPI>
 void launch_gemm_t(const GemmDev& g, int variant, hipStream_t s) {
   if (variant == 1 && g.K % 64 != 0) variant = 0;
@@ -250,6 +429,8 @@ void launch_gemm_t(const GemmDev& g, int variant, hipStream_t s) {
     case 7: launch_tile<EPI, 128, 128, 32, true, true>(g, s); break;
     case 8: launch_tile<EPI, 128, 64, 32, true, true>(g, s); break;
     case 9: launch_tile<EPI, 192, 128, 32, false>(g, s); break;
+    case 10: launch_split<EPI, 3>(g, s); break;  // fp32 result from six bf16 plane products
+    case 11: launch_split<EPI, 1>(g, s); break;  // bf16-rounded operands (configs[3] compute mode)
     default: abort();
   }
 }
@@ -262,12 +443,7 @@ void launch_gemm(const GemmArgs& a, int epi, hipStream_t s) {
             a.kv_dmodel};
   if (a.N % 128 != 0 || a.K % 32 != 0 || a.M < 1) abort();  // shape contract of the kernels
   int v = a.variant;
-  if (v < 0) {
-    // auto: 128x128 tiles unless they make fewer than three rounds of 3 blocks x 256 CUs, where
-    // the ragged last round costs 15-20 % (measured); 64x128 tiles halve the quantum
-    const long blocks128 = (long)((a.M + 127) / 128) * (a.N / 128);
-    v = blocks128 < 3 * 768 ? 4 : 0;
-  }
+  if (v < 0) v = 10;  // auto: the split kernel beats every fp32-MFMA tile shape on every encoder shape
   switch (epi) {
     case 0: launch_gemm_t<0>(g, v, s); break;
     case kEpiBias: launch_gemm_t<kEpiBias>(g, v, s); break;
