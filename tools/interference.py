@@ -35,3 +35,21 @@ for n_enc, chain, blocks in [(4, 0, 1), (0, 6000, 1), (0, 6000, 64), (4, 6000, 1
     e, c = probe(n_enc, chain, blocks)
     print(f"encoders {n_enc} chain {chain:5d} x {blocks:3d} blocks: encoder {e / max(n_enc, 1):7.3f} ms each, "
           f"chain {c:8.3f} ms = {1e3 * c / max(chain, 1):6.2f} us per launch", flush=True)
+
+
+def conc(n_dec, n_enc):
+    d = (ctypes.c_float * 4)()
+    e = ctypes.c_float()
+    rc = lib.wt_dbg_concurrency(eng._h, ctypes.c_void_p(d_mel.data_ptr()), B, n_dec, n_enc, d, ctypes.byref(e))
+    assert rc == 0, eng.last_error() if hasattr(eng, "last_error") else rc
+    return [round(d[i], 2) for i in range(n_dec)], round(e.value, 2)
+
+
+for _ in range(9):
+    eng.pipeline_submit_dev(d_mel.data_ptr(), B)
+    eng.pipeline_collect()
+conc(1, 1)
+for n_dec, n_enc in [(1, 0), (2, 0), (3, 0), (4, 0), (0, 2), (1, 2), (2, 3), (3, 4), (4, 4)]:
+    d, e = conc(n_dec, n_enc)
+    print(f"{n_dec} decodes + {n_enc} encoder passes: decode ms {d}, encoder passes {e} ms"
+          + (f" ({e / n_enc:.2f} each)" if n_enc else ""), flush=True)

@@ -45,7 +45,7 @@ CAPI_SYMBOLS = [
 ]
 DEBUG_SYMBOLS = [
     "wt_dbg_gemm", "wt_dbg_gemm_bench", "wt_dbg_dec_gemm_bench", "wt_dbg_dec_gemm", "wt_dbg_dec_ln_gemm", "wt_dbg_layernorm", "wt_dbg_encoder_attention",
-    "wt_dbg_cross_attention", "wt_dbg_self_attention", "wt_dbg_interference",
+    "wt_dbg_cross_attention", "wt_dbg_self_attention", "wt_dbg_interference", "wt_dbg_concurrency",
 ]
 
 

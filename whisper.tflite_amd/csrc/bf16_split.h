@@ -1,0 +1,43 @@
+// Exact three-plane bf16 split of fp32 values (device code shared by k_gemm.hip and
+// k_attention.hip).  x = h1 + h2 + h3 with h1 = x truncated to its upper 16 bits, h2 = (x - h1)
+// truncated likewise and h3 = x - h1 - h2, which has at most 8 significant bits left and is
+// therefore exact in bf16; both subtractions are exact in fp32.  A product a.b is then
+//   a1b1 + (a1b2 + a2b1) + (a2b2 + a1b3 + a3b1) + O(2^-24 |a||b|),
+// six bf16 x bf16 products (each exact in fp32) for the bf16 matrix cores.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace wt {
+
+using u32x4_t = __attribute__((ext_vector_type(4))) unsigned;
+
+// 8 consecutive-k values -> one 16-byte fragment (8 bf16) per plane
+__device__ __forceinline__ void split8_planes(const float (&x)[8], u32x4_t (&o)[3]) {
+  unsigned h[3][8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const unsigned u = __float_as_uint(x[e]);
+    h[0][e] = u;  // the pack below keeps the upper half only
+    const float r1 = x[e] - __uint_as_float(u & 0xFFFF0000u);
+    h[1][e] = __float_as_uint(r1);
+    const float r2 = r1 - __uint_as_float(h[1][e] & 0xFFFF0000u);
+    h[2][e] = __float_as_uint(r2);
+  }
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[p][j] = __builtin_amdgcn_perm(h[p][2 * j + 1], h[p][2 * j], 0x07060302u);
+}
+
+// two values (lo -> bits 0..15, hi -> bits 16..31) -> one packed dword per plane
+__device__ __forceinline__ void split2_planes(float lo, float hi, unsigned (&o)[3]) {
+  const unsigned ul = __float_as_uint(lo), uh = __float_as_uint(hi);
+  const float l1 = lo - __uint_as_float(ul & 0xFFFF0000u), h1 = hi - __uint_as_float(uh & 0xFFFF0000u);
+  const unsigned ul1 = __float_as_uint(l1), uh1 = __float_as_uint(h1);
+  const float l2 = l1 - __uint_as_float(ul1 & 0xFFFF0000u), h2 = h1 - __uint_as_float(uh1 & 0xFFFF0000u);
+  o[0] = __builtin_amdgcn_perm(uh, ul, 0x07060302u);
+  o[1] = __builtin_amdgcn_perm(uh1, ul1, 0x07060302u);
+  o[2] = __builtin_amdgcn_perm(__float_as_uint(h2), __float_as_uint(l2), 0x07060302u);
+}
+
+}  // namespace wt

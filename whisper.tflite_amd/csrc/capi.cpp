@@ -116,13 +116,16 @@ int wt_engine_set_option(wt_engine* h, const char* key, long value) {
   } else if (k == "cross_chunks") {
     if (value != 1 && value != 2 && value != 4 && value != 8) return fail(h, WT_ERR_INVALID_ARG, "cross_chunks must be 1, 2, 4 or 8");
     e.cross_chunks = value;
+  } else if (k == "attn_variant") {
+    if (value != 0 && value != 1) return fail(h, WT_ERR_INVALID_ARG, "attn_variant must be 0 (fp32 MFMA) or 1 (bf16 split)");
+    e.attn_variant = value;
   } else if (k == "resid_waves") {
     if (value != 4 && value != 8 && value != 16) return fail(h, WT_ERR_INVALID_ARG, "resid_waves must be 4, 8 or 16");
     e.resid_waves = value;
   } else if (k == "use_graphs") {
     e.use_graphs = value != 0;
   } else if (k == "gemm_variant") {
-    if (value < -1 || value > 11) return fail(h, WT_ERR_INVALID_ARG, "gemm_variant must be in [-1, 11]");
+    if (value < -1 || value > 14) return fail(h, WT_ERR_INVALID_ARG, "gemm_variant must be in [-1, 14]");
     e.gemm_variant = value;
   } else {
     return fail(h, WT_ERR_INVALID_ARG, "unknown option: " + k);
@@ -148,6 +151,7 @@ int wt_engine_get_option(const wt_engine* h, const char* key, long* value) {
   else if (k == "gemm_variant") *value = e.gemm_variant;
   else if (k == "use_graphs") *value = e.use_graphs;
   else if (k == "resid_waves") *value = e.resid_waves;
+  else if (k == "attn_variant") *value = e.attn_variant;
   else return WT_ERR_INVALID_ARG;
   return WT_OK;
 }
@@ -477,6 +481,12 @@ int wt_dbg_gemm_bench(wt_engine* h, int M, int N, int K, int epi, int variant, i
     g.A = dA.p; g.lda = K; g.W = dW.p; g.bias = dB.p; g.C = dC.p; g.R = dC.p; g.ldc = N;
     g.M = M; g.N = N; g.K = K; g.variant = variant;
     hipStream_t st = h->impl->stream();
+    DevBuf dWp(variant == 12 ? size_t(N) * K * 3 / 2 + 4 : 1);  // 3 bf16 planes
+    if (variant == 12) {
+      wt::launch_split_planes(dW.p, reinterpret_cast<unsigned short*>(dWp.p), long(N) * K, st);
+      g.Wp = reinterpret_cast<const unsigned short*>(dWp.p);
+      g.variant = 10;
+    }
     hipEvent_t e0, e1;
     hipchk(hipEventCreate(&e0), "event");
     hipchk(hipEventCreate(&e1), "event");
@@ -517,6 +527,12 @@ int wt_dbg_interference(wt_engine* h, const float* d_mel, int batch, int n_enc, 
     hipchk(hipEventElapsedTime(chain_ms, ev[2], ev[3]), "elapsed");
     for (auto& x : ev) (void)hipEventDestroy(x);
   });
+}
+
+int wt_dbg_concurrency(wt_engine* h, const float* d_mel, int batch, int n_dec, int n_enc, float* dec_ms,
+                       float* enc_ms) {
+  if (!h || !d_mel || !dec_ms || !enc_ms || batch < 1 || batch > 64) return WT_ERR_INVALID_ARG;
+  return guarded(h, [&] { h->impl->debug_concurrency(d_mel, batch, n_dec, n_enc, dec_ms, enc_ms); });
 }
 
 int wt_dbg_dec_gemm_bench(wt_engine* h, int kind, int B, int N, int K, int waves, int iters, float* avg_us) {
@@ -634,7 +650,7 @@ int wt_dbg_encoder_attention(wt_engine* h, int batch, int T, int heads, const fl
   return guarded(h, [&] {
     const size_t d = size_t(heads) * 64;
     DevBuf dq(qkv, size_t(batch) * T * 3 * d), dout(size_t(batch) * T * d);
-    wt::launch_encoder_attention(dq.p, dout.p, batch, T, heads, h->impl->stream());
+    wt::launch_encoder_attention(dq.p, dout.p, batch, T, heads, int(h->impl->attn_variant), h->impl->stream());
     h->impl->sync();
     dout.to_host(out, size_t(batch) * T * d);
   });

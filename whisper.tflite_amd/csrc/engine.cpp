@@ -636,7 +636,7 @@ void Engine::encode_enqueue(const float* d_mel, int batch) {
     launch_gemm(q, kEpiBias, stream_);
     kt_end();
     kt_begin(kKcEncAttn, 4.0 * batch * c.n_audio_head * double(T) * T * 64, 0);
-    launch_encoder_attention(ws_.qkv, ws_.att, batch, T, c.n_audio_head, stream_);
+    launch_encoder_attention(ws_.qkv, ws_.att, batch, T, c.n_audio_head, int(attn_variant), stream_);
     kt_end();
     GemmArgs o; o.variant = int(gemm_variant);
     o.A = ws_.att; o.lda = d; o.W = w.attn.wo; o.bias = w.attn.bo; o.C = ws_.x; o.R = ws_.x; o.ldc = d;
@@ -859,6 +859,30 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
   }
   HIPCHK(hipEventRecord(slot.dec_done, stream_));
   slot.steps = steps;
+}
+
+void Engine::debug_concurrency(const float* d_mel, int batch, int n_dec, int n_enc, float* dec_ms,
+                               float* enc_ms) {
+  if (!inflight_.empty()) throw Error(1, "collect the submitted batches first");
+  if (n_dec < 0 || n_dec > 4 || n_enc < 0 || n_enc > 4) throw Error(1, "debug_concurrency: 0..4 decodes, 0..4 encoder passes");
+  ensure_batch(batch);
+  sync();
+  for (int i = 0; i < n_dec; ++i)
+    if (!slots_[i].used) throw Error(1, "debug_concurrency: run eight batches first so every slot holds a cross-KV cache");
+  select_stream(true);
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  for (int i = 0; i < n_dec; ++i) decode_enqueue(batch, i, nullptr, 0);
+  HIPCHK(hipEventRecord(e0, stream_));
+  enc_slot_ = 4;  // encoder passes fill slots 4..7, away from the decoders' caches
+  for (int i = 0; i < n_enc; ++i) encode_enqueue(d_mel, batch);
+  HIPCHK(hipEventRecord(e1, stream_));
+  sync();
+  for (int i = 0; i < n_dec; ++i) HIPCHK(hipEventElapsedTime(&dec_ms[i], slots_[i].dec_begin, slots_[i].dec_done));
+  HIPCHK(hipEventElapsedTime(enc_ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
 }
 
 void Engine::decode_collect(int slot_idx, int64_t* ids, int32_t* n_ids) {

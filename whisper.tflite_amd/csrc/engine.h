@@ -73,6 +73,7 @@ class Engine {
   long stop_at_eot = 1;
   long verbose = 0;
   long cross_chunks = 4;
+  long attn_variant = 1;  // encoder attention: 0 = fp32 MFMA, 1 = bf16 matrix cores with the exact split
   long resid_waves = 16;  // wavefronts per block of the decoder's residual GEMMs (4, 8, 16)
   long use_graphs = 1;  // replay the decoder's launch sequence from a captured hipGraph
   long gemm_variant = -1;  // encoder GEMM tile variant (k_gemm.hip); -1 = per-shape choice
@@ -108,6 +109,9 @@ class Engine {
   float* staging_mel(int batch);  // device buffer [B][mel_elems]
   float* staging_pcm(int batch);  // device buffer [B][pcm_elems]
 
+  // test tap: `n_dec` decodes (slots 0..n_dec-1, whose cross-KV caches must hold a previous batch) next
+  // to `n_enc` pipelined encoder passes; device time of each decode and of the encoder passes together
+  void debug_concurrency(const float* d_mel, int batch, int n_dec, int n_enc, float* dec_ms, float* enc_ms);
   // raw device allocator for debug entry points
   float* dalloc(size_t n_floats);
 

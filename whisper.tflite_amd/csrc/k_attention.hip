@@ -6,6 +6,7 @@
 // :375; graph per export/generate_onnx.py:85-120).
 #include <hip/hip_runtime.h>
 
+#include "bf16_split.h"
 #include "kernels.h"
 
 namespace wt {
@@ -188,6 +189,223 @@ __global__ __launch_bounds__(256) void encoder_attention_f32(const float* __rest
   }
 }
 
+// ------------------------------------- encoder attention on the bf16 cores ---
+// Same algorithm and block shape as encoder_attention_f32, with both contractions on
+// v_mfma_f32_32x32x16_bf16 through the exact three-plane split of bf16_split.h: Q (scaled), K
+// and V are split between the global load and the LDS write / fragment registers, the
+// probabilities P = exp2(S^T - m) are split in registers, and each product runs as the six
+// significant plane products with fp32 accumulation (fp32-level error, 6/16 of the MFMA cycles).
+//   S^T[key][q] = K . Q^T     A = K planes (LDS rows, ds_read_b128), B = Q planes (registers)
+//   O^T[d][q]  += V^T . P^T   A = V^T planes (LDS image [d][key], two ds_read_b64), B = P planes
+// The S^T accumulator keeps query q on lane (l31, lh) and key (r&3) + 8(r>>2) + 4lh in register r,
+// so registers 8s..8s+7 are, unmoved, the B fragment of PV step s if V^T is read at keys
+// 16s + 4lh + {0..3} and 16s + 8 + 4lh + {0..3}.
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+constexpr int SKLD = 72;  // K plane row stride (bf16): 144 B, an odd multiple of 16 B
+constexpr int SVLD = 68;  // V^T plane row stride (bf16): 136 B, conflict-free ds_read_b64 per half-wave
+
+__device__ __forceinline__ bf16x8 as_bf16x8(const u32x4_t& v) { return __builtin_bit_cast(bf16x8, v); }
+
+#define WT_SPLIT_PRODUCTS(ACC, AF, BF)                                                        \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF[0], BF[2], ACC, 0, 0, 0);                  \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF[1], BF[1], ACC, 0, 0, 0);                  \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF[2], BF[0], ACC, 0, 0, 0);                  \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF[0], BF[1], ACC, 0, 0, 0);                  \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF[1], BF[0], ACC, 0, 0, 0);                  \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF[0], BF[0], ACC, 0, 0, 0);
+
+__global__ __launch_bounds__(256, 2) void encoder_attention_split(const float* __restrict__ qkv,
+                                                                  float* __restrict__ out, int T, int heads) {
+  __shared__ __attribute__((aligned(16))) unsigned short Kp[3 * AK * SKLD];
+  __shared__ __attribute__((aligned(16))) unsigned short Vt[3 * 64 * SVLD];
+
+  const int d_model = heads * 64, ld = 3 * d_model;
+  const int q_blocks = (T + AQ - 1) / AQ;
+  const int nb = gridDim.x, bid = blockIdx.x;
+  const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int bh = logical / q_blocks, qb = logical % q_blocks;
+  const int b = bh / heads, h = bh % heads;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const float* base = qkv + (long)b * T * ld + h * 64;
+
+  // Q planes: lane (q = l31, half lh) holds Q[q][16c + 8lh + 0..7] for k-step c, pre-scaled by
+  // d_head^-1/2 * log2(e) in fp32 (as the fp32 kernel does) and then split
+  const int q_row = qb * AQ + wid * 32 + l31;
+  const int q_ld = q_row < T ? q_row : T - 1;
+  const float qscale = 0.125f * 1.44269504088896340736f;
+  bf16x8 qf[4][3];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(base + (long)q_ld * ld + 16 * c + 8 * lh);
+    const f32x4 bq = *reinterpret_cast<const f32x4*>(base + (long)q_ld * ld + 16 * c + 8 * lh + 4);
+    const float x[8] = {a[0] * qscale, a[1] * qscale, a[2] * qscale, a[3] * qscale,
+                        bq[0] * qscale, bq[1] * qscale, bq[2] * qscale, bq[3] * qscale};
+    u32x4_t o[3];
+    split8_planes(x, o);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) qf[c][p] = as_bf16x8(o[p]);
+  }
+
+  f32x16 o0, o1;  // O^T tiles: d in [0,32) and [32,64)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.0f;
+  float m_run = -1e30f, l_run = 0.0f;
+
+  // staging maps.  K: 8 threads per key row, 8 d each (two float4), 32 keys per pass.
+  // V: thread = (key pair, 4 d); the pair becomes one dword of the [d][key] image.
+  const int ksrow = tid >> 3, kscol = (tid & 7) * 8;
+  const int vpair = tid >> 4, vdcol = (tid & 15) * 4;
+  const float* kbase = base + d_model + kscol;
+  const float* vbase = base + 2 * d_model + vdcol;
+  f32x4 rk[4], rv[4];
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      // rows past T are loaded from row T - 1 and zeroed by a select (no divergent control flow)
+      const int key = kt * AK + ksrow + 32 * i;
+      const int kc = key < T ? key : T - 1;
+      const float kz = key < T ? 1.0f : 0.0f;
+      rk[2 * i] = *reinterpret_cast<const f32x4*>(kbase + (long)kc * ld) * kz;
+      rk[2 * i + 1] = *reinterpret_cast<const f32x4*>(kbase + (long)kc * ld + 4) * kz;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int vkey = kt * AK + 2 * (vpair + 16 * i) + e;
+        const int vc = vkey < T ? vkey : T - 1;
+        const float vz = vkey < T ? 1.0f : 0.0f;
+        rv[2 * i + e] = *reinterpret_cast<const f32x4*>(vbase + (long)vc * ld) * vz;
+      }
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float x[8] = {rk[2 * i][0], rk[2 * i][1], rk[2 * i][2], rk[2 * i][3],
+                          rk[2 * i + 1][0], rk[2 * i + 1][1], rk[2 * i + 1][2], rk[2 * i + 1][3]};
+      u32x4_t o[3];
+      split8_planes(x, o);
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        *reinterpret_cast<u32x4_t*>(&Kp[p * AK * SKLD + (ksrow + 32 * i) * SKLD + kscol]) = o[p];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        unsigned w[3];
+        split2_planes(rv[2 * i][e], rv[2 * i + 1][e], w);
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          *reinterpret_cast<unsigned*>(&Vt[p * 64 * SVLD + (vdcol + e) * SVLD + 2 * (vpair + 16 * i)]) = w[p];
+      }
+    }
+  };
+  const int n_tiles = (T + AK - 1) / AK;
+  load_tile(0);
+
+  for (int kt = 0; kt < n_tiles; ++kt) {
+    store_tile();
+    __syncthreads();
+    if (kt + 1 < n_tiles) load_tile(kt + 1);
+
+    // S^T for the two 32-key halves of the tile
+    f32x16 s0, s1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s0[r] = s1[r] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      bf16x8 k0[3], k1[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        k0[p] = *reinterpret_cast<const bf16x8*>(&Kp[p * AK * SKLD + l31 * SKLD + 16 * c + 8 * lh]);
+        k1[p] = *reinterpret_cast<const bf16x8*>(&Kp[p * AK * SKLD + (32 + l31) * SKLD + 16 * c + 8 * lh]);
+      }
+      WT_SPLIT_PRODUCTS(s0, k0, qf[c])
+      WT_SPLIT_PRODUCTS(s1, k1, qf[c])
+    }
+    if ((kt + 1) * AK > T) {  // last tile: keys past T do not exist
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (kt * AK + crow(r, lh) >= T) s0[r] = -1e30f;
+        if (kt * AK + 32 + crow(r, lh) >= T) s1[r] = -1e30f;
+      }
+    }
+    // online softmax; the row (query) lives on lanes l and l ^ 32
+    float tmax = s0[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s0[r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s1[r]);
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m_run, tmax);
+    float psum = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s0[r] = __builtin_amdgcn_exp2f(s0[r] - m_new);
+      s1[r] = __builtin_amdgcn_exp2f(s1[r] - m_new);
+      psum += s0[r] + s1[r];
+    }
+    psum += __shfl_xor(psum, 32, 64);
+    if (__any(m_new != m_run)) {
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        o0[r] *= alpha;
+        o1[r] *= alpha;
+      }
+      m_run = m_new;
+    }
+    l_run += psum;
+    // O^T += V^T . P^T, 16 keys per step
+    auto pv_half = [&](const f32x16& sp, const int hf) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const float pv[8] = {sp[8 * s2], sp[8 * s2 + 1], sp[8 * s2 + 2], sp[8 * s2 + 3],
+                             sp[8 * s2 + 4], sp[8 * s2 + 5], sp[8 * s2 + 6], sp[8 * s2 + 7]};
+        u32x4_t po[3];
+        split8_planes(pv, po);
+        bf16x8 pf[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) pf[p] = as_bf16x8(po[p]);
+        const int key0 = hf * 32 + 16 * s2 + 4 * lh;
+        bf16x8 v0[3], v1[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          const unsigned short* r0 = &Vt[p * 64 * SVLD + l31 * SVLD + key0];
+          const unsigned short* r1 = &Vt[p * 64 * SVLD + (32 + l31) * SVLD + key0];
+          const u32x2 a0 = *reinterpret_cast<const u32x2*>(r0), a1 = *reinterpret_cast<const u32x2*>(r0 + 8);
+          const u32x2 b0 = *reinterpret_cast<const u32x2*>(r1), b1 = *reinterpret_cast<const u32x2*>(r1 + 8);
+          v0[p] = as_bf16x8(u32x4_t{a0[0], a0[1], a1[0], a1[1]});
+          v1[p] = as_bf16x8(u32x4_t{b0[0], b0[1], b1[0], b1[1]});
+        }
+        WT_SPLIT_PRODUCTS(o0, v0, pf)
+        WT_SPLIT_PRODUCTS(o1, v1, pf)
+      }
+    };
+    pv_half(s0, 0);
+    pv_half(s1, 1);
+    __syncthreads();
+  }
+
+  if (q_row < T) {
+    const float inv = 1.0f / l_run;
+    float* orow = out + ((long)b * T + q_row) * d_model + h * 64;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 a, c;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        a[j] = o0[4 * g + j] * inv;
+        c[j] = o1[4 * g + j] * inv;
+      }
+      *reinterpret_cast<f32x4*>(orow + 8 * g + 4 * lh) = a;
+      *reinterpret_cast<f32x4*>(orow + 32 + 8 * g + 4 * lh) = c;
+    }
+  }
+}
+#undef WT_SPLIT_PRODUCTS
+
 // ------------------------------------------------- decoder self attention ---
 // One block per clip, one wavefront per head.  Appends this position's k, v to the
 // cache, then lane j scores position j (pos < 64), and lane d accumulates output d.
@@ -313,11 +531,16 @@ __global__ __launch_bounds__(256) void cross_attention_step(const float* __restr
 
 }  // namespace
 
-void launch_encoder_attention(const float* qkv, float* out, int batch, int T, int heads,
+void launch_encoder_attention(const float* qkv, float* out, int batch, int T, int heads, int variant,
                               hipStream_t s) {
   const int q_blocks = (T + AQ - 1) / AQ;
-  hipLaunchKernelGGL(encoder_attention_f32, dim3(batch * heads * q_blocks), dim3(256), 0, s, qkv,
-                     out, T, heads);
+  if (variant == 0) {
+    hipLaunchKernelGGL(encoder_attention_f32, dim3(batch * heads * q_blocks), dim3(256), 0, s, qkv,
+                       out, T, heads);
+  } else {
+    hipLaunchKernelGGL(encoder_attention_split, dim3(batch * heads * q_blocks), dim3(256), 0, s, qkv,
+                       out, T, heads);
+  }
 }
 
 void launch_self_attention(const float* qkv, float* kcache, float* vcache, int cap, int pos,

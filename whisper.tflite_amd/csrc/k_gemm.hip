@@ -12,6 +12,7 @@
 // global accesses).  tools/mfma_probe.hip measures what bounds this loop.
 #include <hip/hip_runtime.h>
 
+#include "bf16_split.h"
 #include "kernels.h"
 
 namespace wt {
@@ -28,6 +29,7 @@ __device__ __forceinline__ float gelu_erf(float x) {
 struct GemmDev {
   const float* A;
   const float* W;
+  const unsigned short* Wp;  // W pre-split into bf16 planes [3][N][K] (split_planes), or nullptr
   float* C;
   const float* bias;
   const float* R;
@@ -49,14 +51,13 @@ struct GemmDev {
 // K = 384 GEMM.  Each wavefront instead transposes 32-row slabs of its tile through a private
 // LDS stage (the operand tiles are dead by now) and moves 16 bytes per lane: 4x fewer memory
 // instructions, whole 128/256-byte row segments per 8/16 lanes.
-template <int EPI, int BM, int BN, int MI, int NI>
-__device__ __forceinline__ void tile_epilogue(const GemmDev& g, f32x16 (&acc)[MI][NI], float* smem, int m0,
-                                              int n0) {
+template <int EPI, int BM, int BN, int MI, int NI, bool FULL>
+__device__ __forceinline__ void tile_epilogue_rows(const GemmDev& g, f32x16 (&acc)[MI][NI], float* smem, int m0,
+                                                   int n0) {
   constexpr int SLD = NI * 32 + 4;  // staging row stride (floats)
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int l31 = lane & 31, lh = lane >> 5;
-  __syncthreads();  // every wavefront is done reading the operand tiles
   float* const stage = smem + wid * (32 * SLD);
   constexpr int LPR = NI * 8;        // lanes per staged row (one float4 each)
   constexpr int RPS = 64 / LPR;      // rows per pass
@@ -64,6 +65,9 @@ __device__ __forceinline__ void tile_epilogue(const GemmDev& g, f32x16 (&acc)[MI
   const int n = n0 + wn * (BN / 2) + c4;
   f32x4 bias4 = {0, 0, 0, 0};
   if (EPI & kEpiBias) bias4 = *reinterpret_cast<const f32x4*>(g.bias + n);
+  // kEpiKvLayout: the column decomposition does not depend on the row
+  const int slab = (EPI & kEpiKvLayout) ? n / g.kv_dmodel : 0, rem = (EPI & kEpiKvLayout) ? n % g.kv_dmodel : 0;
+  const int head = rem >> 6, dd = rem & 63;  // 4 consecutive dd: c4 is a multiple of 4
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -71,23 +75,29 @@ __device__ __forceinline__ void tile_epilogue(const GemmDev& g, f32x16 (&acc)[MI
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         stage[((r & 3) + 8 * (r >> 2) + 4 * lh) * SLD + ni * 32 + l31] = acc[mi][ni][r];
-    // the stage is private to this wavefront and LDS executes a wave's operations in order
+    // the stage is private to this wavefront and LDS executes a wave's operations in order.
+    // One division per 32-row slab: rows advance by at most 31 < c_rpb, pos_period (host-checked).
+    const int mbase = m0 + wm * (BM / 2) + mi * 32;
+    const int mb0 = mbase / g.c_rpb, mt0 = mbase % g.c_rpb;
+    const int mp0 = (EPI & kEpiPos) ? mbase % g.pos_period : 0;
 #pragma unroll
     for (int p = 0; p < 32 / RPS; ++p) {
       const int row = p * RPS + prow;
-      const int m = m0 + wm * (BM / 2) + mi * 32 + row;
       f32x4 v = *reinterpret_cast<const f32x4*>(&stage[row * SLD + c4]);
-      if (m < g.M) {
-        const int mb = m / g.c_rpb, mt = m % g.c_rpb;
+      if (FULL || mbase + row < g.M) {
+        int mb = mb0, mt = mt0 + row;
+        if (mt >= g.c_rpb) mt -= g.c_rpb, mb += 1;
         v += bias4;
         if (EPI & kEpiGelu) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
         }
-        if (EPI & kEpiPos) v += *reinterpret_cast<const f32x4*>(g.pos + (long)(m % g.pos_period) * g.N + n);
+        if (EPI & kEpiPos) {
+          int mp = mp0 + row;
+          if (mp >= g.pos_period) mp -= g.pos_period;
+          v += *reinterpret_cast<const f32x4*>(g.pos + (long)mp * g.N + n);
+        }
         if (EPI & kEpiKvLayout) {
-          const int slab = n / g.kv_dmodel, rem = n % g.kv_dmodel;
-          const int head = rem >> 6, dd = rem & 63;  // 4 consecutive dd: c4 is a multiple of 4
           const long o = (((long)slab * g.kv_batch + mb) * g.kv_heads + head) * (long)g.c_rpb * 64 +
                          (long)mt * 64 + dd;
           *reinterpret_cast<f32x4*>(g.C + o) = v;
@@ -98,6 +108,19 @@ __device__ __forceinline__ void tile_epilogue(const GemmDev& g, f32x16 (&acc)[MI
         }
       }
     }
+  }
+}
+
+template <int EPI, int BM, int BN, int MI, int NI>
+__device__ __forceinline__ void tile_epilogue(const GemmDev& g, f32x16 (&acc)[MI][NI], float* smem, int m0,
+                                              int n0) {
+  __syncthreads();  // every wavefront is done reading the operand tiles
+  // tiles that lie entirely inside M (all of them when M % BM == 0) take a branch-free path: per-row
+  // conditions put every store in its own basic block behind a full s_waitcnt vmcnt(0)
+  if (m0 + BM <= g.M) {
+    tile_epilogue_rows<EPI, BM, BN, MI, NI, true>(g, acc, smem, m0, n0);
+  } else {
+    tile_epilogue_rows<EPI, BM, BN, MI, NI, false>(g, acc, smem, m0, n0);
   }
 }
 
@@ -267,26 +290,13 @@ __device__ __forceinline__ void split_store8(const f32x4& lo, const f32x4& hi, u
     *reinterpret_cast<u32x4*>(dst) = o;
     return;
   }
-  unsigned h[3][8];
+  u32x4_t o[3];
+  split8_planes(x, o);
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const unsigned u = __float_as_uint(x[e]);
-    h[0][e] = u;  // the pack below keeps the upper half only
-    const float r1 = x[e] - __uint_as_float(u & 0xFFFF0000u);
-    h[1][e] = __float_as_uint(r1);
-    const float r2 = r1 - __uint_as_float(h[1][e] & 0xFFFF0000u);
-    h[2][e] = __float_as_uint(r2);  // at most 8 significant bits are left: exact in bf16
-  }
-#pragma unroll
-  for (int p = 0; p < 3; ++p) {
-    u32x4 o;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = __builtin_amdgcn_perm(h[p][2 * j + 1], h[p][2 * j], 0x07060302u);
-    *reinterpret_cast<u32x4*>(dst + p * plane_stride) = o;
-  }
+  for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(dst + p * plane_stride) = o[p];
 }
 
-template <int EPI, int NS>
+template <int EPI, int NS, bool WPRE = false>
 __global__ __launch_bounds__(256, 2) void gemm_split_tile(GemmDev g) {
   constexpr int BM = 128, BN = 128, BK = 32, MI = 2, NI = 2;
   constexpr int LD = BK + 8;            // bf16 per LDS row: 80 B, an odd multiple of 16 B
@@ -319,6 +329,11 @@ __global__ __launch_bounds__(256, 2) void gemm_split_tile(GemmDev g) {
     a_ptr[i] = g.A + (long)(m / g.a_rpb) * g.a_bs + (long)(m % g.a_rpb) * g.lda + scol;
     w_ptr[i] = g.W + (long)(n0 + srow + 64 * i) * g.K + scol;
   }
+  // pre-split W: plane p of row n lives at Wp + (p * N + n) * K, 8 bf16 (16 B) per thread
+  const unsigned short* wp_ptr[2];
+  const long wp_plane = (long)g.N * g.K;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) wp_ptr[i] = g.Wp + (long)(n0 + srow + 64 * i) * g.K + scol;
 
   f32x16 acc[MI][NI];
 #pragma unroll
@@ -328,21 +343,36 @@ __global__ __launch_bounds__(256, 2) void gemm_split_tile(GemmDev g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  f32x4 st0[8], st1[8];  // two register stages: {A pass 0, A pass 1, W pass 0, W pass 1} x 2 float4
+  // two register stages: {A pass 0, A pass 1} x 2 float4, then W: {pass 0, pass 1} x 2 float4, or
+  // (WPRE) {pass 0, pass 1} x NS planes of 8 bf16
+  constexpr int NST = 4 + (WPRE ? 2 * NS : 4);
+  f32x4 st0[NST], st1[NST];
   auto load_into = [&](f32x4* st, int kt) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       st[2 * i] = *reinterpret_cast<const f32x4*>(a_ptr[i] + kt * BK);
       st[2 * i + 1] = *reinterpret_cast<const f32x4*>(a_ptr[i] + kt * BK + 4);
-      st[4 + 2 * i] = *reinterpret_cast<const f32x4*>(w_ptr[i] + kt * BK);
-      st[4 + 2 * i + 1] = *reinterpret_cast<const f32x4*>(w_ptr[i] + kt * BK + 4);
+      if (WPRE) {
+#pragma unroll
+        for (int p = 0; p < NS; ++p)
+          st[4 + NS * i + p] = *reinterpret_cast<const f32x4*>(wp_ptr[i] + p * wp_plane + kt * BK);
+      } else {
+        st[4 + 2 * i] = *reinterpret_cast<const f32x4*>(w_ptr[i] + kt * BK);
+        st[4 + 2 * i + 1] = *reinterpret_cast<const f32x4*>(w_ptr[i] + kt * BK + 4);
+      }
     }
   };
   auto store_from = [&](const f32x4* st) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       split_store8<NS>(st[2 * i], st[2 * i + 1], As + (srow + 64 * i) * LD + scol, PLANE);
-      split_store8<NS>(st[4 + 2 * i], st[4 + 2 * i + 1], Bs + (srow + 64 * i) * LD + scol, PLANE);
+      if (WPRE) {
+#pragma unroll
+        for (int p = 0; p < NS; ++p)
+          *reinterpret_cast<f32x4*>(Bs + p * PLANE + (srow + 64 * i) * LD + scol) = st[4 + NS * i + p];
+      } else {
+        split_store8<NS>(st[4 + 2 * i], st[4 + 2 * i + 1], Bs + (srow + 64 * i) * LD + scol, PLANE);
+      }
     }
   };
   auto compute = [&]() {
@@ -400,7 +430,172 @@ __global__ __launch_bounds__(256, 2) void gemm_split_tile(GemmDev g) {
 template <int EPI, int NS>
 void launch_split(const GemmDev& g, hipStream_t s) {
   const int blocks = ((g.M + 127) / 128) * (g.N / 128);
-  hipLaunchKernelGGL((gemm_split_tile<EPI, NS>), dim3(blocks), dim3(256), 0, s, g);
+  if (g.Wp && NS == 3) {
+    hipLaunchKernelGGL((gemm_split_tile<EPI, NS, true>), dim3(blocks), dim3(256), 0, s, g);
+  } else {
+    hipLaunchKernelGGL((gemm_split_tile<EPI, NS, false>), dim3(blocks), dim3(256), 0, s, g);
+  }
+}
+
+// gemm_split16_tile: the 3-plane split GEMM software-pipelined inside each wavefront.  k-tiles of
+// 16 with two LDS buffers (73.7 KB, 2 blocks per CU): while the 24 MFMAs of k-tile t run, the
+// same wavefront splits the registers of k-tile t+1 and writes them to the other buffer (the
+// MFMA pipe is busy 32 cycles per instruction and holds vector issue for 8 of them), and the
+// global loads of k-tile t+3 are in flight.  One barrier per k-tile.
+template <int EPI, int SCHED, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void gemm_split16_tile(GemmDev g) {
+  constexpr int BM = 128, BN = 128, BK = 16, MI = 2, NI = 2, NS = 3;
+  constexpr int LD = BK + 8;            // bf16 per LDS row: 48 B, an odd multiple of 16 B
+  constexpr int PLANE = BM * LD;        // bf16 per operand plane
+  constexpr int BUF = 2 * NS * PLANE;   // bf16 per buffer (A planes, then W planes)
+  constexpr int kTileBytes = 2 * BUF * 2, kStageBytes = 4 * 32 * (NI * 32 + 4) * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char smem_raw[kTileBytes > kStageBytes ? kTileBytes : kStageBytes];
+  unsigned short* const lds = reinterpret_cast<unsigned short*>(smem_raw);
+
+  const int nb = gridDim.x, bid = blockIdx.x;
+  const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int n_tiles = g.N / BN;
+  const int m0 = (logical / n_tiles) * BM;
+  const int n0 = (logical % n_tiles) * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  // staging: 2 threads per row, 8 consecutive k each (two float4); 128 rows of A and of W per k-tile
+  const int srow = tid >> 1, scol = (tid & 1) * 8;
+  int m = m0 + srow;
+  m = m < g.M ? m : g.M - 1;  // clamp: rows past M are computed and discarded
+  const float* const a_ptr = g.A + (long)(m / g.a_rpb) * g.a_bs + (long)(m % g.a_rpb) * g.lda + scol;
+  const float* const w_ptr = g.W + (long)(n0 + srow) * g.K + scol;
+  const int st_off = srow * LD + scol;  // this thread's slot inside a plane
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  f32x4 st0[4], st1[4];  // {A lo, A hi, W lo, W hi}
+  auto load_into = [&](f32x4* st, int kt) {
+    if ((ABL & 1) && kt > 2) return;  // timing ablation: no global loads in the steady state
+    st[0] = *reinterpret_cast<const f32x4*>(a_ptr + kt * BK);
+    st[1] = *reinterpret_cast<const f32x4*>(a_ptr + kt * BK + 4);
+    st[2] = *reinterpret_cast<const f32x4*>(w_ptr + kt * BK);
+    st[3] = *reinterpret_cast<const f32x4*>(w_ptr + kt * BK + 4);
+  };
+  auto store_from = [&](const f32x4* st, int buf) {
+    if (ABL & 2) {  // timing ablation: no split arithmetic, same LDS writes
+#pragma unroll
+      for (int p = 0; p < NS; ++p) {
+        *reinterpret_cast<f32x4*>(lds + buf * BUF + p * PLANE + st_off) = st[p & 1];
+        *reinterpret_cast<f32x4*>(lds + buf * BUF + (NS + p) * PLANE + st_off) = st[2 + (p & 1)];
+      }
+      return;
+    }
+    split_store8<NS>(st[0], st[1], lds + buf * BUF + st_off, PLANE);
+    split_store8<NS>(st[2], st[3], lds + buf * BUF + NS * PLANE + st_off, PLANE);
+  };
+  const int a_off = (wm * 64 + l31) * LD + 8 * lh, b_off = NS * PLANE + (wn * 64 + l31) * LD + 8 * lh;
+  bf16x8 af[MI][NS], bf[NI][NS];
+  auto read_frags = [&](int buf) {
+    const unsigned short* base = lds + buf * BUF;
+#pragma unroll
+    for (int p = 0; p < NS; ++p) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[i][p] = *reinterpret_cast<const bf16x8*>(base + a_off + p * PLANE + i * 32 * LD);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) bf[j][p] = *reinterpret_cast<const bf16x8*>(base + b_off + p * PLANE + j * 32 * LD);
+    }
+  };
+  auto mfmas = [&]() {
+#pragma unroll
+    for (int w = (ABL & 4) ? 0 : 2; w >= 0; --w)  // smallest products first (ablation 4: one product)
+#pragma unroll
+      for (int pa = 0; pa < NS; ++pa) {
+        const int pb = w - pa;
+        if (pb < 0 || pb >= NS) continue;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][pa], bf[j][pb], acc[i][j], 0, 0, 0);
+      }
+  };
+  auto interleave = [&]() {
+    if (SCHED) {
+      // per MFMA: 4 split VALU ops ride in its shadow; a DS write every fourth
+#pragma unroll
+      for (int i = 0; i < 24; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);  // VALU
+        if ((i & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
+      }
+    }
+  };
+
+  const int nkt = g.K / BK;
+  load_into(st0, 0);
+  if (nkt > 1) load_into(st1, 1);
+  store_from(st0, 0);
+  if (nkt > 2) load_into(st0, 2);
+  __syncthreads();
+  int kt = 0;
+  // steady state, branch-free so that the scheduler can interleave the split with the MFMAs:
+  // even k-tile computes buffer 0 while k-tile kt+1 (st1) is staged into buffer 1, and so on
+  for (; kt + 4 < nkt; kt += 2) {
+    read_frags(0);
+    mfmas();
+    store_from(st1, 1);
+    interleave();
+    load_into(st1, kt + 3);
+    __syncthreads();
+    read_frags(1);
+    mfmas();
+    store_from(st0, 0);
+    interleave();
+    load_into(st0, kt + 4);
+    __syncthreads();
+  }
+  for (; kt < nkt; kt += 2) {  // the last k-tiles: nothing left to load / stage
+    read_frags(0);
+    mfmas();
+    if (kt + 1 < nkt) store_from(st1, 1);
+    if (kt + 3 < nkt) load_into(st1, kt + 3);
+    __syncthreads();
+    if (kt + 1 < nkt) {
+      read_frags(1);
+      mfmas();
+      if (kt + 2 < nkt) store_from(st0, 0);
+      if (kt + 4 < nkt) load_into(st0, kt + 4);
+      __syncthreads();
+    }
+  }
+  tile_epilogue<EPI, BM, BN, MI, NI>(g, acc, reinterpret_cast<float*>(smem_raw), m0, n0);
+}
+
+template <int EPI, int SCHED, int ABL = 0>
+void launch_split16(const GemmDev& g, hipStream_t s) {
+  const int blocks = ((g.M + 127) / 128) * (g.N / 128);
+  hipLaunchKernelGGL((gemm_split16_tile<EPI, SCHED, ABL>), dim3(blocks), dim3(256), 0, s, g);
+}
+
+// x[n] -> three bf16 planes out[p * n + i] with x = h1 + h2 + h3 exactly (see gemm_split_tile)
+__global__ void split_planes_kernel(const float* __restrict__ x, unsigned short* __restrict__ out, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float v = x[i];
+  const unsigned u = __float_as_uint(v);
+  const float r1 = v - __uint_as_float(u & 0xFFFF0000u);
+  const unsigned u1 = __float_as_uint(r1);
+  const float r2 = r1 - __uint_as_float(u1 & 0xFFFF0000u);
+  out[i] = (unsigned short)(u >> 16);
+  out[n + i] = (unsigned short)(u1 >> 16);
+  out[2 * n + i] = (unsigned short)(__float_as_uint(r2) >> 16);
 }
 
 template <int EPI, int BM, int BN, int BK, bool DBUF, bool PF2 = false>
@@ -431,17 +626,29 @@ void launch_gemm_t(const GemmDev& g, int variant, hipStream_t s) {
     case 9: launch_tile<EPI, 192, 128, 32, false>(g, s); break;
     case 10: launch_split<EPI, 3>(g, s); break;  // fp32 result from six bf16 plane products
     case 11: launch_split<EPI, 1>(g, s); break;  // bf16-rounded operands (configs[3] compute mode)
+    case 13: launch_split16<EPI, 0>(g, s); break;  // split-3, k-tiles of 16, double-buffered LDS
+    case 14: launch_split16<EPI, 1>(g, s); break;  // same with an explicit MFMA/VALU interleave
+    case 21: launch_split16<EPI, 0, 1>(g, s); break;  // timing ablations of 13 (wrong results)
+    case 22: launch_split16<EPI, 0, 2>(g, s); break;
+    case 23: launch_split16<EPI, 0, 3>(g, s); break;
+    case 24: launch_split16<EPI, 0, 4>(g, s); break;
+    case 27: launch_split16<EPI, 0, 7>(g, s); break;
     default: abort();
   }
 }
 
 }  // namespace
 
+void launch_split_planes(const float* x, unsigned short* out, long n, hipStream_t s) {
+  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, out, n);
+}
+
 void launch_gemm(const GemmArgs& a, int epi, hipStream_t s) {
-  GemmDev g{a.A,   a.W,   a.C,    a.bias, a.R,   a.pos,        a.M,        a.N,        a.K,
+  GemmDev g{a.A,   a.W, a.Wp,  a.C,    a.bias, a.R,   a.pos,        a.M,        a.N,        a.K,
             a.a_rpb, a.a_bs, a.lda, a.c_rpb, a.c_bs, a.ldc, a.pos_period, a.kv_batch, a.kv_heads,
             a.kv_dmodel};
-  if (a.N % 128 != 0 || a.K % 32 != 0 || a.M < 1) abort();  // shape contract of the kernels
+  // shape contract of the kernels (the epilogue wraps batch / position rows at most once per 32 rows)
+  if (a.N % 128 != 0 || a.K % 32 != 0 || a.M < 1 || a.c_rpb < 32 || a.pos_period < (epi & kEpiPos ? 32 : 1)) abort();
   int v = a.variant;
   if (v < 0) v = 10;  // auto: the split kernel beats every fp32-MFMA tile shape on every encoder shape
   switch (epi) {

@@ -24,6 +24,7 @@ enum GemmEpi : int {
 struct GemmArgs {
   const float* A = nullptr;
   const float* W = nullptr;
+  const unsigned short* Wp = nullptr;  // optional: W as three bf16 planes [3][N][K] (launch_split_planes)
   float* C = nullptr;
   const float* bias = nullptr;
   const float* R = nullptr;
@@ -43,6 +44,8 @@ struct GemmArgs {
   int variant = -1;  // tile shape / pipelining variant (k_gemm.hip launch_gemm_t); -1 = auto
 };
 void launch_gemm(const GemmArgs& a, int epi, hipStream_t s);
+// x[n] fp32 -> out[3][n] bf16 with x = out[0] + out[1] + out[2] exactly
+void launch_split_planes(const float* x, unsigned short* out, long n, hipStream_t s);
 
 // Decoder-step GEMM: out[B][N] = epi(pro(x)[B][K] . W[N][K]^T), B <= 64 (k_decoder.hip).
 // Wt is W pre-tiled by tile_weights(): [ceil(N/32)][K/8][64 lanes][4].
@@ -94,8 +97,8 @@ void launch_layernorm(const float* x, float* y, const float* g, const float* b, 
 // ------------------------------------------------------ encoder attention ---
 // qkv [B*T][3*d] (q | k | v, heads of 64 inside each third) -> out [B*T][d].
 // Non-causal softmax(q k^T / 8) v per (clip, head), flash-style, fp32 MFMA.
-void launch_encoder_attention(const float* qkv, float* out, int batch, int T, int heads,
-                              hipStream_t s);
+void launch_encoder_attention(const float* qkv, float* out, int batch, int T, int heads, int variant,
+                              hipStream_t stream);
 
 // ------------------------------------------------------------- front end ---
 // mel [B][n_mels][T] -> melT [B][T + 2][n_mels] rows 1..T (rows 0 and T+1 stay zero).
