@@ -33,6 +33,7 @@ CLIP_SECONDS = 30.0
 MEL_SEED = 1234
 ID_STRIDE = 32  # int64 ids per clip record (wt_capi.h WT_MAX_IDS)
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16, 32 cycles)
 PEAK_HBM_GBPS = 8000.0
 
 
@@ -300,12 +301,20 @@ def main() -> None:
                     continue
                 mfma = v["flops"] > 0
                 ach = (v["flops"] / 1e12 if mfma else v["bytes"] / 1e9) / (v["ms"] * 1e-3)
-                peak = PEAK_F32_MFMA_TFLOPS if mfma else PEAK_HBM_GBPS
+                split = mfma and "split" in name and "(bf16)" not in name
+                # split kernels spend six bf16 MFMA FLOPs per algorithmic fp32 FLOP (three exact
+                # bf16 planes per operand): their MFMA ceiling in algorithmic FLOP/s is the dense
+                # bf16 peak / 6; fp32-MFMA kernels are priced against the fp32 MFMA peak
+                peak = (round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1) if split else PEAK_F32_MFMA_TFLOPS) if mfma else PEAK_HBM_GBPS
                 det[name] = {"bound": "mfma" if mfma else "hbm", "achieved": round(ach, 2), "peak": peak,
                              "unit": "TFLOP/s" if mfma else "GB/s", "frac": round(ach / peak, 4),
                              "avg_launch_us": round(1e3 * v["ms"] / v["launches"], 2),
                              "launches_per_step": v["launches"] // steps,
                              "ms_per_step": round(v["ms"] / steps, 4)}
+                if split:
+                    det[name].update({"peak_is": "dense bf16 MFMA peak 2500 TFLOP/s / 6 plane products",
+                                      "executed_bf16_tflops": round(6 * ach, 1),
+                                      "vs_fp32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4)})
             return det
 
         # dominant kernel = the class with the most device time inside the timed region
@@ -326,6 +335,7 @@ def main() -> None:
                 pass
             roof = {"kernel": dom, "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"],
                     "unit": d["unit"], "frac": d["frac"], "traffic": traffic, "traffic_source": traffic_src,
+                    **{k: d[k] for k in ("peak_is", "executed_bf16_tflops", "vs_fp32_mfma_peak") if k in d},
                     "algorithmic_flops_per_launch": int(kstats[dom]["flops"] / max(1, kstats[dom]["launches"])),
                     "avg_launch_us": d["avg_launch_us"]}
         # decoder phase against HBM: algorithmic bytes per step of this batch
@@ -346,7 +356,8 @@ def main() -> None:
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32 (encoder contractions: exact 3-plane bf16 split of fp32 operands, 6 bf16-MFMA products, "
+                     "fp32 accumulate; decoder: fp32 MFMA)" if eng.get_option("gemm_variant") < 0 else "f32",
             "data": "synthetic",
             "config": {"workload": f"whisper-{args.arch} batch={B}x30s synthetic mel U(-1,1.5), fp32, random-init "
                                    "weights (BASELINE.json configs[1]); mel resident in HBM -> token ids on host",

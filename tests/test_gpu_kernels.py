@@ -34,6 +34,65 @@ def test_gemm_plain(eng, M, N, K):
     assert rel_err(C, ref) < 2e-6
 
 
+GEMM_VARIANTS = {0: "fp32 MFMA 128x128", 4: "fp32 MFMA 64x128", 10: "bf16x3 split k32", 13: "bf16x3 split k16",
+                 14: "bf16x3 split k16 interleaved"}
+
+
+@pytest.fixture
+def gemm_variant(eng):
+    def use(v):
+        eng.set_option("gemm_variant", v)
+    yield use
+    eng.set_option("gemm_variant", -1)
+
+
+@pytest.mark.parametrize("variant", sorted(GEMM_VARIANTS))
+def test_gemm_variants_have_fp32_error(eng, gemm_variant, variant):
+    """Every tile variant, the fp32-MFMA ones and the ones that run the product as six bf16 plane
+    products, must stay inside the SAME fp32 error budget against fp64 (the split is exact and
+    drops only terms below 2^-24 |a||b|); also on operands with 12 decades of dynamic range."""
+    gemm_variant(variant)
+    rng = np.random.default_rng(variant)
+    for M, N, K in [(257, 384, 416), (128, 128, 1536), (1500, 384, 1152)]:
+        A = rng.standard_normal((M, K)).astype(np.float32)
+        W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+        ref = A.astype(np.float64) @ W.astype(np.float64).T
+        assert rel_err(eng.dbg_gemm(A, W), ref) < 2e-6, (variant, M, N, K)
+    A = (rng.standard_normal((256, 256)) * 10.0 ** rng.uniform(-6, 6, (256, 256))).astype(np.float32)
+    W = (rng.standard_normal((128, 256)) * 10.0 ** rng.uniform(-6, 6, (128, 256))).astype(np.float32)
+    ref = A.astype(np.float64) @ W.astype(np.float64).T
+    bound = np.abs(A.astype(np.float64)) @ np.abs(W.astype(np.float64)).T  # sum |a||b|: the fp32 error scale
+    assert (np.abs(eng.dbg_gemm(A, W) - ref) / bound).max() < 1.5e-6, variant  # fp32 accumulation over K = 256
+
+
+def test_gemm_split_and_fp32_mfma_agree_to_rounding(eng, gemm_variant):
+    """The split kernel and the fp32-MFMA kernel differ only by accumulation-order rounding."""
+    rng = np.random.default_rng(99)
+    A = rng.standard_normal((512, 384)).astype(np.float32)
+    W = (rng.standard_normal((384, 384)) / 20).astype(np.float32)
+    gemm_variant(0)
+    C0 = eng.dbg_gemm(A, W)
+    gemm_variant(14)
+    C1 = eng.dbg_gemm(A, W)
+    assert np.abs(C0 - C1).max() < 4e-6 * np.abs(C0).max()
+
+
+def test_gemm_bf16_mode_matches_bf16_rounded_operands(eng, gemm_variant):
+    """Variant 11 (configs[3] compute mode): operands rounded to bf16 (RNE), fp32 accumulate."""
+    def bf16_rne(x):
+        u = x.astype(np.float32).view(np.uint32).astype(np.uint64)
+        u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+        return u.astype(np.uint32).view(np.float32)
+    rng = np.random.default_rng(11)
+    A = rng.standard_normal((300, 256)).astype(np.float32)
+    W = (rng.standard_normal((128, 256)) / 16).astype(np.float32)
+    gemm_variant(11)
+    C = eng.dbg_gemm(A, W)
+    ref = bf16_rne(A).astype(np.float64) @ bf16_rne(W).astype(np.float64).T
+    assert rel_err(C, ref) < 2e-6
+    assert rel_err(C, A.astype(np.float64) @ W.astype(np.float64).T) > 1e-4  # and it IS a bf16 product
+
+
 def test_gemm_is_exact_on_integers(eng):
     """A = I (padded) against an ASYMMETRIC integer W catches a swapped C/D row-col map."""
     K, N = 128, 256
@@ -152,12 +211,15 @@ def attn_ref(q, k, v, mask_from=None):
     return (p / p.sum(-1, keepdims=True)) @ v
 
 
+@pytest.mark.parametrize("attn_variant", [0, 1])  # 0 = fp32 MFMA, 1 = bf16 matrix cores with the exact split
 @pytest.mark.parametrize("B,T,H", [(1, 64, 1), (2, 100, 2), (1, 1500, 6), (3, 333, 2)])
-def test_encoder_attention(eng, B, T, H):
+def test_encoder_attention(eng, B, T, H, attn_variant):
+    eng.set_option("attn_variant", attn_variant)
     rng = np.random.default_rng(B * 1000 + T + H)
     d = 64 * H
     qkv = rng.standard_normal((B * T, 3 * d)).astype(np.float32)
     out = eng.dbg_encoder_attention(qkv, B, T, H)
+    eng.set_option("attn_variant", 1)
     q64 = qkv.astype(np.float64).reshape(B, T, 3, H, 64)
     for b in range(B):
         for h in range(H):
@@ -166,7 +228,8 @@ def test_encoder_attention(eng, B, T, H):
             assert np.abs(got - ref).max() < 2e-5, (b, h)
 
 
-def test_encoder_attention_forces_rescale(eng):
+@pytest.mark.parametrize("attn_variant", [0, 1])
+def test_encoder_attention_forces_rescale(eng, attn_variant):
     """Online softmax: spike one key late in the sequence so the running max jumps at a chosen
     tile (the rare branch), and check the FULL tensor against fp64."""
     rng = np.random.default_rng(77)
@@ -174,7 +237,9 @@ def test_encoder_attention_forces_rescale(eng):
     qkv = rng.standard_normal((T, 192)).astype(np.float32)
     qkv[250, 64:128] = qkv[10, 0:64] * 6.0  # key 250 lines up with query 10: score >> others
     qkv[120, 64:128] = qkv[11, 0:64] * 4.0
+    eng.set_option("attn_variant", attn_variant)
     out = eng.dbg_encoder_attention(qkv, B, T, H)
+    eng.set_option("attn_variant", 1)
     q = qkv.astype(np.float64)
     ref = attn_ref(q[:, 0:64], q[:, 64:128], q[:, 128:192])
     assert np.abs(out - ref).max() < 2e-5

@@ -102,3 +102,30 @@ def test_synthetic_weights_are_deterministic(pkg, tmp_path):
     assert abs(float(t["encoder.blocks.1.attn_ln.weight"].mean()) - 1.0) < 0.05
     with pytest.raises(pkg.WtError):
         pkg.write_synthetic_weights(a, "huge", 0)
+
+
+def test_three_plane_bf16_split_is_exact():
+    """The identity behind gemm_split_tile / encoder_attention_split (csrc/bf16_split.h), restated in
+    numpy: h1 = x rounded to bf16 (half away from zero), h2 = (x - h1) truncated to bf16,
+    h3 = x - h1 - h2.  The split leaves no remainder, every plane is a bf16 value, and the six plane
+    products kept by the kernels miss a.b by < 2^-22 |a||b| (the dropped terms are a2b3 + a3b2 + a3b3
+    with |a2| <= 2^-8 |a|, |a3| < 2^-15 |a|).  Holds for 2^-100 < |x| < 3.3e38."""
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.standard_normal(20000) * 10.0 ** rng.uniform(-20, 20, 20000),
+                        [0.0, 1.0, -1.0, 3.3e38, 1.0e-30, 1.0000001, 0.33333334, 1.00390625, 255.5]]).astype(np.float32)
+
+    def trunc(v):
+        return (v.view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32)
+
+    h1 = ((x.view(np.uint32) + np.uint32(0x8000)) & np.uint32(0xFFFF0000)).view(np.float32)
+    r1 = x - h1
+    h2 = trunc(r1)
+    h3 = r1 - h2
+    assert np.array_equal(trunc(h3), h3)  # the third plane needs no rounding
+    assert np.array_equal(h1.astype(np.float64) + h2.astype(np.float64) + h3.astype(np.float64), x.astype(np.float64))
+    a, b = x[:10000].astype(np.float64), x[10000:20000].astype(np.float64)
+    pa = [v[:10000].astype(np.float64) for v in (h1, h2, h3)]
+    pb = [v[10000:20000].astype(np.float64) for v in (h1, h2, h3)]
+    kept = sum(pa[i] * pb[j] for i in range(3) for j in range(3) if i + j <= 2)
+    rel = np.abs(kept - a * b) / np.abs(a * b)
+    assert rel.max() < 2.0 ** -22 and rel.mean() < 2.0 ** -25

@@ -339,7 +339,15 @@ Engine::Engine(const std::string& model_prefix, const std::string& vocab_path, b
   stream_ = stream_full_;
   HIPCHK(hipEventCreate(&ev_switch_));
   if (const char* v = getenv("WT_DEC_STREAMS")) n_dec_streams_ = std::min(std::max(atoi(v), 1), kDecStreams);
-  for (auto& ds : dstream_) HIPCHK(hipStreamCreateWithPriority(&ds, hipStreamNonBlocking, prio_hi));
+  const char* confine = getenv("WT_DEC_CONFINE");  // experiment: decoders only on the CUs the encoder leaves free
+  if (confine && atoi(confine) > 0 && stream_masked_) {
+    const int keep = n_cu - 8 * reserve;
+    std::vector<uint32_t> mask((n_cu + 31) / 32, 0u);
+    for (int i = keep; i < n_cu; ++i) mask[i / 32] |= 1u << (i % 32);
+    for (auto& ds : dstream_) HIPCHK(hipExtStreamCreateWithCUMask(&ds, uint32_t(mask.size()), mask.data()));
+  } else {
+    for (auto& ds : dstream_) HIPCHK(hipStreamCreateWithPriority(&ds, hipStreamNonBlocking, prio_hi));
+  }
   for (auto& e : ev_) HIPCHK(hipEventCreate(&e));
   for (Slot& sl : slots_) {
     for (hipEvent_t* e : {&sl.enc_begin, &sl.enc_mid, &sl.enc_done, &sl.dec_begin, &sl.dec_done}) {
@@ -548,6 +556,13 @@ void Engine::kt_end() {
 
 void Engine::resolve_kernel_stats(int slot) {
   Slot& sl = slots_[slot];
+  // class names = the kernels the current options select (what rocprofv3 lists)
+  const long gv = gemm_variant;
+  kstats_[kKcGemm].name = gv < 0 || gv == 13 || gv == 14 ? "gemm_split16_tile"
+                          : gv == 10 || gv == 12         ? "gemm_split_tile"
+                          : gv == 11                     ? "gemm_split_tile(bf16)"
+                                                         : "gemm_f32_tile";
+  kstats_[kKcEncAttn].name = attn_variant ? "encoder_attention_split" : "encoder_attention_f32";
   for (auto& k : kstats_) k.launches = 0, k.ms = 0, k.flops = 0, k.bytes = 0;
   for (size_t i = 0; i < sl.kt_cls.size(); ++i) {
     float ms = 0;
