@@ -147,8 +147,8 @@ def cpu_baseline(prefix: str, mel: np.ndarray, prompt, eot: int) -> dict:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="clips per GPU")
     ap.add_argument("--arch", default="tiny")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -156,6 +156,7 @@ def main() -> None:
                     help="synchronous steps (encoder then decoder) instead of the two-deep pipeline")
     ap.add_argument("--depth", type=int, default=5, choices=tuple(range(1, 9)), help="batches in flight (pipelined mode)")
     ap.add_argument("--resid-waves", type=int, default=None, choices=(4, 8, 16))
+    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the extra fp32-MFMA-only measurement")
     ap.add_argument("--no-graphs", action="store_true", help="launch the decoder eagerly instead of replaying its hipGraph")
     ap.add_argument("--gemm-variant", type=int, default=None, help="encoder GEMM tile variant (k_gemm.hip)")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
@@ -276,6 +277,25 @@ def main() -> None:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # the same pipeline with every encoder contraction on the fp32 MFMA instruction (reported beside
+    # the headline, outside the timed region, so the effect of the bf16-split kernels is visible)
+    fp32_leg = None
+    if pipelined and args.gemm_variant is None and not args.no_fp32_leg:
+        eng.set_option("gemm_variant", 0)
+        eng.set_option("attn_variant", 0)
+        run_steps(3)
+        fence()
+        t1 = time.perf_counter()
+        ids32, n32, _ = run_steps(10)
+        fence()
+        dt = time.perf_counter() - t1
+        fp32_leg = {"value": round(world * B * 10 * CLIP_SECONDS / dt, 1), "unit": "audio-sec/s", "steps": 10,
+                    "ms_per_step": round(1e3 * dt / 10, 3),
+                    "ids_match_split_path": bool(np.array_equal(ids32, ids) and np.array_equal(n32, n)),
+                    "what": "gemm_variant=0 (gemm_f32_tile), attn_variant=0 (encoder_attention_f32): v_mfma_f32_32x32x2_f32 only"}
+        eng.set_option("gemm_variant", -1)
+        eng.set_option("attn_variant", 1)
+
     iso = None
     if pipelined:
         # outside the timed region: two synchronous passes, so the per-kernel figures are also
@@ -356,20 +376,23 @@ def main() -> None:
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 (encoder contractions: exact 3-plane bf16 split of fp32 operands, 6 bf16-MFMA products, "
-                     "fp32 accumulate; decoder: fp32 MFMA)" if eng.get_option("gemm_variant") < 0 else "f32",
+            "dtype": "f32 (bf16x3-split MFMA, f32 accumulate)" if eng.get_option("gemm_variant") < 0 else "f32",
             "data": "synthetic",
             "config": {"workload": f"whisper-{args.arch} batch={B}x30s synthetic mel U(-1,1.5), fp32, random-init "
                                    "weights (BASELINE.json configs[1]); mel resident in HBM -> token ids on host",
                        "clips_per_gpu": B, "global_batch": world * B, "decoder_positions": 30,
                        "argmax_steps": 27, "parallelism": f"clip-parallel dp{world}, RCCL all_gather of id records",
-                       "pipelined": pipelined, "batches_in_flight": args.depth if pipelined else 1},
+                       "pipelined": pipelined, "batches_in_flight": args.depth if pipelined else 1,
+                       "compute": "encoder GEMMs and attention: fp32 operands split exactly into 3 bf16 planes, 6 "
+                                  "bf16-MFMA products, fp32 accumulate (error = fp32-MFMA kernel's, tests/"
+                                  "test_gpu_kernels.py); decoder: fp32 MFMA; no value leaves fp32 storage"},
             "roofline": roof,
             "roofline_detail": detail,
             "roofline_isolated": rooflines(iso, 2) if iso else None,
             "decoder_roofline": {"bound": "hbm", "achieved": round(dec_ach, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                                  "frac": round(dec_ach / PEAK_HBM_GBPS, 4),
                                  "algorithmic_bytes_per_step": int(dec_bytes)},
+            "fp32_mfma_only": fp32_leg,
             "stage_ms_per_step": stage,
             "host_enqueue_ms_per_step": round(1e3 * host["submit_s"] / max(1, host["submits"]), 3) if pipelined else None,
         }

@@ -3,6 +3,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -125,7 +127,7 @@ int wt_engine_set_option(wt_engine* h, const char* key, long value) {
   } else if (k == "use_graphs") {
     e.use_graphs = value != 0;
   } else if (k == "gemm_variant") {
-    if (value < -1 || value > 14) return fail(h, WT_ERR_INVALID_ARG, "gemm_variant must be in [-1, 14]");
+    if (value < -1 || value > 15) return fail(h, WT_ERR_INVALID_ARG, "gemm_variant must be in [-1, 15]");
     e.gemm_variant = value;
   } else {
     return fail(h, WT_ERR_INVALID_ARG, "unknown option: " + k);
@@ -498,6 +500,7 @@ int wt_dbg_gemm_bench(wt_engine* h, int M, int N, int K, int epi, int variant, i
     float ms = 0;
     hipchk(hipEventElapsedTime(&ms, e0, e1), "elapsed");
     *avg_ms = ms / iters;
+    if (getenv("WT_VERBOSE_OCCUPANCY")) fprintf(stderr, "[wt] gemm variant %d: %d blocks per CU\n", g.variant, wt::gemm_occupancy(g.variant));
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
   });

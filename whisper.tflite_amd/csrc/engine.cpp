@@ -348,6 +348,25 @@ Engine::Engine(const std::string& model_prefix, const std::string& vocab_path, b
   } else {
     for (auto& ds : dstream_) HIPCHK(hipStreamCreateWithPriority(&ds, hipStreamNonBlocking, prio_hi));
   }
+  if (const char* ids = getenv("WT_DEC_STREAM_IDS")) {  // experiment: which of the created streams to use
+    hipStream_t pick[kDecStreams];
+    int n = 0;
+    for (const char* p = ids; *p && n < kDecStreams; ++p)
+      if (*p >= '0' && *p < '0' + kDecStreams) pick[n++] = dstream_[*p - '0'];
+    if (n > 0) {
+      // keep every created stream in the array (destroyed later); chosen ones first
+      hipStream_t rest[kDecStreams];
+      int m = 0;
+      for (auto ds : dstream_) {
+        bool used = false;
+        for (int i = 0; i < n; ++i) used |= pick[i] == ds;
+        if (!used) rest[m++] = ds;
+      }
+      for (int i = 0; i < n; ++i) dstream_[i] = pick[i];
+      for (int i = 0; i < m; ++i) dstream_[n + i] = rest[i];
+      n_dec_streams_ = n;
+    }
+  }
   for (auto& e : ev_) HIPCHK(hipEventCreate(&e));
   for (Slot& sl : slots_) {
     for (hipEvent_t* e : {&sl.enc_begin, &sl.enc_mid, &sl.enc_done, &sl.dec_begin, &sl.dec_done}) {

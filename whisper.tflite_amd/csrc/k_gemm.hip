@@ -12,6 +12,8 @@
 // global accesses).  tools/mfma_probe.hip measures what bounds this loop.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "bf16_split.h"
 #include "kernels.h"
 
@@ -445,10 +447,14 @@ void launch_split(const GemmDev& g, hipStream_t s) {
 template <int EPI, int SCHED, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void gemm_split16_tile(GemmDev g) {
   constexpr int BM = 128, BN = 128, BK = 16, MI = 2, NI = 2, NS = 3;
-  constexpr int LD = BK + 8;            // bf16 per LDS row: 48 B, an odd multiple of 16 B
+  // bf16 per LDS row: 32 B, unpadded. The two 16-byte chunks of a row are stored swapped when bit 3
+  // of the row is set: a 16-lane group of a ds_read_b128 (16 consecutive rows, same k half) then
+  // covers all 64 banks once, and the staging writes (both chunks of 4 consecutive rows per 8
+  // lanes) stay 128 contiguous bytes.
+  constexpr int LD = BK;
   constexpr int PLANE = BM * LD;        // bf16 per operand plane
   constexpr int BUF = 2 * NS * PLANE;   // bf16 per buffer (A planes, then W planes)
-  constexpr int kTileBytes = 2 * BUF * 2, kStageBytes = 4 * 32 * (NI * 32 + 4) * 4;
+  constexpr int kTileBytes = 2 * BUF * 2 + ((ABL & 8) ? 20000 : 0), kStageBytes = 4 * 32 * (NI * 32 + 4) * 4;
   __shared__ __attribute__((aligned(16))) unsigned char smem_raw[kTileBytes > kStageBytes ? kTileBytes : kStageBytes];
   unsigned short* const lds = reinterpret_cast<unsigned short*>(smem_raw);
 
@@ -470,7 +476,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split16_tile(GemmDev g) {
   m = m < g.M ? m : g.M - 1;  // clamp: rows past M are computed and discarded
   const float* const a_ptr = g.A + (long)(m / g.a_rpb) * g.a_bs + (long)(m % g.a_rpb) * g.lda + scol;
   const float* const w_ptr = g.W + (long)(n0 + srow) * g.K + scol;
-  const int st_off = srow * LD + scol;  // this thread's slot inside a plane
+  const int st_off = srow * LD + (((tid & 1) ^ ((srow >> 3) & 1)) * 8);  // this thread's slot inside a plane
 
   f32x16 acc[MI][NI];
 #pragma unroll
@@ -500,7 +506,8 @@ __global__ __launch_bounds__(256, 2) void gemm_split16_tile(GemmDev g) {
     split_store8<NS>(st[0], st[1], lds + buf * BUF + st_off, PLANE);
     split_store8<NS>(st[2], st[3], lds + buf * BUF + NS * PLANE + st_off, PLANE);
   };
-  const int a_off = (wm * 64 + l31) * LD + 8 * lh, b_off = NS * PLANE + (wn * 64 + l31) * LD + 8 * lh;
+  const int swz = 8 * (lh ^ ((l31 >> 3) & 1));
+  const int a_off = (wm * 64 + l31) * LD + swz, b_off = NS * PLANE + (wn * 64 + l31) * LD + swz;
   bf16x8 af[MI][NS], bf[NI][NS];
   auto read_frags = [&](int buf) {
     const unsigned short* base = lds + buf * BUF;
@@ -548,6 +555,21 @@ __global__ __launch_bounds__(256, 2) void gemm_split16_tile(GemmDev g) {
   // steady state, branch-free so that the scheduler can interleave the split with the MFMAs:
   // even k-tile computes buffer 0 while k-tile kt+1 (st1) is staged into buffer 1, and so on
   for (; kt + 4 < nkt; kt += 2) {
+    if (SCHED == 2) {
+      // stage first: the registers of k-tile kt+1 go to the idle buffer and are refilled with
+      // k-tile kt+3 a whole MFMA phase earlier than in the compute-first order
+      store_from(st1, 1);
+      load_into(st1, kt + 3);
+      read_frags(0);
+      mfmas();
+      __syncthreads();
+      store_from(st0, 0);
+      load_into(st0, kt + 4);
+      read_frags(1);
+      mfmas();
+      __syncthreads();
+      continue;
+    }
     read_frags(0);
     mfmas();
     store_from(st1, 1);
@@ -628,16 +650,31 @@ void launch_gemm_t(const GemmDev& g, int variant, hipStream_t s) {
     case 11: launch_split<EPI, 1>(g, s); break;  // bf16-rounded operands (configs[3] compute mode)
     case 13: launch_split16<EPI, 0>(g, s); break;  // split-3, k-tiles of 16, double-buffered LDS
     case 14: launch_split16<EPI, 1>(g, s); break;  // same with an explicit MFMA/VALU interleave
+    case 15: launch_split16<EPI, 2>(g, s); break;  // same, staging before the MFMAs of a k-tile
     case 21: launch_split16<EPI, 0, 1>(g, s); break;  // timing ablations of 13 (wrong results)
     case 22: launch_split16<EPI, 0, 2>(g, s); break;
     case 23: launch_split16<EPI, 0, 3>(g, s); break;
     case 24: launch_split16<EPI, 0, 4>(g, s); break;
     case 27: launch_split16<EPI, 0, 7>(g, s); break;
+    case 28: launch_split16<EPI, 0, 8>(g, s); break;  // LDS padded to 94 KB: one block per CU
     default: abort();
   }
 }
 
 }  // namespace
+
+int gemm_occupancy(int variant) {
+  int n = -1;
+  switch (variant) {
+    case 0: (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_f32_tile<kEpiBias, 128, 128, 32, false>, 256, 0); break;
+    case 10: (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_split_tile<kEpiBias, 3, false>, 256, 0); break;
+    case 13: (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_split16_tile<kEpiBias, 0, 0>, 256, 0); break;
+    case 14: (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_split16_tile<kEpiBias, 1, 0>, 256, 0); break;
+    case 15: (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_split16_tile<kEpiBias, 2, 0>, 256, 0); break;
+    default: break;
+  }
+  return n;
+}
 
 void launch_split_planes(const float* x, unsigned short* out, long n, hipStream_t s) {
   hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, out, n);
@@ -650,7 +687,7 @@ void launch_gemm(const GemmArgs& a, int epi, hipStream_t s) {
   // shape contract of the kernels (the epilogue wraps batch / position rows at most once per 32 rows)
   if (a.N % 128 != 0 || a.K % 32 != 0 || a.M < 1 || a.c_rpb < 32 || a.pos_period < (epi & kEpiPos ? 32 : 1)) abort();
   int v = a.variant;
-  if (v < 0) v = 14;  // auto: the pipelined split kernel beats every fp32-MFMA tile shape on every encoder shape
+  if (v < 0) v = 13;  // auto: the k16 split kernel beats every fp32-MFMA tile shape on every encoder shape
   switch (epi) {
     case 0: launch_gemm_t<0>(g, v, s); break;
     case kEpiBias: launch_gemm_t<kEpiBias>(g, v, s); break;

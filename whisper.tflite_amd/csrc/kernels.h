@@ -44,6 +44,8 @@ struct GemmArgs {
   int variant = -1;  // tile shape / pipelining variant (k_gemm.hip launch_gemm_t); -1 = auto
 };
 void launch_gemm(const GemmArgs& a, int epi, hipStream_t s);
+// resident blocks per CU the runtime reports for a tile variant (diagnostics)
+int gemm_occupancy(int variant);
 // x[n] fp32 -> out[3][n] bf16 with x = out[0] + out[1] + out[2] exactly
 void launch_split_planes(const float* x, unsigned short* out, long n, hipStream_t s);
 
