@@ -126,7 +126,7 @@ int wt_transcribe_tokens_batch_dev(wt_engine* h, const float* d_pcm, int batch, 
  * the MFMA-bound encoder of the newest batch shares the chip with the latency/HBM-bound
  * decoder chains of the previous ones.  d_mel must stay valid until that batch is collected.
  * At most WT_PIPELINE_DEPTH uncollected submits; batch <= 64. */
-#define WT_PIPELINE_DEPTH 8
+#define WT_PIPELINE_DEPTH 6
 int wt_pipeline_submit_dev(wt_engine* h, const float* d_mel, int batch);
 int wt_pipeline_collect(wt_engine* h, int64_t* ids, int32_t* n_ids);
 

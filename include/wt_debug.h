@@ -22,7 +22,7 @@ int wt_dbg_gemm_bench(wt_engine* h, int M, int N, int K, int epi, int variant, i
 int wt_dbg_interference(wt_engine* h, const float* d_mel, int batch, int n_enc, int chain_len, int blocks,
                         float* enc_ms, float* chain_ms);
 /* Concurrency probe with the real kernels: `n_dec` (0..4) decodes over cached cross-KV slots next to
- * `n_enc` (0..4) pipelined encoder passes over d_mel (device, [batch][80][3000]); needs eight
+ * `n_enc` (0..4) pipelined encoder passes over d_mel (device, [batch][80][3000]); needs six
  * earlier batches so that every slot is populated. dec_ms[n_dec], enc_ms[1] = device times. */
 int wt_dbg_concurrency(wt_engine* h, const float* d_mel, int batch, int n_dec, int n_enc, float* dec_ms,
                        float* enc_ms);

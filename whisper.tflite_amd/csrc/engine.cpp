@@ -341,7 +341,8 @@ Engine::Engine(const std::string& model_prefix, const std::string& vocab_path, b
   if (const char* v = getenv("WT_DEC_STREAMS")) n_dec_streams_ = std::min(std::max(atoi(v), 1), kDecStreams);
   const char* confine = getenv("WT_DEC_CONFINE");  // experiment: decoders only on the CUs the encoder leaves free
   if (confine && atoi(confine) > 0 && stream_masked_) {
-    const int keep = n_cu - 8 * reserve;
+    // 1: only the CUs the encoder leaves free; 2: every CU (a CU-masked stream has its own hardware queue)
+    const int keep = atoi(confine) == 2 ? 0 : n_cu - 8 * reserve;
     std::vector<uint32_t> mask((n_cu + 31) / 32, 0u);
     for (int i = keep; i < n_cu; ++i) mask[i / 32] |= 1u << (i % 32);
     for (auto& ds : dstream_) HIPCHK(hipExtStreamCreateWithCUMask(&ds, uint32_t(mask.size()), mask.data()));
@@ -726,7 +727,7 @@ void Engine::decode(int batch, int64_t* ids, int32_t* n_ids, float* logits_host,
 }
 
 void Engine::submit(const float* d_mel, int batch) {
-  if (int(inflight_.size()) >= kSlots) throw Error(1, "pipeline is full (8 batches in flight): collect() first");
+  if (int(inflight_.size()) >= kSlots) throw Error(1, "pipeline is full (6 batches in flight): collect() first");
   if (batch > 64) throw Error(1, "decoder batches are limited to 64 clips per call");
   select_stream(true);
   encode_enqueue(d_mel, batch);
@@ -902,15 +903,17 @@ void Engine::debug_concurrency(const float* d_mel, int batch, int n_dec, int n_e
   ensure_batch(batch);
   sync();
   for (int i = 0; i < n_dec; ++i)
-    if (!slots_[i].used) throw Error(1, "debug_concurrency: run eight batches first so every slot holds a cross-KV cache");
+    if (!slots_[i].used) throw Error(1, "debug_concurrency: run six batches first so every slot holds a cross-KV cache");
   select_stream(true);
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0));
   HIPCHK(hipEventCreate(&e1));
   for (int i = 0; i < n_dec; ++i) decode_enqueue(batch, i, nullptr, 0);
   HIPCHK(hipEventRecord(e0, stream_));
-  enc_slot_ = 4;  // encoder passes fill slots 4..7, away from the decoders' caches
-  for (int i = 0; i < n_enc; ++i) encode_enqueue(d_mel, batch);
+  for (int i = 0; i < n_enc; ++i) {
+    if (enc_slot_ < 4) enc_slot_ = 4;  // encoder passes alternate over slots 4 and 5, away from the decoders' caches
+    encode_enqueue(d_mel, batch);
+  }
   HIPCHK(hipEventRecord(e1, stream_));
   sync();
   for (int i = 0; i < n_dec; ++i) HIPCHK(hipEventElapsedTime(&dec_ms[i], slots_[i].dec_begin, slots_[i].dec_done));

@@ -133,7 +133,8 @@ class Engine {
   hipEvent_t ev_switch_ = nullptr;
   void select_stream(bool pipelined);
   void encode_enqueue(const float* d_mel, int batch);
-  static constexpr int kDecStreams = 8, kSlots = 8;
+  static constexpr int kDecStreams = 8, kSlots = 6;  // slots: a multiple of the 3 decoder streams in use, so
+                                                     // batches rotate evenly over them (WT_PIPELINE_DEPTH)
   int n_dec_streams_ = 3;  // decoder streams in use: one hardware queue each (the runtime multiplexes
                            // streams onto 4 queues per priority; two decoders sharing one serialise)
   hipStream_t dstream_[kDecStreams] = {};  // decoders (batches rotate over them)
