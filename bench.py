@@ -155,6 +155,7 @@ def main() -> None:
     ap.add_argument("--no-pipeline", action="store_true",
                     help="synchronous steps (encoder then decoder) instead of the two-deep pipeline")
     ap.add_argument("--depth", type=int, default=5, choices=tuple(range(1, 7)), help="batches in flight (pipelined mode)")
+    ap.add_argument("--cross-chunks", type=int, default=None, choices=(1, 2, 4, 8))
     ap.add_argument("--resid-waves", type=int, default=None, choices=(4, 8, 16))
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the extra fp32-MFMA-only measurement")
     ap.add_argument("--no-graphs", action="store_true", help="launch the decoder eagerly instead of replaying its hipGraph")
@@ -193,6 +194,8 @@ def main() -> None:
     tmp = tempfile.mkdtemp(prefix=f"wt_bench_r{rank}_")
     prefix, vocab = ge._assets(tmp, args.arch, 0)
     eng = pkg.Engine(prefix, vocab, True, device_id=local_rank)
+    if args.cross_chunks:
+        eng.set_option("cross_chunks", args.cross_chunks)
     if args.resid_waves:
         eng.set_option("resid_waves", args.resid_waves)
     if args.no_graphs:

@@ -127,7 +127,7 @@ int wt_engine_set_option(wt_engine* h, const char* key, long value) {
   } else if (k == "use_graphs") {
     e.use_graphs = value != 0;
   } else if (k == "gemm_variant") {
-    if (value < -1 || value > 15) return fail(h, WT_ERR_INVALID_ARG, "gemm_variant must be in [-1, 15]");
+    if (value < -1 || value > 16) return fail(h, WT_ERR_INVALID_ARG, "gemm_variant must be in [-1, 16]");
     e.gemm_variant = value;
   } else {
     return fail(h, WT_ERR_INVALID_ARG, "unknown option: " + k);

@@ -578,7 +578,7 @@ void Engine::resolve_kernel_stats(int slot) {
   Slot& sl = slots_[slot];
   // class names = the kernels the current options select (what rocprofv3 lists)
   const long gv = gemm_variant;
-  kstats_[kKcGemm].name = gv < 0 || gv == 13 || gv == 14 ? "gemm_split16_tile"
+  kstats_[kKcGemm].name = gv < 0 || (gv >= 13 && gv <= 16) ? "gemm_split16_tile"
                           : gv == 10 || gv == 12         ? "gemm_split_tile"
                           : gv == 11                     ? "gemm_split_tile(bf16)"
                                                          : "gemm_f32_tile";
@@ -622,7 +622,7 @@ void Engine::encode_enqueue(const float* d_mel, int batch) {
   launch_mel_transpose(d_mel, ws_.melT, batch, c.n_mels, T0, stream_);
   kt_end();
   {
-    GemmArgs g; g.variant = int(gemm_variant);  // conv1 + GELU: rows (clip, t) read melT rows t..t+2 (input t-1..t+1)
+    GemmArgs g; g.variant = enc_gemm_variant();  // conv1 + GELU: rows (clip, t) read melT rows t..t+2 (input t-1..t+1)
     g.A = ws_.melT;
     g.a_rpb = T0;
     g.a_bs = long(T0 + 2) * c.n_mels;
@@ -641,7 +641,7 @@ void Engine::encode_enqueue(const float* d_mel, int batch) {
     kt_end();
   }
   {
-    GemmArgs g; g.variant = int(gemm_variant);  // conv2 (stride 2) + GELU + positional embedding
+    GemmArgs g; g.variant = enc_gemm_variant();  // conv2 (stride 2) + GELU + positional embedding
     g.A = ws_.h1p;
     g.a_rpb = T;
     g.a_bs = long(T0 + 2) * d;
@@ -664,7 +664,7 @@ void Engine::encode_enqueue(const float* d_mel, int batch) {
     kt_begin(kKcLayerNorm, 0, 2.0 * M * d * 4);
     launch_layernorm(ws_.x, ws_.ln, w.attn_ln_g, w.attn_ln_b, M, d, stream_);
     kt_end();
-    GemmArgs q; q.variant = int(gemm_variant);
+    GemmArgs q; q.variant = enc_gemm_variant();
     q.A = ws_.ln; q.lda = d; q.W = w.attn.wqkv; q.bias = w.attn.bqkv; q.C = ws_.qkv; q.ldc = 3 * d;
     q.M = M; q.N = 3 * d; q.K = d;
     kt_begin(kKcGemm, 2.0 * q.M * q.N * q.K, 0);
@@ -673,7 +673,7 @@ void Engine::encode_enqueue(const float* d_mel, int batch) {
     kt_begin(kKcEncAttn, 4.0 * batch * c.n_audio_head * double(T) * T * 64, 0);
     launch_encoder_attention(ws_.qkv, ws_.att, batch, T, c.n_audio_head, int(attn_variant), stream_);
     kt_end();
-    GemmArgs o; o.variant = int(gemm_variant);
+    GemmArgs o; o.variant = enc_gemm_variant();
     o.A = ws_.att; o.lda = d; o.W = w.attn.wo; o.bias = w.attn.bo; o.C = ws_.x; o.R = ws_.x; o.ldc = d;
     o.M = M; o.N = d; o.K = d;
     kt_begin(kKcGemm, 2.0 * o.M * o.N * o.K, 0);
@@ -682,13 +682,13 @@ void Engine::encode_enqueue(const float* d_mel, int batch) {
     kt_begin(kKcLayerNorm, 0, 2.0 * M * d * 4);
     launch_layernorm(ws_.x, ws_.ln, w.mlp_ln_g, w.mlp_ln_b, M, d, stream_);
     kt_end();
-    GemmArgs f1; f1.variant = int(gemm_variant);
+    GemmArgs f1; f1.variant = enc_gemm_variant();
     f1.A = ws_.ln; f1.lda = d; f1.W = w.w1; f1.bias = w.b1; f1.C = ws_.hid; f1.ldc = 4 * d;
     f1.M = M; f1.N = 4 * d; f1.K = d;
     kt_begin(kKcGemm, 2.0 * f1.M * f1.N * f1.K, 0);
     launch_gemm(f1, kEpiBias | kEpiGelu, stream_);
     kt_end();
-    GemmArgs f2; f2.variant = int(gemm_variant);
+    GemmArgs f2; f2.variant = enc_gemm_variant();
     f2.A = ws_.hid; f2.lda = 4 * d; f2.W = w.w2; f2.bias = w.b2; f2.C = ws_.x; f2.R = ws_.x; f2.ldc = d;
     f2.M = M; f2.N = d; f2.K = 4 * d;
     kt_begin(kKcGemm, 2.0 * f2.M * f2.N * f2.K, 0);
@@ -703,7 +703,7 @@ void Engine::encode_enqueue(const float* d_mel, int batch) {
     // cross-attention K/V of every decoder layer, projected once per clip into the
     // persistent cache [layer][k|v][clip][head][t][64] (the reference recomputes them
     // inside every decoder Invoke(), whisper.cpp:375)
-    GemmArgs g; g.variant = int(gemm_variant);
+    GemmArgs g; g.variant = enc_gemm_variant();
     g.A = ws_.enc_out; g.lda = d; g.W = cross_kv_w; g.bias = cross_kv_b; g.C = slot.cross_kv;
     g.M = M; g.N = c.n_text_layer * 2 * d; g.K = d;
     g.c_rpb = T; g.kv_batch = batch; g.kv_heads = c.n_text_head; g.kv_dmodel = d;

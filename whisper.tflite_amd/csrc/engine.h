@@ -132,6 +132,9 @@ class Engine {
   hipStream_t stream_full_ = nullptr, stream_masked_ = nullptr;
   hipEvent_t ev_switch_ = nullptr;
   void select_stream(bool pipelined);
+  // default GEMM: the k16 split kernel, at 2 blocks per CU when decoders share the chip (pipelined),
+  // at 3 blocks per CU otherwise
+  int enc_gemm_variant() const { return gemm_variant >= 0 ? int(gemm_variant) : (stream_ == stream_masked_ && stream_masked_ ? 16 : 13); }
   void encode_enqueue(const float* d_mel, int batch);
   static constexpr int kDecStreams = 8, kSlots = 6;  // slots: a multiple of the 3 decoder streams in use, so
                                                      // batches rotate evenly over them (WT_PIPELINE_DEPTH)
