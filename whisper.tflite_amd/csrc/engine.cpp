@@ -399,6 +399,7 @@ Engine::~Engine() {
     for (hipEvent_t e : {sl.enc_begin, sl.enc_mid, sl.enc_done, sl.dec_begin, sl.dec_done})
       if (e) (void)hipEventDestroy(e);
     for (auto& e : sl.kt_events) (void)hipEventDestroy(e);
+    for (auto& e : sl.dt_events) (void)hipEventDestroy(e);
     if (sl.h_ids) (void)hipHostFree(sl.h_ids);
     if (sl.h_n) (void)hipHostFree(sl.h_n);
   }
@@ -770,6 +771,29 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
   }
   const int chunks = int(cross_chunks);  // 1, 2, 4 or 8 (wt_engine_set_option)
   int steps = 0;
+  // WT_DEC_KERNEL_TIMERS=1 (diagnostics, eager launches only): event pairs around every decoder launch
+  static const bool dec_timers = getenv("WT_DEC_KERNEL_TIMERS") != nullptr;
+  std::vector<hipEvent_t>& dt_ev = slot.dt_events;
+  std::vector<int>& dt_cls = slot.dt_cls;
+  size_t dt_used = 0;
+  bool dt_on = false;
+#define DT(CLS, CALL)                                                         \
+  do {                                                                        \
+    if (dt_on) {                                                              \
+      while (dt_ev.size() < dt_used + 2) {                                    \
+        hipEvent_t e_;                                                        \
+        HIPCHK(hipEventCreate(&e_));                                          \
+        dt_ev.push_back(e_);                                                  \
+      }                                                                       \
+      HIPCHK(hipEventRecord(dt_ev[dt_used], stream_));                        \
+      CALL;                                                                   \
+      HIPCHK(hipEventRecord(dt_ev[dt_used + 1], stream_));                    \
+      dt_cls.push_back(CLS);                                                  \
+      dt_used += 2;                                                           \
+    } else {                                                                  \
+      CALL;                                                                   \
+    }                                                                         \
+  } while (0)
   auto enqueue_all = [&](int si) {
     Slot& slot = slots_[si];
     DecWorkspace& dw = dws_[si % n_dec_streams_];
@@ -796,54 +820,54 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
           q.n_vocab = V; q.xout = x;
         }
         q.bias = w.attn.bqkv; q.Y = dw.qkvd; q.ldy = 3 * d;
-        launch_dec_gemm(q, kProLn, kDecBias, stream_);
-        launch_self_attention(dw.qkvd, dw.self_kv + (size_t(l) * 2 + 0) * self_slab,
+        DT(0, launch_dec_gemm(q, kProLn, kDecBias, stream_));
+        DT(1, launch_self_attention(dw.qkvd, dw.self_kv + (size_t(l) * 2 + 0) * self_slab,
                               dw.self_kv + (size_t(l) * 2 + 1) * self_slab, self_cap_, pos, dw.attd,
-                              batch, H, stream_);
+                              batch, H, stream_));
         DecGemmArgs o;  // x += attn . Wo^T + bo
         o.Wt = w.attn.wo; o.N = d; o.K = d; o.B = batch; o.X = dw.attd; o.ldx = d;
         o.bias = w.attn.bo; o.R = x; o.Y = x; o.ldy = d; o.resid_waves = int(resid_waves);
-        launch_dec_gemm(o, kProNone, kDecResid, stream_);
+        DT(2, launch_dec_gemm(o, kProNone, kDecResid, stream_));
 
         DecGemmArgs cq;  // LN + cross-attention query projection
         cq.Wt = w.cross.wq; cq.N = d; cq.K = d; cq.B = batch;
         cq.xin = x; cq.ln_g = w.cross_ln_g; cq.ln_b = w.cross_ln_b;
         cq.bias = w.cross.bq; cq.Y = dw.qd; cq.ldy = d;
-        launch_dec_gemm(cq, kProLn, kDecBias, stream_);
-        launch_cross_attention(dw.qd, slot.cross_kv + (size_t(l) * 2 + 0) * kv_slab,
+        DT(3, launch_dec_gemm(cq, kProLn, kDecBias, stream_));
+        DT(4, launch_cross_attention(dw.qd, slot.cross_kv + (size_t(l) * 2 + 0) * kv_slab,
                                slot.cross_kv + (size_t(l) * 2 + 1) * kv_slab, dw.cross_ws, batch, H, T,
-                               chunks, stream_);
+                               chunks, stream_));
         DecGemmArgs co;  // x += combine(chunks) . Wco^T + bco
         co.Wt = w.cross.wo; co.N = d; co.K = d; co.B = batch;
         co.cross_ws = dw.cross_ws; co.heads = H; co.chunks = chunks;
         co.bias = w.cross.bo; co.R = x; co.Y = x; co.ldy = d; co.resid_waves = int(resid_waves);
-        launch_dec_gemm(co, kProCombine, kDecResid, stream_);
+        DT(5, launch_dec_gemm(co, kProCombine, kDecResid, stream_));
 
         DecGemmArgs f1;  // LN + fc1 + GELU
         f1.Wt = w.w1; f1.N = 4 * d; f1.K = d; f1.B = batch;
         f1.xin = x; f1.ln_g = w.mlp_ln_g; f1.ln_b = w.mlp_ln_b;
         f1.bias = w.b1; f1.Y = dw.hd; f1.ldy = 4 * d;
-        launch_dec_gemm(f1, kProLn, kDecBiasGelu, stream_);
+        DT(6, launch_dec_gemm(f1, kProLn, kDecBiasGelu, stream_));
         DecGemmArgs f2;  // x += h . W2^T + b2
         f2.Wt = w.w2; f2.N = d; f2.K = 4 * d; f2.B = batch; f2.X = dw.hd; f2.ldx = 4 * d;
         f2.bias = w.b2; f2.R = x; f2.Y = x; f2.ldy = d; f2.resid_waves = int(resid_waves);
-        launch_dec_gemm(f2, kProNone, kDecResid, stream_);
+        DT(7, launch_dec_gemm(f2, kProNone, kDecResid, stream_));
       }
       if (pos >= n_prompt - 1) {
         // logits against the tied embedding + greedy argmax (whisper.cpp:379-399); only the
         // last position's row exists here, the reference computes and drops the others
-        launch_dec_finalize_ln(x, dec_ln_g, dec_ln_b, dw.lnd, batch, d, stream_);
+        DT(8, launch_dec_finalize_ln(x, dec_ln_g, dec_ln_b, dw.lnd, batch, d, stream_));
         DecGemmArgs lg;
         lg.Wt = tok_emb_tiled; lg.N = V; lg.K = d; lg.B = batch; lg.X = dw.lnd; lg.ldx = d;
         lg.Y = logits_host ? dw.logits : nullptr; lg.ldy = V; lg.best = dw.best;
-        launch_dec_gemm(lg, kProNone, kDecLogits, stream_);
+        DT(9, launch_dec_gemm(lg, kProNone, kDecLogits, stream_));
         if (logits_host && steps < logits_steps_cap) {
           HIPCHK(hipMemcpy2DAsync(logits_host + size_t(steps) * V, size_t(logits_steps_cap) * V * sizeof(float),
                                   dw.logits, size_t(V) * sizeof(float), size_t(V) * sizeof(float), batch,
                                   hipMemcpyDeviceToHost, stream_));
         }
-        launch_select_token(dw.best, (V + 31) / 32, dw.ids, stride, pos, dw.n_ids, dw.finished,
-                            vocab_.token_eot, int(stop_at_eot), batch, stream_);
+        DT(10, launch_select_token(dw.best, (V + 31) / 32, dw.ids, stride, pos, dw.n_ids, dw.finished,
+                            vocab_.token_eot, int(stop_at_eot), batch, stream_));
         ++steps;
       }
     }
@@ -869,7 +893,10 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
   if (exec) {
     HIPCHK(hipGraphLaunch(exec, stream_));
   } else {
+    dt_on = dec_timers && !logits_host;
+    dt_cls.clear();
     enqueue_all(slot_idx);
+    dt_on = false;
     const int eager_steps = steps;
     if (use_graphs && !logits_host) {
       for (int si = 0; si < kSlots; ++si) {
@@ -895,6 +922,8 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
   HIPCHK(hipEventRecord(slot.dec_done, stream_));
   slot.steps = steps;
 }
+
+#undef DT
 
 void Engine::debug_concurrency(const float* d_mel, int batch, int n_dec, int n_enc, float* dec_ms,
                                float* enc_ms) {
@@ -940,6 +969,24 @@ void Engine::decode_collect(int slot_idx, int64_t* ids, int32_t* n_ids) {
   if (hipEventElapsedTime(&ms, slot.enc_mid, slot.enc_done) == hipSuccess) timings_.cross_kv_ms = ms;
   if (hipEventElapsedTime(&ms, slot.dec_begin, slot.dec_done) == hipSuccess) timings_.decoder_ms = ms;
   if (hipEventElapsedTime(&ms, slot.enc_begin, slot.dec_done) == hipSuccess) timings_.total_ms = ms;
+  if (!slot.dt_cls.empty()) {
+    static const char* kNames[11] = {"qkv(LN)", "self_attn", "o_proj", "cq(LN)", "cross_attn", "combine+co",
+                                     "fc1(LN)", "fc2", "final_ln", "logits", "select"};
+    double tot[11] = {0};
+    int cnt[11] = {0};
+    for (size_t i = 0; i < slot.dt_cls.size(); ++i) {
+      float ms_k = 0;
+      if (hipEventElapsedTime(&ms_k, slot.dt_events[2 * i], slot.dt_events[2 * i + 1]) == hipSuccess) {
+        tot[slot.dt_cls[i]] += ms_k;
+        cnt[slot.dt_cls[i]] += 1;
+      }
+    }
+    fprintf(stderr, "[wt-dec-timers] slot %d:", slot_idx);
+    for (int c = 0; c < 11; ++c)
+      if (cnt[c]) fprintf(stderr, " %s %.2f ms (%d x %.1f us)", kNames[c], tot[c], cnt[c], 1e3 * tot[c] / cnt[c]);
+    fprintf(stderr, "\n");
+    slot.dt_cls.clear();
+  }
   static const bool trace = getenv("WT_TRACE_PIPELINE") != nullptr;
   if (trace) {  // device timeline of the batch relative to the first traced batch, for pipeline analysis
     hipEvent_t base = trace_base_;

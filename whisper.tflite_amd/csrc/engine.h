@@ -151,6 +151,8 @@ class Engine {
     int batch = 0, steps = 0, dec = 0;  // dec: decoder stream / workspace of this batch
     bool used = false;
     std::vector<hipEvent_t> kt_events;
+    std::vector<hipEvent_t> dt_events;  // WT_DEC_KERNEL_TIMERS diagnostics
+    std::vector<int> dt_cls;
     std::vector<int> kt_cls;
     std::vector<double> kt_flops, kt_bytes;
   } slots_[kSlots];

@@ -147,6 +147,25 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm(DecGemmDev g) {
     w[i] = *reinterpret_cast<const f32x4*>(wp + (long)ci * 256);
   }
 
+  // The epilogue's operands (bias, residual rows) do not depend on the product either: wave 0, the
+  // only one that reaches the epilogue, requests them now.  Loaded after the split-K reduction they
+  // cost one more dependent round trip to memory per launch, 4-5 us each when the encoder and two
+  // other decoders keep the memory system busy (WT_DEC_KERNEL_TIMERS).
+  constexpr bool kPreR = EPI == kDecResid && MT == 1;  // MT = 2 blocks sit at the 128-VGPR cap
+  const int n_epi = tile * 32 + l31;
+  float bias_pre = 0.0f;
+  float r_pre[kPreR ? 16 : 1];
+  if (wid == 0) {
+    if ((EPI == kDecBias || EPI == kDecResid) && MT == 1) bias_pre = g.bias[n_epi < g.N ? n_epi : 0];
+    if (kPreR) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int b = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        r_pre[r] = g.R[(long)(b < B ? b : B - 1) * g.ldy + (n_epi < g.N ? n_epi : 0)];
+      }
+    }
+  }
+
   if (PRO == kProLn) {
     // LayerNorm of the residual stream; a wavefront handles 8 rows at once, one memory round
     // trip per pass.  With the embedding source the rows are also materialised once (block 0).
@@ -155,6 +174,17 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm(DecGemmDev g) {
     const RowSrc src{g.xin, g.ids, g.ids_stride, g.pos, g.tok_emb, g.pos_emb, g.n_vocab};
     constexpr int NV = NF4 > 0 ? NF4 : 1;
     static_assert(PRO != kProLn || WAVES == 4, "the LayerNorm prologue maps 4 waves x 8 rows");
+    // gain and shift are row-independent: requested together with the rows, not after their statistics
+    // (not for the embedding source, LNMODE 2, nor two M-tiles: register pressure)
+    constexpr bool kHoistLn = LNMODE != 2 && MT == 1;
+    f32x4 lg[kHoistLn ? NV : 1], lb[kHoistLn ? NV : 1];
+    if (kHoistLn) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        lg[j] = *reinterpret_cast<const f32x4*>(g.ln_g + (sub + 8 * j) * 4);
+        lb[j] = *reinterpret_cast<const f32x4*>(g.ln_b + (sub + 8 * j) * 4);
+      }
+    }
 #pragma unroll 1
     for (int pass = 0; pass < MT; ++pass) {
       const int row = pass * 32 + wid * 8 + r8;
@@ -171,8 +201,8 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm(DecGemmDev g) {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
           const int c = (sub + 8 * j) * 4;
-          const f32x4 gg = *reinterpret_cast<const f32x4*>(g.ln_g + c);
-          const f32x4 bb = *reinterpret_cast<const f32x4*>(g.ln_b + c);
+          const f32x4 gg = kHoistLn ? lg[kHoistLn ? j : 0] : *reinterpret_cast<const f32x4*>(g.ln_g + c);
+          const f32x4 bb = kHoistLn ? lb[kHoistLn ? j : 0] : *reinterpret_cast<const f32x4*>(g.ln_b + c);
           f32x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = (v[j][e] - mean) * rstd * gg[e] + bb[e];
@@ -300,9 +330,9 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm(DecGemmDev g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] += red[((wv * MT + t) * 16 + r) * 64 + lane];
 
-  const int n = tile * 32 + l31;
+  const int n = n_epi;
   const bool n_ok = n < g.N;
-  const float bias = ((EPI == kDecBias || EPI == kDecResid) && n_ok) ? g.bias[n] : 0.0f;
+  const float bias = ((EPI == kDecBias || EPI == kDecResid) && n_ok) ? (MT == 1 ? bias_pre : g.bias[n]) : 0.0f;
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
 #pragma unroll
@@ -311,7 +341,8 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm(DecGemmDev g) {
       float v = acc[t][r] + bias;
       if (EPI == kDecBias && g.gelu) v = gelu_erf(v);
       const bool ok = n_ok && b < B;
-      if (EPI == kDecResid && ok) v += g.R[(long)b * g.ldy + n];  // R may alias Y: same thread
+      // R may alias Y: each element is read and written by the same thread
+      if (EPI == kDecResid && ok) v += kPreR ? r_pre[r] : g.R[(long)b * g.ldy + n];
       if (ok && g.Y) g.Y[(long)b * g.ldy + n] = v;
       if (EPI == kDecLogits) {
         // fold (value, column): larger value wins, then the larger column — the reference's
