@@ -32,6 +32,7 @@ BATCH_PER_GPU = 32
 CLIP_SECONDS = 30.0
 MEL_SEED = 1234
 ID_STRIDE = 32  # int64 ids per clip record (wt_capi.h WT_MAX_IDS)
+GATHER_EVERY = 8  # batches per all_gather of id records (N > 1)
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16, 32 cycles)
 PEAK_HBM_GBPS = 8000.0
@@ -212,11 +213,27 @@ def main() -> None:
     pipelined = not args.no_pipeline
     host = {"submit_s": 0.0, "submits": 0}  # host time spent enqueueing (launch-bound check)
 
-    def finish(ids, n):
-        rec = torch.from_numpy(pack_records(ids, n))
+    # N > 1: the id records of GATHER_EVERY consecutive batches travel in one all_gather (fewer, larger
+    # collectives: an RCCL kernel per batch would sit in a hardware queue next to a decoder chain and
+    # couple the ranks batch by batch).  Every record is gathered inside the timed region.
+    pending = []
+    gathered = {"rec": None, "collectives": 0}
+
+    def flush_gather():
+        if not pending:
+            return
+        rec = torch.from_numpy(np.concatenate(pending, axis=0))
+        pending.clear()
         if world > 1:
             rec = gather_records(rec.cuda() if args.backend == "nccl" else rec, world)
-        return ids, n, rec
+            gathered["collectives"] += 1
+        gathered["rec"] = rec
+
+    def finish(ids, n):
+        pending.append(pack_records(ids, n))
+        if len(pending) >= GATHER_EVERY:
+            flush_gather()
+        return ids, n, gathered["rec"]
 
     def step():
         return finish(*eng.encdec_tokens_batch_dev(d_mel.data_ptr(), B))
@@ -231,7 +248,8 @@ def main() -> None:
                 out = step()
                 if on_step:
                     on_step()
-            return out
+            flush_gather()
+            return out[0], out[1], gathered["rec"]
         in_flight = 0
         for _ in range(k):
             t_h = time.perf_counter()
@@ -249,7 +267,8 @@ def main() -> None:
             in_flight -= 1
             if on_step:
                 on_step()
-        return out
+        flush_gather()
+        return out[0], out[1], gathered["rec"]
 
     if args.warmup:
         run_steps(args.warmup)
@@ -384,7 +403,7 @@ def main() -> None:
             "config": {"workload": f"whisper-{args.arch} batch={B}x30s synthetic mel U(-1,1.5), fp32, random-init "
                                    "weights (BASELINE.json configs[1]); mel resident in HBM -> token ids on host",
                        "clips_per_gpu": B, "global_batch": world * B, "decoder_positions": 30,
-                       "argmax_steps": 27, "parallelism": f"clip-parallel dp{world}, RCCL all_gather of id records",
+                       "argmax_steps": 27, "parallelism": f"clip-parallel dp{world}, one RCCL all_gather of id records per {GATHER_EVERY} batches",
                        "pipelined": pipelined, "batches_in_flight": args.depth if pipelined else 1,
                        "compute": "encoder GEMMs and attention: fp32 operands split exactly into 3 bf16 planes, 6 "
                                   "bf16-MFMA products, fp32 accumulate (error = fp32-MFMA kernel's, tests/"
