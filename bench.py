@@ -33,6 +33,7 @@ CLIP_SECONDS = 30.0
 MEL_SEED = 1234
 ID_STRIDE = 32  # int64 ids per clip record (wt_capi.h WT_MAX_IDS)
 GATHER_EVERY = 8  # batches per all_gather of id records (N > 1)
+FORCE_COLLECTIVES = False  # --rehearse-nccl: run the RCCL collectives of the N > 1 path on one rank
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16, 32 cycles)
 PEAK_HBM_GBPS = 8000.0
@@ -61,7 +62,7 @@ def gather_records(rec_tensor, world: int):
     GPUs; gloo in the CPU rehearsal).  Returns [world * B][33]."""
     import torch
     import torch.distributed as dist
-    if world == 1:
+    if world == 1 and not FORCE_COLLECTIVES:
         return rec_tensor
     out = [torch.empty_like(rec_tensor) for _ in range(world)]
     dist.all_gather(out, rec_tensor)
@@ -166,6 +167,8 @@ def main() -> None:
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--dry-run-gloo", action="store_true")
+    ap.add_argument("--rehearse-nccl", action="store_true",
+                    help="single rank: create the RCCL communicator and run the N > 1 collectives anyway")
     args = ap.parse_args()
     if args.dry_run_gloo:
         dry_run_gloo(args)
@@ -185,7 +188,12 @@ def main() -> None:
     if args.single_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    global FORCE_COLLECTIVES
+    FORCE_COLLECTIVES = bool(args.rehearse_nccl) and world == 1
+    if FORCE_COLLECTIVES:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+    if world > 1 or FORCE_COLLECTIVES:
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
@@ -224,7 +232,7 @@ def main() -> None:
             return
         rec = torch.from_numpy(np.concatenate(pending, axis=0))
         pending.clear()
-        if world > 1:
+        if world > 1 or FORCE_COLLECTIVES:
             rec = gather_records(rec.cuda() if args.backend == "nccl" else rec, world)
             gathered["collectives"] += 1
         gathered["rec"] = rec
@@ -274,7 +282,7 @@ def main() -> None:
         run_steps(args.warmup)
 
     def fence():
-        if world > 1:
+        if world > 1 or FORCE_COLLECTIVES:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -294,7 +302,7 @@ def main() -> None:
     ids, n, rec = run_steps(args.steps, accumulate)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or FORCE_COLLECTIVES:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -428,7 +436,7 @@ def main() -> None:
             out["cpu_baseline"] = cb
         print(json.dumps(out))
     eng.close()
-    if world > 1:
+    if world > 1 or FORCE_COLLECTIVES:
         dist.barrier()
         dist.destroy_process_group()
 
