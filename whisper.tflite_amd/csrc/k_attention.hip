@@ -412,27 +412,52 @@ __global__ __launch_bounds__(256, 2) void encoder_attention_split(const float* _
 __global__ void self_attention_step(const float* __restrict__ qkv, float* __restrict__ kcache,
                                     float* __restrict__ vcache, int cap, int pos,
                                     float* __restrict__ out, int heads) {
-  const int b = blockIdx.x, h = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // Everything this (clip, head) needs is requested in one batch of independent loads — the new
+  // q/k/v row and the cached K and V rows of positions < pos (16 lanes x 16 B per row) — and staged
+  // in LDS; scores, softmax and the weighted sum then run out of LDS.  One round trip to memory
+  // instead of one per unrolled group of the old per-lane row walk.
+  // one wavefront per (clip, head): 17 KB of LDS per block
+  const int b = blockIdx.x / heads, h = blockIdx.x % heads, lane = threadIdx.x;
   const int d = heads * 64;
   const float* row = qkv + (long)b * 3 * d;
   float* kc = kcache + ((long)b * cap) * d + h * 64;
   float* vc = vcache + ((long)b * cap) * d + h * 64;
+  __shared__ __attribute__((aligned(16))) float Ks[32][68];
+  __shared__ __attribute__((aligned(16))) float Vs[32][64];
+  __shared__ float qs[64];
+  __shared__ float ps[64];
   const float q = row[h * 64 + lane] * 0.125f;
   const float knew = row[d + h * 64 + lane];
   const float vnew = row[2 * d + h * 64 + lane];
+  const int r16 = lane >> 4, c4 = (lane & 15) * 4;
+  f32x4 kr[8], vr[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {  // rows 4i + r16 < pos (pos <= 31); rows past pos re-read row 0
+    const int j = 4 * i + r16;
+    const int jj = j < pos ? j : 0;
+    kr[i] = *reinterpret_cast<const f32x4*>(kc + (long)jj * d + c4);
+    vr[i] = *reinterpret_cast<const f32x4*>(vc + (long)jj * d + c4);
+  }
   kc[(long)pos * d + lane] = knew;
   vc[(long)pos * d + lane] = vnew;
-  __shared__ float qs[8][64];
-  __shared__ float ps[8][64];
-  qs[h][lane] = q;
-  __syncthreads();  // also orders this block's cache writes before its reads below
+  qs[lane] = q;
+  Ks[pos][lane] = knew;
+  Vs[pos][lane] = vnew;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int j = 4 * i + r16;
+    if (j < pos) {
+      *reinterpret_cast<f32x4*>(&Ks[j][c4]) = kr[i];
+      *reinterpret_cast<f32x4*>(&Vs[j][c4]) = vr[i];
+    }
+  }
+  __syncthreads();
   const int n = pos + 1;
   float s = -1e30f;
   if (lane < n) {
-    const float* kr = kc + (long)lane * d;
     float acc = 0.0f;
 #pragma unroll 8
-    for (int c = 0; c < 64; ++c) acc += qs[h][c] * kr[c];
+    for (int c = 0; c < 64; ++c) acc += qs[c] * Ks[lane][c];
     s = acc;
   }
   float mx = s;
@@ -442,10 +467,10 @@ __global__ void self_attention_step(const float* __restrict__ qkv, float* __rest
   float sum = p;
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
-  ps[h][lane] = p / sum;
+  ps[lane] = p / sum;
   __syncthreads();
   float o = 0.0f;
-  for (int j = 0; j < n; ++j) o += ps[h][j] * vc[(long)j * d + lane];
+  for (int j = 0; j < n; ++j) o += ps[j] * Vs[j][lane];
   out[(long)b * d + h * 64 + lane] = o;
 }
 
@@ -470,9 +495,10 @@ __global__ __launch_bounds__(256) void cross_attention_step(const float* __restr
   constexpr float kLog2e = 1.44269504088896340736f;
   constexpr int U = 4;
 
-  f32x4 qv = *reinterpret_cast<const f32x4*>(q + ((long)b * heads + h) * 64 + gl16 * 4);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) qv[j] *= 0.125f * kLog2e;  // scores in log2 units: p = exp2(s - m)
+  // q is requested together with the first K/V rows: nothing touches it before they are in flight
+  // (scaling q here would make every K/V load wait for q's round trip to memory)
+  const f32x4 qv = *reinterpret_cast<const f32x4*>(q + ((long)b * heads + h) * 64 + gl16 * 4);
+  constexpr float kScale = 0.125f * kLog2e;  // scores in log2 units: p = exp2(s - m)
   const float* kb = kc + ((long)bh * T + k_begin) * 64 + gl16 * 4;
   const float* vb = vc + ((long)bh * T + k_begin) * 64 + gl16 * 4;
 
@@ -494,6 +520,7 @@ __global__ __launch_bounds__(256) void cross_attention_step(const float* __restr
       s += __shfl_xor(s, 4, 64);
       s += __shfl_xor(s, 2, 64);
       s += __shfl_xor(s, 1, 64);
+      s *= kScale;
       if (k0 + 16 * u >= nk) s = -1e30f;
       const float mn = fmaxf(m, s);
       const float a = exp2f(m - mn), p = exp2f(s - mn);
@@ -545,7 +572,8 @@ void launch_encoder_attention(const float* qkv, float* out, int batch, int T, in
 
 void launch_self_attention(const float* qkv, float* kcache, float* vcache, int cap, int pos,
                            float* out, int batch, int heads, hipStream_t s) {
-  hipLaunchKernelGGL(self_attention_step, dim3(batch), dim3(heads * 64), 0, s, qkv, kcache, vcache,
+  if (pos < 0 || pos > 31 || pos >= cap) abort();  // the kernel stages at most 32 cached rows in LDS
+  hipLaunchKernelGGL(self_attention_step, dim3(batch * heads), dim3(64), 0, s, qkv, kcache, vcache,
                      cap, pos, out, heads);
 }
 

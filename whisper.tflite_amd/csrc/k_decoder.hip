@@ -369,18 +369,21 @@ __global__ __launch_bounds__(256) void dec_finalize_ln(RowSrc src, const float* 
   const int r8 = lane >> 3, sub = lane & 7;
   const int row = blockIdx.x * 32 + wid * 8 + r8;
   if (row >= B) return;  // whole 8-lane groups leave together; the shuffles stay inside a group
-  f32x4 v[NF4];
+  f32x4 v[NF4], gg[NF4], bb[NF4];
+#pragma unroll
+  for (int j = 0; j < NF4; ++j) {  // gain / shift requested with the row, not after its statistics
+    gg[j] = *reinterpret_cast<const f32x4*>(g + (sub + 8 * j) * 4);
+    bb[j] = *reinterpret_cast<const f32x4*>(b + (sub + 8 * j) * 4);
+  }
   load_row<NF4, 0>(v, src, row, sub, B, K);
   float mean, rstd;
   row_stats<NF4>(v, K, &mean, &rstd);
 #pragma unroll
   for (int j = 0; j < NF4; ++j) {
     const int c = (sub + 8 * j) * 4;
-    const f32x4 gg = *reinterpret_cast<const f32x4*>(g + c);
-    const f32x4 bb = *reinterpret_cast<const f32x4*>(b + c);
     f32x4 o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = (v[j][e] - mean) * rstd * gg[e] + bb[e];
+    for (int e = 0; e < 4; ++e) o[e] = (v[j][e] - mean) * rstd * gg[j][e] + bb[j][e];
     *reinterpret_cast<f32x4*>(y + (long)row * K + c) = o;
   }
 }
