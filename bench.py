@@ -149,7 +149,7 @@ def cpu_baseline(prefix: str, mel: np.ndarray, prompt, eot: int) -> dict:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="clips per GPU")
     ap.add_argument("--arch", default="tiny")
@@ -157,6 +157,7 @@ def main() -> None:
     ap.add_argument("--no-pipeline", action="store_true",
                     help="synchronous steps (encoder then decoder) instead of the two-deep pipeline")
     ap.add_argument("--depth", type=int, default=5, choices=tuple(range(1, 7)), help="batches in flight (pipelined mode)")
+    ap.add_argument("--attn-variant", type=int, default=None, choices=(0, 1, 2))
     ap.add_argument("--cross-chunks", type=int, default=None, choices=(1, 2, 4, 8))
     ap.add_argument("--resid-waves", type=int, default=None, choices=(4, 8, 16))
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the extra fp32-MFMA-only measurement")
@@ -203,6 +204,8 @@ def main() -> None:
     tmp = tempfile.mkdtemp(prefix=f"wt_bench_r{rank}_")
     prefix, vocab = ge._assets(tmp, args.arch, 0)
     eng = pkg.Engine(prefix, vocab, True, device_id=local_rank)
+    if args.attn_variant is not None:
+        eng.set_option("attn_variant", args.attn_variant)
     if args.cross_chunks:
         eng.set_option("cross_chunks", args.cross_chunks)
     if args.resid_waves:
@@ -310,7 +313,7 @@ def main() -> None:
     # the same pipeline with every encoder contraction on the fp32 MFMA instruction (reported beside
     # the headline, outside the timed region, so the effect of the bf16-split kernels is visible)
     fp32_leg = None
-    if pipelined and args.gemm_variant is None and not args.no_fp32_leg:
+    if pipelined and args.gemm_variant is None and args.attn_variant is None and not args.no_fp32_leg:
         eng.set_option("gemm_variant", 0)
         eng.set_option("attn_variant", 0)
         run_steps(3)

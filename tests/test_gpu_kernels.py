@@ -211,7 +211,7 @@ def attn_ref(q, k, v, mask_from=None):
     return (p / p.sum(-1, keepdims=True)) @ v
 
 
-@pytest.mark.parametrize("attn_variant", [0, 1])  # 0 = fp32 MFMA, 1 = bf16 matrix cores with the exact split
+@pytest.mark.parametrize("attn_variant", [0, 1, 2])  # 0 = fp32 MFMA; 1, 2 = bf16 matrix cores with the exact split (128 / 256 queries per block)
 @pytest.mark.parametrize("B,T,H", [(1, 64, 1), (2, 100, 2), (1, 1500, 6), (3, 333, 2)])
 def test_encoder_attention(eng, B, T, H, attn_variant):
     eng.set_option("attn_variant", attn_variant)
@@ -228,7 +228,7 @@ def test_encoder_attention(eng, B, T, H, attn_variant):
             assert np.abs(got - ref).max() < 2e-5, (b, h)
 
 
-@pytest.mark.parametrize("attn_variant", [0, 1])
+@pytest.mark.parametrize("attn_variant", [0, 1, 2])
 def test_encoder_attention_forces_rescale(eng, attn_variant):
     """Online softmax: spike one key late in the sequence so the running max jumps at a chosen
     tile (the rare branch), and check the FULL tensor against fp64."""

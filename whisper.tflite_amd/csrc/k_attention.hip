@@ -215,13 +215,18 @@ __device__ __forceinline__ bf16x8 as_bf16x8(const u32x4_t& v) { return __builtin
   ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF[1], BF[0], ACC, 0, 0, 0);                  \
   ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF[0], BF[0], ACC, 0, 0, 0);
 
-__global__ __launch_bounds__(256, 2) void encoder_attention_split(const float* __restrict__ qkv,
-                                                                  float* __restrict__ out, int T, int heads) {
+template <int NW>  // wavefronts per block = 32 queries each; the K/V tile staging is shared by all of them
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void encoder_attention_split(const float* __restrict__ qkv,
+                                                                                   float* __restrict__ out, int T,
+                                                                                   int heads) {
+  constexpr int AQS = NW * 32;      // queries per block
+  constexpr int PASSES = 8 / NW;    // staging passes per 64-key tile (NW * 64 threads)
+  constexpr int KROWS = 64 / PASSES, VPAIRS = 32 / PASSES;
   __shared__ __attribute__((aligned(16))) unsigned short Kp[3 * AK * SKLD];
   __shared__ __attribute__((aligned(16))) unsigned short Vt[3 * 64 * SVLD];
 
   const int d_model = heads * 64, ld = 3 * d_model;
-  const int q_blocks = (T + AQ - 1) / AQ;
+  const int q_blocks = (T + AQS - 1) / AQS;
   const int nb = gridDim.x, bid = blockIdx.x;
   const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7;
   const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
@@ -234,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void encoder_attention_split(const float* _
 
   // Q planes: lane (q = l31, half lh) holds Q[q][16c + 8lh + 0..7] for k-step c, pre-scaled by
   // d_head^-1/2 * log2(e) in fp32 (as the fp32 kernel does) and then split
-  const int q_row = qb * AQ + wid * 32 + l31;
+  const int q_row = qb * AQS + wid * 32 + l31;
   const int q_ld = q_row < T ? q_row : T - 1;
   const float qscale = 0.125f * 1.44269504088896340736f;
   bf16x8 qf[4][3];
@@ -261,19 +266,19 @@ __global__ __launch_bounds__(256, 2) void encoder_attention_split(const float* _
   const int vpair = tid >> 4, vdcol = (tid & 15) * 4;
   const float* kbase = base + d_model + kscol;
   const float* vbase = base + 2 * d_model + vdcol;
-  f32x4 rk[4], rv[4];
+  f32x4 rk[2 * PASSES], rv[2 * PASSES];
   auto load_tile = [&](int kt) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < PASSES; ++i) {
       // rows past T are loaded from row T - 1 and zeroed by a select (no divergent control flow)
-      const int key = kt * AK + ksrow + 32 * i;
+      const int key = kt * AK + ksrow + KROWS * i;
       const int kc = key < T ? key : T - 1;
       const float kz = key < T ? 1.0f : 0.0f;
       rk[2 * i] = *reinterpret_cast<const f32x4*>(kbase + (long)kc * ld) * kz;
       rk[2 * i + 1] = *reinterpret_cast<const f32x4*>(kbase + (long)kc * ld + 4) * kz;
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        const int vkey = kt * AK + 2 * (vpair + 16 * i) + e;
+        const int vkey = kt * AK + 2 * (vpair + VPAIRS * i) + e;
         const int vc = vkey < T ? vkey : T - 1;
         const float vz = vkey < T ? 1.0f : 0.0f;
         rv[2 * i + e] = *reinterpret_cast<const f32x4*>(vbase + (long)vc * ld) * vz;
@@ -282,21 +287,21 @@ __global__ __launch_bounds__(256, 2) void encoder_attention_split(const float* _
   };
   auto store_tile = [&]() {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < PASSES; ++i) {
       const float x[8] = {rk[2 * i][0], rk[2 * i][1], rk[2 * i][2], rk[2 * i][3],
                           rk[2 * i + 1][0], rk[2 * i + 1][1], rk[2 * i + 1][2], rk[2 * i + 1][3]};
       u32x4_t o[3];
       split8_planes(x, o);
 #pragma unroll
       for (int p = 0; p < 3; ++p)
-        *reinterpret_cast<u32x4_t*>(&Kp[p * AK * SKLD + (ksrow + 32 * i) * SKLD + kscol]) = o[p];
+        *reinterpret_cast<u32x4_t*>(&Kp[p * AK * SKLD + (ksrow + KROWS * i) * SKLD + kscol]) = o[p];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         unsigned w[3];
         split2_planes(rv[2 * i][e], rv[2 * i + 1][e], w);
 #pragma unroll
         for (int p = 0; p < 3; ++p)
-          *reinterpret_cast<unsigned*>(&Vt[p * 64 * SVLD + (vdcol + e) * SVLD + 2 * (vpair + 16 * i)]) = w[p];
+          *reinterpret_cast<unsigned*>(&Vt[p * 64 * SVLD + (vdcol + e) * SVLD + 2 * (vpair + VPAIRS * i)]) = w[p];
       }
     }
   };
@@ -565,8 +570,13 @@ void launch_encoder_attention(const float* qkv, float* out, int batch, int T, in
     hipLaunchKernelGGL(encoder_attention_f32, dim3(batch * heads * q_blocks), dim3(256), 0, s, qkv,
                        out, T, heads);
   } else {
-    hipLaunchKernelGGL(encoder_attention_split, dim3(batch * heads * q_blocks), dim3(256), 0, s, qkv,
-                       out, T, heads);
+    if (variant == 2) {  // 8 wavefronts = 256 queries per block
+      const int qb8 = (T + 255) / 256;
+      hipLaunchKernelGGL(encoder_attention_split<8>, dim3(batch * heads * qb8), dim3(512), 0, s, qkv, out, T, heads);
+    } else {
+      hipLaunchKernelGGL(encoder_attention_split<4>, dim3(batch * heads * q_blocks), dim3(256), 0, s, qkv,
+                         out, T, heads);
+    }
   }
 }
 
