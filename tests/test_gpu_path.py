@@ -339,3 +339,41 @@ def test_large_batch_runs_as_pipelined_sub_batches(tiny):
     b, _ = e.encdec_tokens_batch(mel[64:])
     assert np.array_equal(ids[:32], a) and np.array_equal(ids[64:], b)
     assert np.array_equal(ids[40], ids[3])
+
+
+def test_graph_replay_and_kernel_variants_keep_ids(tiny):
+    """Every kernel-selection option and the hipGraph replay of the decoder must leave the token
+    ids untouched: eager vs replayed launches, option changes between calls (new graphs are
+    captured per (batch, max_tokens, stop_at_eot, ...)), language changes (prompt data only),
+    fp32-MFMA vs bf16-split encoder kernels, decoder block shapes."""
+    e, _ = tiny
+    rng = np.random.default_rng(4242)
+    mel = rng.uniform(-1.0, 1.5, size=(5,) + e.mel_shape).astype(np.float32)
+    e.set_option("use_graphs", 0)
+    want = {}
+    for mt, lang in ((30, 2), (12, 2), (30, 0)):
+        e.set_option("max_tokens", mt)
+        e.set_option("language", lang)
+        want[(mt, lang)] = e.encdec_tokens_batch(mel)
+    e.set_option("use_graphs", 1)
+    for _ in range(3):  # first call: eager + capture, later calls: replay
+        for (mt, lang), (ids_w, n_w) in want.items():
+            e.set_option("max_tokens", mt)
+            e.set_option("language", lang)
+            ids, n = e.encdec_tokens_batch(mel)
+            assert np.array_equal(ids, ids_w) and np.array_equal(n, n_w), (mt, lang)
+    e.set_option("max_tokens", 30)
+    e.set_option("language", 2)
+    ids_w, n_w = want[(30, 2)]
+    assert not np.array_equal(want[(30, 0)][0], ids_w)  # the language id is part of the prompt
+    for key, values, restore in (("gemm_variant", (0, 4, 10, 13, 14, 15, 16), -1), ("attn_variant", (0, 2), 1),
+                                 ("resid_waves", (4, 8), 16), ("cross_chunks", (1, 2, 8), 4)):
+        for v in values:
+            e.set_option(key, v)
+            ids, n = e.encdec_tokens_batch(mel)
+            assert np.array_equal(ids, ids_w) and np.array_equal(n, n_w), (key, v)
+        e.set_option(key, restore)
+    with pytest.raises(Exception):
+        e.set_option("gemm_variant", 17)
+    with pytest.raises(Exception):
+        e.set_option("attn_variant", 3)
