@@ -121,13 +121,17 @@ int wt_transcribe_tokens_batch_dev(wt_engine* h, const float* d_pcm, int batch, 
                                    int32_t* n_ids);
 
 /* Pipelined form of the same path: submit enqueues encoder (one HIP stream) and decoder (one
- * of six further streams, in rotation) for one device-resident batch and returns at once;
+ * of three further streams, in rotation) for one device-resident batch and returns at once;
  * collect blocks until the OLDEST submitted batch has its ids on the host.  In steady state
  * the MFMA-bound encoder of the newest batch shares the chip with the latency/HBM-bound
  * decoder chains of the previous ones.  d_mel must stay valid until that batch is collected.
  * At most WT_PIPELINE_DEPTH uncollected submits; batch <= 64. */
 #define WT_PIPELINE_DEPTH 6
 int wt_pipeline_submit_dev(wt_engine* h, const float* d_mel, int batch);
+/* Same from device-resident PCM [batch][480000]: the log-mel front end (whisper.cpp:109-216) runs
+ * on the pipeline's encoder stream ahead of the encoder; d_pcm may be reused once the call returns
+ * only after the batch is collected. */
+int wt_pipeline_submit_pcm_dev(wt_engine* h, const float* d_pcm, int batch);
 int wt_pipeline_collect(wt_engine* h, int64_t* ids, int32_t* n_ids);
 
 /* Stage taps for parity tests: encoder output [B][n_audio_ctx][n_audio_state] and the

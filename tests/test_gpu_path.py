@@ -251,6 +251,16 @@ def test_pipeline_submit_collect_matches_sync(tiny):
             in_flight -= 1
         for k, (ids_g, n_g) in zip(order, got):
             assert np.array_equal(want[k][0], ids_g) and np.array_equal(want[k][1], n_g)
+    # the same pipeline fed with PCM: front end + encoder + decoder of a batch, batches overlapping
+    pcms = [synth_pcm("noise", 480000, 60 + i)[None].repeat(b, 0) * np.linspace(0.5, 1.0, b, dtype=np.float32)[:, None]
+            for i, b in enumerate((2, 3))]
+    want_pcm = [e.encdec_tokens_batch(e.logmel_batch(p)) for p in pcms]
+    dpcm = [Dev(np.ascontiguousarray(p, np.float32)) for p in pcms]
+    for k in (0, 1, 1, 0):
+        e.pipeline_submit_pcm_dev(dpcm[k].data_ptr(), pcms[k].shape[0])
+    for k in (0, 1, 1, 0):
+        ids_g, n_g = e.pipeline_collect()
+        assert np.array_equal(want_pcm[k][0], ids_g) and np.array_equal(want_pcm[k][1], n_g)
     # a seventh uncollected submit (WT_PIPELINE_DEPTH = 6) is refused, and so is a sync call with batches in flight
     for k in range(6):
         e.pipeline_submit_dev(dev[k % 4].data_ptr(), mels[k % 4].shape[0])

@@ -38,7 +38,7 @@ CAPI_SYMBOLS = [
     "wt_engine_create", "wt_engine_destroy", "wt_last_error", "wt_engine_dims",
     "wt_engine_set_option", "wt_engine_get_option", "wt_engine_set_prompt", "wt_transcribe_pcm", "wt_transcribe_long_pcm", "wt_transcribe_file",
     "wt_logmel_batch", "wt_logmel_batch_dev", "wt_encdec_tokens_batch",
-    "wt_encdec_tokens_batch_dev", "wt_transcribe_tokens_batch_dev", "wt_pipeline_submit_dev", "wt_pipeline_collect",
+    "wt_encdec_tokens_batch_dev", "wt_transcribe_tokens_batch_dev", "wt_pipeline_submit_dev", "wt_pipeline_submit_pcm_dev", "wt_pipeline_collect",
     "wt_encdec_debug_batch",
     "wt_last_timings", "wt_last_kernel_stats", "wt_decode_text", "wt_language_id", "wt_lang_code", "wt_wav_read_legacy",
     "wt_vocab_info", "wt_filters", "wt_write_synthetic_weights", "wt_write_synthetic_vocab",
@@ -108,6 +108,7 @@ def lib() -> ctypes.CDLL:
         L.wt_encdec_tokens_batch_dev.argtypes = [c_void_p, c_void_p, c_int, ip64, ip32]
         L.wt_transcribe_tokens_batch_dev.argtypes = [c_void_p, c_void_p, c_int, ip64, ip32]
         L.wt_pipeline_submit_dev.argtypes = [c_void_p, c_void_p, c_int]
+        L.wt_pipeline_submit_pcm_dev.argtypes = [c_void_p, c_void_p, c_int]
         L.wt_pipeline_collect.argtypes = [c_void_p, ip64, ip32]
         L.wt_encdec_debug_batch.argtypes = [c_void_p, fp, c_int, ip64, ip32, fp, fp, c_int]
         L.wt_last_timings.argtypes = [c_void_p, POINTER(Timings)]
@@ -283,6 +284,11 @@ class Engine:
 
     def pipeline_submit_dev(self, d_mel_ptr: int, batch: int) -> None:
         self._check(lib().wt_pipeline_submit_dev(self._h, c_void_p(d_mel_ptr), batch))
+        self._submitted = getattr(self, "_submitted", [])
+        self._submitted.append(batch)
+
+    def pipeline_submit_pcm_dev(self, d_pcm_ptr: int, batch: int) -> None:
+        self._check(lib().wt_pipeline_submit_pcm_dev(self._h, c_void_p(d_pcm_ptr), batch))
         self._submitted = getattr(self, "_submitted", [])
         self._submitted.append(batch)
 

@@ -215,6 +215,11 @@ int wt_pipeline_submit_dev(wt_engine* h, const float* d_mel, int batch) {
   return guarded(h, [&] { h->impl->submit(d_mel, batch); });
 }
 
+int wt_pipeline_submit_pcm_dev(wt_engine* h, const float* d_pcm, int batch) {
+  if (!h || !d_pcm) return WT_ERR_INVALID_ARG;
+  return guarded(h, [&] { h->impl->submit_pcm(d_pcm, batch); });
+}
+
 int wt_pipeline_collect(wt_engine* h, int64_t* ids, int32_t* n_ids) {
   if (!h || !ids || !n_ids) return WT_ERR_INVALID_ARG;
   return guarded(h, [&] { h->impl->collect(ids, n_ids); });

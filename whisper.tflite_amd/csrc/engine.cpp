@@ -736,6 +736,18 @@ void Engine::submit(const float* d_mel, int batch) {
   inflight_.push_back(last_enc_slot_);
 }
 
+void Engine::submit_pcm(const float* d_pcm, int batch) {
+  if (int(inflight_.size()) >= kSlots) throw Error(1, "pipeline is full (6 batches in flight): collect() first");
+  if (batch > 64) throw Error(1, "decoder batches are limited to 64 clips per call");
+  select_stream(true);
+  // one staging mel buffer: the front end of batch k+1 follows the encoder of batch k on the same stream
+  float* d_mel = staging_mel(batch);
+  logmel(d_pcm, batch, d_mel);
+  encode_enqueue(d_mel, batch);
+  decode_enqueue(batch, last_enc_slot_, nullptr, 0);
+  inflight_.push_back(last_enc_slot_);
+}
+
 void Engine::collect(int64_t* ids, int32_t* n_ids) {
   if (inflight_.empty()) throw Error(1, "collect() without a submitted batch");
   const int slot = inflight_.front();

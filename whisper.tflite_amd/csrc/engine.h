@@ -98,6 +98,8 @@ class Engine {
   // previous ones: a decoder's ~1000 tiny dependent launches leave most of the chip idle on
   // their own.  collect() waits for the OLDEST submitted batch.
   void submit(const float* d_mel, int batch);
+  // same from PCM: the front end runs on the pipeline's encoder stream into the staging mel buffer
+  void submit_pcm(const float* d_pcm, int batch);
   void collect(int64_t* ids, int32_t* n_ids);
   int in_flight() const { return int(inflight_.size()); }
   void sync();
