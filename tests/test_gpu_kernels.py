@@ -228,6 +228,23 @@ def test_encoder_attention(eng, B, T, H, attn_variant):
             assert np.abs(got - ref).max() < 2e-5, (b, h)
 
 
+def test_encoder_attention_bf16_mode(eng):
+    """attn_variant 3: q (scaled), k, v and the probabilities are rounded to bf16, accumulation is
+    fp32.  Against fp64 on the unrounded inputs the error is bf16-sized (8 significant bits)."""
+    rng = np.random.default_rng(31)
+    B, T, H = 1, 333, 2
+    qkv = rng.standard_normal((B * T, 3 * 64 * H)).astype(np.float32)
+    eng.set_option("attn_variant", 3)
+    out = eng.dbg_encoder_attention(qkv, B, T, H)
+    eng.set_option("attn_variant", 1)
+    q64 = qkv.astype(np.float64).reshape(B, T, 3, H, 64)
+    worst = 0.0
+    for h in range(H):
+        ref = attn_ref(q64[0, :, 0, h], q64[0, :, 1, h], q64[0, :, 2, h])
+        worst = max(worst, np.abs(out.reshape(B, T, H, 64)[0, :, h] - ref).max())
+    assert 1e-4 < worst < 3e-2
+
+
 @pytest.mark.parametrize("attn_variant", [0, 1, 2])
 def test_encoder_attention_forces_rescale(eng, attn_variant):
     """Online softmax: spike one key late in the sequence so the running max jumps at a chosen

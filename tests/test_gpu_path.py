@@ -302,8 +302,8 @@ def test_config3_second_weight_set_multilingual_prompt(pkg, assets, orc):
 
 def test_config4_base_dims_fp32(pkg, assets, orc):
     """BASELINE configs[3] shape (whisper-base: d 512, 8 heads, 6+6 layers) through the fp32
-    kernels against the oracle.  The bf16-MFMA variant named by that config is not built yet
-    (DESIGN.md §9): this pins the architecture generality of the fp32 path."""
+    kernels against the oracle (architecture generality of the default path; the bf16 compute mode
+    of that config is test_config4_base_dims_bf16_compute)."""
     prefix, vocab = assets("base", 0)
     e = pkg.Engine(prefix, vocab, True)
     e.set_option("stop_at_eot", 0)
@@ -317,6 +317,39 @@ def test_config4_base_dims_fp32(pkg, assets, orc):
     ids_ref, lg = m.decode_greedy(enc0, prompt_of(e), 30, -1, False, True, 16, True)
     assert np.abs(logits[0] - lg).max() < LOGIT_TOL
     assert list(ids[0, :31]) == list(ids_ref)
+    m.close()
+    e.close()
+
+
+def test_config4_base_dims_bf16_compute(pkg, assets, orc):
+    """BASELINE configs[3] (whisper-base, batch 64, bf16 compute with fp32 accumulate): encoder
+    contractions with operands rounded to bf16 (gemm_variant 11, attn_variant 3; storage and the
+    decoder stay fp32 this round).  bf16 has 8 significant bits, so the bar against the fp32 oracle
+    is the bf16 one: encoder output within 6e-2 absolute / 1e-2 rms (values are O(1)), and every
+    greedy step whose fp32 top-2 margin exceeds the logit error picks the oracle's token."""
+    prefix, vocab = assets("base", 0)
+    e = pkg.Engine(prefix, vocab, True)
+    e.set_option("stop_at_eot", 0)
+    rng = np.random.default_rng(43)
+    mel = rng.uniform(-1.0, 1.5, size=(64, 80, 3000)).astype(np.float32)
+    ids32, n32, enc32, lg32 = e.encdec_debug_batch(mel[:2])
+    e.set_option("gemm_variant", 11)
+    e.set_option("attn_variant", 3)
+    ids16, n16, enc16, lg16 = e.encdec_debug_batch(mel[:2])
+    m = orc.Model(prefix + ".wtw")
+    enc0 = m.encode(mel[0], 16)
+    err = enc16[0] - enc0
+    assert np.abs(err).max() < 6e-2 and np.sqrt((err ** 2).mean()) < 1e-2
+    assert np.abs(err).max() > 1e-4  # and it is not the fp32 path
+    # first argmax step: both runs see the same prefix
+    dl = np.abs(lg16[:, 0] - lg32[:, 0]).max()
+    top2 = np.sort(lg32[:, 0], axis=1)[:, -2:]
+    for b in range(2):
+        if top2[b, 1] - top2[b, 0] > 2 * dl:
+            assert ids16[b, 4] == ids32[b, 4]
+    # the full BASELINE batch (64 clips) runs in this mode: two pipelined sub-batches of 32
+    ids64, n64 = e.encdec_tokens_batch(mel)
+    assert np.array_equal(ids64[:2], ids16) and (n64 == 31).all()
     m.close()
     e.close()
 
@@ -386,4 +419,4 @@ def test_graph_replay_and_kernel_variants_keep_ids(tiny):
     with pytest.raises(Exception):
         e.set_option("gemm_variant", 17)
     with pytest.raises(Exception):
-        e.set_option("attn_variant", 3)
+        e.set_option("attn_variant", 4)

@@ -45,4 +45,24 @@ __device__ __forceinline__ void split2_planes(float lo, float hi, unsigned (&o)[
   o[2] = __builtin_amdgcn_perm(__float_as_uint(h2), __float_as_uint(l2), 0x07060302u);
 }
 
+// bf16 compute mode (BASELINE configs[3]): 8 values rounded to nearest-even bf16, one fragment
+__device__ __forceinline__ u32x4_t round8_bf16(const float (&x)[8]) {
+  u32x4_t o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    unsigned a = __float_as_uint(x[2 * j]), b = __float_as_uint(x[2 * j + 1]);
+    a += 0x7FFFu + ((a >> 16) & 1u);
+    b += 0x7FFFu + ((b >> 16) & 1u);
+    o[j] = __builtin_amdgcn_perm(b, a, 0x07060302u);
+  }
+  return o;
+}
+
+__device__ __forceinline__ unsigned round2_bf16(float lo, float hi) {
+  unsigned a = __float_as_uint(lo), b = __float_as_uint(hi);
+  a += 0x7FFFu + ((a >> 16) & 1u);
+  b += 0x7FFFu + ((b >> 16) & 1u);
+  return __builtin_amdgcn_perm(b, a, 0x07060302u);
+}
+
 }  // namespace wt

@@ -207,15 +207,20 @@ constexpr int SVLD = 68;  // V^T plane row stride (bf16): 136 B, conflict-free d
 
 __device__ __forceinline__ bf16x8 as_bf16x8(const u32x4_t& v) { return __builtin_bit_cast(bf16x8, v); }
 
+// NS = 3: six plane products; NS = 1 (bf16 compute mode): the single product of the rounded operands
 #define WT_SPLIT_PRODUCTS(ACC, AF, BF)                                                        \
-  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF[0], BF[2], ACC, 0, 0, 0);                  \
+  if (NS == 1) {                                                                              \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF[0], BF[0], ACC, 0, 0, 0);                \
+  } else {                                                                                    \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF[0], BF[NS - 1], ACC, 0, 0, 0);             \
   ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF[1], BF[1], ACC, 0, 0, 0);                  \
-  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF[2], BF[0], ACC, 0, 0, 0);                  \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF[NS - 1], BF[0], ACC, 0, 0, 0);             \
   ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF[0], BF[1], ACC, 0, 0, 0);                  \
   ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF[1], BF[0], ACC, 0, 0, 0);                  \
-  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF[0], BF[0], ACC, 0, 0, 0);
+  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF[0], BF[0], ACC, 0, 0, 0);                  \
+  }
 
-template <int NW>  // wavefronts per block = 32 queries each; the K/V tile staging is shared by all of them
+template <int NW, int NS>  // NW wavefronts per block = 32 queries each, sharing the K/V tile staging; NS planes
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void encoder_attention_split(const float* __restrict__ qkv,
                                                                                    float* __restrict__ out, int T,
                                                                                    int heads) {
@@ -237,6 +242,20 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void encoder_attention_sp
   const int l31 = lane & 31, lh = lane >> 5;
   const float* base = qkv + (long)b * T * ld + h * 64;
 
+  auto planes8 = [](const float (&x)[8], u32x4_t (&o)[3]) {
+    if (NS == 1) {
+      o[0] = round8_bf16(x);
+    } else {
+      split8_planes(x, o);
+    }
+  };
+  auto planes2 = [](float lo, float hi, unsigned (&w)[3]) {
+    if (NS == 1) {
+      w[0] = round2_bf16(lo, hi);
+    } else {
+      split2_planes(lo, hi, w);
+    }
+  };
   // Q planes: lane (q = l31, half lh) holds Q[q][16c + 8lh + 0..7] for k-step c, pre-scaled by
   // d_head^-1/2 * log2(e) in fp32 (as the fp32 kernel does) and then split
   const int q_row = qb * AQS + wid * 32 + l31;
@@ -250,9 +269,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void encoder_attention_sp
     const float x[8] = {a[0] * qscale, a[1] * qscale, a[2] * qscale, a[3] * qscale,
                         bq[0] * qscale, bq[1] * qscale, bq[2] * qscale, bq[3] * qscale};
     u32x4_t o[3];
-    split8_planes(x, o);
+    planes8(x, o);
 #pragma unroll
-    for (int p = 0; p < 3; ++p) qf[c][p] = as_bf16x8(o[p]);
+    for (int p = 0; p < NS; ++p) qf[c][p] = as_bf16x8(o[p]);
   }
 
   f32x16 o0, o1;  // O^T tiles: d in [0,32) and [32,64)
@@ -291,16 +310,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void encoder_attention_sp
       const float x[8] = {rk[2 * i][0], rk[2 * i][1], rk[2 * i][2], rk[2 * i][3],
                           rk[2 * i + 1][0], rk[2 * i + 1][1], rk[2 * i + 1][2], rk[2 * i + 1][3]};
       u32x4_t o[3];
-      split8_planes(x, o);
+      planes8(x, o);
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
+      for (int p = 0; p < NS; ++p)
         *reinterpret_cast<u32x4_t*>(&Kp[p * AK * SKLD + (ksrow + KROWS * i) * SKLD + kscol]) = o[p];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         unsigned w[3];
-        split2_planes(rv[2 * i][e], rv[2 * i + 1][e], w);
+        planes2(rv[2 * i][e], rv[2 * i + 1][e], w);
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < NS; ++p)
           *reinterpret_cast<unsigned*>(&Vt[p * 64 * SVLD + (vdcol + e) * SVLD + 2 * (vpair + VPAIRS * i)]) = w[p];
       }
     }
@@ -321,7 +340,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void encoder_attention_sp
     for (int c = 0; c < 4; ++c) {
       bf16x8 k0[3], k1[3];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) {
+      for (int p = 0; p < NS; ++p) {
         k0[p] = *reinterpret_cast<const bf16x8*>(&Kp[p * AK * SKLD + l31 * SKLD + 16 * c + 8 * lh]);
         k1[p] = *reinterpret_cast<const bf16x8*>(&Kp[p * AK * SKLD + (32 + l31) * SKLD + 16 * c + 8 * lh]);
       }
@@ -369,14 +388,14 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void encoder_attention_sp
         const float pv[8] = {sp[8 * s2], sp[8 * s2 + 1], sp[8 * s2 + 2], sp[8 * s2 + 3],
                              sp[8 * s2 + 4], sp[8 * s2 + 5], sp[8 * s2 + 6], sp[8 * s2 + 7]};
         u32x4_t po[3];
-        split8_planes(pv, po);
+        planes8(pv, po);
         bf16x8 pf[3];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) pf[p] = as_bf16x8(po[p]);
+        for (int p = 0; p < NS; ++p) pf[p] = as_bf16x8(po[p]);
         const int key0 = hf * 32 + 16 * s2 + 4 * lh;
         bf16x8 v0[3], v1[3];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NS; ++p) {
           const unsigned short* r0 = &Vt[p * 64 * SVLD + l31 * SVLD + key0];
           const unsigned short* r1 = &Vt[p * 64 * SVLD + (32 + l31) * SVLD + key0];
           const u32x2 a0 = *reinterpret_cast<const u32x2*>(r0), a1 = *reinterpret_cast<const u32x2*>(r0 + 8);
@@ -572,9 +591,12 @@ void launch_encoder_attention(const float* qkv, float* out, int batch, int T, in
   } else {
     if (variant == 2) {  // 8 wavefronts = 256 queries per block
       const int qb8 = (T + 255) / 256;
-      hipLaunchKernelGGL(encoder_attention_split<8>, dim3(batch * heads * qb8), dim3(512), 0, s, qkv, out, T, heads);
+      hipLaunchKernelGGL((encoder_attention_split<8, 3>), dim3(batch * heads * qb8), dim3(512), 0, s, qkv, out, T, heads);
+    } else if (variant == 3) {  // bf16 compute mode: operands and probabilities rounded to bf16
+      hipLaunchKernelGGL((encoder_attention_split<4, 1>), dim3(batch * heads * q_blocks), dim3(256), 0, s, qkv,
+                         out, T, heads);
     } else {
-      hipLaunchKernelGGL(encoder_attention_split<4>, dim3(batch * heads * q_blocks), dim3(256), 0, s, qkv,
+      hipLaunchKernelGGL((encoder_attention_split<4, 3>), dim3(batch * heads * q_blocks), dim3(256), 0, s, qkv,
                          out, T, heads);
     }
   }
