@@ -157,7 +157,7 @@ def main() -> None:
     ap.add_argument("--no-pipeline", action="store_true",
                     help="synchronous steps (encoder then decoder) instead of the two-deep pipeline")
     ap.add_argument("--depth", type=int, default=5, choices=tuple(range(1, 7)), help="batches in flight (pipelined mode)")
-    ap.add_argument("--attn-variant", type=int, default=None, choices=(0, 1, 2, 3))
+    ap.add_argument("--attn-variant", type=int, default=None, choices=(0, 1, 2, 3, 4))
     ap.add_argument("--cross-chunks", type=int, default=None, choices=(1, 2, 4, 8))
     ap.add_argument("--resid-waves", type=int, default=None, choices=(4, 8, 16))
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the extra fp32-MFMA-only measurement")
@@ -326,8 +326,21 @@ def main() -> None:
                     "ms_per_step": round(1e3 * dt / 10, 3),
                     "ids_match_split_path": bool(np.array_equal(ids32, ids) and np.array_equal(n32, n)),
                     "what": "gemm_variant=0 (gemm_f32_tile), attn_variant=0 (encoder_attention_f32): v_mfma_f32_32x32x2_f32 only"}
-        eng.set_option("gemm_variant", -1)
+        # and on the bf16 three-plane split kernels (full fp32 operand range)
+        eng.set_option("gemm_variant", 16)
         eng.set_option("attn_variant", 1)
+        run_steps(3)
+        fence()
+        t1 = time.perf_counter()
+        ids3, n3, _ = run_steps(20)
+        fence()
+        dt = time.perf_counter() - t1
+        fp32_leg["bf16x3_split"] = {"value": round(world * B * 20 * CLIP_SECONDS / dt, 1), "steps": 20,
+                                    "ms_per_step": round(1e3 * dt / 20, 3),
+                                    "ids_match": bool(np.array_equal(ids3, ids) and np.array_equal(n3, n)),
+                                    "what": "gemm_variant=16, attn_variant=1: three bf16 planes, six products"}
+        eng.set_option("gemm_variant", -1)
+        eng.set_option("attn_variant", 4)
 
     # second number of SURVEY 8(d): the same pipeline fed with device-resident PCM, i.e. with the log-mel
     # front end (whisper.cpp:109-216) inside every step; PCM ~ N(0, 0.1^2) clipped to [-1, 1]
@@ -393,18 +406,21 @@ def main() -> None:
                 mfma = v["flops"] > 0
                 ach = (v["flops"] / 1e12 if mfma else v["bytes"] / 1e9) / (v["ms"] * 1e-3)
                 split = mfma and "split" in name and "(bf16)" not in name
-                # split kernels spend six bf16 MFMA FLOPs per algorithmic fp32 FLOP (three exact
-                # bf16 planes per operand): their MFMA ceiling in algorithmic FLOP/s is the dense
-                # bf16 peak / 6; fp32-MFMA kernels are priced against the fp32 MFMA peak
-                peak = (round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1) if split else PEAK_F32_MFMA_TFLOPS) if mfma else PEAK_HBM_GBPS
+                # split kernels spend 3 (two fp16 planes per operand, the default) or 6 (three bf16
+                # planes) 16-bit MFMA FLOPs per algorithmic fp32 FLOP: their MFMA ceiling in algorithmic
+                # FLOP/s is the dense f16/bf16 peak / products; fp32-MFMA kernels are priced against
+                # the fp32 MFMA peak
+                gv, av = eng.get_option("gemm_variant"), eng.get_option("attn_variant")
+                products = (3 if av == 4 else 6) if "attention" in name else (3 if gv in (-1, 17, 18) else 6)
+                peak = (round(PEAK_BF16_MFMA_TFLOPS / products, 1) if split else PEAK_F32_MFMA_TFLOPS) if mfma else PEAK_HBM_GBPS
                 det[name] = {"bound": "mfma" if mfma else "hbm", "achieved": round(ach, 2), "peak": peak,
                              "unit": "TFLOP/s" if mfma else "GB/s", "frac": round(ach / peak, 4),
                              "avg_launch_us": round(1e3 * v["ms"] / v["launches"], 2),
                              "launches_per_step": v["launches"] // steps,
                              "ms_per_step": round(v["ms"] / steps, 4)}
                 if split:
-                    det[name].update({"peak_is": "dense bf16 MFMA peak 2500 TFLOP/s / 6 plane products",
-                                      "executed_bf16_tflops": round(6 * ach, 1),
+                    det[name].update({"peak_is": f"dense f16/bf16 MFMA peak 2500 TFLOP/s / {products} plane products",
+                                      "executed_16bit_tflops": round(products * ach, 1),
                                       "vs_fp32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4)})
             return det
 
@@ -426,7 +442,7 @@ def main() -> None:
                 pass
             roof = {"kernel": dom, "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"],
                     "unit": d["unit"], "frac": d["frac"], "traffic": traffic, "traffic_source": traffic_src,
-                    **{k: d[k] for k in ("peak_is", "executed_bf16_tflops", "vs_fp32_mfma_peak") if k in d},
+                    **{k: d[k] for k in ("peak_is", "executed_16bit_tflops", "vs_fp32_mfma_peak") if k in d},
                     "algorithmic_flops_per_launch": int(kstats[dom]["flops"] / max(1, kstats[dom]["launches"])),
                     "avg_launch_us": d["avg_launch_us"]}
         # decoder phase against HBM: algorithmic bytes per step of this batch
@@ -447,16 +463,17 @@ def main() -> None:
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 (bf16x3-split MFMA, f32 accumulate)" if eng.get_option("gemm_variant") < 0 else "f32",
+            "dtype": "f32 (fp16x2-split MFMA, f32 accumulate)" if eng.get_option("gemm_variant") < 0 else "f32",
             "data": "synthetic",
             "config": {"workload": f"whisper-{args.arch} batch={B}x30s synthetic mel U(-1,1.5), fp32, random-init "
                                    "weights (BASELINE.json configs[1]); mel resident in HBM -> token ids on host",
                        "clips_per_gpu": B, "global_batch": world * B, "decoder_positions": 30,
                        "argmax_steps": 27, "parallelism": f"clip-parallel dp{world}, one RCCL all_gather of id records per {GATHER_EVERY} batches",
                        "pipelined": pipelined, "batches_in_flight": args.depth if pipelined else 1,
-                       "compute": "encoder GEMMs and attention: fp32 operands split exactly into 3 bf16 planes, 6 "
-                                  "bf16-MFMA products, fp32 accumulate (error = fp32-MFMA kernel's, tests/"
-                                  "test_gpu_kernels.py); decoder: fp32 MFMA; no value leaves fp32 storage"},
+                       "compute": "encoder GEMMs and attention: fp32 operands split into 2 fp16 planes (22 significand "
+                                  "bits), 3 fp16-MFMA products, fp32 accumulate (measured error below the fp32-MFMA "
+                                  "kernel's, tests/test_gpu_kernels.py; bf16 x3 split and fp32 MFMA selectable); "
+                                  "decoder: fp32 MFMA; no value leaves fp32 storage"},
             "roofline": roof,
             "roofline_detail": detail,
             "roofline_isolated": rooflines(iso, 2) if iso else None,

@@ -35,7 +35,8 @@ def test_gemm_plain(eng, M, N, K):
 
 
 GEMM_VARIANTS = {0: "fp32 MFMA 128x128", 4: "fp32 MFMA 64x128", 10: "bf16x3 split k32", 13: "bf16x3 split k16",
-                 14: "bf16x3 split k16 interleaved"}
+                 14: "bf16x3 split k16 interleaved", 16: "bf16x3 split k16, 2 blocks/CU", 17: "fp16x2 split k16",
+                 18: "fp16x2 split k16, 2 blocks/CU"}
 
 
 @pytest.fixture
@@ -58,8 +59,11 @@ def test_gemm_variants_have_fp32_error(eng, gemm_variant, variant):
         W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
         ref = A.astype(np.float64) @ W.astype(np.float64).T
         assert rel_err(eng.dbg_gemm(A, W), ref) < 2e-6, (variant, M, N, K)
-    A = (rng.standard_normal((256, 256)) * 10.0 ** rng.uniform(-6, 6, (256, 256))).astype(np.float32)
-    W = (rng.standard_normal((128, 256)) * 10.0 ** rng.uniform(-6, 6, (128, 256))).astype(np.float32)
+    # 12 decades for the fp32-MFMA and bf16 three-plane kernels; the two-plane fp16 kernels (17, 18) cover
+    # fp16's range by construction: |activation| < 65504, |weight| < 1023, documented in bf16_split.h
+    lo, hi = (-6, 6) if variant < 17 else (-6, 2)
+    A = (rng.standard_normal((256, 256)) * 10.0 ** rng.uniform(lo, hi, (256, 256))).astype(np.float32)
+    W = (rng.standard_normal((128, 256)) * 10.0 ** rng.uniform(lo, hi, (128, 256))).astype(np.float32)
     ref = A.astype(np.float64) @ W.astype(np.float64).T
     bound = np.abs(A.astype(np.float64)) @ np.abs(W.astype(np.float64)).T  # sum |a||b|: the fp32 error scale
     assert (np.abs(eng.dbg_gemm(A, W) - ref) / bound).max() < 1.5e-6, variant  # fp32 accumulation over K = 256
@@ -72,9 +76,10 @@ def test_gemm_split_and_fp32_mfma_agree_to_rounding(eng, gemm_variant):
     W = (rng.standard_normal((384, 384)) / 20).astype(np.float32)
     gemm_variant(0)
     C0 = eng.dbg_gemm(A, W)
-    gemm_variant(14)
-    C1 = eng.dbg_gemm(A, W)
-    assert np.abs(C0 - C1).max() < 4e-6 * np.abs(C0).max()
+    for v in (14, 17):
+        gemm_variant(v)
+        C1 = eng.dbg_gemm(A, W)
+        assert np.abs(C0 - C1).max() < 4e-6 * np.abs(C0).max(), v
 
 
 def test_gemm_bf16_mode_matches_bf16_rounded_operands(eng, gemm_variant):
@@ -211,7 +216,7 @@ def attn_ref(q, k, v, mask_from=None):
     return (p / p.sum(-1, keepdims=True)) @ v
 
 
-@pytest.mark.parametrize("attn_variant", [0, 1, 2])  # 0 = fp32 MFMA; 1, 2 = bf16 matrix cores with the exact split (128 / 256 queries per block)
+@pytest.mark.parametrize("attn_variant", [0, 1, 2, 4])  # 0 = fp32 MFMA; 1, 2 = bf16 x3 split (128 / 256 queries per block); 4 = fp16 x2 split
 @pytest.mark.parametrize("B,T,H", [(1, 64, 1), (2, 100, 2), (1, 1500, 6), (3, 333, 2)])
 def test_encoder_attention(eng, B, T, H, attn_variant):
     eng.set_option("attn_variant", attn_variant)
@@ -219,7 +224,7 @@ def test_encoder_attention(eng, B, T, H, attn_variant):
     d = 64 * H
     qkv = rng.standard_normal((B * T, 3 * d)).astype(np.float32)
     out = eng.dbg_encoder_attention(qkv, B, T, H)
-    eng.set_option("attn_variant", 1)
+    eng.set_option("attn_variant", 4)
     q64 = qkv.astype(np.float64).reshape(B, T, 3, H, 64)
     for b in range(B):
         for h in range(H):
@@ -236,7 +241,7 @@ def test_encoder_attention_bf16_mode(eng):
     qkv = rng.standard_normal((B * T, 3 * 64 * H)).astype(np.float32)
     eng.set_option("attn_variant", 3)
     out = eng.dbg_encoder_attention(qkv, B, T, H)
-    eng.set_option("attn_variant", 1)
+    eng.set_option("attn_variant", 4)
     q64 = qkv.astype(np.float64).reshape(B, T, 3, H, 64)
     worst = 0.0
     for h in range(H):
@@ -245,7 +250,7 @@ def test_encoder_attention_bf16_mode(eng):
     assert 1e-4 < worst < 3e-2
 
 
-@pytest.mark.parametrize("attn_variant", [0, 1, 2])
+@pytest.mark.parametrize("attn_variant", [0, 1, 2, 4])
 def test_encoder_attention_forces_rescale(eng, attn_variant):
     """Online softmax: spike one key late in the sequence so the running max jumps at a chosen
     tile (the rare branch), and check the FULL tensor against fp64."""
@@ -256,7 +261,7 @@ def test_encoder_attention_forces_rescale(eng, attn_variant):
     qkv[120, 64:128] = qkv[11, 0:64] * 4.0
     eng.set_option("attn_variant", attn_variant)
     out = eng.dbg_encoder_attention(qkv, B, T, H)
-    eng.set_option("attn_variant", 1)
+    eng.set_option("attn_variant", 4)
     q = qkv.astype(np.float64)
     ref = attn_ref(q[:, 0:64], q[:, 64:128], q[:, 128:192])
     assert np.abs(out - ref).max() < 2e-5

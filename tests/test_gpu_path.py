@@ -354,6 +354,28 @@ def test_config4_base_dims_bf16_compute(pkg, assets, orc):
     e.close()
 
 
+def test_operand_outside_fp16_range_is_reported_not_hidden(tiny):
+    """The default encoder contractions split fp32 operands into two fp16 planes: an activation above
+    65504 cannot be represented.  The engine must then fail loudly (non-finite encoder output ->
+    error), and the bf16 three-plane kernels (full fp32 range) must still transcribe the clip."""
+    e, _ = tiny
+    rng = np.random.default_rng(5)
+    mel = rng.uniform(-1.0, 1.5, size=(2,) + e.mel_shape).astype(np.float32)
+    ids_ok, n_ok = e.encdec_tokens_batch(mel)
+    mel_big = mel.copy()
+    mel_big[1, 40, 1000:1010] = 1.0e5
+    with pytest.raises(Exception, match="non-finite"):
+        e.encdec_tokens_batch(mel_big)
+    e.set_option("gemm_variant", 16)
+    e.set_option("attn_variant", 1)
+    ids_b, n_b = e.encdec_tokens_batch(mel_big)
+    assert np.array_equal(ids_b[0], ids_ok[0]) and n_b[0] == n_ok[0]  # the clean clip of the batch is untouched
+    e.set_option("gemm_variant", -1)
+    e.set_option("attn_variant", 4)
+    ids2, n2 = e.encdec_tokens_batch(mel)  # and the engine keeps working after the error
+    assert np.array_equal(ids2, ids_ok) and np.array_equal(n2, n_ok)
+
+
 def test_long_audio_windows_and_language(tiny):
     """SURVEY §8 f2: audio longer than 30 s is cut into windows that are transcribed as one batch;
     every window's text equals the single-clip call on that window."""
@@ -409,7 +431,7 @@ def test_graph_replay_and_kernel_variants_keep_ids(tiny):
     e.set_option("language", 2)
     ids_w, n_w = want[(30, 2)]
     assert not np.array_equal(want[(30, 0)][0], ids_w)  # the language id is part of the prompt
-    for key, values, restore in (("gemm_variant", (0, 4, 10, 13, 14, 15, 16), -1), ("attn_variant", (0, 2), 1),
+    for key, values, restore in (("gemm_variant", (0, 4, 10, 13, 14, 15, 16, 17, 18), -1), ("attn_variant", (0, 1, 2), 4),
                                  ("resid_waves", (4, 8), 16), ("cross_chunks", (1, 2, 8), 4)):
         for v in values:
             e.set_option(key, v)
@@ -417,6 +439,6 @@ def test_graph_replay_and_kernel_variants_keep_ids(tiny):
             assert np.array_equal(ids, ids_w) and np.array_equal(n, n_w), (key, v)
         e.set_option(key, restore)
     with pytest.raises(Exception):
-        e.set_option("gemm_variant", 17)
+        e.set_option("gemm_variant", 19)
     with pytest.raises(Exception):
-        e.set_option("attn_variant", 4)
+        e.set_option("attn_variant", 5)

@@ -45,6 +45,32 @@ __device__ __forceinline__ void split2_planes(float lo, float hi, unsigned (&o)[
   o[2] = __builtin_amdgcn_perm(__float_as_uint(h2), __float_as_uint(l2), 0x07060302u);
 }
 
+// Two-plane fp16 split: x*scale = h1 + h2 + r with h1 = fp16(x*scale) and h2 = fp16(x*scale - h1), both
+// round-to-nearest; 22 significand bits are kept (|r| <= 2^-23 |x|, against 2^-25 for fp32 itself),
+// and a.b = a1b1 + a1b2 + a2b1 + O(2^-22 |a||b|): three fp16 MFMA products instead of six bf16 ones.
+// `scale` is a power of two chosen by the caller so that the operand sits inside fp16's normal range
+// (6.1e-5 .. 65504; |x*scale| above 65504 overflows to infinity — bf16_split3 has no such limit).
+__device__ __forceinline__ void split8_f16x2(const float (&x)[8], float scale, u32x4_t (&o)[3]) {
+  using half2_t = __attribute__((ext_vector_type(2))) _Float16;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float a = x[2 * j] * scale, b = x[2 * j + 1] * scale;
+    const _Float16 ha = (_Float16)a, hb = (_Float16)b;
+    const _Float16 la = (_Float16)(a - (float)ha), lb = (_Float16)(b - (float)hb);
+    o[0][j] = __builtin_bit_cast(unsigned, half2_t{ha, hb});
+    o[1][j] = __builtin_bit_cast(unsigned, half2_t{la, lb});
+  }
+}
+
+__device__ __forceinline__ void split2_f16x2(float lo, float hi, float scale, unsigned (&o)[3]) {
+  using half2_t = __attribute__((ext_vector_type(2))) _Float16;
+  const float a = lo * scale, b = hi * scale;
+  const _Float16 ha = (_Float16)a, hb = (_Float16)b;
+  const _Float16 la = (_Float16)(a - (float)ha), lb = (_Float16)(b - (float)hb);
+  o[0] = __builtin_bit_cast(unsigned, half2_t{ha, hb});
+  o[1] = __builtin_bit_cast(unsigned, half2_t{la, lb});
+}
+
 // bf16 compute mode (BASELINE configs[3]): 8 values rounded to nearest-even bf16, one fragment
 __device__ __forceinline__ u32x4_t round8_bf16(const float (&x)[8]) {
   u32x4_t o;

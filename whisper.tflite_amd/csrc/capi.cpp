@@ -119,7 +119,7 @@ int wt_engine_set_option(wt_engine* h, const char* key, long value) {
     if (value != 1 && value != 2 && value != 4 && value != 8) return fail(h, WT_ERR_INVALID_ARG, "cross_chunks must be 1, 2, 4 or 8");
     e.cross_chunks = value;
   } else if (k == "attn_variant") {
-    if (value < 0 || value > 3) return fail(h, WT_ERR_INVALID_ARG, "attn_variant must be 0 (fp32 MFMA), 1 or 2 (bf16 split, 128 / 256 queries per block) or 3 (bf16 operands)");
+    if (value < 0 || value > 4) return fail(h, WT_ERR_INVALID_ARG, "attn_variant must be 0 (fp32 MFMA), 1 or 2 (bf16 x3 split, 128 / 256 queries per block), 3 (bf16 operands) or 4 (fp16 x2 split)");
     e.attn_variant = value;
   } else if (k == "resid_waves") {
     if (value != 4 && value != 8 && value != 16) return fail(h, WT_ERR_INVALID_ARG, "resid_waves must be 4, 8 or 16");
@@ -127,7 +127,7 @@ int wt_engine_set_option(wt_engine* h, const char* key, long value) {
   } else if (k == "use_graphs") {
     e.use_graphs = value != 0;
   } else if (k == "gemm_variant") {
-    if (value < -1 || value > 16) return fail(h, WT_ERR_INVALID_ARG, "gemm_variant must be in [-1, 16]");
+    if (value < -1 || value > 18) return fail(h, WT_ERR_INVALID_ARG, "gemm_variant must be in [-1, 18]");
     e.gemm_variant = value;
   } else {
     return fail(h, WT_ERR_INVALID_ARG, "unknown option: " + k);

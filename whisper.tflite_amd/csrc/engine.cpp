@@ -375,6 +375,9 @@ Engine::Engine(const std::string& model_prefix, const std::string& vocab_path, b
     }
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&sl.h_ids), 4096 * 32 * sizeof(long long), hipHostMallocDefault));
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&sl.h_n), 4096 * sizeof(int), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&sl.h_flag), sizeof(int), hipHostMallocDefault));
+    *sl.h_flag = 0;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&sl.d_flag), sizeof(int)));
   }
   upload_weights(model_prefix + ".wtw");
   if (vocab_.n_vocab != dims_.n_vocab && verbose) {
@@ -402,6 +405,8 @@ Engine::~Engine() {
     for (auto& e : sl.dt_events) (void)hipEventDestroy(e);
     if (sl.h_ids) (void)hipHostFree(sl.h_ids);
     if (sl.h_n) (void)hipHostFree(sl.h_n);
+    if (sl.h_flag) (void)hipHostFree(sl.h_flag);
+    if (sl.d_flag) (void)hipFree(sl.d_flag);
   }
   if (ev_switch_) (void)hipEventDestroy(ev_switch_);
   if (trace_base_) (void)hipEventDestroy(trace_base_);
@@ -535,6 +540,7 @@ void Engine::logmel(const float* d_pcm, int batch, float* d_mel) {
   g.N = dft_n;
   g.K = dft_k;
   g.ldc = dft_n;
+  g.variant = gemm_variant >= 0 ? int(gemm_variant) : 13;  // full fp32 range: the power spectrum exceeds fp16's
   launch_gemm(g, 0, stream_);
   launch_power_fold(ws_.spec, dft_n, dft_im_off, ws_.pw, mel_k, 400, M, stream_);
   GemmArgs m;
@@ -546,6 +552,7 @@ void Engine::logmel(const float* d_pcm, int batch, float* d_mel) {
   m.N = mel_n;
   m.K = mel_k;
   m.ldc = mel_n;
+  m.variant = gemm_variant >= 0 ? int(gemm_variant) : 13;
   launch_gemm(m, 0, stream_);
   HIPCHK(hipMemsetAsync(ws_.clip_max, 0, sizeof(unsigned) * batch, stream_));
   launch_log_clipmax(ws_.melacc, mel_n, d_mel, ws_.clip_max, batch, dims_.n_mels, int(T0), stream_);
@@ -579,7 +586,7 @@ void Engine::resolve_kernel_stats(int slot) {
   Slot& sl = slots_[slot];
   // class names = the kernels the current options select (what rocprofv3 lists)
   const long gv = gemm_variant;
-  kstats_[kKcGemm].name = gv < 0 || (gv >= 13 && gv <= 16) ? "gemm_split16_tile"
+  kstats_[kKcGemm].name = gv < 0 || (gv >= 13 && gv <= 18) ? "gemm_split16_tile"
                           : gv == 10 || gv == 12         ? "gemm_split_tile"
                           : gv == 11                     ? "gemm_split_tile(bf16)"
                                                          : "gemm_f32_tile";
@@ -618,6 +625,7 @@ void Engine::encode_enqueue(const float* d_mel, int batch) {
     HIPCHK(hipEventCreate(&trace_base_));
     HIPCHK(hipEventRecord(trace_base_, stream_));
   }
+  HIPCHK(hipMemsetAsync(slot.d_flag, 0, sizeof(int), stream_));
   HIPCHK(hipEventRecord(slot.enc_begin, stream_));
   kt_begin(kKcTranspose, 0, 2.0 * batch * c.n_mels * T0 * 4);
   launch_mel_transpose(d_mel, ws_.melT, batch, c.n_mels, T0, stream_);
@@ -697,7 +705,8 @@ void Engine::encode_enqueue(const float* d_mel, int batch) {
     kt_end();
   }
   kt_begin(kKcLayerNorm, 0, 2.0 * M * d * 4);
-  launch_layernorm(ws_.x, ws_.enc_out, enc_ln_post_g, enc_ln_post_b, M, d, stream_);
+  launch_layernorm(ws_.x, ws_.enc_out, enc_ln_post_g, enc_ln_post_b, M, d, stream_, slot.d_flag);
+  HIPCHK(hipMemcpyAsync(slot.h_flag, slot.d_flag, sizeof(int), hipMemcpyDeviceToHost, stream_));
   kt_end();
   HIPCHK(hipEventRecord(slot.enc_mid, stream_));
   {
@@ -967,6 +976,12 @@ void Engine::decode_collect(int slot_idx, int64_t* ids, int32_t* n_ids) {
   Slot& slot = slots_[slot_idx];
   HIPCHK(hipEventSynchronize(slot.dec_done));
   HIPCHK(hipGetLastError());
+  if (*slot.h_flag != 0) {
+    *slot.h_flag = 0;
+    throw Error(5, "non-finite encoder output: an operand left the fp16 range of the default contraction kernels "
+                   "(|activation| > 65504 or |weight| > 1023) or the input holds NaN/Inf; gemm_variant 16 and "
+                   "attn_variant 1 (bf16 three-plane split) have the full fp32 range");
+  }
   const int batch = slot.batch, stride = 32;
   for (int b = 0; b < batch; ++b) {
     n_ids[b] = slot.h_n[b];

@@ -73,7 +73,7 @@ class Engine {
   long stop_at_eot = 1;
   long verbose = 0;
   long cross_chunks = 4;
-  long attn_variant = 1;  // encoder attention: 0 = fp32 MFMA, 1 = bf16 matrix cores with the exact split
+  long attn_variant = 4;  // encoder attention: 0 = fp32 MFMA, 1/2 = bf16 x3 split, 3 = bf16 operands, 4 = fp16 x2 split
   long resid_waves = 16;  // wavefronts per block of the decoder's residual GEMMs (4, 8, 16)
   long use_graphs = 1;  // replay the decoder's launch sequence from a captured hipGraph
   long gemm_variant = -1;  // encoder GEMM tile variant (k_gemm.hip); -1 = per-shape choice
@@ -134,9 +134,9 @@ class Engine {
   hipStream_t stream_full_ = nullptr, stream_masked_ = nullptr;
   hipEvent_t ev_switch_ = nullptr;
   void select_stream(bool pipelined);
-  // default GEMM: the k16 split kernel, at 2 blocks per CU when decoders share the chip (pipelined),
-  // at 3 blocks per CU otherwise
-  int enc_gemm_variant() const { return gemm_variant >= 0 ? int(gemm_variant) : (stream_ == stream_masked_ && stream_masked_ ? 16 : 13); }
+  // default encoder GEMM: the k16 split kernel in its two-plane fp16 form, at 2 blocks per CU when decoders
+  // share the chip (pipelined), at 3 blocks per CU otherwise
+  int enc_gemm_variant() const { return gemm_variant >= 0 ? int(gemm_variant) : (stream_ == stream_masked_ && stream_masked_ ? 18 : 17); }
   void encode_enqueue(const float* d_mel, int batch);
   static constexpr int kDecStreams = 8, kSlots = 6;  // slots: a multiple of the 3 decoder streams in use, so
                                                      // batches rotate evenly over them (WT_PIPELINE_DEPTH)
@@ -150,6 +150,7 @@ class Engine {
     hipEvent_t dec_begin = nullptr, dec_done = nullptr;
     long long* h_ids = nullptr;  // pinned [4096][32]
     int* h_n = nullptr;          // pinned [4096]
+    int *h_flag = nullptr, *d_flag = nullptr;  // non-finite encoder output (pinned copy / device word)
     int batch = 0, steps = 0, dec = 0;  // dec: decoder stream / workspace of this batch
     bool used = false;
     std::vector<hipEvent_t> kt_events;

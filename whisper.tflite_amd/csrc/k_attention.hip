@@ -207,10 +207,17 @@ constexpr int SVLD = 68;  // V^T plane row stride (bf16): 136 B, conflict-free d
 
 __device__ __forceinline__ bf16x8 as_bf16x8(const u32x4_t& v) { return __builtin_bit_cast(bf16x8, v); }
 
-// NS = 3: six plane products; NS = 1 (bf16 compute mode): the single product of the rounded operands
+// NS = 3: six bf16 plane products; NS = 2: three fp16 plane products (two-plane fp16 split, bf16_split.h);
+// NS = 1 (bf16 compute mode): the single product of the rounded operands
+using half8 = __attribute__((ext_vector_type(8))) _Float16;
+#define WT_MM16(A, B, ACC) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, A), __builtin_bit_cast(half8, B), ACC, 0, 0, 0)
 #define WT_SPLIT_PRODUCTS(ACC, AF, BF)                                                        \
   if (NS == 1) {                                                                              \
     ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF[0], BF[0], ACC, 0, 0, 0);                \
+  } else if (NS == 2) {                                                                       \
+    ACC = WT_MM16(AF[0], BF[1], ACC);                                                         \
+    ACC = WT_MM16(AF[1], BF[0], ACC);                                                         \
+    ACC = WT_MM16(AF[0], BF[0], ACC);                                                         \
   } else {                                                                                    \
   ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF[0], BF[NS - 1], ACC, 0, 0, 0);             \
   ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF[1], BF[1], ACC, 0, 0, 0);                  \
@@ -221,6 +228,8 @@ __device__ __forceinline__ bf16x8 as_bf16x8(const u32x4_t& v) { return __builtin
   }
 
 template <int NW, int NS>  // NW wavefronts per block = 32 queries each, sharing the K/V tile staging; NS planes
+// (NS = 2: the probabilities are scaled by 2^14 into fp16's normal range before their split and the
+// output is scaled back with the softmax normalisation)
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void encoder_attention_split(const float* __restrict__ qkv,
                                                                                    float* __restrict__ out, int T,
                                                                                    int heads) {
@@ -242,9 +251,12 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void encoder_attention_sp
   const int l31 = lane & 31, lh = lane >> 5;
   const float* base = qkv + (long)b * T * ld + h * 64;
 
-  auto planes8 = [](const float (&x)[8], u32x4_t (&o)[3]) {
+  constexpr float kPScale = NS == 2 ? 16384.0f : 1.0f;
+  auto planes8 = [](const float (&x)[8], u32x4_t (&o)[3], float scale = 1.0f) {
     if (NS == 1) {
       o[0] = round8_bf16(x);
+    } else if (NS == 2) {
+      split8_f16x2(x, scale, o);
     } else {
       split8_planes(x, o);
     }
@@ -252,6 +264,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void encoder_attention_sp
   auto planes2 = [](float lo, float hi, unsigned (&w)[3]) {
     if (NS == 1) {
       w[0] = round2_bf16(lo, hi);
+    } else if (NS == 2) {
+      split2_f16x2(lo, hi, 1.0f, w);
     } else {
       split2_planes(lo, hi, w);
     }
@@ -388,7 +402,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void encoder_attention_sp
         const float pv[8] = {sp[8 * s2], sp[8 * s2 + 1], sp[8 * s2 + 2], sp[8 * s2 + 3],
                              sp[8 * s2 + 4], sp[8 * s2 + 5], sp[8 * s2 + 6], sp[8 * s2 + 7]};
         u32x4_t po[3];
-        planes8(pv, po);
+        planes8(pv, po, kPScale);
         bf16x8 pf[3];
 #pragma unroll
         for (int p = 0; p < NS; ++p) pf[p] = as_bf16x8(po[p]);
@@ -413,7 +427,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void encoder_attention_sp
   }
 
   if (q_row < T) {
-    const float inv = 1.0f / l_run;
+    const float inv = (1.0f / kPScale) / l_run;
     float* orow = out + ((long)b * T + q_row) * d_model + h * 64;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -429,6 +443,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void encoder_attention_sp
   }
 }
 #undef WT_SPLIT_PRODUCTS
+#undef WT_MM16
 
 // ------------------------------------------------- decoder self attention ---
 // One block per clip, one wavefront per head.  Appends this position's k, v to the
@@ -592,6 +607,9 @@ void launch_encoder_attention(const float* qkv, float* out, int batch, int T, in
     if (variant == 2) {  // 8 wavefronts = 256 queries per block
       const int qb8 = (T + 255) / 256;
       hipLaunchKernelGGL((encoder_attention_split<8, 3>), dim3(batch * heads * qb8), dim3(512), 0, s, qkv, out, T, heads);
+    } else if (variant == 4) {  // two fp16 planes, three products
+      hipLaunchKernelGGL((encoder_attention_split<4, 2>), dim3(batch * heads * q_blocks), dim3(256), 0, s, qkv,
+                         out, T, heads);
     } else if (variant == 3) {  // bf16 compute mode: operands and probabilities rounded to bf16
       hipLaunchKernelGGL((encoder_attention_split<4, 1>), dim3(batch * heads * q_blocks), dim3(256), 0, s, qkv,
                          out, T, heads);

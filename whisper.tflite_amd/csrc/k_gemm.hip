@@ -274,6 +274,7 @@ __global__ __launch_bounds__(256) void gemm_f32_tile(GemmDev g) {
 // wavefront's MFMAs at 2 blocks per CU).  128 x 128 x 32 tiles, 4 wavefronts as 2 x 2, two
 // k-tiles of global loads in flight (a k-tile is ~1500 MFMA cycles, shorter than HBM latency).
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using half8 = __attribute__((ext_vector_type(8))) _Float16;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
 template <int NS>
@@ -444,9 +445,12 @@ void launch_split(const GemmDev& g, hipStream_t s) {
 // same wavefront splits the registers of k-tile t+1 and writes them to the other buffer (the
 // MFMA pipe is busy 32 cycles per instruction and holds vector issue for 8 of them), and the
 // global loads of k-tile t+3 are in flight.  One barrier per k-tile.
-template <int EPI, int SCHED, int ABL = 0>
+template <int EPI, int SCHED, int ABL = 0, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void gemm_split16_tile(GemmDev g) {
-  constexpr int BM = 128, BN = 128, BK = 16, MI = 2, NI = 2, NS = 3;
+  // F16: two fp16 planes and three products (bf16_split.h, split8_f16x2) instead of three bf16 planes and
+  // six; W is scaled by 2^6 into fp16's normal range and the accumulators are scaled back before the epilogue
+  constexpr int BM = 128, BN = 128, BK = 16, MI = 2, NI = 2, NS = F16 ? 2 : 3;
+  constexpr float kWScale = 64.0f;
   // bf16 per LDS row: 32 B, unpadded. The two 16-byte chunks of a row are stored swapped when bit 3
   // of the row is set: a 16-lane group of a ds_read_b128 (16 consecutive rows, same k half) then
   // covers all 64 banks once, and the staging writes (both chunks of 4 consecutive rows per 8
@@ -503,8 +507,21 @@ __global__ __launch_bounds__(256, 2) void gemm_split16_tile(GemmDev g) {
       }
       return;
     }
-    split_store8<NS>(st[0], st[1], lds + buf * BUF + st_off, PLANE);
-    split_store8<NS>(st[2], st[3], lds + buf * BUF + NS * PLANE + st_off, PLANE);
+    if (F16) {
+      const float xa[8] = {st[0][0], st[0][1], st[0][2], st[0][3], st[1][0], st[1][1], st[1][2], st[1][3]};
+      const float xw[8] = {st[2][0], st[2][1], st[2][2], st[2][3], st[3][0], st[3][1], st[3][2], st[3][3]};
+      u32x4_t oa[3], ow[3];
+      split8_f16x2(xa, 1.0f, oa);
+      split8_f16x2(xw, kWScale, ow);
+#pragma unroll
+      for (int p = 0; p < NS; ++p) {
+        *reinterpret_cast<u32x4_t*>(lds + buf * BUF + p * PLANE + st_off) = oa[p];
+        *reinterpret_cast<u32x4_t*>(lds + buf * BUF + (NS + p) * PLANE + st_off) = ow[p];
+      }
+      return;
+    }
+    split_store8<3>(st[0], st[1], lds + buf * BUF + st_off, PLANE);
+    split_store8<3>(st[2], st[3], lds + buf * BUF + NS * PLANE + st_off, PLANE);
   };
   const int swz = 8 * (lh ^ ((l31 >> 3) & 1));
   const int a_off = (wm * 64 + l31) * LD + swz, b_off = NS * PLANE + (wn * 64 + l31) * LD + swz;
@@ -521,7 +538,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split16_tile(GemmDev g) {
   };
   auto mfmas = [&]() {
 #pragma unroll
-    for (int w = (ABL & 4) ? 0 : 2; w >= 0; --w)  // smallest products first (ablation 4: one product)
+    for (int w = (ABL & 4) ? 0 : NS - 1; w >= 0; --w)  // smallest products first (ablation 4: one product)
 #pragma unroll
       for (int pa = 0; pa < NS; ++pa) {
         const int pb = w - pa;
@@ -530,7 +547,12 @@ __global__ __launch_bounds__(256, 2) void gemm_split16_tile(GemmDev g) {
         for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int j = 0; j < NI; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][pa], bf[j][pb], acc[i][j], 0, 0, 0);
+            if (F16) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, af[i][pa]),
+                                                                 __builtin_bit_cast(half8, bf[j][pb]), acc[i][j], 0, 0, 0);
+            } else {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][pa], bf[j][pb], acc[i][j], 0, 0, 0);
+            }
       }
   };
   auto interleave = [&]() {
@@ -597,13 +619,19 @@ __global__ __launch_bounds__(256, 2) void gemm_split16_tile(GemmDev g) {
       __syncthreads();
     }
   }
+  if (F16) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] *= 1.0f / kWScale;
+  }
   tile_epilogue<EPI, BM, BN, MI, NI>(g, acc, reinterpret_cast<float*>(smem_raw), m0, n0);
 }
 
-template <int EPI, int SCHED, int ABL = 0>
+template <int EPI, int SCHED, int ABL = 0, bool F16 = false>
 void launch_split16(const GemmDev& g, hipStream_t s) {
   const int blocks = ((g.M + 127) / 128) * (g.N / 128);
-  hipLaunchKernelGGL((gemm_split16_tile<EPI, SCHED, ABL>), dim3(blocks), dim3(256), 0, s, g);
+  hipLaunchKernelGGL((gemm_split16_tile<EPI, SCHED, ABL, F16>), dim3(blocks), dim3(256), 0, s, g);
 }
 
 // x[n] -> three bf16 planes out[p * n + i] with x = h1 + h2 + h3 exactly (see gemm_split_tile)
@@ -653,6 +681,8 @@ void launch_gemm_t(const GemmDev& g, int variant, hipStream_t s) {
     case 15: launch_split16<EPI, 2>(g, s); break;  // same, staging before the MFMAs of a k-tile
     case 16: launch_split16<EPI, 0, 8>(g, s); break;  // variant 13 with LDS padded to 69 KB: 2 blocks per CU, which
                                                       // leaves registers and LDS for co-resident decoder blocks
+    case 17: launch_split16<EPI, 0, 0, true>(g, s); break;  // two fp16 planes, three products (22-bit operands)
+    case 18: launch_split16<EPI, 0, 8, true>(g, s); break;  // same at 2 blocks per CU
     case 21: launch_split16<EPI, 0, 1>(g, s); break;  // timing ablations of 13 (wrong results)
     case 22: launch_split16<EPI, 0, 2>(g, s); break;
     case 23: launch_split16<EPI, 0, 3>(g, s); break;
@@ -688,7 +718,7 @@ void launch_gemm(const GemmArgs& a, int epi, hipStream_t s) {
   // shape contract of the kernels (the epilogue wraps batch / position rows at most once per 32 rows)
   if (a.N % 128 != 0 || a.K % 32 != 0 || a.M < 1 || a.c_rpb < 32 || a.pos_period < (epi & kEpiPos ? 32 : 1)) abort();
   int v = a.variant;
-  if (v < 0) v = 13;  // auto: the k16 split kernel beats every fp32-MFMA tile shape on every encoder shape
+  if (v < 0) v = 13;  // auto for callers that do not choose: the full-range bf16 three-plane split kernel
   switch (epi) {
     case 0: launch_gemm_t<0>(g, v, s); break;
     case kEpiBias: launch_gemm_t<kEpiBias>(g, v, s); break;

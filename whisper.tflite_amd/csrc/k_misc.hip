@@ -19,7 +19,8 @@ template <int PER>
 __global__ __launch_bounds__(256) void layernorm_rows(const float* __restrict__ x,
                                                       float* __restrict__ y,
                                                       const float* __restrict__ g,
-                                                      const float* __restrict__ b, int M, int d) {
+                                                      const float* __restrict__ b, int M, int d,
+                                                      int* __restrict__ nonfinite) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -40,7 +41,11 @@ __global__ __launch_bounds__(256) void layernorm_rows(const float* __restrict__ 
     const float t = c < d ? v[i] - mean : 0.0f;
     q += t * t;
   }
-  const float rstd = rsqrtf(wave_sum(q) / (float)d + 1e-5f);
+  const float var = wave_sum(q) / (float)d;
+  // a row with an infinity or a NaN (an operand outside the fp16 range of the default contraction
+  // kernels, or bad input) is reported, not hidden: the engine turns the flag into an error
+  if (nonfinite != nullptr && lane == 0 && !(fabsf(mean) <= 3.0e38f && var <= 3.0e38f)) atomicOr(nonfinite, 1);
+  const float rstd = rsqrtf(var + 1e-5f);
   float* yr = y + row * d;
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
@@ -183,14 +188,14 @@ __global__ __launch_bounds__(256) void select_token(const unsigned long long* __
 }  // namespace
 
 void launch_layernorm(const float* x, float* y, const float* g, const float* b, int M, int d,
-                      hipStream_t s) {
+                      hipStream_t s, int* nonfinite) {
   const int blocks = (M + 3) / 4;
   if (d <= 128) {
-    hipLaunchKernelGGL(layernorm_rows<2>, dim3(blocks), dim3(256), 0, s, x, y, g, b, M, d);
+    hipLaunchKernelGGL(layernorm_rows<2>, dim3(blocks), dim3(256), 0, s, x, y, g, b, M, d, nonfinite);
   } else if (d <= 384) {
-    hipLaunchKernelGGL(layernorm_rows<6>, dim3(blocks), dim3(256), 0, s, x, y, g, b, M, d);
+    hipLaunchKernelGGL(layernorm_rows<6>, dim3(blocks), dim3(256), 0, s, x, y, g, b, M, d, nonfinite);
   } else if (d <= 512) {
-    hipLaunchKernelGGL(layernorm_rows<8>, dim3(blocks), dim3(256), 0, s, x, y, g, b, M, d);
+    hipLaunchKernelGGL(layernorm_rows<8>, dim3(blocks), dim3(256), 0, s, x, y, g, b, M, d, nonfinite);
   } else {
     abort();
   }

@@ -94,7 +94,7 @@ void launch_dec_finalize_ln(const float* xin, const float* g, const float* b, fl
 // ------------------------------------------------------------- LayerNorm ---
 // y[m][:] = (x[m][:] - mean) * rstd * g + b, eps 1e-5, one wavefront per row.
 void launch_layernorm(const float* x, float* y, const float* g, const float* b, int M, int d,
-                      hipStream_t s);
+                      hipStream_t s, int* nonfinite = nullptr);
 
 // ------------------------------------------------------ encoder attention ---
 // qkv [B*T][3*d] (q | k | v, heads of 64 inside each third) -> out [B*T][d].
