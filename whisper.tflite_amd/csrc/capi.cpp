@@ -466,6 +466,13 @@ int wt_dbg_gemm(wt_engine* h, int M, int N, int K, const float* A, const float* 
     g.A = dA.p; g.lda = K; g.W = dW.p; g.bias = dB.p; g.C = dC.p; g.R = dC.p; g.ldc = N;
     g.pos = dP.p; g.pos_period = pos_period > 0 ? pos_period : 1;
     g.M = M; g.N = N; g.K = K; g.variant = int(h->impl->gemm_variant);
+    {  // operand scales of the two-plane fp16 variants: from the data, as the engine derives them from bounds
+      float ma = 0.0f, mw = 0.0f;
+      for (size_t i = 0; i < size_t(M) * K; ++i) ma = std::max(ma, std::fabs(A[i]));
+      for (size_t i = 0; i < size_t(N) * K; ++i) mw = std::max(mw, std::fabs(W[i]));
+      g.a_scale = wt::f16_scale_for(ma);
+      g.w_scale = wt::f16_scale_for(mw);
+    }
     wt::launch_gemm(g, epi, h->impl->stream());
     h->impl->sync();
     dC.to_host(C, size_t(M) * N);
@@ -487,6 +494,8 @@ int wt_dbg_gemm_bench(wt_engine* h, int M, int N, int K, int epi, int variant, i
     wt::GemmArgs g;
     g.A = dA.p; g.lda = K; g.W = dW.p; g.bias = dB.p; g.C = dC.p; g.R = dC.p; g.ldc = N;
     g.M = M; g.N = N; g.K = K; g.variant = variant;
+    g.a_scale = wt::f16_scale_for(1.0f);
+    g.w_scale = wt::f16_scale_for(0.05f);
     hipStream_t st = h->impl->stream();
     DevBuf dWp(variant == 12 ? size_t(N) * K * 3 / 2 + 4 : 1);  // 3 bf16 planes
     if (variant == 12) {
@@ -658,7 +667,18 @@ int wt_dbg_encoder_attention(wt_engine* h, int batch, int T, int heads, const fl
   return guarded(h, [&] {
     const size_t d = size_t(heads) * 64;
     DevBuf dq(qkv, size_t(batch) * T * 3 * d), dout(size_t(batch) * T * d);
-    wt::launch_encoder_attention(dq.p, dout.p, batch, T, heads, int(h->impl->attn_variant), h->impl->stream());
+    float mq = 0.0f, mk = 0.0f, mv = 0.0f;  // operand scales of variant 4 from the data
+    for (size_t r = 0; r < size_t(batch) * T; ++r) {
+      const float* row = qkv + r * 3 * d;
+      for (size_t c = 0; c < d; ++c) {
+        mq = std::max(mq, std::fabs(row[c]));
+        mk = std::max(mk, std::fabs(row[d + c]));
+        mv = std::max(mv, std::fabs(row[2 * d + c]));
+      }
+    }
+    wt::launch_encoder_attention(dq.p, dout.p, batch, T, heads, int(h->impl->attn_variant), h->impl->stream(),
+                                 wt::f16_scale_for(mq * 0.125f * 1.44269504f), wt::f16_scale_for(mk),
+                                 wt::f16_scale_for(mv));
     h->impl->sync();
     dout.to_host(out, size_t(batch) * T * d);
   });

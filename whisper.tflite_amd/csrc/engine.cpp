@@ -213,6 +213,79 @@ void Engine::upload_weights(const std::string& path) {
   cross_kv_b = upload(ckv_b);
   dec_ln_g = up("decoder.ln.weight", d);
   dec_ln_b = up("decoder.ln.bias", d);
+  // ---- operand bounds -> fp16 plane scales (engine.h, GemmScale) ----
+  {
+    auto maxabs = [](const float* w, size_t n) {
+      float m = 0.0f;
+      for (size_t i = 0; i < n; ++i) m = std::max(m, std::fabs(w[i]));
+      return m;
+    };
+    auto vmax = [](const std::vector<float>& v) {
+      float m = 0.0f;
+      for (float x : v) m = std::max(m, x);
+      return m;
+    };
+    auto ln_bound = [&](const std::string& gname, const std::string& bname) {
+      const float* gg = H(gname, d);
+      const float* bb = H(bname, d);
+      std::vector<float> o(d);
+      const float r = std::sqrt(float(d - 1));
+      for (int i = 0; i < d; ++i) o[i] = std::fabs(gg[i]) * r + std::fabs(bb[i]);
+      return o;
+    };
+    // out[n] = sum_k |W[n][k]| in[k % in.size()] + |bias[n]|   (conv taps repeat the input bound)
+    auto linear_bound = [&](const float* w, const float* bias, int N, int K, const std::vector<float>& in) {
+      std::vector<float> o(N);
+      for (int n = 0; n < N; ++n) {
+        double acc = bias ? std::fabs(bias[n]) : 0.0;
+        for (int k = 0; k < K; ++k) acc += std::fabs(w[size_t(n) * K + k]) * in[size_t(k) % in.size()];
+        o[n] = float(acc);
+      }
+      return o;
+    };
+    auto gelu_bound = [](std::vector<float> v) {
+      for (float& x : v) x = std::max(x, 0.17f);  // gelu(x) in [-0.17, max(x, 0)]
+      return v;
+    };
+    auto scale_of = [&](const std::vector<float>& in_bound, const float* w, size_t n) {
+      return GemmScale{f16_scale_for(vmax(in_bound)), f16_scale_for(maxabs(w, n))};
+    };
+    // conv1: host copy in the kernel's [co][kpad] order is gone; bounds use the original [co][ci][3] tensor,
+    // which has the same absolute values
+    const std::vector<float> mel_b(1, kMelBound);
+    const float* c1w = H("encoder.conv1.weight", size_t(d) * nm * 3);
+    sc_conv1_ = scale_of(mel_b, c1w, size_t(d) * nm * 3);
+    const std::vector<float> h1_b = gelu_bound(linear_bound(c1w, H("encoder.conv1.bias", d), d, nm * 3, mel_b));
+    const float* c2w = H("encoder.conv2.weight", size_t(d) * d * 3);
+    sc_conv2_ = scale_of(h1_b, c2w, size_t(d) * d * 3);
+    sc_layers_.assign(c.n_audio_layer, EncLayerScales{});
+    const size_t dd2 = size_t(d) * d;
+    for (int l = 0; l < c.n_audio_layer; ++l) {
+      const std::string blk = "encoder.blocks." + std::to_string(l);
+      EncLayerScales& sl = sc_layers_[l];
+      const std::vector<float> ln1 = ln_bound(blk + ".attn_ln.weight", blk + ".attn_ln.bias");
+      const float* wq = H(blk + ".attn.query.weight", dd2);
+      const float* wk = H(blk + ".attn.key.weight", dd2);
+      const float* wv = H(blk + ".attn.value.weight", dd2);
+      const float wmax = std::max(maxabs(wq, dd2), std::max(maxabs(wk, dd2), maxabs(wv, dd2)));
+      sl.qkv = GemmScale{f16_scale_for(vmax(ln1)), f16_scale_for(wmax)};
+      const std::vector<float> qb = linear_bound(wq, H(blk + ".attn.query.bias", d), d, d, ln1);
+      const std::vector<float> kb = linear_bound(wk, nullptr, d, d, ln1);
+      const std::vector<float> vb = linear_bound(wv, H(blk + ".attn.value.bias", d), d, d, ln1);
+      sl.q = f16_scale_for(vmax(qb) * 0.125f * 1.44269504f);  // the kernel splits q * d_head^-1/2 * log2(e)
+      sl.k = f16_scale_for(vmax(kb));
+      sl.v = f16_scale_for(vmax(vb));
+      sl.out = scale_of(vb, H(blk + ".attn.out.weight", dd2), dd2);  // a convex combination of V rows
+      const std::vector<float> ln2 = ln_bound(blk + ".mlp_ln.weight", blk + ".mlp_ln.bias");
+      const float* w1 = H(blk + ".mlp.0.weight", 4 * dd2);
+      sl.fc1 = scale_of(ln2, w1, 4 * dd2);
+      const std::vector<float> hb = gelu_bound(linear_bound(w1, H(blk + ".mlp.0.bias", size_t(4) * d), 4 * d, d, ln2));
+      sl.fc2 = scale_of(hb, H(blk + ".mlp.2.weight", 4 * dd2), 4 * dd2);
+    }
+    const std::vector<float> lnp = ln_bound("encoder.ln_post.weight", "encoder.ln_post.bias");
+    sc_cross_kv_ = GemmScale{f16_scale_for(vmax(lnp)), f16_scale_for(maxabs(ckv_w.data(), ckv_w.size()))};
+  }
+
 }
 
 namespace {
@@ -631,7 +704,7 @@ void Engine::encode_enqueue(const float* d_mel, int batch) {
   launch_mel_transpose(d_mel, ws_.melT, batch, c.n_mels, T0, stream_);
   kt_end();
   {
-    GemmArgs g; g.variant = enc_gemm_variant();  // conv1 + GELU: rows (clip, t) read melT rows t..t+2 (input t-1..t+1)
+    GemmArgs g; g.variant = enc_gemm_variant(); g.a_scale = sc_conv1_.a; g.w_scale = sc_conv1_.w;  // conv1 + GELU: rows (clip, t) read melT rows t..t+2 (input t-1..t+1)
     g.A = ws_.melT;
     g.a_rpb = T0;
     g.a_bs = long(T0 + 2) * c.n_mels;
@@ -650,7 +723,7 @@ void Engine::encode_enqueue(const float* d_mel, int batch) {
     kt_end();
   }
   {
-    GemmArgs g; g.variant = enc_gemm_variant();  // conv2 (stride 2) + GELU + positional embedding
+    GemmArgs g; g.variant = enc_gemm_variant(); g.a_scale = sc_conv2_.a; g.w_scale = sc_conv2_.w;  // conv2 (stride 2) + GELU + positional embedding
     g.A = ws_.h1p;
     g.a_rpb = T;
     g.a_bs = long(T0 + 2) * d;
@@ -673,16 +746,17 @@ void Engine::encode_enqueue(const float* d_mel, int batch) {
     kt_begin(kKcLayerNorm, 0, 2.0 * M * d * 4);
     launch_layernorm(ws_.x, ws_.ln, w.attn_ln_g, w.attn_ln_b, M, d, stream_);
     kt_end();
-    GemmArgs q; q.variant = enc_gemm_variant();
+    const EncLayerScales& sc = sc_layers_[l];
+    GemmArgs q; q.variant = enc_gemm_variant(); q.a_scale = sc.qkv.a; q.w_scale = sc.qkv.w;
     q.A = ws_.ln; q.lda = d; q.W = w.attn.wqkv; q.bias = w.attn.bqkv; q.C = ws_.qkv; q.ldc = 3 * d;
     q.M = M; q.N = 3 * d; q.K = d;
     kt_begin(kKcGemm, 2.0 * q.M * q.N * q.K, 0);
     launch_gemm(q, kEpiBias, stream_);
     kt_end();
     kt_begin(kKcEncAttn, 4.0 * batch * c.n_audio_head * double(T) * T * 64, 0);
-    launch_encoder_attention(ws_.qkv, ws_.att, batch, T, c.n_audio_head, int(attn_variant), stream_);
+    launch_encoder_attention(ws_.qkv, ws_.att, batch, T, c.n_audio_head, int(attn_variant), stream_, sc.q, sc.k, sc.v);
     kt_end();
-    GemmArgs o; o.variant = enc_gemm_variant();
+    GemmArgs o; o.variant = enc_gemm_variant(); o.a_scale = sc.out.a; o.w_scale = sc.out.w;
     o.A = ws_.att; o.lda = d; o.W = w.attn.wo; o.bias = w.attn.bo; o.C = ws_.x; o.R = ws_.x; o.ldc = d;
     o.M = M; o.N = d; o.K = d;
     kt_begin(kKcGemm, 2.0 * o.M * o.N * o.K, 0);
@@ -691,13 +765,13 @@ void Engine::encode_enqueue(const float* d_mel, int batch) {
     kt_begin(kKcLayerNorm, 0, 2.0 * M * d * 4);
     launch_layernorm(ws_.x, ws_.ln, w.mlp_ln_g, w.mlp_ln_b, M, d, stream_);
     kt_end();
-    GemmArgs f1; f1.variant = enc_gemm_variant();
+    GemmArgs f1; f1.variant = enc_gemm_variant(); f1.a_scale = sc.fc1.a; f1.w_scale = sc.fc1.w;
     f1.A = ws_.ln; f1.lda = d; f1.W = w.w1; f1.bias = w.b1; f1.C = ws_.hid; f1.ldc = 4 * d;
     f1.M = M; f1.N = 4 * d; f1.K = d;
     kt_begin(kKcGemm, 2.0 * f1.M * f1.N * f1.K, 0);
     launch_gemm(f1, kEpiBias | kEpiGelu, stream_);
     kt_end();
-    GemmArgs f2; f2.variant = enc_gemm_variant();
+    GemmArgs f2; f2.variant = enc_gemm_variant(); f2.a_scale = sc.fc2.a; f2.w_scale = sc.fc2.w;
     f2.A = ws_.hid; f2.lda = 4 * d; f2.W = w.w2; f2.bias = w.b2; f2.C = ws_.x; f2.R = ws_.x; f2.ldc = d;
     f2.M = M; f2.N = d; f2.K = 4 * d;
     kt_begin(kKcGemm, 2.0 * f2.M * f2.N * f2.K, 0);
@@ -713,7 +787,7 @@ void Engine::encode_enqueue(const float* d_mel, int batch) {
     // cross-attention K/V of every decoder layer, projected once per clip into the
     // persistent cache [layer][k|v][clip][head][t][64] (the reference recomputes them
     // inside every decoder Invoke(), whisper.cpp:375)
-    GemmArgs g; g.variant = enc_gemm_variant();
+    GemmArgs g; g.variant = enc_gemm_variant(); g.a_scale = sc_cross_kv_.a; g.w_scale = sc_cross_kv_.w;
     g.A = ws_.enc_out; g.lda = d; g.W = cross_kv_w; g.bias = cross_kv_b; g.C = slot.cross_kv;
     g.M = M; g.N = c.n_text_layer * 2 * d; g.K = d;
     g.c_rpb = T; g.kv_batch = batch; g.kv_heads = c.n_text_head; g.kv_dmodel = d;

@@ -182,6 +182,20 @@ class Engine {
   int conv1_kpad = 0;
   const float* enc_pos = nullptr;
   std::vector<BlockWeights> enc_blocks_, dec_blocks_;
+  // Operand scales of the two-plane fp16 encoder kernels (powers of two, f16_scale_for): derived at load
+  // time from weight-only upper bounds of every contraction operand (LayerNorm output <= |g| sqrt(d-1) + |b|,
+  // Linear output <= sum |W| * input bound + |bias|, GELU(x) <= max(x, 0.17), attention output <= V bound),
+  // so no operand can overflow fp16 for an input mel inside kMelBound
+  struct GemmScale {
+    float a = 1.0f, w = 64.0f;
+  };
+  struct EncLayerScales {
+    GemmScale qkv, out, fc1, fc2;
+    float q = 1.0f, k = 1.0f, v = 1.0f;
+  };
+  static constexpr float kMelBound = 8.0f;
+  GemmScale sc_conv1_, sc_conv2_, sc_cross_kv_;
+  std::vector<EncLayerScales> sc_layers_;
   const float *enc_ln_post_g = nullptr, *enc_ln_post_b = nullptr;
   const float *cross_kv_w = nullptr, *cross_kv_b = nullptr;  // [L*2*d][d], [L*2*d]
   const float *tok_emb = nullptr, *tok_emb_tiled = nullptr, *dec_pos = nullptr, *dec_ln_g = nullptr, *dec_ln_b = nullptr;

@@ -232,7 +232,8 @@ template <int NW, int NS>  // NW wavefronts per block = 32 queries each, sharing
 // output is scaled back with the softmax normalisation)
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void encoder_attention_split(const float* __restrict__ qkv,
                                                                                    float* __restrict__ out, int T,
-                                                                                   int heads) {
+                                                                                   int heads, float q_scale, float k_scale,
+                                                                                   float v_scale) {
   constexpr int AQS = NW * 32;      // queries per block
   constexpr int PASSES = 8 / NW;    // staging passes per 64-key tile (NW * 64 threads)
   constexpr int KROWS = 64 / PASSES, VPAIRS = 32 / PASSES;
@@ -261,11 +262,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void encoder_attention_sp
       split8_planes(x, o);
     }
   };
-  auto planes2 = [](float lo, float hi, unsigned (&w)[3]) {
+  auto planes2 = [v_scale](float lo, float hi, unsigned (&w)[3]) {
     if (NS == 1) {
       w[0] = round2_bf16(lo, hi);
     } else if (NS == 2) {
-      split2_f16x2(lo, hi, 1.0f, w);
+      split2_f16x2(lo, hi, v_scale, w);
     } else {
       split2_planes(lo, hi, w);
     }
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void encoder_attention_sp
     const float x[8] = {a[0] * qscale, a[1] * qscale, a[2] * qscale, a[3] * qscale,
                         bq[0] * qscale, bq[1] * qscale, bq[2] * qscale, bq[3] * qscale};
     u32x4_t o[3];
-    planes8(x, o);
+    planes8(x, o, NS == 2 ? q_scale : 1.0f);
 #pragma unroll
     for (int p = 0; p < NS; ++p) qf[c][p] = as_bf16x8(o[p]);
   }
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void encoder_attention_sp
       const float x[8] = {rk[2 * i][0], rk[2 * i][1], rk[2 * i][2], rk[2 * i][3],
                           rk[2 * i + 1][0], rk[2 * i + 1][1], rk[2 * i + 1][2], rk[2 * i + 1][3]};
       u32x4_t o[3];
-      planes8(x, o);
+      planes8(x, o, NS == 2 ? k_scale : 1.0f);
 #pragma unroll
       for (int p = 0; p < NS; ++p)
         *reinterpret_cast<u32x4_t*>(&Kp[p * AK * SKLD + (ksrow + KROWS * i) * SKLD + kscol]) = o[p];
@@ -360,6 +361,14 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void encoder_attention_sp
       }
       WT_SPLIT_PRODUCTS(s0, k0, qf[c])
       WT_SPLIT_PRODUCTS(s1, k1, qf[c])
+    }
+    if (NS == 2) {  // the operand scales of the fp16 planes leave the scores
+      const float s_inv = 1.0f / (q_scale * k_scale);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s0[r] *= s_inv;
+        s1[r] *= s_inv;
+      }
     }
     if ((kt + 1) * AK > T) {  // last tile: keys past T do not exist
 #pragma unroll
@@ -427,7 +436,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void encoder_attention_sp
   }
 
   if (q_row < T) {
-    const float inv = (1.0f / kPScale) / l_run;
+    const float inv = (1.0f / (kPScale * (NS == 2 ? v_scale : 1.0f))) / l_run;
     float* orow = out + ((long)b * T + q_row) * d_model + h * 64;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -598,25 +607,22 @@ __global__ __launch_bounds__(256) void cross_attention_step(const float* __restr
 }  // namespace
 
 void launch_encoder_attention(const float* qkv, float* out, int batch, int T, int heads, int variant,
-                              hipStream_t s) {
+                              hipStream_t s, float q_scale, float k_scale, float v_scale) {
   const int q_blocks = (T + AQ - 1) / AQ;
+  const dim3 grid(batch * heads * q_blocks);
   if (variant == 0) {
-    hipLaunchKernelGGL(encoder_attention_f32, dim3(batch * heads * q_blocks), dim3(256), 0, s, qkv,
-                       out, T, heads);
+    hipLaunchKernelGGL(encoder_attention_f32, grid, dim3(256), 0, s, qkv, out, T, heads);
+  } else if (variant == 2) {  // 8 wavefronts = 256 queries per block
+    const int qb8 = (T + 255) / 256;
+    hipLaunchKernelGGL((encoder_attention_split<8, 3>), dim3(batch * heads * qb8), dim3(512), 0, s, qkv, out, T, heads,
+                       1.0f, 1.0f, 1.0f);
+  } else if (variant == 4) {  // two fp16 planes, three products
+    hipLaunchKernelGGL((encoder_attention_split<4, 2>), grid, dim3(256), 0, s, qkv, out, T, heads, q_scale, k_scale,
+                       v_scale);
+  } else if (variant == 3) {  // bf16 compute mode: operands and probabilities rounded to bf16
+    hipLaunchKernelGGL((encoder_attention_split<4, 1>), grid, dim3(256), 0, s, qkv, out, T, heads, 1.0f, 1.0f, 1.0f);
   } else {
-    if (variant == 2) {  // 8 wavefronts = 256 queries per block
-      const int qb8 = (T + 255) / 256;
-      hipLaunchKernelGGL((encoder_attention_split<8, 3>), dim3(batch * heads * qb8), dim3(512), 0, s, qkv, out, T, heads);
-    } else if (variant == 4) {  // two fp16 planes, three products
-      hipLaunchKernelGGL((encoder_attention_split<4, 2>), dim3(batch * heads * q_blocks), dim3(256), 0, s, qkv,
-                         out, T, heads);
-    } else if (variant == 3) {  // bf16 compute mode: operands and probabilities rounded to bf16
-      hipLaunchKernelGGL((encoder_attention_split<4, 1>), dim3(batch * heads * q_blocks), dim3(256), 0, s, qkv,
-                         out, T, heads);
-    } else {
-      hipLaunchKernelGGL((encoder_attention_split<4, 3>), dim3(batch * heads * q_blocks), dim3(256), 0, s, qkv,
-                         out, T, heads);
-    }
+    hipLaunchKernelGGL((encoder_attention_split<4, 3>), grid, dim3(256), 0, s, qkv, out, T, heads, 1.0f, 1.0f, 1.0f);
   }
 }
 

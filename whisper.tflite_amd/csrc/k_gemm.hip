@@ -12,6 +12,7 @@
 // global accesses).  tools/mfma_probe.hip measures what bounds this loop.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdlib>
 
 #include "bf16_split.h"
@@ -45,6 +46,7 @@ struct GemmDev {
   int ldc;
   int pos_period;
   int kv_batch, kv_heads, kv_dmodel;
+  float a_scale, w_scale, descale;  // two-plane fp16 kernels
 };
 
 // Epilogue shared by the GEMM kernels.  The C/D layout (col = lane & 31, row = (r & 3) +
@@ -448,9 +450,9 @@ void launch_split(const GemmDev& g, hipStream_t s) {
 template <int EPI, int SCHED, int ABL = 0, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void gemm_split16_tile(GemmDev g) {
   // F16: two fp16 planes and three products (bf16_split.h, split8_f16x2) instead of three bf16 planes and
-  // six; W is scaled by 2^6 into fp16's normal range and the accumulators are scaled back before the epilogue
+  // six; A and W are scaled by powers of two (GemmArgs::a_scale, w_scale: from operand bounds) into fp16's
+  // normal range and the accumulators are scaled back before the epilogue
   constexpr int BM = 128, BN = 128, BK = 16, MI = 2, NI = 2, NS = F16 ? 2 : 3;
-  constexpr float kWScale = 64.0f;
   // bf16 per LDS row: 32 B, unpadded. The two 16-byte chunks of a row are stored swapped when bit 3
   // of the row is set: a 16-lane group of a ds_read_b128 (16 consecutive rows, same k half) then
   // covers all 64 banks once, and the staging writes (both chunks of 4 consecutive rows per 8
@@ -511,8 +513,8 @@ __global__ __launch_bounds__(256, 2) void gemm_split16_tile(GemmDev g) {
       const float xa[8] = {st[0][0], st[0][1], st[0][2], st[0][3], st[1][0], st[1][1], st[1][2], st[1][3]};
       const float xw[8] = {st[2][0], st[2][1], st[2][2], st[2][3], st[3][0], st[3][1], st[3][2], st[3][3]};
       u32x4_t oa[3], ow[3];
-      split8_f16x2(xa, 1.0f, oa);
-      split8_f16x2(xw, kWScale, ow);
+      split8_f16x2(xa, g.a_scale, oa);
+      split8_f16x2(xw, g.w_scale, ow);
 #pragma unroll
       for (int p = 0; p < NS; ++p) {
         *reinterpret_cast<u32x4_t*>(lds + buf * BUF + p * PLANE + st_off) = oa[p];
@@ -623,7 +625,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split16_tile(GemmDev g) {
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int j = 0; j < NI; ++j) acc[i][j] *= 1.0f / kWScale;
+      for (int j = 0; j < NI; ++j) acc[i][j] *= g.descale;
   }
   tile_epilogue<EPI, BM, BN, MI, NI>(g, acc, reinterpret_cast<float*>(smem_raw), m0, n0);
 }
@@ -707,6 +709,15 @@ int gemm_occupancy(int variant) {
   return n;
 }
 
+float f16_scale_for(float bound) {
+  if (!(bound > 0.0f)) return 1.0f;
+  int e = 0;
+  (void)std::frexp(16384.0f / bound, &e);  // 16384 / bound = m * 2^e, m in [0.5, 1)
+  e -= 1;
+  e = e > 24 ? 24 : (e < -24 ? -24 : e);
+  return std::ldexp(1.0f, e);
+}
+
 void launch_split_planes(const float* x, unsigned short* out, long n, hipStream_t s) {
   hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, out, n);
 }
@@ -714,7 +725,7 @@ void launch_split_planes(const float* x, unsigned short* out, long n, hipStream_
 void launch_gemm(const GemmArgs& a, int epi, hipStream_t s) {
   GemmDev g{a.A,   a.W, a.Wp,  a.C,    a.bias, a.R,   a.pos,        a.M,        a.N,        a.K,
             a.a_rpb, a.a_bs, a.lda, a.c_rpb, a.c_bs, a.ldc, a.pos_period, a.kv_batch, a.kv_heads,
-            a.kv_dmodel};
+            a.kv_dmodel, a.a_scale, a.w_scale, 1.0f / (a.a_scale * a.w_scale)};
   // shape contract of the kernels (the epilogue wraps batch / position rows at most once per 32 rows)
   if (a.N % 128 != 0 || a.K % 32 != 0 || a.M < 1 || a.c_rpb < 32 || a.pos_period < (epi & kEpiPos ? 32 : 1)) abort();
   int v = a.variant;

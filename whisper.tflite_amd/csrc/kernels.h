@@ -42,8 +42,13 @@ struct GemmArgs {
   // where slab enumerates (layer, k|v); T = c_rpb.
   int kv_batch = 0, kv_heads = 0, kv_dmodel = 0;
   int variant = -1;  // tile shape / pipelining variant (k_gemm.hip launch_gemm_t); -1 = auto
+  // two-plane fp16 kernels (variants 17, 18): powers of two that bring the operands into fp16's normal
+  // range, |A * a_scale| and |W * w_scale| <= 32768 (f16_scale_for); the epilogue divides them out
+  float a_scale = 1.0f, w_scale = 64.0f;
 };
 void launch_gemm(const GemmArgs& a, int epi, hipStream_t s);
+// largest power of two s with bound * s <= 16384 (a factor 4 below fp16's maximum), clamped to 2^+-24
+float f16_scale_for(float bound);
 // resident blocks per CU the runtime reports for a tile variant (diagnostics)
 int gemm_occupancy(int variant);
 // x[n] fp32 -> out[3][n] bf16 with x = out[0] + out[1] + out[2] exactly
@@ -99,8 +104,9 @@ void launch_layernorm(const float* x, float* y, const float* g, const float* b, 
 // ------------------------------------------------------ encoder attention ---
 // qkv [B*T][3*d] (q | k | v, heads of 64 inside each third) -> out [B*T][d].
 // Non-causal softmax(q k^T / 8) v per (clip, head), flash-style, fp32 MFMA.
+// q_scale, k_scale, v_scale: f16_scale_for() of the operands' bounds (variant 4 only)
 void launch_encoder_attention(const float* qkv, float* out, int batch, int T, int heads, int variant,
-                              hipStream_t stream);
+                              hipStream_t stream, float q_scale = 1.0f, float k_scale = 1.0f, float v_scale = 1.0f);
 
 // ------------------------------------------------------------- front end ---
 // mel [B][n_mels][T] -> melT [B][T + 2][n_mels] rows 1..T (rows 0 and T+1 stay zero).
