@@ -71,10 +71,13 @@ int wt_engine_dims(const wt_engine* h, wt_dims* out);
  * default 30), "stop_at_eot" (whisper.cpp:397-399, default 1), "verbose" (default 0),
  * "cross_chunks" (key chunks per (clip, head) in the decoder cross attention: 1, 2, 4 or 8).
  * Kernel selection (results stay within the fp32 error budget for every value except
- * gemm_variant 11 / attn_variant 3, the bf16 compute mode of BASELINE configs[3]): "gemm_variant" (-1 = default: encoder GEMMs on the bf16 matrix cores with the
- * exact three-plane split of fp32 operands, csrc/bf16_split.h; 0..9 = fp32-MFMA tile shapes; 10,
- * 13..16 = split-kernel variants; 11 = operands rounded to bf16), "attn_variant" (1 = default,
- * split; 2 = split, 256 queries per block; 0 = fp32 MFMA; 3 = operands rounded to bf16), "resid_waves" (4, 8, 16 wavefronts per block of the decoder's residual
+ * gemm_variant 11 / attn_variant 3, the bf16 compute mode of BASELINE configs[3]): "gemm_variant"
+ * (-1 = default: encoder GEMMs on the f16 matrix cores, fp32 operands split into two fp16 planes
+ * with power-of-two scales from weight-derived bounds, csrc/bf16_split.h; 17, 18 = the same at 3 / 2
+ * blocks per CU; 10, 13..16 = three bf16 planes, full fp32 operand range; 0..9 = fp32-MFMA tile
+ * shapes; 11 = operands rounded to bf16), "attn_variant" (4 = default, two fp16 planes; 1, 2 = three
+ * bf16 planes with 128 / 256 queries per block; 0 = fp32 MFMA; 3 = operands rounded to bf16),
+ * "resid_waves" (4, 8, 16 wavefronts per block of the decoder's residual
  * GEMMs), "use_graphs" (1 = default: the decoder's launch sequence is replayed from a hipGraph).
  * Environment, read at wt_engine_create: WT_ENC_CU_RESERVE (CUs per XCD the pipelined encoder
  * stream leaves to the decoders, default 4, 0 = none), WT_DEC_STREAMS (decoder streams, default 3),
