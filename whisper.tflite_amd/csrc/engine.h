@@ -74,7 +74,7 @@ class Engine {
   long verbose = 0;
   long cross_chunks = 2;  // key chunks per (clip, head) of the decoder cross-attention (measured: 2 beats 4 by 6 % alone)
   long attn_variant = 4;  // encoder attention: 0 = fp32 MFMA, 1/2 = bf16 x3 split, 3 = bf16 operands, 4 = fp16 x2 split
-  long resid_waves = 16;  // wavefronts per block of the decoder's residual GEMMs (4, 8, 16)
+  long resid_waves = 8;   // wavefronts per block of the decoder's residual GEMMs (4, 8, 16)
   long use_graphs = 1;  // replay the decoder's launch sequence from a captured hipGraph
   long gemm_variant = -1;  // encoder GEMM tile variant (k_gemm.hip); -1 = per-shape choice
   // non-empty: replaces the reference's hard-coded prompt (test-sized vocabularies)
