@@ -251,7 +251,7 @@ def main() -> None:
 
     def run_steps(k, on_step=None):
         """k passes of the hot path.  Pipelined: up to --depth batches are in flight (encoder on
-        one HIP stream, decoders alternating between two more); all k batches start and
+        one HIP stream, decoders rotating over three more); all k batches start and
         finish inside the call."""
         out = None
         if not pipelined:

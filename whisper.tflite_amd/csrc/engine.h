@@ -92,8 +92,8 @@ class Engine {
   // greedy loop over the slot encode() just filled, on the decoder stream; synchronises and
   // returns ids [B][32], n [B].
   void decode(int batch, int64_t* ids, int32_t* n_ids, float* logits_host, int logits_steps_cap);
-  // Pipeline, kSlots deep: submit() enqueues encoder (stream E) + decoder (one of kDecStreams
-  // decoder streams, in rotation) for one batch and returns.  In steady state the MFMA-bound
+  // Pipeline, kSlots deep: submit() enqueues encoder (stream E) + decoder (one of the three
+  // decoder streams in use, in rotation) for one batch and returns.  In steady state the MFMA-bound
   // encoder of the newest batch shares the chip with the latency-bound decoder chains of the
   // previous ones: a decoder's ~1000 tiny dependent launches leave most of the chip idle on
   // their own.  collect() waits for the OLDEST submitted batch.

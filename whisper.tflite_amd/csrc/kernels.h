@@ -11,8 +11,10 @@ namespace wt {
 // ------------------------------------------------------------------ GEMM ---
 // C = epilogue(A . W^T): A [M][K] activations (row m at
 // A + (m / a_rpb) * a_bs + (m % a_rpb) * lda), W [N][K] row-major (torch Linear
-// layout), fp32 in, fp32 MFMA (v_mfma_f32_32x32x2_f32) accumulate: bit-for-bit a
-// k-ordered fmaf chain.  Requires N % 128 == 0 and K % 32 == 0; M is arbitrary.
+// layout), fp32 in, fp32 out.  The contraction runs on the matrix cores in one of three forms selected
+// by `variant` (k_gemm.hip): fp32 MFMA (v_mfma_f32_32x32x2_f32, a k-ordered fmaf chain), or fp32
+// operands split into three bf16 / two fp16 planes with fp32 accumulation (fp32-level error,
+// bf16_split.h).  Requires N % 128 == 0 and K % 32 == 0; M is arbitrary.
 enum GemmEpi : int {
   kEpiBias = 1,      // + bias[n]
   kEpiGelu = 2,      // exact erf GELU
@@ -103,7 +105,8 @@ void launch_layernorm(const float* x, float* y, const float* g, const float* b, 
 
 // ------------------------------------------------------ encoder attention ---
 // qkv [B*T][3*d] (q | k | v, heads of 64 inside each third) -> out [B*T][d].
-// Non-causal softmax(q k^T / 8) v per (clip, head), flash-style, fp32 MFMA.
+// Non-causal softmax(q k^T / 8) v per (clip, head), flash-style; `variant`: 0 fp32 MFMA, 1/2 three bf16
+// planes (128 / 256 queries per block), 3 bf16 operands, 4 two fp16 planes.
 // q_scale, k_scale, v_scale: f16_scale_for() of the operands' bounds (variant 4 only)
 void launch_encoder_attention(const float* qkv, float* out, int batch, int T, int heads, int variant,
                               hipStream_t stream, float q_scale = 1.0f, float k_scale = 1.0f, float v_scale = 1.0f);
