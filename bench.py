@@ -445,6 +445,7 @@ def main() -> None:
                     **{k: d[k] for k in ("peak_is", "executed_16bit_tflops", "vs_fp32_mfma_peak") if k in d},
                     "algorithmic_flops_per_launch": int(kstats[dom]["flops"] / max(1, kstats[dom]["launches"])),
                     "avg_launch_us": d["avg_launch_us"]}
+        iso_det = rooflines(iso, 2) if iso else None
         # decoder phase against HBM: algorithmic bytes per step of this batch
         dm = eng.dims
         dstate, L, T, V = dm.n_text_state, dm.n_text_layer, dm.n_audio_ctx, dm.n_vocab
@@ -474,9 +475,13 @@ def main() -> None:
                                   "bits), 3 fp16-MFMA products, fp32 accumulate (measured error below the fp32-MFMA "
                                   "kernel's, tests/test_gpu_kernels.py; bf16 x3 split and fp32 MFMA selectable); "
                                   "decoder: fp32 MFMA; no value leaves fp32 storage"},
-            "roofline": roof,
+            "roofline": ({**roof, "isolated": {k: iso_det[dom][k] for k in ("achieved", "frac", "avg_launch_us")},
+                          "note": "achieved/avg_launch_us: HIP events inside the timed (pipelined) region, where decoder "
+                                  "chains share the chip; isolated: the same launches in two synchronous passes after it — "
+                                  "the figure a serialising profiler (rocprofv3 --kernel-trace, profiles/) reproduces"}
+                         if roof and iso_det and dom in iso_det else roof),
             "roofline_detail": detail,
-            "roofline_isolated": rooflines(iso, 2) if iso else None,
+            "roofline_isolated": iso_det,
             "decoder_roofline": {"bound": "hbm", "achieved": round(dec_ach, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                                  "frac": round(dec_ach / PEAK_HBM_GBPS, 4),
                                  "algorithmic_bytes_per_step": int(dec_bytes)},
