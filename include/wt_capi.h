@@ -80,7 +80,7 @@ int wt_engine_dims(const wt_engine* h, wt_dims* out);
  * "resid_waves" (4, 8, 16 wavefronts per block of the decoder's residual
  * GEMMs), "use_graphs" (1 = default: the decoder's launch sequence is replayed from a hipGraph).
  * Environment, read at wt_engine_create: WT_ENC_CU_RESERVE (CUs per XCD the pipelined encoder
- * stream leaves to the decoders, default 5, 0 = none), WT_DEC_STREAMS (decoder streams, default 3),
+ * stream leaves to the decoders, default 4, 0 = none), WT_DEC_STREAMS (decoder streams, default 3),
  * WT_TRACE_PIPELINE (per-batch device timeline on stderr). */
 int wt_engine_set_option(wt_engine* h, const char* key, long value);
 int wt_engine_get_option(const wt_engine* h, const char* key, long* value);

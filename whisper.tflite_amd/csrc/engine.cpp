@@ -401,7 +401,7 @@ Engine::Engine(const std::string& model_prefix, const std::string& vocab_path, b
   // to an encoder that owns every CU stretch it by 2.5 ms per batch, next to one that owns
   // 224 of 256 CUs by 0.9 ms; with the faster encoder kernels 4..8 CUs per XCD measure
   // within 2 % of each other. Synchronous calls keep the whole chip.
-  int reserve = 5;
+  int reserve = 4;
   if (const char* v = getenv("WT_ENC_CU_RESERVE")) reserve = std::min(std::max(atoi(v), 0), 16);
   const int n_cu = prop.multiProcessorCount;
   if (reserve > 0 && n_cu >= 64 && n_cu % 8 == 0) {

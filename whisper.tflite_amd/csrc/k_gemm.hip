@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split16_tile(GemmDev g) {
   constexpr int LD = BK;
   constexpr int PLANE = BM * LD;        // bf16 per operand plane
   constexpr int BUF = 2 * NS * PLANE;   // bf16 per buffer (A planes, then W planes)
-  constexpr int kTileBytes = 2 * BUF * 2 + ((ABL & 8) ? 20000 : 0)  /* ABL 8: occupancy pad, results unchanged */, kStageBytes = 4 * 32 * (NI * 32 + 4) * 4;
+  constexpr int kTileBytes = 2 * BUF * 2 + ((ABL & 8) ? (55700 - 2 * BUF * 2 > 0 ? 55700 - 2 * BUF * 2 : 0) : 0)  /* ABL 8: occupancy pad, results unchanged */, kStageBytes = 4 * 32 * (NI * 32 + 4) * 4;
   __shared__ __attribute__((aligned(16))) unsigned char smem_raw[kTileBytes > kStageBytes ? kTileBytes : kStageBytes];
   unsigned short* const lds = reinterpret_cast<unsigned short*>(smem_raw);
 
@@ -681,7 +681,7 @@ void launch_gemm_t(const GemmDev& g, int variant, hipStream_t s) {
     case 13: launch_split16<EPI, 0>(g, s); break;  // split-3, k-tiles of 16, double-buffered LDS
     case 14: launch_split16<EPI, 1>(g, s); break;  // same with an explicit MFMA/VALU interleave
     case 15: launch_split16<EPI, 2>(g, s); break;  // same, staging before the MFMAs of a k-tile
-    case 16: launch_split16<EPI, 0, 8>(g, s); break;  // variant 13 with LDS padded to 69 KB: 2 blocks per CU, which
+    case 16: launch_split16<EPI, 0, 8>(g, s); break;  // variant 13 with LDS padded to 54 KB: 2 blocks per CU, which
                                                       // leaves registers and LDS for co-resident decoder blocks
     case 17: launch_split16<EPI, 0, 0, true>(g, s); break;  // two fp16 planes, three products (22-bit operands)
     case 18: launch_split16<EPI, 0, 8, true>(g, s); break;  // same at 2 blocks per CU
