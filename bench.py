@@ -281,6 +281,9 @@ def main() -> None:
         flush_gather()
         return out[0], out[1], gathered["rec"]
 
+    # engine initialisation, outside warm-up and timing like the weight upload: the first batch sets kernel
+    # attributes and captures the decoder's hipGraphs (one per pipeline slot)
+    run_steps(1)
     if args.warmup:
         run_steps(args.warmup)
 
@@ -471,6 +474,7 @@ def main() -> None:
                        "clips_per_gpu": B, "global_batch": world * B, "decoder_positions": 30,
                        "argmax_steps": 27, "parallelism": f"clip-parallel dp{world}, one RCCL all_gather of id records per {GATHER_EVERY} batches",
                        "pipelined": pipelined, "batches_in_flight": args.depth if pipelined else 1,
+                       "priming_batches": 1,
                        "compute": "encoder GEMMs and attention: fp32 operands split into 2 fp16 planes (22 significand "
                                   "bits), 3 fp16-MFMA products, fp32 accumulate (measured error below the fp32-MFMA "
                                   "kernel's, tests/test_gpu_kernels.py; bf16 x3 split and fp32 MFMA selectable); "
