@@ -78,7 +78,8 @@ int wt_engine_dims(const wt_engine* h, wt_dims* out);
  * shapes; 11 = operands rounded to bf16), "attn_variant" (4 = default, two fp16 planes; 1, 2 = three
  * bf16 planes with 128 / 256 queries per block; 0 = fp32 MFMA; 3 = operands rounded to bf16),
  * "resid_waves" (4, 8, 16 wavefronts per block of the decoder's residual
- * GEMMs), "use_graphs" (1 = default: the decoder's launch sequence is replayed from a hipGraph).
+ * GEMMs), "fc2_ksplit" (2 = default: the decoder's fc2 GEMM over twice the blocks, halves added by the
+ * consumer; 1 = one block per column tile), "use_graphs" (1 = default: the decoder's launch sequence is replayed from a hipGraph).
  * Environment, read at wt_engine_create: WT_ENC_CU_RESERVE (CUs per XCD the pipelined encoder
  * stream leaves to the decoders, default 4, 0 = none), WT_DEC_STREAMS (decoder streams, default 3),
  * WT_TRACE_PIPELINE (per-batch device timeline on stderr). */

@@ -124,6 +124,9 @@ int wt_engine_set_option(wt_engine* h, const char* key, long value) {
   } else if (k == "resid_waves") {
     if (value != 4 && value != 8 && value != 16) return fail(h, WT_ERR_INVALID_ARG, "resid_waves must be 4, 8 or 16");
     e.resid_waves = value;
+  } else if (k == "fc2_ksplit") {
+    if (value != 1 && value != 2) return fail(h, WT_ERR_INVALID_ARG, "fc2_ksplit must be 1 or 2");
+    e.fc2_ksplit = value;
   } else if (k == "use_graphs") {
     e.use_graphs = value != 0;
   } else if (k == "gemm_variant") {
@@ -152,6 +155,7 @@ int wt_engine_get_option(const wt_engine* h, const char* key, long* value) {
   else if (k == "cross_chunks") *value = e.cross_chunks;
   else if (k == "gemm_variant") *value = e.gemm_variant;
   else if (k == "use_graphs") *value = e.use_graphs;
+  else if (k == "fc2_ksplit") *value = e.fc2_ksplit;
   else if (k == "resid_waves") *value = e.resid_waves;
   else if (k == "attn_variant") *value = e.attn_variant;
   else return WT_ERR_INVALID_ARG;

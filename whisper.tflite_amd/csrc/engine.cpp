@@ -543,6 +543,8 @@ void Engine::ensure_batch(int batch) {
   }
   for (DecWorkspace& dw : dws_) {
     dw.xd = alloc(B * d, false);
+    dw.xb = alloc(B * d, false);
+    dw.xpart = alloc(B * d, false);
     dw.lnd = alloc(B * d, false);
     dw.qkvd = alloc(B * 3 * d, false);
     dw.attd = alloc(B * d, false);
@@ -905,12 +907,17 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
     const size_t kv_slab = size_t(batch) * T * d;  // one (layer, k|v) slab of the cross cache
     const size_t self_slab = size_t(batch) * self_cap_ * d;
     float* const x = dw.xd;  // residual stream [B][d], updated in place by the residual GEMMs
+    // fc2 (K = 4 d) runs over twice the blocks when its K splits evenly over 2 x waves x 8
+    const bool split = fc2_ksplit == 2 && (4 * d) % (16 * int(resid_waves)) == 0;
     for (int pos = 0; pos < max_pos; ++pos) {
       for (int l = 0; l < c.n_text_layer; ++l) {
         const BlockWeights& w = dec_blocks_[l];
         DecGemmArgs q;  // LN + fused q|k|v projection (+ token/positional embedding at layer 0)
         q.Wt = w.attn.wqkv; q.N = 3 * d; q.K = d; q.B = batch;
         q.xin = x; q.ln_g = w.attn_ln_g; q.ln_b = w.attn_ln_b;
+        if (l > 0 && split) {  // the previous layer's fc2 left x in two halves: sum them, block 0 completes x
+          q.xin = dw.xb; q.xpart = dw.xpart; q.xout = x;
+        }
         if (l == 0) {
           q.ids = dw.ids; q.ids_stride = stride; q.pos = pos; q.tok_emb = tok_emb; q.pos_emb = dec_pos;
           q.n_vocab = V; q.xout = x;
@@ -947,12 +954,16 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
         DecGemmArgs f2;  // x += h . W2^T + b2
         f2.Wt = w.w2; f2.N = d; f2.K = 4 * d; f2.B = batch; f2.X = dw.hd; f2.ldx = 4 * d;
         f2.bias = w.b2; f2.R = x; f2.Y = x; f2.ldy = d; f2.resid_waves = int(resid_waves);
+        if (split) {
+          f2.Y = dw.xb; f2.ksplit = 2; f2.part = dw.xpart;
+        }
         DT(7, launch_dec_gemm(f2, kProNone, kDecResid, stream_));
       }
       if (pos >= n_prompt - 1) {
         // logits against the tied embedding + greedy argmax (whisper.cpp:379-399); only the
         // last position's row exists here, the reference computes and drops the others
-        DT(8, launch_dec_finalize_ln(x, dec_ln_g, dec_ln_b, dw.lnd, batch, d, stream_));
+        DT(8, launch_dec_finalize_ln(split ? dw.xb : x, dec_ln_g, dec_ln_b, dw.lnd, batch, d, stream_,
+                                     split ? dw.xpart : nullptr));
         DecGemmArgs lg;
         lg.Wt = tok_emb_tiled; lg.N = V; lg.K = d; lg.B = batch; lg.X = dw.lnd; lg.ldx = d;
         lg.Y = logits_host ? dw.logits : nullptr; lg.ldy = V; lg.best = dw.best;
@@ -976,7 +987,7 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
   // kernels' one-time attribute set-up) and then captures one hipGraph per slot; later calls
   // replay the slot's graph: one host call instead of ~1100. The logits tap stays eager.
   auto key_of = [&](int si) {
-    return std::vector<long long>{si, batch, max_pos, n_prompt, chunks, long(stop_at_eot), resid_waves};
+    return std::vector<long long>{si, batch, max_pos, n_prompt, chunks, long(stop_at_eot), resid_waves, fc2_ksplit};
   };
   hipGraphExec_t exec = nullptr;
   if (use_graphs && !logits_host) {

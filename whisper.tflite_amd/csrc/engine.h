@@ -75,6 +75,7 @@ class Engine {
   long cross_chunks = 2;  // key chunks per (clip, head) of the decoder cross-attention (measured: 2 beats 4 by 6 % alone)
   long attn_variant = 4;  // encoder attention: 0 = fp32 MFMA, 1/2 = bf16 x3 split, 3 = bf16 operands, 4 = fp16 x2 split
   long resid_waves = 8;   // wavefronts per block of the decoder's residual GEMMs (4, 8, 16)
+  long fc2_ksplit = 2;  // decoder fc2 (K = 4 d_model) over twice the blocks, halves summed by the consumer
   long use_graphs = 1;  // replay the decoder's launch sequence from a captured hipGraph
   long gemm_variant = -1;  // encoder GEMM tile variant (k_gemm.hip); -1 = per-shape choice
   // non-empty: replaces the reference's hard-coded prompt (test-sized vocabularies)
@@ -205,6 +206,7 @@ class Engine {
   int dft_n = 0, dft_k = 0, dft_im_off = 0, mel_n = 0, mel_k = 0;
 
   struct DecWorkspace {  // one per decoder stream
+    float *xb = nullptr, *xpart = nullptr;  // fc2's K-split: first-half result / second-half partial
     float *xd = nullptr, *lnd = nullptr, *qkvd = nullptr, *attd = nullptr, *qd = nullptr,
           *hd = nullptr, *cross_ws = nullptr, *self_kv = nullptr, *logits = nullptr;
     unsigned long long* best = nullptr;

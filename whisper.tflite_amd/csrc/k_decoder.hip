@@ -60,11 +60,16 @@ struct DecGemmDev {
   float* Y;
   int ldy;
   unsigned long long* best;
+  int ksplit;
+  float* part;
+  const float* xpart;
 };
 
-// Row sources of the residual stream.  LNMODE 0: x = xin;  2: x = tok_emb[id] + pos_emb.
+// Row sources of the residual stream.  LNMODE 0: x = xin;  2: x = tok_emb[id] + pos_emb;  3: x = xin + xpart
+// (the second K-half of the previous residual GEMM is still pending in xpart).
 struct RowSrc {
   const float* xin;
+  const float* xpart;
   const long long* ids;
   int ids_stride, pos;
   const float* tok_emb;
@@ -89,6 +94,11 @@ __device__ __forceinline__ void load_row(f32x4 (&v)[NF4], const RowSrc& r, int r
     const float* pe = r.pos_emb + (long)r.pos * K;
 #pragma unroll
     for (int j = 0; j < NF4; ++j) v[j] += *reinterpret_cast<const f32x4*>(pe + (sub + 8 * j) * 4);
+  }
+  if (LNMODE == 3) {
+    const float* pp = r.xpart + (long)row * K;
+#pragma unroll
+    for (int j = 0; j < NF4; ++j) v[j] += *reinterpret_cast<const f32x4*>(pp + (sub + 8 * j) * 4);
   }
 }
 
@@ -130,11 +140,14 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm(DecGemmDev g) {
   float* xs = smem + (WAVES - 1) * MT * 16 * 64;  // [MT*32][K + 4] LayerNorm rows (kProLn)
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
-  const int tile = blockIdx.x;
+  // ksplit = 2 (kProNone + kDecResid only): blocks [0, n_tiles) take the first half of K and finish the
+  // residual, blocks [n_tiles, 2 n_tiles) take the second half and leave their partial in g.part
+  const int n_tiles = (g.N + 31) / 32;
+  const int tile = blockIdx.x % n_tiles, khalf = blockIdx.x / n_tiles;
   const int K = g.K, B = g.B, xld = K + 4;
 
-  const int kwave = K / WAVES;
-  const int k0 = wid * kwave;
+  const int kwave = (K / g.ksplit) / WAVES;
+  const int k0 = khalf * (K / g.ksplit) + wid * kwave;
   const int nchunks = kwave >> 3;
   const float* wp = g.Wt + ((long)tile * (K >> 3) + (k0 >> 3)) * 256 + lane * 4;
   // the weight stream does not depend on the prologue: its first group goes in flight now so
@@ -155,7 +168,7 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm(DecGemmDev g) {
   const int n_epi = tile * 32 + l31;
   float bias_pre = 0.0f;
   float r_pre[kPreR ? 16 : 1];
-  if (wid == 0) {
+  if (wid == 0 && khalf == 0) {
     if ((EPI == kDecBias || EPI == kDecResid) && MT == 1) bias_pre = g.bias[n_epi < g.N ? n_epi : 0];
     if (kPreR) {
 #pragma unroll
@@ -169,14 +182,15 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm(DecGemmDev g) {
   if (PRO == kProLn) {
     // LayerNorm of the residual stream; a wavefront handles 8 rows at once, one memory round
     // trip per pass.  With the embedding source the rows are also materialised once (block 0).
-    const bool writer = LNMODE == 2 && blockIdx.x == 0 && g.xout != nullptr;
+    const bool writer = (LNMODE == 2 || LNMODE == 3) && blockIdx.x == 0 && g.xout != nullptr;
     const int r8 = lane >> 3, sub = lane & 7;
-    const RowSrc src{g.xin, g.ids, g.ids_stride, g.pos, g.tok_emb, g.pos_emb, g.n_vocab};
+    const RowSrc src{g.xin, g.xpart, g.ids, g.ids_stride, g.pos, g.tok_emb, g.pos_emb, g.n_vocab};
     constexpr int NV = NF4 > 0 ? NF4 : 1;
     static_assert(PRO != kProLn || WAVES == 4, "the LayerNorm prologue maps 4 waves x 8 rows");
     // gain and shift are row-independent: requested together with the rows, not after their statistics
-    // (not for the embedding source, LNMODE 2, nor two M-tiles: register pressure)
-    constexpr bool kHoistLn = LNMODE != 2 && MT == 1;
+    // (plain rows only: the embedding gather, LNMODE 2, the two-array sum, LNMODE 3, and two M-tiles already
+    // sit at the register budget)
+    constexpr bool kHoistLn = LNMODE == 0 && MT == 1;
     f32x4 lg[kHoistLn ? NV : 1], lb[kHoistLn ? NV : 1];
     if (kHoistLn) {
 #pragma unroll
@@ -341,6 +355,10 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm(DecGemmDev g) {
       float v = acc[t][r] + bias;
       if (EPI == kDecBias && g.gelu) v = gelu_erf(v);
       const bool ok = n_ok && b < B;
+      if (EPI == kDecResid && khalf == 1) {  // second K-half: the raw partial, summed by the consumer
+        if (ok) g.part[(long)b * g.ldy + n] = acc[t][r];
+        continue;
+      }
       // R may alias Y: each element is read and written by the same thread
       if (EPI == kDecResid && ok) v += kPreR ? r_pre[r] : g.R[(long)b * g.ldy + n];
       if (ok && g.Y) g.Y[(long)b * g.ldy + n] = v;
@@ -361,7 +379,7 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm(DecGemmDev g) {
 }
 
 // y = LayerNorm(x)   (input rows of the logits GEMM).
-template <int NF4>
+template <int NF4, int LNMODE>
 __global__ __launch_bounds__(256) void dec_finalize_ln(RowSrc src, const float* __restrict__ g,
                                                        const float* __restrict__ b,
                                                        float* __restrict__ y, int B, int K) {
@@ -375,7 +393,7 @@ __global__ __launch_bounds__(256) void dec_finalize_ln(RowSrc src, const float* 
     gg[j] = *reinterpret_cast<const f32x4*>(g + (sub + 8 * j) * 4);
     bb[j] = *reinterpret_cast<const f32x4*>(b + (sub + 8 * j) * 4);
   }
-  load_row<NF4, 0>(v, src, row, sub, B, K);
+  load_row<NF4, LNMODE>(v, src, row, sub, B, K);
   float mean, rstd;
   row_stats<NF4>(v, K, &mean, &rstd);
 #pragma unroll
@@ -394,7 +412,7 @@ void launch_mt(const DecGemmDev& g, hipStream_t s) {
   const int MT = g.B <= 32 ? 1 : 2;
   const size_t smem =
       (size_t)((WAVES - 1) * MT * 16 * 64 + (PRO == kProLn ? MT * 32 * (g.K + 4) : 0)) * sizeof(float);
-  const dim3 grid(n_tiles);
+  const dim3 grid(n_tiles * (PRO == kProNone && EPI == kDecResid ? g.ksplit : 1));
   // dynamic LDS beyond the 64 KiB default needs an opt-in, once per kernel
   static const bool raised = [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_gemm<PRO, EPI, 1, NF4, LNMODE, WAVES, CH>),
@@ -428,17 +446,25 @@ void launch_dec_gemm(const DecGemmArgs& a, int pro, int epi, hipStream_t s) {
   if (epi == kDecBiasGelu) epi = kDecBias;
   DecGemmDev g{a.Wt,      a.N,       a.K,       a.B,        a.X,     a.ldx,    a.xin,  a.xout, a.ln_g,
                a.ln_b,    a.ids,     a.ids_stride, a.pos,   a.tok_emb, a.pos_emb, a.n_vocab,
-               a.cross_ws, a.heads,  a.chunks,  a.bias,     gelu,    a.R,      a.Y,    a.ldy,  a.best};
+               a.cross_ws, a.heads,  a.chunks,  a.bias,     gelu,    a.R,      a.Y,    a.ldy,  a.best,
+               a.ksplit,  a.part,    a.xpart};
   // host-side shape contract: operands must match what the kernel indexes
   const bool wide = epi == kDecResid;  // N = d_model: 16 wavefronts split K
   if (a.B < 1 || a.B > 64 || a.K > 2048 || a.K % (wide ? 8 * a.resid_waves : 32) != 0 || (a.resid_waves != 4 && a.resid_waves != 8 && a.resid_waves != 16) ||
       (pro == kProCombine && (a.K / (8 * a.resid_waves) > (a.resid_waves > 8 ? 6 : 12) || a.K != a.heads * 64)) || (wide && (!a.R || !a.Y))) {
     abort();
   }
+  if (a.ksplit != 1 && !(a.ksplit == 2 && pro == kProNone && epi == kDecResid && a.part &&
+                         a.K % (16 * a.resid_waves) == 0 && a.R != a.Y)) {
+    abort();  // split K: residual GEMM only, with a partial buffer, out of place (the consumer completes the rows into R)
+  }
   if (pro == kProLn) {
     if (epi != kDecBias) abort();
     if (a.ids) {
+      if (a.xpart) abort();
       launch_ln<2>(g, s);
+    } else if (a.xpart) {
+      launch_ln<3>(g, s);
     } else {
       launch_ln<0>(g, s);
     }
@@ -476,15 +502,25 @@ void launch_dec_gemm(const DecGemmArgs& a, int pro, int epi, hipStream_t s) {
   }
 }
 
-void launch_dec_finalize_ln(const float* xin, const float* g, const float* b, float* y, int B, int K,
-                            hipStream_t s) {
-  const RowSrc src{xin, nullptr, 0, 0, nullptr, nullptr, 0};
+template <int LNMODE>
+static void launch_finalize_mode(const RowSrc& src, const float* g, const float* b, float* y, int B, int K,
+                                 hipStream_t s) {
   const dim3 grid((B + 31) / 32);
   switch (K) {
-    case 128: hipLaunchKernelGGL(dec_finalize_ln<4>, grid, dim3(256), 0, s, src, g, b, y, B, K); break;
-    case 384: hipLaunchKernelGGL(dec_finalize_ln<12>, grid, dim3(256), 0, s, src, g, b, y, B, K); break;
-    case 512: hipLaunchKernelGGL(dec_finalize_ln<16>, grid, dim3(256), 0, s, src, g, b, y, B, K); break;
+    case 128: hipLaunchKernelGGL((dec_finalize_ln<4, LNMODE>), grid, dim3(256), 0, s, src, g, b, y, B, K); break;
+    case 384: hipLaunchKernelGGL((dec_finalize_ln<12, LNMODE>), grid, dim3(256), 0, s, src, g, b, y, B, K); break;
+    case 512: hipLaunchKernelGGL((dec_finalize_ln<16, LNMODE>), grid, dim3(256), 0, s, src, g, b, y, B, K); break;
     default: abort();
+  }
+}
+
+void launch_dec_finalize_ln(const float* xin, const float* g, const float* b, float* y, int B, int K,
+                            hipStream_t s, const float* xpart) {
+  const RowSrc src{xin, xpart, nullptr, 0, 0, nullptr, nullptr, 0};
+  if (xpart) {
+    launch_finalize_mode<3>(src, g, b, y, B, K, s);
+  } else {
+    launch_finalize_mode<0>(src, g, b, y, B, K, s);
   }
 }
 

@@ -92,11 +92,19 @@ struct DecGemmArgs {
   int ldy = 0;
   unsigned long long* best = nullptr;
   int resid_waves = 16;  // wavefronts per block of the kDecResid GEMMs (4, 8 or 16)
+  // kProNone + kDecResid with ksplit = 2: twice the blocks, each over half of K (a K = 1536 GEMM on 12 column
+  // tiles is bound by what one CU can stream).  Blocks of the first half write Y = R + bias + partial, blocks
+  // of the second half write their raw partial to `part` [B][ldy]; the consumer adds the two (xpart below).
+  int ksplit = 1;
+  float* part = nullptr;
+  // kProLn: rows = xin + xpart (the pending second half of the previous residual GEMM); block 0 stores the
+  // completed rows to xout
+  const float* xpart = nullptr;
 };
 void launch_dec_gemm(const DecGemmArgs& a, int pro, int epi, hipStream_t s);
 // y = LayerNorm(x) * g + b : input rows of the logits GEMM
 void launch_dec_finalize_ln(const float* xin, const float* g, const float* b, float* y, int B, int K,
-                            hipStream_t s);
+                            hipStream_t s, const float* xpart = nullptr);
 
 // ------------------------------------------------------------- LayerNorm ---
 // y[m][:] = (x[m][:] - mean) * rstd * g + b, eps 1e-5, one wavefront per row.
