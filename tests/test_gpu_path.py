@@ -376,6 +376,24 @@ def test_operand_outside_fp16_range_is_reported_not_hidden(tiny):
     assert np.array_equal(ids2, ids_ok) and np.array_equal(n2, n_ok)
 
 
+def test_mel_at_its_bound_matches_the_full_range_kernels(tiny):
+    """The fp16 two-plane kernels take their operand scales from bounds that assume |mel| <= 8.  An input AT
+    that bound (far outside what the front end produces) must stay finite and agree with the bf16
+    three-plane kernels, which have no range assumptions."""
+    e, _ = tiny
+    rng = np.random.default_rng(8)
+    mel = (rng.integers(0, 2, size=(2,) + e.mel_shape) * 16.0 - 8.0).astype(np.float32)  # +-8 everywhere
+    ids_a, n_a, enc_a, _ = e.encdec_debug_batch(mel, want_logits=False)
+    e.set_option("gemm_variant", 16)
+    e.set_option("attn_variant", 1)
+    ids_b, n_b, enc_b, _ = e.encdec_debug_batch(mel, want_logits=False)
+    e.set_option("gemm_variant", -1)
+    e.set_option("attn_variant", 4)
+    assert np.isfinite(enc_a).all() and np.isfinite(enc_b).all()
+    assert np.abs(enc_a - enc_b).max() < 2e-4  # LayerNorm output, O(1): both carry fp32-level error
+    assert np.array_equal(n_a, n_b)
+
+
 def test_long_audio_windows_and_language(tiny):
     """SURVEY §8 f2: audio longer than 30 s is cut into windows that are transcribed as one batch;
     every window's text equals the single-clip call on that window."""
