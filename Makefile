@@ -1,6 +1,6 @@
 # Builds the MI355X (gfx950) engine in-tree:
 #   whisper.tflite_amd/lib/libwhisper-tflite.so   C ABI (include/wt_capi.h) + C++ surface
-#   whisper.tflite_amd/bin/encdec                 the reference's CLI, same flags
+#   whisper.tflite_amd/bin/encdec, bin/minimal    the reference's CLIs, same arguments
 #   whisper.tflite_amd/bin/wt-make-assets         synthetic weights / vocab writer
 #   oracle/libwt_oracle.so (+ oracle/_ref/)       test infrastructure (see oracle/)
 HIPCC ?= /opt/rocm/bin/hipcc
@@ -12,12 +12,12 @@ CXXFLAGS := -std=c++17 -O3 -fPIC -Iinclude -I$(SRC) -Wall -Wno-unused-result
 HIPFLAGS := $(CXXFLAGS) --offload-arch=$(ARCH) -ffp-contract=fast
 
 KERNELS := k_gemm k_misc k_attention k_decoder
-HOSTSRC := engine capi host_util weights_gen whisper_api
+HOSTSRC := engine capi host_util weights_gen whisper_api tflite_extract
 OBJS := $(addprefix $(OBJ)/,$(addsuffix .o,$(KERNELS) $(HOSTSRC)))
 
 all: lib apps oracle
 lib: $(PKG)/lib/libwhisper-tflite.so
-apps: $(PKG)/bin/encdec $(PKG)/bin/wt-make-assets
+apps: $(PKG)/bin/encdec $(PKG)/bin/minimal $(PKG)/bin/wt-make-assets
 oracle:
 	$(MAKE) -C oracle
 
@@ -34,6 +34,10 @@ $(PKG)/lib/libwhisper-tflite.so: $(OBJS)
 	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(OBJS)
 
 $(PKG)/bin/encdec: $(PKG)/app/encdec.cpp $(PKG)/lib/libwhisper-tflite.so
+	@mkdir -p $(PKG)/bin
+	$(HIPCC) $(CXXFLAGS) -o $@ $< -L$(PKG)/lib -lwhisper-tflite -Wl,-rpath,'$$ORIGIN/../lib'
+
+$(PKG)/bin/minimal: $(PKG)/app/minimal.cpp $(PKG)/lib/libwhisper-tflite.so
 	@mkdir -p $(PKG)/bin
 	$(HIPCC) $(CXXFLAGS) -o $@ $< -L$(PKG)/lib -lwhisper-tflite -Wl,-rpath,'$$ORIGIN/../lib'
 

@@ -168,6 +168,7 @@ def main() -> None:
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--dry-run-gloo", action="store_true")
+    ap.add_argument("--emit-ids", action="store_true", help="add a CRC of every step's ids and the gathered record count to the line")
     ap.add_argument("--rehearse-nccl", action="store_true",
                     help="single rank: create the RCCL communicator and run the N > 1 collectives anyway")
     args = ap.parse_args()
@@ -228,7 +229,7 @@ def main() -> None:
     # collectives: an RCCL kernel per batch would sit in a hardware queue next to a decoder chain and
     # couple the ranks batch by batch).  Every record is gathered inside the timed region.
     pending = []
-    gathered = {"rec": None, "collectives": 0}
+    gathered = {"rec": None, "collectives": 0, "records": 0, "crc": 0}
 
     def flush_gather():
         if not pending:
@@ -239,6 +240,10 @@ def main() -> None:
             rec = gather_records(rec.cuda() if args.backend == "nccl" else rec, world)
             gathered["collectives"] += 1
         gathered["rec"] = rec
+        gathered["records"] += int(rec.shape[0])
+        if args.emit_ids:
+            import zlib
+            gathered["crc"] = zlib.crc32(np.ascontiguousarray(rec.cpu().numpy()).tobytes(), gathered["crc"])
 
     def finish(ids, n):
         pending.append(pack_records(ids, n))
@@ -303,11 +308,13 @@ def main() -> None:
             for k in acc:
                 acc[k] += v[k]
 
+    gathered.update(collectives=0, records=0, crc=0)  # count the timed region only
     fence()
     t0 = time.perf_counter()
     ids, n, rec = run_steps(args.steps, accumulate)
     fence()
     elapsed = time.perf_counter() - t0
+    timed = dict(gathered)
     if world > 1 or FORCE_COLLECTIVES:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -408,7 +415,7 @@ def main() -> None:
                     continue
                 mfma = v["flops"] > 0
                 ach = (v["flops"] / 1e12 if mfma else v["bytes"] / 1e9) / (v["ms"] * 1e-3)
-                split = mfma and "split" in name and "(bf16)" not in name
+                split = mfma and "split" in name
                 # split kernels spend 3 (two fp16 planes per operand, the default) or 6 (three bf16
                 # planes) 16-bit MFMA FLOPs per algorithmic fp32 FLOP: their MFMA ceiling in algorithmic
                 # FLOP/s is the dense f16/bf16 peak / products; fp32-MFMA kernels are priced against
@@ -494,6 +501,10 @@ def main() -> None:
             "stage_ms_per_step": stage,
             "host_enqueue_ms_per_step": round(1e3 * host["submit_s"] / max(1, host["submits"]), 3) if pipelined else None,
         }
+        out["collectives"] = timed["collectives"]
+        if args.emit_ids:
+            out["gathered_records"] = timed["records"]
+            out["ids_crc"] = timed["crc"]
         if not args.no_cpu_baseline:
             info = eng.vocab_info()
             prompt = [info["sot"], 50259 + eng.get_option("language"), info["transcribe"], info["not"]]

@@ -3,7 +3,8 @@
  * Drop-in boundary for the reference's engine surface (jerinphilip/whisper.tflite @ v2):
  * every entry point below is what a binding for that path would call instead of the
  * TFLite-interpreter-backed implementation.  Plain pointers and sizes only; nothing here
- * throws or exits; errors are int status codes plus wt_last_error().
+ * throws, exits or aborts: a file, shape or option the kernels do not support comes back as an int
+ * status code plus wt_last_error().
  *
  * Threading contract = the reference's (an engine is NOT re-entrant; callers serialise,
  * cf. io/github/jerinphilip/whisper/Whisper.java:109-113): one in-flight call per handle,
@@ -26,7 +27,7 @@ enum wt_status {
   WT_ERR_INVALID_ARG = 1,
   WT_ERR_IO = 2,          /* file missing / unreadable (reference: MmapFile throws, mmap_file.cpp:16-29) */
   WT_ERR_FORMAT = 3,      /* malformed weight or vocab file */
-  WT_ERR_UNSUPPORTED = 4, /* e.g. EngineType Monolith (out of scope) */
+  WT_ERR_UNSUPPORTED = 4, /* e.g. an audio geometry other than the reference's fixed one */
   WT_ERR_DEVICE = 5,      /* no usable gfx950 device / HIP failure: the product has NO CPU fallback */
   WT_ERR_BUFFER = 6       /* caller buffer too small; *len still reports the needed size */
 };
@@ -57,6 +58,13 @@ typedef struct wt_timings {
  * EncDec::EncDec (whisper.cpp:740-750).  `model_prefix` resolves to "<prefix>.wtw" (this
  * build's weight file, standing in for "<prefix>.encoder.tflite"/"<prefix>.decoder.tflite",
  * whisper.cpp:743-744); `vocab_path` is the reference's filters+vocab .bin, byte-compatible.
+ * When "<prefix>.wtw" does not exist but the reference's "<prefix>.encoder.tflite" and
+ * "<prefix>.decoder.tflite" do, their weights are extracted (wt_convert_tflite below) into
+ * "<prefix>.wtw" first.  WT_ENGINE_MONOLITH (reference Monolith, whisper.cpp:667-738: one graph with HF
+ * generate() inside) runs the same encoder / decoder kernels from "<prefix>.wtw" with the prompt that
+ * graph forces: [sot, notimestamps] for an English-only model (the head of kGoldenGeneratedIDs,
+ * whisper.h:27-32), [sot, <|en|>, transcribe, notimestamps] for a multilingual one; ids are capped at the
+ * engine's 31 positions where HF generate() allows 448.
  * On failure *out is NULL and wt_last_error(NULL) describes why. */
 int wt_engine_create(int engine_type, const char* model_prefix, const char* vocab_path,
                      int multilingual, int device_id, wt_engine** out);
@@ -80,6 +88,9 @@ int wt_engine_dims(const wt_engine* h, wt_dims* out);
  * "resid_waves" (4, 8, 16 wavefronts per block of the decoder's residual
  * GEMMs), "fc2_ksplit" (2 = default: the decoder's fc2 GEMM over twice the blocks, halves added by the
  * consumer; 1 = one block per column tile), "use_graphs" (1 = default: the decoder's launch sequence is replayed from a hipGraph).
+ * Read-only (wt_engine_get_option): "f16_fallbacks" = contractions that were given the full-range bf16
+ * three-plane kernels at load time because an operand's weight-derived bound lies more than 2^12 above its
+ * typical magnitude (csrc/engine.cpp, upload_weights); "in_flight" = submitted, uncollected batches.
  * Environment, read at wt_engine_create: WT_ENC_CU_RESERVE (CUs per XCD the pipelined encoder
  * stream leaves to the decoders, default 4, 0 = none), WT_DEC_STREAMS (decoder streams, default 3),
  * WT_TRACE_PIPELINE (per-batch device timeline on stderr). */
@@ -174,7 +185,38 @@ int wt_vocab_info(const wt_engine* h, int32_t out[9]);
 /* mel filter bank as loaded from the vocab file: [n_mel][n_fft]; returns element count. */
 int wt_filters(const wt_engine* h, float* out, size_t cap, int32_t* n_mel, int32_t* n_fft);
 
-/* ---- asset tooling (stand-ins for the reference's offline export) ---------- */
+/* ---- vocab / filter file on the host (no GPU needed) --------------------------------------
+ * Replace MmapFile + Reader::read (mmap_file.cpp:13-31, whisper.cpp:519-611, :746-749), Vocab
+ * (whisper.h:44-94) and decode() (whisper.cpp:634-665) for callers that only need the tables. */
+typedef struct wt_vocab wt_vocab;
+int wt_vocab_open(const char* vocab_path, int multilingual, wt_vocab** out);
+void wt_vocab_close(wt_vocab* v);
+/* out[0..8] as wt_vocab_info */
+int wt_vocab_get_info(const wt_vocab* v, int32_t out[9]);
+/* as wt_filters */
+int wt_vocab_get_filters(const wt_vocab* v, float* out, size_t cap, int32_t* n_mel, int32_t* n_fft);
+/* number of id -> token entries (file tokens + synthesised specials) */
+int wt_vocab_size(const wt_vocab* v);
+/* bytes of one token (WT_ERR_INVALID_ARG when the id has no entry) */
+int wt_vocab_token(const wt_vocab* v, int id, char* out, size_t cap, size_t* len);
+int wt_vocab_decode(const wt_vocab* v, const int64_t* ids, int n, int omit_special_tokens, char* out,
+                    size_t cap, size_t* len);
+
+/* ---- the log-mel front end as a free function ---------------------------------------------
+ * Replaces whisper::log_mel_spectrogram (whisper.h:123, whisper.cpp:109-216) for callers that hold a
+ * Filters table but no engine: the same gfx950 kernels the engine uses, on `device_id`, through a
+ * process-wide front-end context created at the first call.  Only the reference's fixed geometry is
+ * provided (16 kHz, fft 400, hop 160, 80 x 201 filters, n_samples <= 480000), anything else is
+ * WT_ERR_UNSUPPORTED.  mel_out [n_mel][n_len] with n_len = n_samples / 160, the layout of Mel::data. */
+int wt_log_mel_spectrogram(const float* samples, int n_samples, const float* filters, int n_mel,
+                           int n_fft_bins, int device_id, float* mel_out, size_t cap, int* n_len);
+
+/* ---- asset tooling (stand-ins for the reference's offline export) -------- */
+/* Weight extractor: reads the reference's model pair "<prefix>.encoder.tflite" + "<prefix>.decoder.tflite"
+ * (TFLite FlatBuffers, parsed by hand; float32 / float16 constants and dynamic-range int8 weights with
+ * per-tensor or per-axis scales are de-quantised) and writes "<out_path>" in .wtw format.  Tensors are
+ * identified by shape and by their position in each graph's operator order (csrc/tflite_extract.cpp). */
+int wt_convert_tflite(const char* model_prefix, const char* out_path);
 /* Deterministic random-init weights of a named architecture ("tiny", "tiny.en", "base",
  * "micro") -> "<path>" in .wtw format. */
 int wt_write_synthetic_weights(const char* path, const char* arch, uint64_t seed);

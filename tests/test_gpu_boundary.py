@@ -1,0 +1,391 @@
+"""GPU (-m gpu): the drop-in boundary and the parity corners the path tests do not reach.
+
+  * rows a3 / a7 on the PRODUCT side through an engine handle (golden vectors produced by the reference's own code);
+  * BASELINE configs[0]: tiny.en weights + multilingual = false (English vocabulary ids), through the C ABI, the
+    `encdec` CLI and the Monolith-compatible `minimal` entry;
+  * the C ABI never aborts: unsupported weight files / options come back as status codes;
+  * synchronous calls refuse to run over uncollected pipeline batches;
+  * the fp16 two-plane encoder kernels on adversarial weight statistics, and the load-time fall-back;
+  * the free-function front end (whisper::log_mel_spectrogram);
+  * the RCCL branch of bench.py, executed once on hardware.
+"""
+import ctypes
+import json
+import os
+import struct
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, ROOT, synth_pcm
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = 1e-4
+ENC_TOL = 1e-4
+MEL_TOL = 1e-4
+
+
+def _wav(path, pcm):
+    pcm16 = np.clip(np.round(pcm * 32767), -32768, 32767).astype("<i2")
+    path.write_bytes(b"RIFF" + struct.pack("<I", 36 + pcm16.nbytes) + b"WAVEfmt " +
+                     struct.pack("<IHHIIHH", 16, 1, 1, 16000, 32000, 2, 16) + b"data" +
+                     struct.pack("<I", pcm16.nbytes) + pcm16.tobytes())
+
+
+# ----------------------------------------------------------------------------- a3 / a7 ---
+
+def test_engine_vocab_tables_and_text_match_reference_golden(pkg, assets, tmp_path):
+    """wt_vocab_info / wt_filters / wt_decode_text of an ENGINE handle (the tables the hot path uses) against
+    tests/golden/frontend_host.npz: ids, filter bank bit-exact, every sampled token, decode with and without
+    special tokens (reference whisper.cpp:519-665)."""
+    g = np.load(os.path.join(GOLD, "frontend_host.npz"))
+    prefix, _ = assets("micro")
+    vocab = str(tmp_path / "v300.bin")
+    pkg.write_synthetic_vocab(vocab, 300)  # the file the goldens were made from
+    e = pkg.Engine(prefix, vocab, True)
+    info = e.vocab_info()
+    assert [info[k] for k in ("n_vocab", "eot", "sot", "translate", "transcribe", "prev", "solm", "not", "beg")] == list(g["info"])
+    assert np.array_equal(e.filters().view(np.uint32), g["filters"].view(np.uint32))
+    for i, b in zip(g["tok_ids"], g["tok_bytes"]):
+        assert e.decode_bytes([int(i)]) == bytes(b), i
+    assert e.decode_bytes(g["decode_ids"], False) == g["decode_text"].tobytes()
+    assert e.decode_bytes(g["decode_ids"], True) == g["decode_text_omit"].tobytes()
+    with pytest.raises(pkg.WtError):
+        e.decode_bytes([70000])
+    e.close()
+
+
+# -------------------------------------------------------------------------- configs[0] ---
+
+@pytest.fixture(scope="module")
+def tiny_en(pkg, assets):
+    prefix, vocab = assets("tiny.en")
+    e = pkg.Engine(prefix, vocab, False)  # multilingual = false: English vocabulary ids (whisper.h:69-91)
+    yield e, prefix, vocab
+    e.close()
+
+
+def test_config1_tiny_en_english_vocab_path(tiny_en, orc):
+    """BASELINE configs[0] on the HIP path: whisper-tiny.en dims (n_vocab 51864), multilingual = false ->
+    eot 50256, sot 50257, notimestamps 50362 (no transform_vocab_multilingual, whisper.cpp:218-226, :560-562);
+    EncDec prompt [50257, 50259 + 2, 50359, 50362] (whisper.cpp:327-339).  Ids exact, logits < 1e-4, vs the oracle."""
+    e, prefix, _ = tiny_en
+    assert e.dims.n_vocab == 51864
+    info = e.vocab_info()
+    assert (info["eot"], info["sot"], info["not"], info["transcribe"], info["n_vocab"]) == (50256, 50257, 50362, 50359, 50257)
+    prompt = [50257, 50261, 50359, 50362]
+    e.set_option("stop_at_eot", 0)
+    rng = np.random.default_rng(77)
+    mel = rng.uniform(-1.0, 1.5, size=(2, 80, 3000)).astype(np.float32)
+    ids, n, enc, logits = e.encdec_debug_batch(mel)
+    assert list(ids[0, :4]) == prompt and list(n) == [31, 31]
+    m = orc.Model(prefix + ".wtw")
+    for b in range(2):
+        enc_ref = m.encode(mel[b], 16)
+        assert np.abs(enc[b] - enc_ref).max() < ENC_TOL
+        ids_ref, lg = m.decode_greedy(enc_ref, prompt, 30, 50256, False, True, 16, True)
+        assert np.abs(logits[b] - lg).max() < LOGIT_TOL
+        assert list(ids[b, :31]) == list(ids_ref)
+    # the EOT stop uses the ENGLISH eot id (50256): same ids and counts as the oracle with the stop enabled
+    e.set_option("stop_at_eot", 1)
+    ids_s, n_s = e.encdec_tokens_batch(mel)
+    ids_o, n_o = m.encdec_batch(mel, prompt, 30, 50256, True, True, n_threads=16)
+    assert list(n_s) == list(n_o)
+    for b in range(2):
+        assert list(ids_s[b, :n_s[b]]) == list(ids_o[b, :n_o[b]])
+    m.close()
+
+
+def test_config1_single_wav_through_encdec_cli_and_minimal(tiny_en, orc, tmp_path):
+    """configs[0] as the reference runs it: ONE 30 s WAV through the `encdec` binary (same three flags; `--english`
+    selects multilingual = false, which the reference hard-codes to true, app/encdec.cpp:47) and through `minimal`
+    (reference app/minimal.cpp: Monolith, multilingual = false -> prompt [sot 50257, notimestamps 50362], the head
+    of kGoldenGeneratedIDs, whisper.h:27-32).  The transcript is the last stdout line / sits between blank lines."""
+    e, prefix, vocab = tiny_en
+    exe = os.path.join(ROOT, "whisper.tflite_amd", "bin", "encdec")
+    mini = os.path.join(ROOT, "whisper.tflite_amd", "bin", "minimal")
+    if not (os.path.exists(exe) and os.path.exists(mini)):
+        pytest.skip("CLI binaries not built")
+    pcm = synth_pcm("sweep", 480000, 5)
+    wav = tmp_path / "clip30.wav"
+    _wav(wav, pcm)
+    e.set_option("stop_at_eot", 1)
+    want = e.transcribe(str(wav))
+    # English ids: 50261 = sot + 1 + 3, so the reference's table names the "de" prompt token <|lang-es|> here
+    # (whisper.cpp:596-598: lang_code(i - (token_sot + 1)))
+    assert want.startswith("<|startoftranscript_|><|lang-es|><|transcribe|><|notimestamps|>")
+    r = subprocess.run([exe, "--model-prefix", prefix, "--vocab", vocab, "--input", str(wav), "--english"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.splitlines()[-1] == want
+    # Monolith-compatible entry: same kernels, the prompt HF generate() forces for an English-only model
+    mono = e.__class__(prefix, vocab, False, engine_type=0)
+    mono.set_option("stop_at_eot", 1)
+    samples = orc.frontend().wav_read_legacy(str(wav))
+    padded = np.zeros(480000, np.float32)
+    padded[: min(len(samples), 480000)] = samples[:480000]
+    mel = mono.logmel_batch(padded[None])
+    ids, n = mono.encdec_tokens_batch(mel)
+    assert list(ids[0, :2]) == [50257, 50362]
+    m = orc.Model(prefix + ".wtw")
+    ids_ref, _ = m.decode_greedy(m.encode(mel[0], 16), [50257, 50362], 30, 50256, True, True, 16, False)
+    assert list(ids[0, :n[0]]) == list(ids_ref)
+    m.close()
+    text = mono.decode_text(ids[0, :n[0]])
+    mono.close()
+    r = subprocess.run([mini, prefix, vocab, str(wav)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    import re
+    assert r.stdout == "\n" + re.sub(" +", " ", text) + "\n\n"
+    e.set_option("stop_at_eot", 0)
+
+
+def test_monolith_multilingual_prompt(pkg, assets):
+    """EngineType::Monolith with a multilingual vocabulary: [sot, <|en|>, transcribe, notimestamps] — the forced
+    decoder ids of the HF generate() graph the reference's Monolith runs (export/generate.py:24-30)."""
+    prefix, vocab = assets("tiny")
+    e = pkg.create_engine(0, prefix, vocab, True)
+    assert e is not None
+    e.set_option("stop_at_eot", 0)
+    e.set_option("max_tokens", 6)
+    mel = np.random.default_rng(3).uniform(-1.0, 1.5, size=(1, 80, 3000)).astype(np.float32)
+    ids, n = e.encdec_tokens_batch(mel)
+    assert list(ids[0, :4]) == [50258, 50259, 50359, 50363] and n[0] == 7
+    e.close()
+
+
+# ------------------------------------------------------------------- never abort behind the ABI ---
+
+def test_unsupported_weight_files_and_options_return_status_codes(pkg, assets, tmp_path):
+    """d_model 256 passes the reference-style file checks but has no kernel instantiation; zero heads would
+    divide by zero; a context below the kernels' minimum; a wrapped tensor range; an unaligned payload; an
+    unknown GEMM variant.  Each must come back as a status code with a message — the process survives
+    (before: abort() inside launch_ln / launch_gemm_t, SIGFPE in upload_weights)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from wtw import read_wtw, write_wtw
+    prefix, vocab = assets("micro")
+    dims, t = read_wtw(prefix + ".wtw")
+    L = pkg.lib()
+
+    def create(path_prefix):
+        h = ctypes.c_void_p()
+        rc = L.wt_engine_create(1, path_prefix.encode(), vocab.encode(), 1, 0, ctypes.byref(h))
+        assert not h.value
+        return rc, L.wt_last_error(None).decode()
+
+    def variant(name, **over):
+        d = dict(dims)
+        d.update(over)
+        p = str(tmp_path / name)
+        write_wtw(p + ".wtw", d, t)
+        return p
+
+    rc, msg = create(variant("d256", n_audio_state=256, n_text_state=256, n_audio_head=4, n_text_head=4))
+    assert rc == 3 and "d_model" in msg                      # WT_ERR_FORMAT
+    rc, msg = create(variant("heads0", n_audio_head=0))
+    assert rc == 3 and "heads" in msg
+    rc, msg = create(variant("ctx8", n_audio_ctx=8))
+    assert rc == 3
+    rc, msg = create(variant("tctx16", n_text_ctx=16))
+    assert rc == 3
+    rc, msg = create(variant("vocab0", n_vocab=0))
+    assert rc == 3
+    # tensor table: offset + nbytes wraps around 2^64 / payload not 4-byte aligned
+    raw = bytearray(open(prefix + ".wtw", "rb").read())
+    e0 = 128
+    bad = bytearray(raw)
+    struct.pack_into("<QQ", bad, e0 + 104, 2 ** 64 - 4, 8)
+    (tmp_path / "wrap.wtw").write_bytes(bad)
+    assert create(str(tmp_path / "wrap"))[0] == 3
+    bad = bytearray(raw)
+    off, nb = struct.unpack_from("<QQ", raw, e0 + 104)
+    struct.pack_into("<QQ", bad, e0 + 104, off + 2, nb - 4)
+    (tmp_path / "unaligned.wtw").write_bytes(bad)
+    assert create(str(tmp_path / "unaligned"))[0] == 3
+    (tmp_path / "trunc.wtw").write_bytes(raw[:1000])
+    assert create(str(tmp_path / "trunc"))[0] == 3
+    assert create(str(tmp_path / "missing"))[0] == 2          # WT_ERR_IO
+    # options: variants that do not exist are refused when they are set, not when a kernel is launched
+    e = pkg.Engine(prefix, vocab, True)
+    for bad_v in (12, 1, 10, 14, 19, -2):
+        with pytest.raises(pkg.WtError) as ei:
+            e.set_option("gemm_variant", bad_v)
+        assert ei.value.code == 1
+    with pytest.raises(pkg.WtError):
+        e.set_option("attn_variant", 5)
+    e.set_prompt([3, 5, 7, 11])
+    mel = np.random.default_rng(1).uniform(-1, 1.5, size=(1,) + e.mel_shape).astype(np.float32)
+    ids, n = e.encdec_tokens_batch(mel)  # and the engine works after the refused options
+    assert n[0] >= 5
+    # kernel-level taps: shapes outside a kernel's contract are errors too
+    with pytest.raises(pkg.WtError):
+        e.dbg_layernorm(np.zeros((4, 600), np.float32), np.ones(600, np.float32), np.zeros(600, np.float32))
+    with pytest.raises(pkg.WtError):
+        e.dbg_dec_gemm(np.zeros((4, 96), np.float32), np.zeros((64, 96), np.float32), mode=2, R=np.zeros((4, 64), np.float32))
+    e.close()
+
+
+def test_sync_call_with_batches_in_flight_is_refused_before_any_work(pkg, assets):
+    """With the pipeline FULL (6 uncollected batches) a synchronous call used to enqueue its encoder first — onto
+    the oldest uncollected slot, overwriting that batch — and throw only at decode().  Now every synchronous entry
+    point checks first: error, nothing enqueued, and the later collects return the ORIGINAL ids (also when the
+    refused call carried a larger batch than the submitted ones)."""
+    import torch
+    prefix, vocab = assets("micro")
+    e = pkg.Engine(prefix, vocab, True)
+    e.set_option("stop_at_eot", 0)
+    e.set_prompt([3, 5, 7, 11])
+    rng = np.random.default_rng(21)
+    mels = [rng.uniform(-1.0, 1.5, size=(3,) + e.mel_shape).astype(np.float32) for _ in range(6)]
+    big = rng.uniform(-1.0, 1.5, size=(9,) + e.mel_shape).astype(np.float32)
+    want = [e.encdec_tokens_batch(m) for m in mels]
+    e.encdec_tokens_batch(big)  # grows the workspace now, not while batches are in flight
+    dev = [torch.from_numpy(m).cuda() for m in mels]
+    d_big = torch.from_numpy(big).cuda()
+    pcm = torch.zeros(9, e.pcm_len, device="cuda")
+    torch.cuda.synchronize()
+    for d in dev:
+        e.pipeline_submit_dev(d.data_ptr(), 3)
+    assert e.get_option("in_flight") == 6
+    for call in (lambda: e.encdec_tokens_batch(big), lambda: e.encdec_tokens_batch_dev(d_big.data_ptr(), 9),
+                 lambda: e.encdec_debug_batch(big), lambda: e.transcribe(np.zeros(1000, np.float32)),
+                 lambda: e.logmel_batch(np.zeros((1, e.pcm_len), np.float32)),
+                 lambda: e.transcribe_tokens_batch_dev(pcm.data_ptr(), 9),
+                 lambda: e.transcribe_long(np.zeros(1000, np.float32))):
+        with pytest.raises(pkg.WtError) as ei:
+            call()
+        assert ei.value.code == 1 and "collect" in str(ei.value)
+    with pytest.raises(pkg.WtError):
+        e.pipeline_submit_dev(dev[0].data_ptr(), 3)  # a seventh submit: pipeline full
+    assert e.get_option("in_flight") == 6
+    for k in range(6):
+        ids, n = e.pipeline_collect()
+        assert ids.shape == (3, 32) and np.array_equal(ids, want[k][0]) and np.array_equal(n, want[k][1]), k
+    ids, n = e.encdec_tokens_batch(mels[2])  # synchronous calls work again
+    assert np.array_equal(ids, want[2][0])
+    e.close()
+
+
+# ----------------------------------------------------- fp16 two-plane kernels, adversarial weights ---
+
+def _adversarial_tiny(assets, tmp_path, gain, name):
+    """whisper-tiny random-init weights with the statistics a trained checkpoint can have and N(0, 1/fan_in)
+    does not: LayerNorm gains `gain` x larger on six channels of every encoder LayerNorm, LayerNorm shifts on
+    others, and heavy-tailed rows (2 % of the entries of every encoder Linear 8..40 x larger)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from wtw import read_wtw, write_wtw
+    prefix, vocab = assets("tiny")
+    dims, t = read_wtw(prefix + ".wtw")
+    rng = np.random.default_rng(1234)
+    out = {}
+    for k, v in t.items():
+        a = np.array(v, dtype=np.float32)
+        if k.startswith("encoder.") and k.endswith("_ln.weight") or k == "encoder.ln_post.weight":
+            a[rng.choice(a.size, 6, replace=False)] *= gain
+        elif k.startswith("encoder.") and (k.endswith("_ln.bias") or k == "encoder.ln_post.bias"):
+            a[rng.choice(a.size, 6, replace=False)] += rng.uniform(-3, 3, 6).astype(np.float32)
+        elif k.startswith("encoder.blocks.") and k.endswith(".weight") and a.ndim == 2:
+            mask = rng.random(a.shape) < 0.02
+            a[mask] *= rng.uniform(8, 40, int(mask.sum())).astype(np.float32)
+        out[k] = a
+    p = str(tmp_path / name)
+    write_wtw(p + ".wtw", dims, out)
+    return p, vocab
+
+
+def test_fp16_split_on_outlier_weights_matches_oracle(pkg, assets, orc, tmp_path):
+    """LayerNorm gains x30 on a few channels and heavy-tailed rows inflate the weight-derived bounds far above the
+    typical activations (the bound of a Linear output is sum |W| * input bound).  The default two-plane fp16
+    kernels must still deliver fp32-level results: encoder output within 1e-4 of the oracle
+    (relative to its scale: LayerNorm output with gains up to 30), identical to the full-range bf16 three-plane
+    kernels within rounding, token ids equal."""
+    prefix, vocab = _adversarial_tiny(assets, tmp_path, 30.0, "tiny-outliers")
+    e = pkg.Engine(prefix, vocab, True)
+    e.set_option("stop_at_eot", 0)
+    assert e.get_option("f16_fallbacks") == 0  # x30 stays inside the slack the fp16 form is used for
+    rng = np.random.default_rng(9)
+    mel = rng.uniform(-1.0, 1.5, size=(2, 80, 3000)).astype(np.float32)
+    ids_a, n_a, enc_a, lg_a = e.encdec_debug_batch(mel)
+    e.set_option("gemm_variant", 16)
+    e.set_option("attn_variant", 1)
+    ids_b, n_b, enc_b, lg_b = e.encdec_debug_batch(mel)
+    e.close()
+    m = orc.Model(prefix + ".wtw")
+    enc_ref = m.encode(mel[0], 16)
+    scale = max(1.0, float(np.abs(enc_ref).max()))  # ln_post with gains up to ~30: outputs are O(30)
+    assert np.abs(enc_a[0] - enc_ref).max() < ENC_TOL * scale
+    assert np.abs(enc_b[0] - enc_ref).max() < ENC_TOL * scale
+    assert np.abs(enc_a - enc_b).max() < ENC_TOL * scale
+    info_prompt = [50258, 50261, 50359, 50363]
+    ids_ref, lg_ref = m.decode_greedy(enc_ref, info_prompt, 30, -1, False, True, 16, True)
+    m.close()
+    assert np.abs(lg_a[0] - lg_ref).max() < LOGIT_TOL * max(1.0, float(np.abs(lg_ref).max()))
+    assert list(ids_a[0, :31]) == list(ids_ref) and np.array_equal(ids_a, ids_b)
+
+
+def test_fp16_split_falls_back_to_full_range_when_bounds_explode(pkg, assets, orc, tmp_path):
+    """A LayerNorm gain 1e5 x its neighbours puts the weight-derived bound of that LayerNorm's output (and of
+    everything computed from it) more than 2^12 above the typical magnitude: the second fp16 plane of typical
+    elements would go subnormal.  The engine must give those contractions the bf16 three-plane kernels by itself
+    at load time (f16_fallbacks > 0) and stay at fp32-level error."""
+    prefix, vocab = _adversarial_tiny(assets, tmp_path, 1.0e5, "tiny-exploded")
+    e = pkg.Engine(prefix, vocab, True)
+    e.set_option("stop_at_eot", 0)
+    assert e.get_option("f16_fallbacks") > 0
+    mel = np.random.default_rng(10).uniform(-1.0, 1.5, size=(1, 80, 3000)).astype(np.float32)
+    ids, n, enc, _ = e.encdec_debug_batch(mel, want_logits=False)
+    e.close()
+    m = orc.Model(prefix + ".wtw")
+    enc_ref = m.encode(mel[0], 16)
+    m.close()
+    assert np.isfinite(enc).all()
+    assert np.abs(enc[0] - enc_ref).max() < 2e-4 * max(1.0, float(np.abs(enc_ref).max()))
+
+
+# ------------------------------------------------------------------ front end as a free function ---
+
+def test_log_mel_spectrogram_free_function(pkg, orc):
+    """whisper::log_mel_spectrogram (whisper.h:123) without an engine: wt_log_mel_spectrogram runs the same kernels
+    through a front-end-only context.  Full 30 s clip vs the reference-produced golden; a 2 s clip (n_len = 200
+    frames: the maximum runs over those frames only) vs the golden and the oracle; unsupported geometry refused."""
+    g = np.load(os.path.join(GOLD, "frontend_logmel.npz"))
+    host = np.load(os.path.join(GOLD, "frontend_host.npz"))
+    filters = host["filters"]
+    pcm = synth_pcm("noise", 480000, int(g["noise_480000_seed"]))
+    mel = pkg.log_mel_spectrogram(pcm, filters)
+    assert mel.shape == (80, 3000)
+    assert np.abs(mel[:, :31] - g["noise_480000_cols"]).max() < MEL_TOL
+    short = synth_pcm("noise", 32000, int(g["noise_32000_seed"]))
+    mel_s = pkg.log_mel_spectrogram(short, filters)
+    assert mel_s.shape == (80, 200)
+    assert np.abs(mel_s - g["noise_32000_full"]).max() < MEL_TOL
+    odd = short[:31999]  # n_samples not a multiple of the hop: n_len = 199
+    assert np.abs(pkg.log_mel_spectrogram(odd, filters) - orc.frontend().logmel(odd, filters, 4)).max() < MEL_TOL
+    with pytest.raises(pkg.WtError) as ei:
+        pkg.log_mel_spectrogram(np.zeros(480001, np.float32), filters)
+    assert ei.value.code == 4
+    assert pkg.log_mel_spectrogram(np.zeros(0, np.float32), filters).shape == (80, 0)
+
+
+# -------------------------------------------------------------------------- RCCL on hardware ---
+
+def test_bench_rccl_branch_executes_on_one_rank(tmp_path):
+    """The N > 1 path of bench.py (init_process_group("nccl") = RCCL, device-tensor all_gather of the id records,
+    barrier, all_reduce of the elapsed time) executed on ONE rank in a fresh child process, so that the driver's
+    8-GPU run is not the first time it runs.  Ids must equal those of the same run without collectives."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "9", "--warmup", "1",
+            "--no-cpu-baseline", "--no-fp32-leg", "--emit-ids"]
+    r1 = subprocess.run(base + ["--rehearse-nccl"], capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    a = json.loads(r1.stdout.strip().splitlines()[-1])
+    r2 = subprocess.run(base, capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    b = json.loads(r2.stdout.strip().splitlines()[-1])
+    assert a["collectives"] >= 1 and b["collectives"] == 0
+    assert a["n_gpus"] == 1 and a["steps"] == 9 and a["value"] > 0 and a["unit"] == "audio-sec/s"
+    assert a["gathered_records"] == 32 * 9 and a["ids_crc"] == b["ids_crc"]
+    assert "roofline" in a and "config" in a

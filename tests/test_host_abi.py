@@ -42,16 +42,70 @@ def test_error_conventions(pkg, assets, tmp_path):
     prefix, vocab = assets("micro")
     h = ctypes.c_void_p()
     L = pkg.lib()
-    # Monolith is out of scope -> unsupported, handle stays NULL
-    assert L.wt_engine_create(0, prefix.encode(), vocab.encode(), 1, 0, ctypes.byref(h)) == 4
-    assert not h.value and b"Monolith" in L.wt_last_error(None)
     assert L.wt_engine_create(7, prefix.encode(), vocab.encode(), 1, 0, ctypes.byref(h)) == 1
-    # missing vocab file -> IO error with the reference's message (mmap_file.cpp:16)
-    rc = L.wt_engine_create(1, prefix.encode(), str(tmp_path / "nope.bin").encode(), 1, 0, ctypes.byref(h))
-    assert rc == 2 and L.wt_last_error(None).startswith(b"Failed to open file")
-    assert pkg.create_engine(0, prefix, vocab, True) is None
+    assert not h.value and b"Unknown engine-type" in L.wt_last_error(None)
+    # missing vocab file -> IO error with the reference's message (mmap_file.cpp:16), for both engine types
+    for et in (0, 1):
+        rc = L.wt_engine_create(et, prefix.encode(), str(tmp_path / "nope.bin").encode(), 1, 0, ctypes.byref(h))
+        assert rc == 2 and L.wt_last_error(None).startswith(b"Failed to open file")
     assert pkg.create_engine(9, prefix, vocab, True) is None
     L.wt_engine_destroy(None)  # no-op
+    L.wt_vocab_close(None)
+    v = ctypes.c_void_p()
+    assert L.wt_vocab_open(str(tmp_path / "nope.bin").encode(), 1, ctypes.byref(v)) == 2 and not v.value
+    (tmp_path / "short.bin").write_bytes(b"\0" * 20)
+    assert L.wt_vocab_open(str(tmp_path / "short.bin").encode(), 1, ctypes.byref(v)) == 3 and not v.value
+    # the free-function front end refuses geometries the kernels do not implement, without touching a device
+    f = np.zeros((80, 201), np.float32)
+    n_len = ctypes.c_int(0)
+    out = np.zeros(10, np.float32)
+    fp = ctypes.POINTER(ctypes.c_float)
+    rc = L.wt_log_mel_spectrogram(out.ctypes.data_as(fp), 10, f.ctypes.data_as(fp), 64, 201, 0, out.ctypes.data_as(fp), 10,
+                                  ctypes.byref(n_len))
+    assert rc == 4  # WT_ERR_UNSUPPORTED
+
+
+def test_product_vocab_reader_and_decode_match_reference_golden(pkg, tmp_path):
+    """Rows a3 / a7 on the PRODUCT side: the library's own reader (csrc/host_util.cpp parse_vocab) and
+    decode_tokens, through the host-only wt_vocab_* entry points, against the vectors the reference's own
+    Reader / decode produced (tests/golden/frontend_host.npz, generator tools/gen_golden.py;
+    reference whisper.cpp:519-665, :218-226)."""
+    g = np.load(os.path.join(GOLD, "frontend_host.npz"))
+    path = str(tmp_path / "v.bin")
+    pkg.write_synthetic_vocab(path, 300)  # the file the goldens were made from
+    v = pkg.Vocab(path, True)
+    info = v.info()
+    assert [info[k] for k in pkg.Vocab.INFO_KEYS] == list(g["info"])
+    f = v.filters()
+    assert f.shape == (80, 201) and np.array_equal(f.view(np.uint32), g["filters"].view(np.uint32))
+    for i, b in zip(g["tok_ids"], g["tok_bytes"]):
+        assert v.token(int(i)) == bytes(b), i
+    assert v.size() == 51865
+    assert v.decode(g["decode_ids"], False) == g["decode_text"].tobytes()
+    assert v.decode(g["decode_ids"], True) == g["decode_text_omit"].tobytes()
+    with pytest.raises(pkg.WtError):
+        v.token(60000)
+    with pytest.raises(pkg.WtError):
+        v.decode([60000], False)
+    v.close()
+    en = pkg.Vocab(path, False)
+    assert en.info()["eot"] == 50256 and en.info()["sot"] == 50257 and en.info()["not"] == 50362
+    assert en.info()["n_vocab"] == 300 and en.size() == 51864
+    assert en.token(50257) == b"<|startoftranscript_|>" and en.token(50362) == b"<|notimestamps|>"
+    en.close()
+
+
+def test_product_reader_agrees_with_oracle_on_every_token(pkg, orc, tmp_path):
+    """Every id -> token of the product reader equals the reference-pinned oracle's, multilingual and English."""
+    path = str(tmp_path / "v.bin")
+    pkg.write_synthetic_vocab(path, 1000)
+    for multilingual in (True, False):
+        a, b = pkg.Vocab(path, multilingual), orc.frontend().open_vocab(path, multilingual)
+        assert a.size() == b.size()
+        for i in list(range(0, 1000, 37)) + list(range(50250, a.size())):
+            assert a.token(i) == b.token(i), (multilingual, i)
+        a.close()
+        b.close()
 
 
 def test_language_table_matches_oracle(pkg, orc):

@@ -22,3 +22,34 @@ def read_wtw(path):
         assert dtype == 0
         tensors[name] = np.frombuffer(buf, dtype=np.float32, count=nbytes // 4, offset=off).reshape(shape)
     return dims, tensors
+
+
+def write_wtw(path, dims, tensors, seed=0):
+    """Writes a .wtw file from a dict name -> float32 array (same layout as csrc/weights_gen.cpp emits):
+    128-byte header, 128-byte table entries, every payload 256-byte aligned."""
+    names = list(tensors)
+    table_off = 128
+    payload_off = table_off + 128 * len(names)
+    payload_off = (payload_off + 255) // 256 * 256
+    offs, pos = [], payload_off
+    for n in names:
+        a = np.ascontiguousarray(tensors[n], dtype=np.float32)
+        offs.append(pos)
+        pos = (pos + a.nbytes + 255) // 256 * 256
+    file_bytes = pos
+    buf = bytearray(file_bytes)
+    struct.pack_into("<IIII", buf, 0, 0x31575457, 1, len(names), table_off)
+    struct.pack_into("<10i", buf, 16, *[int(dims[k]) for k in DIM_KEYS])
+    struct.pack_into("<QQQ", buf, 56, payload_off, file_bytes, seed)
+    for i, n in enumerate(names):
+        a = np.ascontiguousarray(tensors[n], dtype=np.float32)
+        e = table_off + i * 128
+        nb = n.encode()
+        assert len(nb) < 80
+        buf[e:e + len(nb)] = nb
+        shape = list(a.shape) + [0] * (4 - a.ndim)
+        struct.pack_into("<II4I", buf, e + 80, 0, a.ndim, *shape)
+        struct.pack_into("<QQ", buf, e + 104, offs[i], a.nbytes)
+        buf[offs[i]:offs[i] + a.nbytes] = a.tobytes()
+    with open(path, "wb") as f:
+        f.write(buf)

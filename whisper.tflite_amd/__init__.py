@@ -42,6 +42,8 @@ CAPI_SYMBOLS = [
     "wt_encdec_debug_batch",
     "wt_last_timings", "wt_last_kernel_stats", "wt_decode_text", "wt_language_id", "wt_lang_code", "wt_wav_read_legacy",
     "wt_vocab_info", "wt_filters", "wt_write_synthetic_weights", "wt_write_synthetic_vocab",
+    "wt_vocab_open", "wt_vocab_close", "wt_vocab_get_info", "wt_vocab_get_filters", "wt_vocab_size", "wt_vocab_token",
+    "wt_vocab_decode", "wt_log_mel_spectrogram", "wt_convert_tflite",
 ]
 DEBUG_SYMBOLS = [
     "wt_dbg_gemm", "wt_dbg_gemm_bench", "wt_dbg_dec_gemm_bench", "wt_dbg_dec_gemm", "wt_dbg_dec_ln_gemm", "wt_dbg_layernorm", "wt_dbg_encoder_attention",
@@ -122,6 +124,16 @@ def lib() -> ctypes.CDLL:
         L.wt_filters.argtypes = [c_void_p, fp, c_size_t, ip32, ip32]
         L.wt_write_synthetic_weights.argtypes = [c_char_p, c_char_p, c_uint64]
         L.wt_write_synthetic_vocab.argtypes = [c_char_p, c_int]
+        L.wt_vocab_open.argtypes = [c_char_p, c_int, POINTER(c_void_p)]
+        L.wt_vocab_close.argtypes = [c_void_p]
+        L.wt_vocab_close.restype = None
+        L.wt_vocab_get_info.argtypes = [c_void_p, ip32]
+        L.wt_vocab_get_filters.argtypes = [c_void_p, fp, c_size_t, ip32, ip32]
+        L.wt_vocab_size.argtypes = [c_void_p]
+        L.wt_vocab_token.argtypes = [c_void_p, c_int, c_char_p, c_size_t, POINTER(c_size_t)]
+        L.wt_vocab_decode.argtypes = [c_void_p, ip64, c_int, c_int, c_char_p, c_size_t, POINTER(c_size_t)]
+        L.wt_log_mel_spectrogram.argtypes = [fp, c_int, fp, c_int, c_int, c_int, fp, c_size_t, POINTER(c_int)]
+        L.wt_convert_tflite.argtypes = [c_char_p, c_char_p]
         L.wt_dbg_gemm.argtypes = [c_void_p, c_int, c_int, c_int, fp, fp, fp, fp, fp, c_int, c_int, fp]
         L.wt_dbg_gemm_bench.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_float)]
         L.wt_dbg_dec_gemm_bench.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_float)]
@@ -174,8 +186,85 @@ def wav_read_legacy(path: str) -> np.ndarray:
     return out
 
 
+class Vocab:
+    """Host-side mirror of the reference's ``Vocab`` + ``Filters`` as ``Reader::read`` fills them
+    (whisper.h:44-101, :236-248) and of ``decode`` (whisper.h:252-257).  Needs no GPU."""
+
+    INFO_KEYS = ("n_vocab", "eot", "sot", "translate", "transcribe", "prev", "solm", "not", "beg")
+
+    def __init__(self, vocab_path: str, multilingual: bool = True):
+        self._v = c_void_p()
+        rc = lib().wt_vocab_open(os.fsencode(vocab_path), int(bool(multilingual)), byref(self._v))
+        if rc != WT_OK:
+            self._v = c_void_p()
+            raise WtError(rc, lib().wt_last_error(None).decode())
+
+    def close(self) -> None:
+        if getattr(self, "_v", None) and self._v.value:
+            lib().wt_vocab_close(self._v)
+            self._v = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self) -> dict:
+        out = (c_int32 * 9)()
+        lib().wt_vocab_get_info(self._v, out)
+        return dict(zip(self.INFO_KEYS, list(out)))
+
+    def filters(self) -> np.ndarray:
+        nm, nf = c_int32(0), c_int32(0)
+        total = lib().wt_vocab_get_filters(self._v, None, 0, byref(nm), byref(nf))
+        out = np.zeros(total, np.float32)
+        lib().wt_vocab_get_filters(self._v, _fp(out), out.size, byref(nm), byref(nf))
+        return out.reshape(nm.value, nf.value)
+
+    def size(self) -> int:
+        return lib().wt_vocab_size(self._v)
+
+    def token(self, idx: int) -> bytes:
+        buf = ctypes.create_string_buffer(512)
+        n = c_size_t(0)
+        rc = lib().wt_vocab_token(self._v, int(idx), buf, len(buf), byref(n))
+        if rc != WT_OK:
+            raise WtError(rc, lib().wt_last_error(None).decode())
+        return buf.raw[: n.value]
+
+    def decode(self, ids, omit_special_tokens: bool = False) -> bytes:
+        ids = np.ascontiguousarray(ids, dtype=np.int64).reshape(-1)
+        buf = ctypes.create_string_buffer(1 << 16)
+        n = c_size_t(0)
+        rc = lib().wt_vocab_decode(self._v, ids.ctypes.data_as(POINTER(c_int64)), ids.size, int(omit_special_tokens),
+                                   buf, len(buf), byref(n))
+        if rc != WT_OK:
+            raise WtError(rc, lib().wt_last_error(None).decode())
+        return buf.raw[: n.value]
+
+
+def log_mel_spectrogram(samples, filters, device_id: int = 0) -> np.ndarray:
+    """Mirror of the free function ``whisper::log_mel_spectrogram`` (whisper.h:123): [n_mel][n_samples // 160]."""
+    pcm = _f32(samples).reshape(-1)
+    f = _f32(filters)
+    n_len = c_int(0)
+    out = np.zeros((f.shape[0], pcm.size // 160), np.float32)
+    rc = lib().wt_log_mel_spectrogram(_fp(pcm), pcm.size, _fp(f), f.shape[0], f.shape[1], device_id, _fp(out),
+                                      out.size, byref(n_len))
+    if rc != WT_OK:
+        raise WtError(rc, lib().wt_last_error(None).decode())
+    return out
+
+
+def convert_tflite(model_prefix: str, out_path: str) -> None:
+    rc = lib().wt_convert_tflite(os.fsencode(model_prefix), os.fsencode(out_path))
+    if rc != WT_OK:
+        raise WtError(rc, lib().wt_last_error(None).decode())
+
+
 class Engine:
-    """Mirror of ``whisper::Engine`` / ``whisper::EncDec`` (reference whisper.h:159-197)."""
+    """Mirror of ``whisper::Engine`` / ``whisper::EncDec`` / ``whisper::Monolith`` (reference whisper.h:159-197)."""
 
     def __init__(self, model_prefix: str, vocab_path: str, multilingual: bool = True,
                  engine_type: EngineType = EngineType.EncDec, device_id: int = 0):
@@ -327,13 +416,16 @@ class Engine:
                                        "bytes": arr[i].bytes} for i in range(min(n, 8))}
 
     # -- host helpers ----------------------------------------------------------------
-    def decode_text(self, ids, omit_special_tokens: bool = False) -> str:
+    def decode_bytes(self, ids, omit_special_tokens: bool = False) -> bytes:
         ids = np.ascontiguousarray(ids, dtype=np.int64).reshape(-1)
         buf = ctypes.create_string_buffer(16384)
         n = c_size_t(0)
         self._check(lib().wt_decode_text(self._h, ids.ctypes.data_as(POINTER(c_int64)), ids.size,
                                          int(omit_special_tokens), buf, len(buf), byref(n)))
-        return buf.raw[: n.value].decode("utf-8", errors="replace")
+        return buf.raw[: n.value]
+
+    def decode_text(self, ids, omit_special_tokens: bool = False) -> str:
+        return self.decode_bytes(ids, omit_special_tokens).decode("utf-8", errors="replace")
 
     def vocab_info(self) -> dict:
         out = (c_int32 * 9)()
@@ -438,8 +530,5 @@ def create_engine(engine_type, model_prefix: str, vocab_path: str, multilingual:
         et = EngineType(int(engine_type))
     except ValueError:
         print("Unknown engine-type", file=sys.stderr)
-        return None
-    if et == EngineType.Monolith:
-        print("EngineType::Monolith is not provided by the MI355X build", file=sys.stderr)
         return None
     return Engine(model_prefix, vocab_path, multilingual, et)

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <memory>
 #include <string>
 
 #include <vector>
@@ -20,13 +21,14 @@ void usage(const char* argv0) {
             << "  --vocab         Path to vocabulary                 REQUIRED\n"
             << "  --input         Path to the 16 kHz mono WAV        REQUIRED\n"
             << "  --lang          language code of the prompt (default de, as the reference hard-codes)\n"
+            << "  --english       English-only vocabulary ids (multilingual = false; the reference hard-codes true)\n"
             << "  --long          transcribe every 30 s window of the file, not only the first\n";
 }
 }  // namespace
 
 int main(int argc, char* argv[]) {
   std::string model_prefix, vocab, input, lang;
-  bool long_audio = false;
+  bool long_audio = false, english = false;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i], v;
     if (a == "-h" || a == "--help") {
@@ -35,6 +37,10 @@ int main(int argc, char* argv[]) {
     }
     if (a == "--long") {
       long_audio = true;
+      continue;
+    }
+    if (a == "--english") {
+      english = true;
       continue;
     }
     const size_t eq = a.find('=');
@@ -64,8 +70,15 @@ int main(int argc, char* argv[]) {
     return 106;
   }
   using namespace whisper;  // NOLINT
-  const bool multilingual = true;  // hard-coded in the reference (app/encdec.cpp:47)
-  EncDec encdec(model_prefix, vocab, multilingual);
+  const bool multilingual = !english;  // true is hard-coded in the reference (app/encdec.cpp:47)
+  std::unique_ptr<EncDec> engine;
+  try {
+    engine.reset(new EncDec(model_prefix, vocab, multilingual));
+  } catch (const std::exception& e) {  // the reference lets it terminate the process
+    std::cerr << "encdec: " << e.what() << "\n";
+    return 1;
+  }
+  EncDec& encdec = *engine;
   if (!lang.empty()) {
     const int id = language_id(lang);
     if (wt_engine_set_option(encdec.handle(), "language", id) != WT_OK) {
@@ -85,6 +98,10 @@ int main(int argc, char* argv[]) {
     text.assign(buf.data(), len);
   } else {
     text = encdec.transcribe(input.c_str());
+    // Engine::transcribe returns "" on failure like the reference (whisper.cpp:760): a device error must not
+    // look like an empty transcript
+    const char* err = wt_last_error(encdec.handle());
+    if (err && *err) return 2;
   }
   std::cout << text << "\n";
   return 0;

@@ -10,7 +10,10 @@
 #include <string>
 #include <vector>
 
+#include <mutex>
+
 #include "engine.h"
+#include "tflite_extract.h"
 #include "weights_gen.h"
 #include "wt_debug.h"
 #include "kernels.h"
@@ -74,14 +77,19 @@ int wt_engine_create(int engine_type, const char* model_prefix, const char* voca
   if (!out) return fail(nullptr, WT_ERR_INVALID_ARG, "out is NULL");
   *out = nullptr;
   if (!model_prefix || !vocab_path) return fail(nullptr, WT_ERR_INVALID_ARG, "NULL path");
-  if (engine_type == WT_ENGINE_MONOLITH) {
-    return fail(nullptr, WT_ERR_UNSUPPORTED,
-                "EngineType::Monolith is not provided by the MI355X build (EncDec only)");
+  if (engine_type != WT_ENGINE_ENCDEC && engine_type != WT_ENGINE_MONOLITH) {
+    return fail(nullptr, WT_ERR_INVALID_ARG, "Unknown engine-type");
   }
-  if (engine_type != WT_ENGINE_ENCDEC) return fail(nullptr, WT_ERR_INVALID_ARG, "Unknown engine-type");
   std::unique_ptr<wt_engine> h(new wt_engine);
   const int rc = guarded(nullptr, [&] {
-    h->impl.reset(new wt::Engine(model_prefix, vocab_path, multilingual != 0, device_id));
+    const std::string prefix(model_prefix);
+    // the reference's users hold <prefix>.encoder.tflite / .decoder.tflite (whisper.cpp:743-744): extract
+    // their weights once when no .wtw sits next to them
+    if (!wt::file_exists(prefix + ".wtw") && wt::file_exists(prefix + ".encoder.tflite") &&
+        wt::file_exists(prefix + ".decoder.tflite")) {
+      wt::convert_tflite(prefix, prefix + ".wtw");
+    }
+    h->impl.reset(new wt::Engine(prefix, vocab_path, multilingual != 0, device_id, engine_type == WT_ENGINE_MONOLITH));
   });
   if (rc != WT_OK) return rc;
   *out = h.release();
@@ -130,7 +138,9 @@ int wt_engine_set_option(wt_engine* h, const char* key, long value) {
   } else if (k == "use_graphs") {
     e.use_graphs = value != 0;
   } else if (k == "gemm_variant") {
-    if (value < -1 || value > 18) return fail(h, WT_ERR_INVALID_ARG, "gemm_variant must be in [-1, 18]");
+    if (value != -1 && !wt::gemm_variant_supported(int(value))) {
+      return fail(h, WT_ERR_INVALID_ARG, "gemm_variant must be -1 (default), 0, 11, 13, 16, 17 or 18");
+    }
     e.gemm_variant = value;
   } else {
     return fail(h, WT_ERR_INVALID_ARG, "unknown option: " + k);
@@ -158,6 +168,8 @@ int wt_engine_get_option(const wt_engine* h, const char* key, long* value) {
   else if (k == "fc2_ksplit") *value = e.fc2_ksplit;
   else if (k == "resid_waves") *value = e.resid_waves;
   else if (k == "attn_variant") *value = e.attn_variant;
+  else if (k == "f16_fallbacks") *value = e.f16_fallbacks();  // read-only
+  else if (k == "in_flight") *value = e.in_flight();          // read-only
   else return WT_ERR_INVALID_ARG;
   return WT_OK;
 }
@@ -167,6 +179,7 @@ int wt_engine_get_option(const wt_engine* h, const char* key, long* value) {
 int wt_logmel_batch_dev(wt_engine* h, const float* d_pcm, int batch, float* d_mel) {
   if (!h || !d_pcm || !d_mel) return WT_ERR_INVALID_ARG;
   return guarded(h, [&] {
+    h->impl->require_idle();
     h->impl->logmel(d_pcm, batch, d_mel);
     h->impl->sync();
   });
@@ -176,6 +189,7 @@ int wt_logmel_batch(wt_engine* h, const float* pcm, int batch, float* mel) {
   if (!h || !pcm || !mel) return WT_ERR_INVALID_ARG;
   return guarded(h, [&] {
     wt::Engine& e = *h->impl;
+    e.require_idle();
     float* d_pcm = e.staging_pcm(batch);
     float* d_mel = e.staging_mel(batch);
     hipchk(hipMemcpyAsync(d_pcm, pcm, size_t(batch) * e.pcm_elems() * sizeof(float), hipMemcpyHostToDevice, e.stream()), "H2D pcm");
@@ -190,6 +204,7 @@ int wt_encdec_tokens_batch_dev(wt_engine* h, const float* d_mel, int batch, int6
   if (!h || !d_mel || !ids || !n_ids || batch < 1) return WT_ERR_INVALID_ARG;
   return guarded(h, [&] {
     wt::Engine& e = *h->impl;
+    e.require_idle();
     if (batch <= 32) {
       e.encode(d_mel, batch);
       e.decode(batch, ids, n_ids, nullptr, 0);
@@ -197,7 +212,6 @@ int wt_encdec_tokens_batch_dev(wt_engine* h, const float* d_mel, int batch, int6
     }
     // larger batches run as pipelined sub-batches of 32 clips: the encoder of a later
     // sub-batch overlaps the decoders of the earlier ones
-    if (e.in_flight()) throw wt::Error(WT_ERR_INVALID_ARG, "collect the submitted batches first");
     const int n_sub = (batch + 31) / 32;
     int submitted = 0, collected = 0;
     auto collect_one = [&] {
@@ -235,6 +249,7 @@ int wt_encdec_tokens_batch(wt_engine* h, const float* mel, int batch, int64_t* i
   float* d_mel = nullptr;
   const int rc = guarded(h, [&] {
     wt::Engine& e = *h->impl;
+    e.require_idle();
     d_mel = e.staging_mel(batch);
     hipchk(hipMemcpyAsync(d_mel, mel, size_t(batch) * e.mel_elems() * sizeof(float), hipMemcpyHostToDevice, e.stream()), "H2D mel");
   });
@@ -247,6 +262,7 @@ int wt_transcribe_tokens_batch_dev(wt_engine* h, const float* d_pcm, int batch, 
   if (!h || !d_pcm || !ids || !n_ids) return WT_ERR_INVALID_ARG;
   return guarded(h, [&] {
     wt::Engine& e = *h->impl;
+    e.require_idle();
     float* d_mel = e.staging_mel(batch);
     e.logmel(d_pcm, batch, d_mel);
     e.encode(d_mel, batch);
@@ -259,6 +275,7 @@ int wt_encdec_debug_batch(wt_engine* h, const float* mel, int batch, int64_t* id
   if (!h || !mel || !ids || !n_ids) return WT_ERR_INVALID_ARG;
   return guarded(h, [&] {
     wt::Engine& e = *h->impl;
+    e.require_idle();
     float* d_mel = e.staging_mel(batch);
     hipchk(hipMemcpyAsync(d_mel, mel, size_t(batch) * e.mel_elems() * sizeof(float), hipMemcpyHostToDevice, e.stream()), "H2D mel");
     e.encode(d_mel, batch);
@@ -306,6 +323,7 @@ int wt_transcribe_pcm(wt_engine* h, const float* pcm, size_t n_samples, char* ou
   std::string text;
   const int rc = guarded(h, [&] {
     wt::Engine& e = *h->impl;
+    e.require_idle();
     // pad with zeros or truncate to one 30 s window (whisper.cpp:753)
     std::vector<float> clip(e.pcm_elems(), 0.0f);
     std::memcpy(clip.data(), pcm, std::min(n_samples, clip.size()) * sizeof(float));
@@ -336,6 +354,7 @@ int wt_transcribe_long_pcm(wt_engine* h, const float* pcm, size_t n_samples, cha
   std::string text;
   const int rc = guarded(h, [&] {
     wt::Engine& e = *h->impl;
+    e.require_idle();
     const size_t win = e.pcm_elems();
     const size_t n_win = std::max<size_t>(1, (n_samples + win - 1) / win);
     for (size_t w0 = 0; w0 < n_win; w0 += 32) {
@@ -409,12 +428,10 @@ int wt_wav_read_legacy(const char* path, float* out, size_t cap, size_t* n) {
   return WT_OK;
 }
 
+static void vocab_info_of(const wt::VocabData& v, int32_t out[9]);
 int wt_vocab_info(const wt_engine* h, int32_t out[9]) {
   if (!h || !out) return WT_ERR_INVALID_ARG;
-  const wt::VocabData& v = h->impl->vocab();
-  const int32_t vals[9] = {v.n_vocab,    v.token_eot,  v.token_sot, v.token_translate, v.token_transcribe,
-                           v.token_prev, v.token_solm, v.token_not, v.token_beg};
-  std::memcpy(out, vals, sizeof(vals));
+  vocab_info_of(h->impl->vocab(), out);
   return WT_OK;
 }
 
@@ -425,6 +442,136 @@ int wt_filters(const wt_engine* h, float* out, size_t cap, int32_t* n_mel, int32
   if (n_fft) *n_fft = f.n_fft;
   if (out) std::memcpy(out, f.data.data(), std::min(cap, f.data.size()) * sizeof(float));
   return static_cast<int>(f.data.size());
+}
+
+// ------------------------------------------------ vocab file on the host ---
+
+}  // extern "C"
+
+struct wt_vocab {
+  wt::VocabData vocab;
+  wt::FilterBank filters;
+};
+
+extern "C" {
+
+int wt_vocab_open(const char* vocab_path, int multilingual, wt_vocab** out) {
+  if (!out) return fail(nullptr, WT_ERR_INVALID_ARG, "out is NULL");
+  *out = nullptr;
+  if (!vocab_path) return fail(nullptr, WT_ERR_INVALID_ARG, "NULL path");
+  std::unique_ptr<wt_vocab> v(new wt_vocab);
+  const int rc = guarded(nullptr, [&] { wt::read_vocab_file(vocab_path, multilingual != 0, &v->filters, &v->vocab); });
+  if (rc != WT_OK) return rc;
+  *out = v.release();
+  return WT_OK;
+}
+
+void wt_vocab_close(wt_vocab* v) { delete v; }
+
+static void vocab_info_of(const wt::VocabData& v, int32_t out[9]) {
+  const int32_t vals[9] = {v.n_vocab,    v.token_eot,  v.token_sot, v.token_translate, v.token_transcribe,
+                           v.token_prev, v.token_solm, v.token_not, v.token_beg};
+  std::memcpy(out, vals, sizeof(vals));
+}
+
+int wt_vocab_get_info(const wt_vocab* v, int32_t out[9]) {
+  if (!v || !out) return WT_ERR_INVALID_ARG;
+  vocab_info_of(v->vocab, out);
+  return WT_OK;
+}
+
+int wt_vocab_get_filters(const wt_vocab* v, float* out, size_t cap, int32_t* n_mel, int32_t* n_fft) {
+  if (!v) return 0;
+  if (n_mel) *n_mel = v->filters.n_mel;
+  if (n_fft) *n_fft = v->filters.n_fft;
+  if (out) std::memcpy(out, v->filters.data.data(), std::min(cap, v->filters.data.size()) * sizeof(float));
+  return static_cast<int>(v->filters.data.size());
+}
+
+int wt_vocab_size(const wt_vocab* v) { return v ? static_cast<int>(v->vocab.id_to_token.size()) : 0; }
+
+int wt_vocab_token(const wt_vocab* v, int id, char* out, size_t cap, size_t* len) {
+  if (!v) return WT_ERR_INVALID_ARG;
+  auto it = v->vocab.id_to_token.find(id);
+  if (it == v->vocab.id_to_token.end()) {
+    if (len) *len = 0;
+    return fail(nullptr, WT_ERR_INVALID_ARG, "token id without a vocab entry");
+  }
+  return copy_text(it->second, out, cap, len);
+}
+
+int wt_vocab_decode(const wt_vocab* v, const int64_t* ids, int n, int omit_special_tokens, char* out,
+                    size_t cap, size_t* len) {
+  if (!v || (!ids && n)) return WT_ERR_INVALID_ARG;
+  bool missing = false;
+  const std::string s = wt::decode_tokens(v->vocab, ids, n, omit_special_tokens != 0, &missing);
+  if (missing) {  // the reference asserts (whisper.cpp:642)
+    if (len) *len = 0;
+    return fail(nullptr, WT_ERR_INVALID_ARG, "token id without a vocab entry");
+  }
+  return copy_text(s, out, cap, len);
+}
+
+// ------------------------------------------- log-mel as a free function ---
+
+int wt_log_mel_spectrogram(const float* samples, int n_samples, const float* filters, int n_mel,
+                           int n_fft_bins, int device_id, float* mel_out, size_t cap, int* n_len) {
+  if ((!samples && n_samples) || !filters || !mel_out || n_samples < 0) return fail(nullptr, WT_ERR_INVALID_ARG, "NULL argument");
+  if (n_mel != 80 || n_fft_bins != 201 || n_samples > WT_CHUNK_SAMPLES) {
+    return fail(nullptr, WT_ERR_UNSUPPORTED,
+                "log_mel_spectrogram: only the reference's fixed geometry (80 x 201 filters, <= 480000 samples at "
+                "16 kHz, fft 400, hop 160) runs on the gfx950 front end");
+  }
+  // one front-end context per (device, filter table): the DFT basis and the mel matrix are uploaded once
+  struct Ctx {
+    int device;
+    std::vector<float> filters;
+    std::unique_ptr<wt::Engine> eng;
+  };
+  static std::mutex mu;
+  static std::vector<std::unique_ptr<Ctx>> ctxs;
+  std::lock_guard<std::mutex> lock(mu);
+  return guarded(nullptr, [&] {
+    const size_t nf = size_t(n_mel) * n_fft_bins;
+    Ctx* c = nullptr;
+    for (auto& x : ctxs)
+      if (x->device == device_id && std::memcmp(x->filters.data(), filters, nf * sizeof(float)) == 0) c = x.get();
+    if (!c) {
+      std::unique_ptr<Ctx> n(new Ctx);
+      n->device = device_id;
+      n->filters.assign(filters, filters + nf);
+      wt::FilterBank fb;
+      fb.n_mel = n_mel;
+      fb.n_fft = n_fft_bins;
+      fb.data = n->filters;
+      n->eng.reset(new wt::Engine(fb, device_id));
+      ctxs.push_back(std::move(n));
+      c = ctxs.back().get();
+    }
+    wt::Engine& e = *c->eng;
+    e.bind_device();
+    const int frames = n_samples / WT_HOP;  // Mel::n_len (whisper.cpp:123)
+    if (n_len) *n_len = frames;
+    if (cap < size_t(n_mel) * frames) throw wt::Error(WT_ERR_BUFFER, "mel_out too small");
+    std::vector<float> clip(e.pcm_elems(), 0.0f);
+    std::memcpy(clip.data(), samples, size_t(n_samples) * sizeof(float));
+    float* d_pcm = e.staging_pcm(1);
+    float* d_mel = e.staging_mel(1);
+    hipchk(hipMemcpyAsync(d_pcm, clip.data(), clip.size() * sizeof(float), hipMemcpyHostToDevice, e.stream()), "H2D pcm");
+    // frames past n_len exist only in the 30 s window the kernels work on: they take no part in the
+    // reference's maximum (whisper.cpp:198-203 runs over n_mel * n_len values)
+    e.logmel(d_pcm, 1, d_mel, frames);
+    std::vector<float> full(e.mel_elems());
+    hipchk(hipMemcpyAsync(full.data(), d_mel, full.size() * sizeof(float), hipMemcpyDeviceToHost, e.stream()), "D2H mel");
+    e.sync();
+    const size_t T0 = size_t(e.mel_frames());
+    for (int j = 0; j < n_mel; ++j) std::memcpy(mel_out + size_t(j) * frames, full.data() + size_t(j) * T0, size_t(frames) * sizeof(float));
+  });
+}
+
+int wt_convert_tflite(const char* model_prefix, const char* out_path) {
+  if (!model_prefix || !out_path) return fail(nullptr, WT_ERR_INVALID_ARG, "NULL path");
+  return guarded(nullptr, [&] { wt::convert_tflite(model_prefix, out_path); });
 }
 
 int wt_write_synthetic_weights(const char* path, const char* arch, uint64_t seed) {
@@ -501,12 +648,6 @@ int wt_dbg_gemm_bench(wt_engine* h, int M, int N, int K, int epi, int variant, i
     g.a_scale = wt::f16_scale_for(1.0f);
     g.w_scale = wt::f16_scale_for(0.05f);
     hipStream_t st = h->impl->stream();
-    DevBuf dWp(variant == 12 ? size_t(N) * K * 3 / 2 + 4 : 1);  // 3 bf16 planes
-    if (variant == 12) {
-      wt::launch_split_planes(dW.p, reinterpret_cast<unsigned short*>(dWp.p), long(N) * K, st);
-      g.Wp = reinterpret_cast<const unsigned short*>(dWp.p);
-      g.variant = 10;
-    }
     hipEvent_t e0, e1;
     hipchk(hipEventCreate(&e0), "event");
     hipchk(hipEventCreate(&e1), "event");

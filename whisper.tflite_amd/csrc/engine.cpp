@@ -89,23 +89,34 @@ void Engine::upload_weights(const std::string& path) {
   const char* base = static_cast<const char*>(map);
   wtw::WtwHeader hdr;
   std::memcpy(&hdr, base, sizeof(hdr));
-  if (hdr.magic != wtw::kMagic || hdr.version != wtw::kVersion ||
+  if (hdr.magic != wtw::kMagic || hdr.version != wtw::kVersion || hdr.n_tensors > (1u << 20) ||
       size_t(hdr.table_offset) + size_t(hdr.n_tensors) * sizeof(wtw::WtwTensor) > size_t(st.st_size)) {
     throw Error(3, "not a .wtw weight file: " + path);
   }
   dims_ = hdr.dims;
   const wtw::Dims& c = dims_;
-  if (c.n_audio_state != c.n_text_state || c.n_audio_state % 64 != 0 ||
-      c.n_audio_state / c.n_audio_head != 64 || c.n_text_state / c.n_text_head != 64 ||
-      c.n_audio_state % 128 != 0 || c.n_audio_state > 512) {
-    throw Error(3, "unsupported model dims (need d_head 64, d % 128 == 0, d <= 512)");
+  // Everything the kernels index with comes from this header: reject what they do not support here, as a
+  // format error, instead of faulting (or dividing by zero) later.
+  const auto in = [](int v, int lo, int hi) { return v >= lo && v <= hi; };
+  const int dm = c.n_audio_state;
+  if (!(dm == 128 || dm == 384 || dm == 512) || c.n_text_state != dm) {
+    throw Error(kErrFormat, "unsupported model dims: d_model must be 128, 384 or 512 (encoder == decoder)");
+  }
+  if (!in(c.n_audio_head, 1, 64) || !in(c.n_text_head, 1, 64) || dm != 64 * c.n_audio_head || dm != 64 * c.n_text_head) {
+    throw Error(kErrFormat, "unsupported model dims: heads must be d_model / 64");
+  }
+  if (!in(c.n_mels, 1, 128) || !in(c.n_audio_ctx, 32, 4096) || !in(c.n_text_ctx, 32, 4096) ||
+      !in(c.n_audio_layer, 1, 64) || !in(c.n_text_layer, 1, 64) || !in(c.n_vocab, 1, 1 << 20)) {
+    throw Error(kErrFormat, "unsupported model dims: n_mels 1..128, n_audio_ctx / n_text_ctx 32..4096, layers 1..64, n_vocab 1..2^20");
   }
   std::map<std::string, std::pair<const float*, size_t>> host;
+  const uint64_t file_bytes = uint64_t(st.st_size);
   for (uint32_t i = 0; i < hdr.n_tensors; ++i) {
     wtw::WtwTensor t;
     std::memcpy(&t, base + hdr.table_offset + size_t(i) * sizeof(t), sizeof(t));
-    if (t.dtype != 0 || t.offset + t.nbytes > uint64_t(st.st_size)) {
-      throw Error(3, "corrupt tensor table in " + path);
+    // overflow-safe range check; fp32 payloads are read in place, so they must be 4-byte aligned
+    if (t.dtype != 0 || t.offset > file_bytes || t.nbytes > file_bytes - t.offset || t.offset % 4 != 0 || t.nbytes % 4 != 0) {
+      throw Error(kErrFormat, "corrupt tensor table in " + path);
     }
     t.name[sizeof(t.name) - 1] = 0;
     host[t.name] = {reinterpret_cast<const float*>(base + t.offset), t.nbytes / sizeof(float)};
@@ -214,6 +225,13 @@ void Engine::upload_weights(const std::string& path) {
   dec_ln_g = up("decoder.ln.weight", d);
   dec_ln_b = up("decoder.ln.bias", d);
   // ---- operand bounds -> fp16 plane scales (engine.h, GemmScale) ----
+  // Next to every bound a TYPICAL magnitude of the same operand is propagated (rms under unit-variance inputs:
+  // LayerNorm sqrt(mean g^2 + mean b^2), Linear sqrt(mean_n sum_k W^2) * typical input).  The two-plane fp16
+  // form keeps 22 significand bits only while the second plane stays a normal fp16 number, i.e. while
+  // |x| * scale >= 2^-3; with scale = 2^14 / bound that needs typical / bound >= 2^-17.  A contraction whose
+  // operand has bound / typical above kF16Slack (2^12: a factor 32 of margin for elements below the typical
+  // magnitude) is given the full-range bf16 three-plane kernels instead — decided here, once, from the
+  // weights alone (LayerNorm gains with outliers, heavy-tailed rows: tests/test_gpu_boundary.py).
   {
     auto maxabs = [](const float* w, size_t n) {
       float m = 0.0f;
@@ -225,65 +243,89 @@ void Engine::upload_weights(const std::string& path) {
       for (float x : v) m = std::max(m, x);
       return m;
     };
-    auto ln_bound = [&](const std::string& gname, const std::string& bname) {
+    struct Op {  // one contraction operand: per-channel bound, typical magnitude
+      std::vector<float> bound;
+      float typ;
+    };
+    auto ln_op = [&](const std::string& gname, const std::string& bname) {
       const float* gg = H(gname, d);
       const float* bb = H(bname, d);
-      std::vector<float> o(d);
+      Op o{std::vector<float>(d), 0.0f};
       const float r = std::sqrt(float(d - 1));
-      for (int i = 0; i < d; ++i) o[i] = std::fabs(gg[i]) * r + std::fabs(bb[i]);
+      double acc = 0.0;
+      for (int i = 0; i < d; ++i) {
+        o.bound[i] = std::fabs(gg[i]) * r + std::fabs(bb[i]);
+        acc += double(gg[i]) * gg[i] + double(bb[i]) * bb[i];
+      }
+      o.typ = float(std::sqrt(acc / d));
       return o;
     };
     // out[n] = sum_k |W[n][k]| in[k % in.size()] + |bias[n]|   (conv taps repeat the input bound)
-    auto linear_bound = [&](const float* w, const float* bias, int N, int K, const std::vector<float>& in) {
-      std::vector<float> o(N);
+    auto linear_op = [&](const float* w, const float* bias, int N, int K, const Op& in) {
+      Op o{std::vector<float>(N), 0.0f};
+      double sq = 0.0;
       for (int n = 0; n < N; ++n) {
         double acc = bias ? std::fabs(bias[n]) : 0.0;
-        for (int k = 0; k < K; ++k) acc += std::fabs(w[size_t(n) * K + k]) * in[size_t(k) % in.size()];
-        o[n] = float(acc);
+        for (int k = 0; k < K; ++k) {
+          const double wv = w[size_t(n) * K + k];
+          acc += std::fabs(wv) * in.bound[size_t(k) % in.bound.size()];
+          sq += wv * wv;
+        }
+        o.bound[n] = float(acc);
       }
+      o.typ = float(std::sqrt(sq / N)) * in.typ;
       return o;
     };
-    auto gelu_bound = [](std::vector<float> v) {
-      for (float& x : v) x = std::max(x, 0.17f);  // gelu(x) in [-0.17, max(x, 0)]
-      return v;
+    auto gelu_op = [](Op o) {
+      for (float& x : o.bound) x = std::max(x, 0.17f);  // gelu(x) in [-0.17, max(x, 0)]
+      o.typ *= 0.5f;
+      return o;
     };
-    auto scale_of = [&](const std::vector<float>& in_bound, const float* w, size_t n) {
-      return GemmScale{f16_scale_for(vmax(in_bound)), f16_scale_for(maxabs(w, n))};
+    n_f16_fallbacks_ = 0;
+    auto slack_ok = [&](const Op& o) { return !(vmax(o.bound) > kF16Slack * o.typ); };
+    auto scale_of = [&](const Op& in, const float* w, size_t n) {
+      GemmScale g{f16_scale_for(vmax(in.bound)), f16_scale_for(maxabs(w, n)), slack_ok(in)};
+      if (!g.f16_ok) ++n_f16_fallbacks_;
+      return g;
     };
     // conv1: host copy in the kernel's [co][kpad] order is gone; bounds use the original [co][ci][3] tensor,
     // which has the same absolute values
-    const std::vector<float> mel_b(1, kMelBound);
+    const Op mel_op{std::vector<float>(1, kMelBound), 1.0f};
     const float* c1w = H("encoder.conv1.weight", size_t(d) * nm * 3);
-    sc_conv1_ = scale_of(mel_b, c1w, size_t(d) * nm * 3);
-    const std::vector<float> h1_b = gelu_bound(linear_bound(c1w, H("encoder.conv1.bias", d), d, nm * 3, mel_b));
+    sc_conv1_ = scale_of(mel_op, c1w, size_t(d) * nm * 3);
+    const Op h1 = gelu_op(linear_op(c1w, H("encoder.conv1.bias", d), d, nm * 3, mel_op));
     const float* c2w = H("encoder.conv2.weight", size_t(d) * d * 3);
-    sc_conv2_ = scale_of(h1_b, c2w, size_t(d) * d * 3);
+    sc_conv2_ = scale_of(h1, c2w, size_t(d) * d * 3);
     sc_layers_.assign(c.n_audio_layer, EncLayerScales{});
     const size_t dd2 = size_t(d) * d;
     for (int l = 0; l < c.n_audio_layer; ++l) {
       const std::string blk = "encoder.blocks." + std::to_string(l);
       EncLayerScales& sl = sc_layers_[l];
-      const std::vector<float> ln1 = ln_bound(blk + ".attn_ln.weight", blk + ".attn_ln.bias");
+      const Op ln1 = ln_op(blk + ".attn_ln.weight", blk + ".attn_ln.bias");
       const float* wq = H(blk + ".attn.query.weight", dd2);
       const float* wk = H(blk + ".attn.key.weight", dd2);
       const float* wv = H(blk + ".attn.value.weight", dd2);
       const float wmax = std::max(maxabs(wq, dd2), std::max(maxabs(wk, dd2), maxabs(wv, dd2)));
-      sl.qkv = GemmScale{f16_scale_for(vmax(ln1)), f16_scale_for(wmax)};
-      const std::vector<float> qb = linear_bound(wq, H(blk + ".attn.query.bias", d), d, d, ln1);
-      const std::vector<float> kb = linear_bound(wk, nullptr, d, d, ln1);
-      const std::vector<float> vb = linear_bound(wv, H(blk + ".attn.value.bias", d), d, d, ln1);
-      sl.q = f16_scale_for(vmax(qb) * 0.125f * 1.44269504f);  // the kernel splits q * d_head^-1/2 * log2(e)
-      sl.k = f16_scale_for(vmax(kb));
-      sl.v = f16_scale_for(vmax(vb));
-      sl.out = scale_of(vb, H(blk + ".attn.out.weight", dd2), dd2);  // a convex combination of V rows
-      const std::vector<float> ln2 = ln_bound(blk + ".mlp_ln.weight", blk + ".mlp_ln.bias");
+      sl.qkv = GemmScale{f16_scale_for(vmax(ln1.bound)), f16_scale_for(wmax), slack_ok(ln1)};
+      if (!sl.qkv.f16_ok) ++n_f16_fallbacks_;
+      const Op qo = linear_op(wq, H(blk + ".attn.query.bias", d), d, d, ln1);
+      const Op ko = linear_op(wk, nullptr, d, d, ln1);
+      const Op vo = linear_op(wv, H(blk + ".attn.value.bias", d), d, d, ln1);
+      sl.q = f16_scale_for(vmax(qo.bound) * 0.125f * 1.44269504f);  // the kernel splits q * d_head^-1/2 * log2(e)
+      sl.k = f16_scale_for(vmax(ko.bound));
+      sl.v = f16_scale_for(vmax(vo.bound));
+      sl.attn_f16_ok = slack_ok(qo) && slack_ok(ko) && slack_ok(vo);
+      if (!sl.attn_f16_ok) ++n_f16_fallbacks_;
+      sl.out = scale_of(vo, H(blk + ".attn.out.weight", dd2), dd2);  // a convex combination of V rows
+      const Op ln2 = ln_op(blk + ".mlp_ln.weight", blk + ".mlp_ln.bias");
       const float* w1 = H(blk + ".mlp.0.weight", 4 * dd2);
       sl.fc1 = scale_of(ln2, w1, 4 * dd2);
-      const std::vector<float> hb = gelu_bound(linear_bound(w1, H(blk + ".mlp.0.bias", size_t(4) * d), 4 * d, d, ln2));
+      const Op hb = gelu_op(linear_op(w1, H(blk + ".mlp.0.bias", size_t(4) * d), 4 * d, d, ln2));
       sl.fc2 = scale_of(hb, H(blk + ".mlp.2.weight", 4 * dd2), 4 * dd2);
     }
-    const std::vector<float> lnp = ln_bound("encoder.ln_post.weight", "encoder.ln_post.bias");
-    sc_cross_kv_ = GemmScale{f16_scale_for(vmax(lnp)), f16_scale_for(maxabs(ckv_w.data(), ckv_w.size()))};
+    const Op lnp = ln_op("encoder.ln_post.weight", "encoder.ln_post.bias");
+    sc_cross_kv_ = GemmScale{f16_scale_for(vmax(lnp.bound)), f16_scale_for(maxabs(ckv_w.data(), ckv_w.size())), slack_ok(lnp)};
+    if (!sc_cross_kv_.f16_ok) ++n_f16_fallbacks_;
   }
 
 }
@@ -376,16 +418,12 @@ void Engine::build_frontend_tables() {
 
 // ---------------------------------------------------------- lifecycle ---
 
-Engine::Engine(const std::string& model_prefix, const std::string& vocab_path, bool multilingual,
-               int device_id)
-    : device_(device_id) {
-  // vocab first: a missing vocab file throws exactly like the reference's MmapFile
-  read_vocab_file(vocab_path, multilingual, &filters_, &vocab_);
+void Engine::open_device() {
   int n_dev = 0;
   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) {
     throw Error(5, "no HIP device available: this engine has no CPU fallback");
   }
-  if (device_id < 0 || device_id >= n_dev) throw Error(5, "device_id out of range");
+  if (device_ < 0 || device_ >= n_dev) throw Error(5, "device_id out of range");
   HIPCHK(hipSetDevice(device_));
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, device_));
@@ -393,6 +431,10 @@ Engine::Engine(const std::string& model_prefix, const std::string& vocab_path, b
     throw Error(5, std::string("device is ") + prop.gcnArchName +
                             ", kernels are built for gfx950 only");
   }
+  n_cu_ = prop.multiProcessorCount;
+}
+
+void Engine::create_streams() {
   int prio_lo = 0, prio_hi = 0;
   HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
   HIPCHK(hipStreamCreateWithPriority(&stream_full_, hipStreamNonBlocking, prio_lo));
@@ -403,7 +445,7 @@ Engine::Engine(const std::string& model_prefix, const std::string& vocab_path, b
   // within 2 % of each other. Synchronous calls keep the whole chip.
   int reserve = 4;
   if (const char* v = getenv("WT_ENC_CU_RESERVE")) reserve = std::min(std::max(atoi(v), 0), 16);
-  const int n_cu = prop.multiProcessorCount;
+  const int n_cu = n_cu_;
   if (reserve > 0 && n_cu >= 64 && n_cu % 8 == 0) {
     const int keep = n_cu - 8 * reserve;
     std::vector<uint32_t> mask((n_cu + 31) / 32, 0u);
@@ -413,35 +455,7 @@ Engine::Engine(const std::string& model_prefix, const std::string& vocab_path, b
   stream_ = stream_full_;
   HIPCHK(hipEventCreate(&ev_switch_));
   if (const char* v = getenv("WT_DEC_STREAMS")) n_dec_streams_ = std::min(std::max(atoi(v), 1), kDecStreams);
-  const char* confine = getenv("WT_DEC_CONFINE");  // experiment: decoders only on the CUs the encoder leaves free
-  if (confine && atoi(confine) > 0 && stream_masked_) {
-    // 1: only the CUs the encoder leaves free; 2: every CU (a CU-masked stream has its own hardware queue)
-    const int keep = atoi(confine) == 2 ? 0 : n_cu - 8 * reserve;
-    std::vector<uint32_t> mask((n_cu + 31) / 32, 0u);
-    for (int i = keep; i < n_cu; ++i) mask[i / 32] |= 1u << (i % 32);
-    for (auto& ds : dstream_) HIPCHK(hipExtStreamCreateWithCUMask(&ds, uint32_t(mask.size()), mask.data()));
-  } else {
-    for (auto& ds : dstream_) HIPCHK(hipStreamCreateWithPriority(&ds, hipStreamNonBlocking, prio_hi));
-  }
-  if (const char* ids = getenv("WT_DEC_STREAM_IDS")) {  // experiment: which of the created streams to use
-    hipStream_t pick[kDecStreams];
-    int n = 0;
-    for (const char* p = ids; *p && n < kDecStreams; ++p)
-      if (*p >= '0' && *p < '0' + kDecStreams) pick[n++] = dstream_[*p - '0'];
-    if (n > 0) {
-      // keep every created stream in the array (destroyed later); chosen ones first
-      hipStream_t rest[kDecStreams];
-      int m = 0;
-      for (auto ds : dstream_) {
-        bool used = false;
-        for (int i = 0; i < n; ++i) used |= pick[i] == ds;
-        if (!used) rest[m++] = ds;
-      }
-      for (int i = 0; i < n; ++i) dstream_[i] = pick[i];
-      for (int i = 0; i < m; ++i) dstream_[n + i] = rest[i];
-      n_dec_streams_ = n;
-    }
-  }
+  for (auto& ds : dstream_) HIPCHK(hipStreamCreateWithPriority(&ds, hipStreamNonBlocking, prio_hi));
   for (auto& e : ev_) HIPCHK(hipEventCreate(&e));
   for (Slot& sl : slots_) {
     for (hipEvent_t* e : {&sl.enc_begin, &sl.enc_mid, &sl.enc_done, &sl.dec_begin, &sl.dec_done}) {
@@ -453,41 +467,93 @@ Engine::Engine(const std::string& model_prefix, const std::string& vocab_path, b
     *sl.h_flag = 0;
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&sl.d_flag), sizeof(int)));
   }
-  upload_weights(model_prefix + ".wtw");
-  if (vocab_.n_vocab != dims_.n_vocab && verbose) {
-    std::fprintf(stderr, "[wt] note: vocab file n_vocab %d != model n_vocab %d\n", vocab_.n_vocab,
-                 dims_.n_vocab);
-  }
-  build_frontend_tables();
 }
 
-Engine::~Engine() {
+Engine::Engine(const std::string& model_prefix, const std::string& vocab_path, bool multilingual,
+               int device_id, bool monolith)
+    : device_(device_id), monolith_(monolith), multilingual_(multilingual) {
+  // vocab first: a missing vocab file throws exactly like the reference's MmapFile
+  read_vocab_file(vocab_path, multilingual, &filters_, &vocab_);
+  if (monolith) language = 0;  // HF generate() forces <|en|> for a multilingual checkpoint (export/generate.py:24-30)
+  open_device();
+  // A constructor that throws does not run the destructor: everything acquired below (streams, events,
+  // pinned host memory, device allocations) is released here before the exception leaves, so a failed
+  // wt_engine_create (missing or malformed .wtw) leaks nothing.
+  try {
+    create_streams();
+    upload_weights(model_prefix + ".wtw");
+    if (vocab_.n_vocab != dims_.n_vocab && verbose) {
+      std::fprintf(stderr, "[wt] note: vocab file n_vocab %d != model n_vocab %d\n", vocab_.n_vocab,
+                   dims_.n_vocab);
+    }
+    build_frontend_tables();
+  } catch (...) {
+    release();
+    throw;
+  }
+}
+
+Engine::Engine(const FilterBank& filters, int device_id) : device_(device_id), filters_(filters) {
+  // front end only (whisper::log_mel_spectrogram as a free function, whisper.h:123): no weights, the
+  // reference's fixed audio geometry (whisper.h:34-39)
+  dims_ = wtw::Dims{};
+  dims_.n_mels = filters.n_mel;
+  dims_.n_audio_ctx = 1500;
+  open_device();
+  try {
+    create_streams();
+    build_frontend_tables();
+  } catch (...) {
+    release();
+    throw;
+  }
+}
+
+Engine::~Engine() { release(); }
+
+void Engine::release() noexcept {
   (void)hipSetDevice(device_);
   for (hipStream_t st : {stream_full_, stream_masked_})
     if (st) (void)hipStreamSynchronize(st);
   for (auto& ds : dstream_)
     if (ds) (void)hipStreamSynchronize(ds);
   for (auto& g : graphs_) (void)hipGraphExecDestroy(g.second.exec);
+  graphs_.clear();
   for (void* p : ws_.owned) (void)hipFree(p);
+  ws_.owned.clear();
   for (void* p : allocations_) (void)hipFree(p);
-  for (auto& e : ev_)
+  allocations_.clear();
+  for (auto& e : ev_) {
     if (e) (void)hipEventDestroy(e);
+    e = nullptr;
+  }
   for (Slot& sl : slots_) {
-    for (hipEvent_t e : {sl.enc_begin, sl.enc_mid, sl.enc_done, sl.dec_begin, sl.dec_done})
-      if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t* e : {&sl.enc_begin, &sl.enc_mid, &sl.enc_done, &sl.dec_begin, &sl.dec_done}) {
+      if (*e) (void)hipEventDestroy(*e);
+      *e = nullptr;
+    }
     for (auto& e : sl.kt_events) (void)hipEventDestroy(e);
     for (auto& e : sl.dt_events) (void)hipEventDestroy(e);
+    sl.kt_events.clear();
+    sl.dt_events.clear();
     if (sl.h_ids) (void)hipHostFree(sl.h_ids);
     if (sl.h_n) (void)hipHostFree(sl.h_n);
     if (sl.h_flag) (void)hipHostFree(sl.h_flag);
     if (sl.d_flag) (void)hipFree(sl.d_flag);
+    sl.h_ids = nullptr, sl.h_n = nullptr, sl.h_flag = nullptr, sl.d_flag = nullptr;
   }
   if (ev_switch_) (void)hipEventDestroy(ev_switch_);
   if (trace_base_) (void)hipEventDestroy(trace_base_);
-  for (hipStream_t st : {stream_full_, stream_masked_})
-    if (st) (void)hipStreamDestroy(st);
-  for (auto& ds : dstream_)
+  ev_switch_ = nullptr, trace_base_ = nullptr;
+  for (hipStream_t* st : {&stream_full_, &stream_masked_}) {
+    if (*st) (void)hipStreamDestroy(*st);
+    *st = nullptr;
+  }
+  for (auto& ds : dstream_) {
     if (ds) (void)hipStreamDestroy(ds);
+    ds = nullptr;
+  }
+  stream_ = nullptr;
 }
 
 void Engine::select_stream(bool pipelined) {
@@ -529,6 +595,12 @@ void Engine::ensure_batch(int batch) {
   };
   // time-major, one zero row before and after each clip: the k=3 convolutions become
   // plain GEMMs over three consecutive rows
+  if (d == 0) {  // front-end-only engine: the staging mel buffer is all the batch needs
+    ws_.mel_stage = alloc(B * mel_elems(), false);
+    ws_.batch = batch;
+    HIPCHK(hipStreamSynchronize(stream_));
+    return;
+  }
   ws_.melT = alloc(B * (T0 + 2) * c.n_mels + 256, true);
   ws_.h1p = alloc(B * (T0 + 2) * d + 256, true);
   ws_.x = alloc(B * T * d, false);
@@ -581,7 +653,7 @@ float* Engine::staging_pcm(int batch) {
 
 // ---------------------------------------------------------- front end ---
 
-void Engine::logmel(const float* d_pcm, int batch, float* d_mel) {
+void Engine::logmel(const float* d_pcm, int batch, float* d_mel, int valid_frames) {
   if (!have_logmel_) throw Error(3, "vocab file carries no 80x201 mel filter bank");
   ensure_batch(batch);
   const size_t T0 = mel_frames(), n_samples = pcm_elems(), pad = n_samples + 512;
@@ -631,7 +703,7 @@ void Engine::logmel(const float* d_pcm, int batch, float* d_mel) {
   m.variant = gemm_variant >= 0 ? int(gemm_variant) : 13;
   launch_gemm(m, 0, stream_);
   HIPCHK(hipMemsetAsync(ws_.clip_max, 0, sizeof(unsigned) * batch, stream_));
-  launch_log_clipmax(ws_.melacc, mel_n, d_mel, ws_.clip_max, batch, dims_.n_mels, int(T0), stream_);
+  launch_log_clipmax(ws_.melacc, mel_n, d_mel, ws_.clip_max, batch, dims_.n_mels, int(T0), stream_, valid_frames);
   launch_mel_normalize(d_mel, ws_.clip_max, batch, dims_.n_mels, int(T0), stream_);
   HIPCHK(hipEventRecord(ev_[1], stream_));
   timings_.logmel_ms = -1.0f;  // resolved lazily in decode()/sync by the C ABI
@@ -662,10 +734,7 @@ void Engine::resolve_kernel_stats(int slot) {
   Slot& sl = slots_[slot];
   // class names = the kernels the current options select (what rocprofv3 lists)
   const long gv = gemm_variant;
-  kstats_[kKcGemm].name = gv < 0 || (gv >= 13 && gv <= 18) ? "gemm_split16_tile"
-                          : gv == 10 || gv == 12         ? "gemm_split_tile"
-                          : gv == 11                     ? "gemm_split_tile(bf16)"
-                                                         : "gemm_f32_tile";
+  kstats_[kKcGemm].name = gv < 0 || (gv >= 13 && gv <= 18) ? "gemm_split16_tile" : gv == 11 ? "gemm_bf16_tile" : "gemm_f32_tile";
   kstats_[kKcEncAttn].name = attn_variant ? "encoder_attention_split" : "encoder_attention_f32";
   for (auto& k : kstats_) k.launches = 0, k.ms = 0, k.flops = 0, k.bytes = 0;
   for (size_t i = 0; i < sl.kt_cls.size(); ++i) {
@@ -681,12 +750,20 @@ void Engine::resolve_kernel_stats(int slot) {
 
 // ------------------------------------------------------------ encoder ---
 
+void Engine::require_idle() const {
+  // A synchronous call would take the next pipeline slot: with batches in flight that slot may still hold an
+  // uncollected batch (its cross-KV cache, its id buffers).  Refuse BEFORE anything is enqueued.
+  if (!inflight_.empty()) throw Error(kErrInvalidArg, "collect the submitted batches before a synchronous call");
+}
+
 void Engine::encode(const float* d_mel, int batch) {
+  require_idle();
   select_stream(false);
   encode_enqueue(d_mel, batch);
 }
 
 void Engine::encode_enqueue(const float* d_mel, int batch) {
+  if (dims_.n_audio_state == 0) throw Error(kErrUnsupported, "front-end-only engine: no model weights loaded");
   ensure_batch(batch);
   const wtw::Dims& c = dims_;
   const int T0 = mel_frames(), T = c.n_audio_ctx, d = c.n_audio_state, M = batch * T;
@@ -707,7 +784,7 @@ void Engine::encode_enqueue(const float* d_mel, int batch) {
   launch_mel_transpose(d_mel, ws_.melT, batch, c.n_mels, T0, stream_);
   kt_end();
   {
-    GemmArgs g; g.variant = enc_gemm_variant(); g.a_scale = sc_conv1_.a; g.w_scale = sc_conv1_.w;  // conv1 + GELU: rows (clip, t) read melT rows t..t+2 (input t-1..t+1)
+    GemmArgs g; g.variant = enc_gemm_variant(sc_conv1_); g.a_scale = sc_conv1_.a; g.w_scale = sc_conv1_.w;  // conv1 + GELU: rows (clip, t) read melT rows t..t+2 (input t-1..t+1)
     g.A = ws_.melT;
     g.a_rpb = T0;
     g.a_bs = long(T0 + 2) * c.n_mels;
@@ -726,7 +803,7 @@ void Engine::encode_enqueue(const float* d_mel, int batch) {
     kt_end();
   }
   {
-    GemmArgs g; g.variant = enc_gemm_variant(); g.a_scale = sc_conv2_.a; g.w_scale = sc_conv2_.w;  // conv2 (stride 2) + GELU + positional embedding
+    GemmArgs g; g.variant = enc_gemm_variant(sc_conv2_); g.a_scale = sc_conv2_.a; g.w_scale = sc_conv2_.w;  // conv2 (stride 2) + GELU + positional embedding
     g.A = ws_.h1p;
     g.a_rpb = T;
     g.a_bs = long(T0 + 2) * d;
@@ -750,16 +827,17 @@ void Engine::encode_enqueue(const float* d_mel, int batch) {
     launch_layernorm(ws_.x, ws_.ln, w.attn_ln_g, w.attn_ln_b, M, d, stream_);
     kt_end();
     const EncLayerScales& sc = sc_layers_[l];
-    GemmArgs q; q.variant = enc_gemm_variant(); q.a_scale = sc.qkv.a; q.w_scale = sc.qkv.w;
+    GemmArgs q; q.variant = enc_gemm_variant(sc.qkv); q.a_scale = sc.qkv.a; q.w_scale = sc.qkv.w;
     q.A = ws_.ln; q.lda = d; q.W = w.attn.wqkv; q.bias = w.attn.bqkv; q.C = ws_.qkv; q.ldc = 3 * d;
     q.M = M; q.N = 3 * d; q.K = d;
     kt_begin(kKcGemm, 2.0 * q.M * q.N * q.K, 0);
     launch_gemm(q, kEpiBias, stream_);
     kt_end();
     kt_begin(kKcEncAttn, 4.0 * batch * c.n_audio_head * double(T) * T * 64, 0);
-    launch_encoder_attention(ws_.qkv, ws_.att, batch, T, c.n_audio_head, int(attn_variant), stream_, sc.q, sc.k, sc.v);
+    launch_encoder_attention(ws_.qkv, ws_.att, batch, T, c.n_audio_head,
+                             attn_variant == 4 && !sc.attn_f16_ok ? 1 : int(attn_variant), stream_, sc.q, sc.k, sc.v);
     kt_end();
-    GemmArgs o; o.variant = enc_gemm_variant(); o.a_scale = sc.out.a; o.w_scale = sc.out.w;
+    GemmArgs o; o.variant = enc_gemm_variant(sc.out); o.a_scale = sc.out.a; o.w_scale = sc.out.w;
     o.A = ws_.att; o.lda = d; o.W = w.attn.wo; o.bias = w.attn.bo; o.C = ws_.x; o.R = ws_.x; o.ldc = d;
     o.M = M; o.N = d; o.K = d;
     kt_begin(kKcGemm, 2.0 * o.M * o.N * o.K, 0);
@@ -768,13 +846,13 @@ void Engine::encode_enqueue(const float* d_mel, int batch) {
     kt_begin(kKcLayerNorm, 0, 2.0 * M * d * 4);
     launch_layernorm(ws_.x, ws_.ln, w.mlp_ln_g, w.mlp_ln_b, M, d, stream_);
     kt_end();
-    GemmArgs f1; f1.variant = enc_gemm_variant(); f1.a_scale = sc.fc1.a; f1.w_scale = sc.fc1.w;
+    GemmArgs f1; f1.variant = enc_gemm_variant(sc.fc1); f1.a_scale = sc.fc1.a; f1.w_scale = sc.fc1.w;
     f1.A = ws_.ln; f1.lda = d; f1.W = w.w1; f1.bias = w.b1; f1.C = ws_.hid; f1.ldc = 4 * d;
     f1.M = M; f1.N = 4 * d; f1.K = d;
     kt_begin(kKcGemm, 2.0 * f1.M * f1.N * f1.K, 0);
     launch_gemm(f1, kEpiBias | kEpiGelu, stream_);
     kt_end();
-    GemmArgs f2; f2.variant = enc_gemm_variant(); f2.a_scale = sc.fc2.a; f2.w_scale = sc.fc2.w;
+    GemmArgs f2; f2.variant = enc_gemm_variant(sc.fc2); f2.a_scale = sc.fc2.a; f2.w_scale = sc.fc2.w;
     f2.A = ws_.hid; f2.lda = 4 * d; f2.W = w.w2; f2.bias = w.b2; f2.C = ws_.x; f2.R = ws_.x; f2.ldc = d;
     f2.M = M; f2.N = d; f2.K = 4 * d;
     kt_begin(kKcGemm, 2.0 * f2.M * f2.N * f2.K, 0);
@@ -790,7 +868,7 @@ void Engine::encode_enqueue(const float* d_mel, int batch) {
     // cross-attention K/V of every decoder layer, projected once per clip into the
     // persistent cache [layer][k|v][clip][head][t][64] (the reference recomputes them
     // inside every decoder Invoke(), whisper.cpp:375)
-    GemmArgs g; g.variant = enc_gemm_variant(); g.a_scale = sc_cross_kv_.a; g.w_scale = sc_cross_kv_.w;
+    GemmArgs g; g.variant = enc_gemm_variant(sc_cross_kv_); g.a_scale = sc_cross_kv_.a; g.w_scale = sc_cross_kv_.w;
     g.A = ws_.enc_out; g.lda = d; g.W = cross_kv_w; g.bias = cross_kv_b; g.C = slot.cross_kv;
     g.M = M; g.N = c.n_text_layer * 2 * d; g.K = d;
     g.c_rpb = T; g.kv_batch = batch; g.kv_heads = c.n_text_head; g.kv_dmodel = d;
@@ -808,7 +886,7 @@ void Engine::encode_enqueue(const float* d_mel, int batch) {
 
 void Engine::decode(int batch, int64_t* ids, int32_t* n_ids, float* logits_host,
                     int logits_steps_cap) {
-  if (!inflight_.empty()) throw Error(1, "collect the submitted batches before a synchronous call");
+  require_idle();
   decode_enqueue(batch, last_enc_slot_, logits_host, logits_steps_cap);
   decode_collect(last_enc_slot_, ids, n_ids);
 }
@@ -841,6 +919,17 @@ void Engine::collect(int64_t* ids, int32_t* n_ids) {
   decode_collect(slot, ids, n_ids);
 }
 
+std::vector<long long> Engine::prompt() const {
+  if (!prompt_override.empty()) return prompt_override;
+  // EncDec (whisper.cpp:327-339): [sot, 50259 + language, transcribe, notimestamps] whatever `multilingual` is
+  // (the ids come from the Vocab, which transform_vocab_multilingual shifted or not, whisper.cpp:218-226).
+  // Monolith: the forced decoder ids HF generate() applies inside the reference's single graph
+  // (export/generate.py:24-30): English-only checkpoints [sot, notimestamps] — the head of kGoldenGeneratedIDs,
+  // whisper.h:27-32 — multilingual ones [sot, language, transcribe, notimestamps].
+  if (monolith_ && !multilingual_) return {vocab_.token_sot, vocab_.token_not};
+  return {vocab_.token_sot, 50259 + language, vocab_.token_transcribe, vocab_.token_not};
+}
+
 void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int logits_steps_cap) {
   ensure_batch(batch);
   Slot& slot = slots_[slot_idx];
@@ -854,10 +943,7 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
   if (batch > 64) throw Error(1, "decoder batches are limited to 64 clips per call");
   const wtw::Dims& c = dims_;
   const int d = c.n_text_state, T = c.n_audio_ctx, H = c.n_text_head, V = c.n_vocab;
-  // prompt (whisper.cpp:327-339): [sot, 50259 + language, transcribe, notimestamps]
-  std::vector<long long> prompt = {vocab_.token_sot, 50259 + language, vocab_.token_transcribe,
-                                   vocab_.token_not};
-  if (!prompt_override.empty()) prompt = prompt_override;
+  const std::vector<long long> prompt = this->prompt();
   const int n_prompt = int(prompt.size()), stride = 32;
   for (long long id : prompt) {
     if (id < 0 || id >= V) throw Error(1, "prompt token id outside the model's vocabulary");

@@ -9,16 +9,11 @@
 #include <string>
 #include <vector>
 
+#include "error.h"
 #include "host_util.h"
 #include "wtw_format.h"
 
 namespace wt {
-
-// Failure with the wt_status code the C ABI reports (wt_capi.h).
-struct Error : std::runtime_error {
-  int code;
-  Error(int c, const std::string& what) : std::runtime_error(what), code(c) {}
-};
 
 struct Timings {
   float logmel_ms = 0, encoder_ms = 0, cross_kv_ms = 0, decoder_ms = 0, total_ms = 0;
@@ -54,8 +49,12 @@ std::vector<float> tile_weights(const float* W, int N, int K);
 class Engine {
  public:
   // Throws std::runtime_error with a message; the C ABI maps it to a status code.
+  // monolith: the reference's other engine type (whisper.h:165-179) routed to the same encoder / decoder
+  // kernels; it differs in the prompt only (prompt(), engine.cpp)
   Engine(const std::string& model_prefix, const std::string& vocab_path, bool multilingual,
-         int device_id);
+         int device_id, bool monolith = false);
+  // front end only: log-mel kernels over `filters` (80 x 201), no weights; encode()/decode() must not be called
+  Engine(const FilterBank& filters, int device_id);
   ~Engine();
   Engine(const Engine&) = delete;
   Engine& operator=(const Engine&) = delete;
@@ -80,13 +79,16 @@ class Engine {
   long gemm_variant = -1;  // encoder GEMM tile variant (k_gemm.hip); -1 = per-shape choice
   // non-empty: replaces the reference's hard-coded prompt (test-sized vocabularies)
   std::vector<long long> prompt_override;
+  // ids the decoder starts from (prompt_override, or the reference's rule for the engine type)
+  std::vector<long long> prompt() const;
 
   int mel_frames() const { return 2 * dims_.n_audio_ctx; }
   size_t mel_elems() const { return size_t(dims_.n_mels) * mel_frames(); }
   size_t pcm_elems() const { return size_t(mel_frames()) * 160; }
 
-  // d_pcm [B][pcm_elems] -> d_mel [B][n_mels][frames]; device pointers, async on stream()
-  void logmel(const float* d_pcm, int batch, float* d_mel);
+  // d_pcm [B][pcm_elems] -> d_mel [B][n_mels][frames]; device pointers, async on stream().  valid_frames >= 0:
+  // the normalisation maximum runs over frames [0, valid_frames) only (a clip shorter than the window)
+  void logmel(const float* d_pcm, int batch, float* d_mel, int valid_frames = -1);
   // d_mel -> encoder output (internal) -> cross KV cache of the next pipeline slot; async on
   // the encoder stream
   void encode(const float* d_mel, int batch);
@@ -103,6 +105,10 @@ class Engine {
   void submit_pcm(const float* d_pcm, int batch);
   void collect(int64_t* ids, int32_t* n_ids);
   int in_flight() const { return int(inflight_.size()); }
+  // contractions that were given the full-range bf16 three-plane kernels at load time (bound slack, engine.cpp)
+  int f16_fallbacks() const { return n_f16_fallbacks_; }
+  // throws unless no submitted batch is waiting for collect(): every synchronous entry point calls it first
+  void require_idle() const;
   void sync();
   // makes this engine's GPU the calling thread's current device (every C-ABI entry does it)
   void bind_device();
@@ -122,6 +128,9 @@ class Engine {
   const KernelStat* kernel_stats() const { return kstats_; }
 
  private:
+  void open_device();     // selects the GPU, checks it is gfx950
+  void create_streams();  // streams, events, pinned id buffers of the pipeline slots
+  void release() noexcept;  // frees every device / host resource; idempotent (destructor and failed constructor)
   void upload_weights(const std::string& path);
   const float* dev(const std::string& name) const;
   float* upload(const std::vector<float>& host);
@@ -130,14 +139,14 @@ class Engine {
   void decode_enqueue(int batch, int slot, float* logits_host, int logits_steps_cap);
   void decode_collect(int slot, int64_t* ids, int32_t* n_ids);
 
-  int device_ = 0;
+  int device_ = 0, n_cu_ = 0;
+  bool monolith_ = false, multilingual_ = true;
   hipStream_t stream_ = nullptr;   // encoder + front end: stream_full_ or stream_masked_ (select_stream)
   hipStream_t stream_full_ = nullptr, stream_masked_ = nullptr;
   hipEvent_t ev_switch_ = nullptr;
   void select_stream(bool pipelined);
   // default encoder GEMM: the k16 split kernel in its two-plane fp16 form, at 2 blocks per CU when decoders
   // share the chip (pipelined), at 3 blocks per CU otherwise
-  int enc_gemm_variant() const { return gemm_variant >= 0 ? int(gemm_variant) : (stream_ == stream_masked_ && stream_masked_ ? 18 : 17); }
   void encode_enqueue(const float* d_mel, int batch);
   static constexpr int kDecStreams = 8, kSlots = 6;  // slots: a multiple of the 3 decoder streams in use, so
                                                      // batches rotate evenly over them (WT_PIPELINE_DEPTH)
@@ -189,12 +198,21 @@ class Engine {
   // so no operand can overflow fp16 for an input mel inside kMelBound
   struct GemmScale {
     float a = 1.0f, w = 64.0f;
+    bool f16_ok = true;  // false: the operand's bound is too far above its typical magnitude (upload_weights)
   };
   struct EncLayerScales {
     GemmScale qkv, out, fc1, fc2;
     float q = 1.0f, k = 1.0f, v = 1.0f;
+    bool attn_f16_ok = true;
   };
   static constexpr float kMelBound = 8.0f;
+  static constexpr float kF16Slack = 4096.0f;  // largest bound / typical ratio the two-plane fp16 form is used for
+  int n_f16_fallbacks_ = 0;
+  int enc_gemm_variant(const GemmScale& sc) const {
+    if (gemm_variant >= 0) return int(gemm_variant);
+    const bool two_per_cu = stream_ == stream_masked_ && stream_masked_;
+    return sc.f16_ok ? (two_per_cu ? 18 : 17) : (two_per_cu ? 16 : 13);  // load-time fall-back to the full-range form
+  }
   GemmScale sc_conv1_, sc_conv2_, sc_cross_kv_;
   std::vector<EncLayerScales> sc_layers_;
   const float *enc_ln_post_g = nullptr, *enc_ln_post_b = nullptr;

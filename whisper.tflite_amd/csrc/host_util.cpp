@@ -65,13 +65,23 @@ const std::string& lang_name(size_t id) { return languages().at(id).name; }
 namespace {
 template <class T>
 T take(const char*& p, const char* end) {
-  if (p + sizeof(T) > end) throw std::runtime_error("vocab file truncated");
+  if (size_t(end - p) < sizeof(T)) throw std::runtime_error("vocab file truncated");
   T v;
   std::memcpy(&v, p, sizeof(T));
   p += sizeof(T);
   return v;
 }
 }  // namespace
+
+void transform_vocab_multilingual(VocabData* vocab) {  // six ids move up by one; translate/transcribe stay
+  vocab->n_vocab = 51865;
+  vocab->token_eot += 1;
+  vocab->token_sot += 1;
+  vocab->token_prev += 1;
+  vocab->token_solm += 1;
+  vocab->token_not += 1;
+  vocab->token_beg += 1;
+}
 
 void read_vocab_file(const std::string& path, bool multilingual, FilterBank* filters,
                      VocabData* vocab) {
@@ -81,33 +91,30 @@ void read_vocab_file(const std::string& path, bool multilingual, FilterBank* fil
   const char* p = bytes.data();
   const char* const end = p + bytes.size();
   (void)take<uint64_t>(p, end);  // payload size written by the asset dumper; unused
+  parse_vocab(p, end, multilingual, filters, vocab);
+}
+
+void parse_vocab(const char* p, const char* end, bool multilingual, FilterBank* filters, VocabData* vocab) {
   (void)take<uint32_t>(p, end);  // magic: the reference reads it and checks nothing
   filters->n_mel = take<int32_t>(p, end);
   filters->n_fft = take<int32_t>(p, end);
   if (filters->n_mel <= 0 || filters->n_fft <= 0 || filters->n_mel > 1024 || filters->n_fft > 65536)
     throw std::runtime_error("vocab file: implausible filter shape");
   const size_t nf = size_t(filters->n_mel) * size_t(filters->n_fft);
-  if (p + nf * sizeof(float) > end) throw std::runtime_error("vocab file truncated");
+  if (size_t(end - p) < nf * sizeof(float)) throw std::runtime_error("vocab file truncated");
   filters->data.resize(nf);
   std::memcpy(filters->data.data(), p, nf * sizeof(float));
   p += nf * sizeof(float);
 
   *vocab = VocabData();
   const int32_t n_file = take<int32_t>(p, end);
+  if (n_file < 0) throw std::runtime_error("vocab file: negative token count");
   vocab->n_vocab = n_file;
-  if (multilingual) {  // six ids move up by one; translate/transcribe stay
-    vocab->n_vocab = 51865;
-    vocab->token_eot += 1;
-    vocab->token_sot += 1;
-    vocab->token_prev += 1;
-    vocab->token_solm += 1;
-    vocab->token_not += 1;
-    vocab->token_beg += 1;
-  }
+  if (multilingual) transform_vocab_multilingual(vocab);
   for (int i = 0; i < n_file; ++i) {
     const uint32_t len = take<uint32_t>(p, end);
     if (len > 255) throw std::runtime_error("vocab file: token longer than 255 bytes");
-    if (p + len > end) throw std::runtime_error("vocab file truncated");
+    if (size_t(end - p) < len) throw std::runtime_error("vocab file truncated");
     // the reference round-trips through a C string, so an embedded NUL ends the token
     vocab->id_to_token[i] = std::string(std::string(p, len).c_str());
     p += len;

@@ -37,6 +37,11 @@ struct FilterBank {
 // cannot be opened (as the reference's MmapFile does) or is truncated.
 void read_vocab_file(const std::string& path, bool multilingual, FilterBank* filters,
                      VocabData* vocab);
+// The same parse over memory that starts at the u32 magic (i.e. after the file's leading u64 payload size),
+// as the reference's Reader does (whisper.cpp:519-611); never reads at or past `end`.
+void parse_vocab(const char* head, const char* end, bool multilingual, FilterBank* filters, VocabData* vocab);
+// whisper.cpp:218-226
+void transform_vocab_multilingual(VocabData* vocab);
 
 // Inverse of read_vocab_file: [u64 payload][u32 magic "USEN"][n_mel][n_fft][filters]
 // [n_vocab]{u32 len, bytes}.

@@ -628,7 +628,8 @@ void launch_encoder_attention(const float* qkv, float* out, int batch, int T, in
 
 void launch_self_attention(const float* qkv, float* kcache, float* vcache, int cap, int pos,
                            float* out, int batch, int heads, hipStream_t s) {
-  if (pos < 0 || pos > 31 || pos >= cap) abort();  // the kernel stages at most 32 cached rows in LDS
+  // the kernel stages at most 32 cached rows in LDS
+  if (pos < 0 || pos > 31 || pos >= cap) throw Error(kErrInvalidArg, "decoder self-attention: position outside [0, 31]");
   hipLaunchKernelGGL(self_attention_step, dim3(batch * heads), dim3(64), 0, s, qkv, kcache, vcache,
                      cap, pos, out, heads);
 }

@@ -435,7 +435,7 @@ void launch_ln(const DecGemmDev& g, hipStream_t s) {
     case 128: launch_mt<kProLn, kDecBias, 4, LNMODE, 4, 1>(g, s); break;
     case 384: launch_mt<kProLn, kDecBias, 12, LNMODE, 4, 1>(g, s); break;
     case 512: launch_mt<kProLn, kDecBias, 16, LNMODE, 4, 1>(g, s); break;
-    default: abort();  // d_model of the supported architectures (micro / tiny / base)
+    default: throw Error(kErrFormat, "decoder kernels support d_model 128, 384 or 512");
   }
 }
 
@@ -452,16 +452,17 @@ void launch_dec_gemm(const DecGemmArgs& a, int pro, int epi, hipStream_t s) {
   const bool wide = epi == kDecResid;  // N = d_model: 16 wavefronts split K
   if (a.B < 1 || a.B > 64 || a.K > 2048 || a.K % (wide ? 8 * a.resid_waves : 32) != 0 || (a.resid_waves != 4 && a.resid_waves != 8 && a.resid_waves != 16) ||
       (pro == kProCombine && (a.K / (8 * a.resid_waves) > (a.resid_waves > 8 ? 6 : 12) || a.K != a.heads * 64)) || (wide && (!a.R || !a.Y))) {
-    abort();
+    throw Error(kErrInvalidArg, "decoder GEMM shape outside the kernel contract");
   }
   if (a.ksplit != 1 && !(a.ksplit == 2 && pro == kProNone && epi == kDecResid && a.part &&
                          a.K % (16 * a.resid_waves) == 0 && a.R != a.Y)) {
-    abort();  // split K: residual GEMM only, with a partial buffer, out of place (the consumer completes the rows into R)
+    // split K: residual GEMM only, with a partial buffer, out of place (the consumer completes the rows into R)
+    throw Error(kErrInvalidArg, "decoder GEMM: K split needs the out-of-place residual form");
   }
   if (pro == kProLn) {
-    if (epi != kDecBias) abort();
+    if (epi != kDecBias) throw Error(kErrInvalidArg, "decoder GEMM: the LayerNorm prologue pairs with the bias epilogue");
     if (a.ids) {
-      if (a.xpart) abort();
+      if (a.xpart) throw Error(kErrInvalidArg, "decoder GEMM: embedding rows have no pending partial");
       launch_ln<2>(g, s);
     } else if (a.xpart) {
       launch_ln<3>(g, s);
@@ -495,10 +496,10 @@ void launch_dec_gemm(const DecGemmArgs& a, int pro, int epi, hipStream_t s) {
           }
           break;
         case 8: launch_mt<kProCombine, kDecResid, 0, 0, 16, 8>(g, s); break;
-        default: abort();
+        default: throw Error(kErrInvalidArg, "cross_chunks must be 1, 2, 4 or 8");
       }
       break;
-    default: abort();
+    default: throw Error(kErrInvalidArg, "unsupported decoder GEMM prologue / epilogue pair");
   }
 }
 
@@ -510,7 +511,7 @@ static void launch_finalize_mode(const RowSrc& src, const float* g, const float*
     case 128: hipLaunchKernelGGL((dec_finalize_ln<4, LNMODE>), grid, dim3(256), 0, s, src, g, b, y, B, K); break;
     case 384: hipLaunchKernelGGL((dec_finalize_ln<12, LNMODE>), grid, dim3(256), 0, s, src, g, b, y, B, K); break;
     case 512: hipLaunchKernelGGL((dec_finalize_ln<16, LNMODE>), grid, dim3(256), 0, s, src, g, b, y, B, K); break;
-    default: abort();
+    default: throw Error(kErrFormat, "decoder kernels support d_model 128, 384 or 512");
   }
 }
 

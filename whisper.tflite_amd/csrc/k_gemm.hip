@@ -10,10 +10,13 @@
 // tiles of one XCD (blockIdx % 8) are consecutive in (m, n) order and share their A panel
 // through that XCD's L2.  The epilogue goes through a per-wavefront LDS transpose (16-byte
 // global accesses).  tools/mfma_probe.hip measures what bounds this loop.
+//
+// This translation unit holds the three supported forms of the fp32-in / fp32-out GEMM
+// (variant 0 = fp32 MFMA, 13/16 = three bf16 planes, 17/18 = two fp16 planes) and the bf16 compute
+// mode (variant 11).  Tile-shape experiments and timing ablations live in tools/gemm_lab.hip only.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
-#include <cstdlib>
 
 #include "bf16_split.h"
 #include "kernels.h"
@@ -32,7 +35,6 @@ __device__ __forceinline__ float gelu_erf(float x) {
 struct GemmDev {
   const float* A;
   const float* W;
-  const unsigned short* Wp;  // W pre-split into bf16 planes [3][N][K] (split_planes), or nullptr
   float* C;
   const float* bias;
   const float* R;
@@ -128,22 +130,20 @@ __device__ __forceinline__ void tile_epilogue(const GemmDev& g, f32x16 (&acc)[MI
   }
 }
 
-// Tile template: BM x BN output tile (64 or 128 each), 4 wavefronts as 2 x 2, each owning
-// (BM/2) x (BN/2) = MI x NI MFMA tiles of 32 x 32; k-tile BK (32 or 64); DBUF = two LDS
-// buffers and one barrier per k-tile instead of two.
-template <int EPI, int BM, int BN, int BK, bool DBUF, bool PF2 = false>
+// gemm_f32_tile: BM x BN output tile, 4 wavefronts as 2 x 2, each owning (BM/2) x (BN/2) = MI x NI MFMA
+// tiles of 32 x 32; k-tile BK; one LDS buffer, global loads of k-tile t+1 in flight during the MFMAs of t.
+template <int EPI, int BM, int BN, int BK>
 __global__ __launch_bounds__(256) void gemm_f32_tile(GemmDev g) {
   constexpr int LDS_LD = BK + 4;  // odd multiple of 16 B: conflict-free ds_read_b128
   constexpr int MI = BM / 64, NI = BN / 64;
-  constexpr int TPR = BK / 4;     // threads covering one row's k-tile (128 or 256 contiguous B)
+  constexpr int TPR = BK / 4;     // threads covering one row's k-tile (128 contiguous B)
   constexpr int RPP = 256 / TPR;  // rows staged per pass
   constexpr int NA = BM / RPP, NB = BN / RPP;  // float4 per thread per k-tile (A, W)
-  constexpr int NBUF = DBUF ? 2 : 1;
   constexpr int SLD = NI * 32 + 4;  // epilogue staging row stride (floats)
-  constexpr int kTileFloats = NBUF * (BM + BN) * LDS_LD, kStageFloats = 4 * 32 * SLD;
+  constexpr int kTileFloats = (BM + BN) * LDS_LD, kStageFloats = 4 * 32 * SLD;
   __shared__ __attribute__((aligned(16))) float smem[kTileFloats > kStageFloats ? kTileFloats : kStageFloats];
   float* const As = smem;
-  float* const Bs = smem + NBUF * BM * LDS_LD;
+  float* const Bs = smem + BM * LDS_LD;
 
   // XCD-aware bijective remap: blocks with equal blockIdx % 8 share an XCD (speed only).
   const int nb = gridDim.x, bid = blockIdx.x;
@@ -179,26 +179,23 @@ __global__ __launch_bounds__(256) void gemm_f32_tile(GemmDev g) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
   f32x4 ra[NA], rb[NB];
-  f32x4 ra2[PF2 ? NA : 1], rb2[PF2 ? NB : 1];  // second register stage (prefetch depth 2)
-  auto load_into = [&](f32x4* xa, f32x4* xb, int kt) {
+  auto load_tile = [&](int kt) {
 #pragma unroll
-    for (int i = 0; i < NA; ++i) xa[i] = *reinterpret_cast<const f32x4*>(a_ptr[i] + kt * BK);
+    for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(a_ptr[i] + kt * BK);
 #pragma unroll
-    for (int i = 0; i < NB; ++i) xb[i] = *reinterpret_cast<const f32x4*>(w_ptr[i] + kt * BK);
+    for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const f32x4*>(w_ptr[i] + kt * BK);
   };
-  auto store_from = [&](const f32x4* xa, const f32x4* xb, int buf) {
+  auto store_tile = [&]() {
 #pragma unroll
     for (int i = 0; i < NA; ++i)
-      *reinterpret_cast<f32x4*>(&As[buf * BM * LDS_LD + (srow + RPP * i) * LDS_LD + scol]) = xa[i];
+      *reinterpret_cast<f32x4*>(&As[(srow + RPP * i) * LDS_LD + scol]) = ra[i];
 #pragma unroll
     for (int i = 0; i < NB; ++i)
-      *reinterpret_cast<f32x4*>(&Bs[buf * BN * LDS_LD + (srow + RPP * i) * LDS_LD + scol]) = xb[i];
+      *reinterpret_cast<f32x4*>(&Bs[(srow + RPP * i) * LDS_LD + scol]) = rb[i];
   };
-  auto load_tile = [&](int kt) { load_into(ra, rb, kt); };
-  auto store_tile = [&](int buf) { store_from(ra, rb, buf); };
-  auto compute = [&](int buf) {
-    const float* Ab = As + buf * BM * LDS_LD + (wm * (BM / 2) + l31) * LDS_LD + 4 * lh;
-    const float* Bb = Bs + buf * BN * LDS_LD + (wn * (BN / 2) + l31) * LDS_LD + 4 * lh;
+  auto compute = [&]() {
+    const float* Ab = As + (wm * (BM / 2) + l31) * LDS_LD + 4 * lh;
+    const float* Bb = Bs + (wn * (BN / 2) + l31) * LDS_LD + 4 * lh;
 #pragma unroll
     for (int kq = 0; kq < BK / 8; ++kq) {
       // lane (row l31, half lh) takes k = 8*kq + 4*lh + j for MFMA step j: A and B use the
@@ -220,96 +217,48 @@ __global__ __launch_bounds__(256) void gemm_f32_tile(GemmDev g) {
 
   const int nkt = g.K / BK;
   load_tile(0);
-  if (PF2) {
-    // Two k-tiles of global loads in flight: HBM latency (~2-3 us under load) exceeds one
-    // k-tile of MFMA work (4096 cycles), so a tile is requested two iterations before its
-    // LDS write.  Register stages alternate (static names: the loop is unrolled by two).
-    static_assert(!PF2 || DBUF, "prefetch depth 2 uses both LDS buffers");
-    store_tile(0);
-    if (nkt > 1) load_into(ra, rb, 1);
+  for (int kt = 0; kt < nkt; ++kt) {
+    store_tile();
     __syncthreads();
-    for (int kt = 0; kt < nkt; kt += 2) {
-      if (kt + 2 < nkt) load_into(ra2, rb2, kt + 2);
-      compute(0);
-      if (kt + 1 < nkt) store_from(ra, rb, 1);
-      __syncthreads();
-      if (kt + 1 < nkt) {
-        if (kt + 3 < nkt) load_into(ra, rb, kt + 3);
-        compute(1);
-        if (kt + 2 < nkt) store_from(ra2, rb2, 0);
-        __syncthreads();
-      }
-    }
-  } else if (DBUF) {
-    store_tile(0);
+    if (kt + 1 < nkt) load_tile(kt + 1);
+    compute();
     __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-      const int cur = kt & 1;
-      if (kt + 1 < nkt) load_tile(kt + 1);
-      compute(cur);
-      if (kt + 1 < nkt) store_tile(cur ^ 1);
-      __syncthreads();
-    }
-  } else {
-    for (int kt = 0; kt < nkt; ++kt) {
-      store_tile(0);
-      __syncthreads();
-      if (kt + 1 < nkt) load_tile(kt + 1);
-      compute(0);
-      __syncthreads();
-    }
   }
 
   tile_epilogue<EPI, BM, BN, MI, NI>(g, acc, smem, m0, n0);
 }
 
-// gemm_split_tile: the same GEMM on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, 16x the
-// fp32 MFMA rate per k).  NS = 3: every fp32 operand element is split EXACTLY into three bf16
-// planes (bf16_split.h: x = h1 + h2 + h3, 8 significant bits each, the subtractions are exact),
-// and the six plane products with weight >= 2^-16 are accumulated in fp32:
-//   a.b = a1b1 + (a1b2 + a2b1) + (a2b2 + a1b3 + a3b1) + dropped, |dropped| < 2^-22 |a||b| (bf16_split.h)
-// Each bf16 x bf16 product is exact in fp32, so the result carries fp32-level error (measured
-// against fp64 next to the fp32-MFMA kernel in tests/test_gpu_kernels.py) at 6/16 of the MFMA
-// cycles.  NS = 1 rounds the operands to bf16 (RNE) and is the bf16 compute mode of
-// BASELINE configs[3].  Operands stay fp32 in HBM; the split happens between the global load
-// and the LDS write (4 VALU ops + 1.5 v_perm per element, hidden behind the partner
-// wavefront's MFMAs at 2 blocks per CU).  128 x 128 x 32 tiles, 4 wavefronts as 2 x 2, two
-// k-tiles of global loads in flight (a k-tile is ~1500 MFMA cycles, shorter than HBM latency).
+// gemm_bf16_tile: the bf16 compute mode of BASELINE configs[3] on fp32 storage: operands rounded to bf16
+// (RNE) between the global load and the LDS write, one v_mfma_f32_32x32x16_bf16 product, fp32
+// accumulation.  128 x 128 x 32 tiles, 4 wavefronts as 2 x 2, two k-tiles of global loads in flight.
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using half8 = __attribute__((ext_vector_type(8))) _Float16;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
+__device__ __forceinline__ void round_store8(const f32x4& lo, const f32x4& hi, unsigned short* dst) {
+  const float x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  *reinterpret_cast<u32x4_t*>(dst) = round8_bf16(x);
+}
+
 template <int NS>
 __device__ __forceinline__ void split_store8(const f32x4& lo, const f32x4& hi, unsigned short* dst, int plane_stride) {
-  float x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  if (NS == 1) {
-    u32x4 o;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      // round to nearest even on the upper 16 bits
-      unsigned a = __float_as_uint(x[2 * j]), b = __float_as_uint(x[2 * j + 1]);
-      a += 0x7FFFu + ((a >> 16) & 1u);
-      b += 0x7FFFu + ((b >> 16) & 1u);
-      o[j] = __builtin_amdgcn_perm(b, a, 0x07060302u);
-    }
-    *reinterpret_cast<u32x4*>(dst) = o;
-    return;
-  }
+  static_assert(NS == 3, "three bf16 planes");
+  const float x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   u32x4_t o[3];
   split8_planes(x, o);
 #pragma unroll
   for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(dst + p * plane_stride) = o[p];
 }
 
-template <int EPI, int NS, bool WPRE = false>
-__global__ __launch_bounds__(256, 2) void gemm_split_tile(GemmDev g) {
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_tile(GemmDev g) {
   constexpr int BM = 128, BN = 128, BK = 32, MI = 2, NI = 2;
   constexpr int LD = BK + 8;            // bf16 per LDS row: 80 B, an odd multiple of 16 B
-  constexpr int PLANE = BM * LD;        // bf16 per operand plane
-  constexpr int kTileBytes = 2 * NS * PLANE * 2, kStageBytes = 4 * 32 * (NI * 32 + 4) * 4;
+  constexpr int PLANE = BM * LD;        // bf16 per operand
+  constexpr int kTileBytes = 2 * PLANE * 2, kStageBytes = 4 * 32 * (NI * 32 + 4) * 4;
   __shared__ __attribute__((aligned(16))) unsigned char smem_raw[kTileBytes > kStageBytes ? kTileBytes : kStageBytes];
   unsigned short* const As = reinterpret_cast<unsigned short*>(smem_raw);
-  unsigned short* const Bs = As + NS * PLANE;
+  unsigned short* const Bs = As + PLANE;
 
   const int nb = gridDim.x, bid = blockIdx.x;
   const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7;
@@ -334,11 +283,6 @@ __global__ __launch_bounds__(256, 2) void gemm_split_tile(GemmDev g) {
     a_ptr[i] = g.A + (long)(m / g.a_rpb) * g.a_bs + (long)(m % g.a_rpb) * g.lda + scol;
     w_ptr[i] = g.W + (long)(n0 + srow + 64 * i) * g.K + scol;
   }
-  // pre-split W: plane p of row n lives at Wp + (p * N + n) * K, 8 bf16 (16 B) per thread
-  const unsigned short* wp_ptr[2];
-  const long wp_plane = (long)g.N * g.K;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) wp_ptr[i] = g.Wp + (long)(n0 + srow + 64 * i) * g.K + scol;
 
   f32x16 acc[MI][NI];
 #pragma unroll
@@ -348,36 +292,21 @@ __global__ __launch_bounds__(256, 2) void gemm_split_tile(GemmDev g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  // two register stages: {A pass 0, A pass 1} x 2 float4, then W: {pass 0, pass 1} x 2 float4, or
-  // (WPRE) {pass 0, pass 1} x NS planes of 8 bf16
-  constexpr int NST = 4 + (WPRE ? 2 * NS : 4);
-  f32x4 st0[NST], st1[NST];
+  f32x4 st0[8], st1[8];  // two register stages: {A pass 0, A pass 1, W pass 0, W pass 1} x 2 float4
   auto load_into = [&](f32x4* st, int kt) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       st[2 * i] = *reinterpret_cast<const f32x4*>(a_ptr[i] + kt * BK);
       st[2 * i + 1] = *reinterpret_cast<const f32x4*>(a_ptr[i] + kt * BK + 4);
-      if (WPRE) {
-#pragma unroll
-        for (int p = 0; p < NS; ++p)
-          st[4 + NS * i + p] = *reinterpret_cast<const f32x4*>(wp_ptr[i] + p * wp_plane + kt * BK);
-      } else {
-        st[4 + 2 * i] = *reinterpret_cast<const f32x4*>(w_ptr[i] + kt * BK);
-        st[4 + 2 * i + 1] = *reinterpret_cast<const f32x4*>(w_ptr[i] + kt * BK + 4);
-      }
+      st[4 + 2 * i] = *reinterpret_cast<const f32x4*>(w_ptr[i] + kt * BK);
+      st[4 + 2 * i + 1] = *reinterpret_cast<const f32x4*>(w_ptr[i] + kt * BK + 4);
     }
   };
   auto store_from = [&](const f32x4* st) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      split_store8<NS>(st[2 * i], st[2 * i + 1], As + (srow + 64 * i) * LD + scol, PLANE);
-      if (WPRE) {
-#pragma unroll
-        for (int p = 0; p < NS; ++p)
-          *reinterpret_cast<f32x4*>(Bs + p * PLANE + (srow + 64 * i) * LD + scol) = st[4 + NS * i + p];
-      } else {
-        split_store8<NS>(st[4 + 2 * i], st[4 + 2 * i + 1], Bs + (srow + 64 * i) * LD + scol, PLANE);
-      }
+      round_store8(st[2 * i], st[2 * i + 1], As + (srow + 64 * i) * LD + scol);
+      round_store8(st[4 + 2 * i], st[4 + 2 * i + 1], Bs + (srow + 64 * i) * LD + scol);
     }
   };
   auto compute = [&]() {
@@ -386,29 +315,16 @@ __global__ __launch_bounds__(256, 2) void gemm_split_tile(GemmDev g) {
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       // lane (row l31, half lh) holds k = 16*ks + 8*lh + 0..7 of its row, for A and W alike
-      bf16x8 af[MI][NS], bf[NI][NS];
+      bf16x8 af[MI], bf[NI];
 #pragma unroll
-      for (int p = 0; p < NS; ++p) {
+      for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * LD + ks * 16);
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
-          af[i][p] = *reinterpret_cast<const bf16x8*>(Ab + p * PLANE + i * 32 * LD + ks * 16);
+      for (int j = 0; j < NI; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * LD + ks * 16);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
-          bf[j][p] = *reinterpret_cast<const bf16x8*>(Bb + p * PLANE + j * 32 * LD + ks * 16);
-      }
-      // smallest products first
-#pragma unroll
-      for (int w = 2 * (NS - 1) > 2 ? 2 : 2 * (NS - 1); w >= 0; --w)
-#pragma unroll
-        for (int pa = 0; pa < NS; ++pa) {
-          const int pb = w - pa;
-          if (pb < 0 || pb >= NS) continue;
-#pragma unroll
-          for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][pa], bf[j][pb], acc[i][j], 0, 0, 0);
-        }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
   };
 
@@ -432,14 +348,10 @@ __global__ __launch_bounds__(256, 2) void gemm_split_tile(GemmDev g) {
   tile_epilogue<EPI, BM, BN, MI, NI>(g, acc, reinterpret_cast<float*>(smem_raw), m0, n0);
 }
 
-template <int EPI, int NS>
-void launch_split(const GemmDev& g, hipStream_t s) {
+template <int EPI>
+void launch_bf16(const GemmDev& g, hipStream_t s) {
   const int blocks = ((g.M + 127) / 128) * (g.N / 128);
-  if (g.Wp && NS == 3) {
-    hipLaunchKernelGGL((gemm_split_tile<EPI, NS, true>), dim3(blocks), dim3(256), 0, s, g);
-  } else {
-    hipLaunchKernelGGL((gemm_split_tile<EPI, NS, false>), dim3(blocks), dim3(256), 0, s, g);
-  }
+  hipLaunchKernelGGL((gemm_bf16_tile<EPI>), dim3(blocks), dim3(256), 0, s, g);
 }
 
 // gemm_split16_tile: the 3-plane split GEMM software-pipelined inside each wavefront.  k-tiles of
@@ -447,7 +359,9 @@ void launch_split(const GemmDev& g, hipStream_t s) {
 // same wavefront splits the registers of k-tile t+1 and writes them to the other buffer (the
 // MFMA pipe is busy 32 cycles per instruction and holds vector issue for 8 of them), and the
 // global loads of k-tile t+3 are in flight.  One barrier per k-tile.
-template <int EPI, int SCHED, int ABL = 0, bool F16 = false>
+// PAD2: LDS padded to 54 KB so that exactly two blocks share a CU (pipelined mode: leaves registers and LDS
+// to co-resident decoder blocks; results unchanged).
+template <int EPI, bool PAD2 = false, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void gemm_split16_tile(GemmDev g) {
   // F16: two fp16 planes and three products (bf16_split.h, split8_f16x2) instead of three bf16 planes and
   // six; A and W are scaled by powers of two (GemmArgs::a_scale, w_scale: from operand bounds) into fp16's
@@ -460,7 +374,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split16_tile(GemmDev g) {
   constexpr int LD = BK;
   constexpr int PLANE = BM * LD;        // bf16 per operand plane
   constexpr int BUF = 2 * NS * PLANE;   // bf16 per buffer (A planes, then W planes)
-  constexpr int kTileBytes = 2 * BUF * 2 + ((ABL & 8) ? (55700 - 2 * BUF * 2 > 0 ? 55700 - 2 * BUF * 2 : 0) : 0)  /* ABL 8: occupancy pad, results unchanged */, kStageBytes = 4 * 32 * (NI * 32 + 4) * 4;
+  constexpr int kTileBytes = 2 * BUF * 2 + (PAD2 ? (55700 - 2 * BUF * 2 > 0 ? 55700 - 2 * BUF * 2 : 0) : 0), kStageBytes = 4 * 32 * (NI * 32 + 4) * 4;
   __shared__ __attribute__((aligned(16))) unsigned char smem_raw[kTileBytes > kStageBytes ? kTileBytes : kStageBytes];
   unsigned short* const lds = reinterpret_cast<unsigned short*>(smem_raw);
 
@@ -494,21 +408,12 @@ __global__ __launch_bounds__(256, 2) void gemm_split16_tile(GemmDev g) {
 
   f32x4 st0[4], st1[4];  // {A lo, A hi, W lo, W hi}
   auto load_into = [&](f32x4* st, int kt) {
-    if ((ABL & 1) && kt > 2) return;  // timing ablation: no global loads in the steady state
     st[0] = *reinterpret_cast<const f32x4*>(a_ptr + kt * BK);
     st[1] = *reinterpret_cast<const f32x4*>(a_ptr + kt * BK + 4);
     st[2] = *reinterpret_cast<const f32x4*>(w_ptr + kt * BK);
     st[3] = *reinterpret_cast<const f32x4*>(w_ptr + kt * BK + 4);
   };
   auto store_from = [&](const f32x4* st, int buf) {
-    if (ABL & 2) {  // timing ablation: no split arithmetic, same LDS writes
-#pragma unroll
-      for (int p = 0; p < NS; ++p) {
-        *reinterpret_cast<f32x4*>(lds + buf * BUF + p * PLANE + st_off) = st[p & 1];
-        *reinterpret_cast<f32x4*>(lds + buf * BUF + (NS + p) * PLANE + st_off) = st[2 + (p & 1)];
-      }
-      return;
-    }
     if (F16) {
       const float xa[8] = {st[0][0], st[0][1], st[0][2], st[0][3], st[1][0], st[1][1], st[1][2], st[1][3]};
       const float xw[8] = {st[2][0], st[2][1], st[2][2], st[2][3], st[3][0], st[3][1], st[3][2], st[3][3]};
@@ -540,7 +445,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split16_tile(GemmDev g) {
   };
   auto mfmas = [&]() {
 #pragma unroll
-    for (int w = (ABL & 4) ? 0 : NS - 1; w >= 0; --w)  // smallest products first (ablation 4: one product)
+    for (int w = NS - 1; w >= 0; --w)  // smallest products first
 #pragma unroll
       for (int pa = 0; pa < NS; ++pa) {
         const int pb = w - pa;
@@ -557,18 +462,6 @@ __global__ __launch_bounds__(256, 2) void gemm_split16_tile(GemmDev g) {
             }
       }
   };
-  auto interleave = [&]() {
-    if (SCHED) {
-      // per MFMA: 4 split VALU ops ride in its shadow; a DS write every fourth
-#pragma unroll
-      for (int i = 0; i < 24; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);  // VALU
-        if ((i & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
-      }
-    }
-  };
-
   const int nkt = g.K / BK;
   load_into(st0, 0);
   if (nkt > 1) load_into(st1, 1);
@@ -579,31 +472,14 @@ __global__ __launch_bounds__(256, 2) void gemm_split16_tile(GemmDev g) {
   // steady state, branch-free so that the scheduler can interleave the split with the MFMAs:
   // even k-tile computes buffer 0 while k-tile kt+1 (st1) is staged into buffer 1, and so on
   for (; kt + 4 < nkt; kt += 2) {
-    if (SCHED == 2) {
-      // stage first: the registers of k-tile kt+1 go to the idle buffer and are refilled with
-      // k-tile kt+3 a whole MFMA phase earlier than in the compute-first order
-      store_from(st1, 1);
-      load_into(st1, kt + 3);
-      read_frags(0);
-      mfmas();
-      __syncthreads();
-      store_from(st0, 0);
-      load_into(st0, kt + 4);
-      read_frags(1);
-      mfmas();
-      __syncthreads();
-      continue;
-    }
     read_frags(0);
     mfmas();
     store_from(st1, 1);
-    interleave();
     load_into(st1, kt + 3);
     __syncthreads();
     read_frags(1);
     mfmas();
     store_from(st0, 0);
-    interleave();
     load_into(st0, kt + 4);
     __syncthreads();
   }
@@ -630,80 +506,41 @@ __global__ __launch_bounds__(256, 2) void gemm_split16_tile(GemmDev g) {
   tile_epilogue<EPI, BM, BN, MI, NI>(g, acc, reinterpret_cast<float*>(smem_raw), m0, n0);
 }
 
-template <int EPI, int SCHED, int ABL = 0, bool F16 = false>
+template <int EPI, bool PAD2, bool F16>
 void launch_split16(const GemmDev& g, hipStream_t s) {
   const int blocks = ((g.M + 127) / 128) * (g.N / 128);
-  hipLaunchKernelGGL((gemm_split16_tile<EPI, SCHED, ABL, F16>), dim3(blocks), dim3(256), 0, s, g);
+  hipLaunchKernelGGL((gemm_split16_tile<EPI, PAD2, F16>), dim3(blocks), dim3(256), 0, s, g);
 }
 
-// x[n] -> three bf16 planes out[p * n + i] with x = h1 + h2 + h3 exactly (see gemm_split_tile)
-__global__ void split_planes_kernel(const float* __restrict__ x, unsigned short* __restrict__ out, long n) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float v = x[i];
-  const unsigned u = __float_as_uint(v) + 0x8000u;
-  const float r1 = v - __uint_as_float(u & 0xFFFF0000u);
-  const unsigned u1 = __float_as_uint(r1);
-  const float r2 = r1 - __uint_as_float(u1 & 0xFFFF0000u);
-  out[i] = (unsigned short)(u >> 16);
-  out[n + i] = (unsigned short)(u1 >> 16);
-  out[2 * n + i] = (unsigned short)(__float_as_uint(r2) >> 16);
-}
-
-template <int EPI, int BM, int BN, int BK, bool DBUF, bool PF2 = false>
-void launch_tile(const GemmDev& g, hipStream_t s) {
-  const int blocks = ((g.M + BM - 1) / BM) * (g.N / BN);
-  hipLaunchKernelGGL((gemm_f32_tile<EPI, BM, BN, BK, DBUF, PF2>), dim3(blocks), dim3(256), 0, s, g);
-}
-
-// variant: 0 = 128x128x32 (3 blocks/CU), 1 = 128x128x64, 2 = 128x128x32 double-buffered,
-//          3 = 128x64x32, 4 = 64x128x32, 5 = 128x64x32 double-buffered, 6 = 64x64x32,
-//          7 = 128x128x32 double-buffered + global prefetch depth 2, 8 = 128x64x32 likewise,
-//          9 = 192x128x32 (wave tile 96x64)
-//          10 = 128x128x32 on the bf16 matrix cores, exact 3-plane operand split (fp32 result)
-//          11 = 128x128x32 on the bf16 matrix cores, operands rounded to bf16
 template <int EPI>
 void launch_gemm_t(const GemmDev& g, int variant, hipStream_t s) {
-  if (variant == 1 && g.K % 64 != 0) variant = 0;
   switch (variant) {
-    case 0: launch_tile<EPI, 128, 128, 32, false>(g, s); break;
-    case 1: launch_tile<EPI, 128, 128, 64, false>(g, s); break;
-    case 2: launch_tile<EPI, 128, 128, 32, true>(g, s); break;
-    case 3: launch_tile<EPI, 128, 64, 32, false>(g, s); break;
-    case 4: launch_tile<EPI, 64, 128, 32, false>(g, s); break;
-    case 5: launch_tile<EPI, 128, 64, 32, true>(g, s); break;
-    case 6: launch_tile<EPI, 64, 64, 32, false>(g, s); break;
-    case 7: launch_tile<EPI, 128, 128, 32, true, true>(g, s); break;
-    case 8: launch_tile<EPI, 128, 64, 32, true, true>(g, s); break;
-    case 9: launch_tile<EPI, 192, 128, 32, false>(g, s); break;
-    case 10: launch_split<EPI, 3>(g, s); break;  // fp32 result from six bf16 plane products
-    case 11: launch_split<EPI, 1>(g, s); break;  // bf16-rounded operands (configs[3] compute mode)
-    case 13: launch_split16<EPI, 0>(g, s); break;  // split-3, k-tiles of 16, double-buffered LDS
-    case 14: launch_split16<EPI, 1>(g, s); break;  // same with an explicit MFMA/VALU interleave
-    case 15: launch_split16<EPI, 2>(g, s); break;  // same, staging before the MFMAs of a k-tile
-    case 16: launch_split16<EPI, 0, 8>(g, s); break;  // variant 13 with LDS padded to 54 KB: 2 blocks per CU, which
-                                                      // leaves registers and LDS for co-resident decoder blocks
-    case 17: launch_split16<EPI, 0, 0, true>(g, s); break;  // two fp16 planes, three products (22-bit operands)
-    case 18: launch_split16<EPI, 0, 8, true>(g, s); break;  // same at 2 blocks per CU
-    case 21: launch_split16<EPI, 0, 1>(g, s); break;  // timing ablations of 13 (wrong results)
-    case 22: launch_split16<EPI, 0, 2>(g, s); break;
-    case 23: launch_split16<EPI, 0, 3>(g, s); break;
-    case 24: launch_split16<EPI, 0, 4>(g, s); break;
-    case 27: launch_split16<EPI, 0, 7>(g, s); break;
-    default: abort();
+    case 0: {  // fp32 MFMA, 128 x 128 x 32 (3 blocks per CU)
+      const int blocks = ((g.M + 127) / 128) * (g.N / 128);
+      hipLaunchKernelGGL((gemm_f32_tile<EPI, 128, 128, 32>), dim3(blocks), dim3(256), 0, s, g);
+      break;
+    }
+    case 11: launch_bf16<EPI>(g, s); break;                   // operands rounded to bf16 (configs[3] compute mode)
+    case 13: launch_split16<EPI, false, false>(g, s); break;  // three bf16 planes, six products: full fp32 range
+    case 16: launch_split16<EPI, true, false>(g, s); break;   // same at 2 blocks per CU
+    case 17: launch_split16<EPI, false, true>(g, s); break;   // two fp16 planes, three products (22-bit operands)
+    case 18: launch_split16<EPI, true, true>(g, s); break;    // same at 2 blocks per CU
+    default: throw Error(kErrInvalidArg, "gemm_variant must be one of 0, 11, 13, 16, 17, 18");
   }
 }
 
 }  // namespace
 
+bool gemm_variant_supported(int variant) {
+  return variant == 0 || variant == 11 || variant == 13 || variant == 16 || variant == 17 || variant == 18;
+}
+
 int gemm_occupancy(int variant) {
   int n = -1;
   switch (variant) {
-    case 0: (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_f32_tile<kEpiBias, 128, 128, 32, false>, 256, 0); break;
-    case 10: (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_split_tile<kEpiBias, 3, false>, 256, 0); break;
-    case 13: (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_split16_tile<kEpiBias, 0, 0>, 256, 0); break;
-    case 14: (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_split16_tile<kEpiBias, 1, 0>, 256, 0); break;
-    case 15: (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_split16_tile<kEpiBias, 2, 0>, 256, 0); break;
+    case 0: (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_f32_tile<kEpiBias, 128, 128, 32>, 256, 0); break;
+    case 13: (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_split16_tile<kEpiBias, false, false>, 256, 0); break;
+    case 17: (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_split16_tile<kEpiBias, false, true>, 256, 0); break;
     default: break;
   }
   return n;
@@ -718,16 +555,14 @@ float f16_scale_for(float bound) {
   return std::ldexp(1.0f, e);
 }
 
-void launch_split_planes(const float* x, unsigned short* out, long n, hipStream_t s) {
-  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, out, n);
-}
-
 void launch_gemm(const GemmArgs& a, int epi, hipStream_t s) {
-  GemmDev g{a.A,   a.W, a.Wp,  a.C,    a.bias, a.R,   a.pos,        a.M,        a.N,        a.K,
+  GemmDev g{a.A,   a.W,  a.C,    a.bias, a.R,   a.pos,        a.M,        a.N,        a.K,
             a.a_rpb, a.a_bs, a.lda, a.c_rpb, a.c_bs, a.ldc, a.pos_period, a.kv_batch, a.kv_heads,
             a.kv_dmodel, a.a_scale, a.w_scale, 1.0f / (a.a_scale * a.w_scale)};
   // shape contract of the kernels (the epilogue wraps batch / position rows at most once per 32 rows)
-  if (a.N % 128 != 0 || a.K % 32 != 0 || a.M < 1 || a.c_rpb < 32 || a.pos_period < (epi & kEpiPos ? 32 : 1)) abort();
+  if (a.N % 128 != 0 || a.K % 32 != 0 || a.M < 1 || a.c_rpb < 32 || a.pos_period < (epi & kEpiPos ? 32 : 1)) {
+    throw Error(kErrInvalidArg, "GEMM shape outside the kernel contract (N % 128, K % 32, M >= 1, rows per clip >= 32)");
+  }
   int v = a.variant;
   if (v < 0) v = 13;  // auto for callers that do not choose: the full-range bf16 three-plane split kernel
   switch (epi) {
@@ -737,7 +572,7 @@ void launch_gemm(const GemmArgs& a, int epi, hipStream_t s) {
     case kEpiBias | kEpiResidual: launch_gemm_t<kEpiBias | kEpiResidual>(g, v, s); break;
     case kEpiBias | kEpiGelu | kEpiPos: launch_gemm_t<kEpiBias | kEpiGelu | kEpiPos>(g, v, s); break;
     case kEpiBias | kEpiKvLayout: launch_gemm_t<kEpiBias | kEpiKvLayout>(g, v, s); break;
-    default: abort();
+    default: throw Error(kErrInvalidArg, "unsupported GEMM epilogue combination");
   }
 }
 

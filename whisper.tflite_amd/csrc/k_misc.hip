@@ -109,7 +109,7 @@ __device__ __forceinline__ float from_ordered(unsigned o) {
 __global__ __launch_bounds__(256) void log_clipmax(const float* __restrict__ melacc, int ld,
                                                    float* __restrict__ logmel,
                                                    unsigned* __restrict__ clip_max, int n_mel,
-                                                   int T) {
+                                                   int T, int t_valid) {
   __shared__ float tile[32][33];
   __shared__ unsigned smax;
   const int b = blockIdx.z, t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void log_clipmax(const float* __restrict__ mel
       e = e < 1e-10f ? 1e-10f : e;         // whisper.cpp:176-180 (a float epsilon)
       v = (float)log10((double)e);          // :182 log10 in double, stored as float
       const unsigned o = ordered_bits(v);
-      lmax = o > lmax ? o : lmax;
+      if (t < t_valid) lmax = o > lmax ? o : lmax;  // the reference's maximum runs over n_len frames only
     }
     tile[ty + 8 * i][tx] = v;
   }
@@ -197,7 +197,7 @@ void launch_layernorm(const float* x, float* y, const float* g, const float* b, 
   } else if (d <= 512) {
     hipLaunchKernelGGL(layernorm_rows<8>, dim3(blocks), dim3(256), 0, s, x, y, g, b, M, d, nonfinite);
   } else {
-    abort();
+    throw Error(kErrFormat, "LayerNorm kernel supports rows of at most 512 elements");
   }
 }
 
@@ -223,9 +223,9 @@ void launch_power_fold(const float* spec, int ld, int im_off, float* pw, int ldp
 }
 
 void launch_log_clipmax(const float* melacc, int ld, float* logmel, unsigned* clip_max, int batch,
-                        int n_mel, int T, hipStream_t s) {
+                        int n_mel, int T, hipStream_t s, int t_valid) {
   hipLaunchKernelGGL(log_clipmax, dim3((T + 31) / 32, (n_mel + 31) / 32, batch), dim3(256), 0, s,
-                     melacc, ld, logmel, clip_max, n_mel, T);
+                     melacc, ld, logmel, clip_max, n_mel, T, t_valid < 0 ? T : t_valid);
 }
 
 void launch_mel_normalize(float* logmel, const unsigned* clip_max, int batch, int n_mel, int T,

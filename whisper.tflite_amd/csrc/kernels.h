@@ -1,10 +1,13 @@
 // Host-side launchers for the gfx950 kernels of the EncDec hot path.
 // Every launcher enqueues on the given stream and never synchronises or
 // allocates, so a caller may capture a sequence of them into a hipGraph.
+// A shape outside a kernel's contract throws wt::Error (never abort()).
 #pragma once
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+
+#include "error.h"
 
 namespace wt {
 
@@ -26,7 +29,6 @@ enum GemmEpi : int {
 struct GemmArgs {
   const float* A = nullptr;
   const float* W = nullptr;
-  const unsigned short* Wp = nullptr;  // optional: W as three bf16 planes [3][N][K] (launch_split_planes)
   float* C = nullptr;
   const float* bias = nullptr;
   const float* R = nullptr;
@@ -43,7 +45,7 @@ struct GemmArgs {
   //   -> C[((slab * kv_batch + b) * kv_heads + head) * T * 64 + t * 64 + dd]
   // where slab enumerates (layer, k|v); T = c_rpb.
   int kv_batch = 0, kv_heads = 0, kv_dmodel = 0;
-  int variant = -1;  // tile shape / pipelining variant (k_gemm.hip launch_gemm_t); -1 = auto
+  int variant = -1;  // contraction form (k_gemm.hip launch_gemm_t: 0, 11, 13, 16, 17, 18); -1 = auto
   // two-plane fp16 kernels (variants 17, 18): powers of two that bring the operands into fp16's normal
   // range, |A * a_scale| and |W * w_scale| <= 32768 (f16_scale_for); the epilogue divides them out
   float a_scale = 1.0f, w_scale = 64.0f;
@@ -53,8 +55,8 @@ void launch_gemm(const GemmArgs& a, int epi, hipStream_t s);
 float f16_scale_for(float bound);
 // resident blocks per CU the runtime reports for a tile variant (diagnostics)
 int gemm_occupancy(int variant);
-// x[n] fp32 -> out[3][n] bf16 with x = out[0] + out[1] + out[2] exactly
-void launch_split_planes(const float* x, unsigned short* out, long n, hipStream_t s);
+// variants launch_gemm accepts: 0 fp32 MFMA, 11 bf16 operands, 13/16 three bf16 planes, 17/18 two fp16 planes
+bool gemm_variant_supported(int variant);
 
 // Decoder-step GEMM: out[B][N] = epi(pro(x)[B][K] . W[N][K]^T), B <= 64 (k_decoder.hip).
 // Wt is W pre-tiled by tile_weights(): [ceil(N/32)][K/8][64 lanes][4].
@@ -131,9 +133,10 @@ void launch_mel_transpose(const float* mel, float* melT, int batch, int n_mels, 
 void launch_power_fold(const float* spec, int ld, int im_off, float* pw, int ldp, int n_fft,
                        long M, hipStream_t s);
 // melacc [B*T][ld] (first n_mel columns) -> logmel [B][n_mel][T] = log10(max(x,1e-10)),
-// and per-clip maximum into clip_max[b] (ordered-uint encoding, pre-zeroed).
+// and per-clip maximum over frames [0, t_valid) (t_valid < 0: all T) into clip_max[b] (ordered-uint
+// encoding, pre-zeroed).
 void launch_log_clipmax(const float* melacc, int ld, float* logmel, unsigned* clip_max, int batch,
-                        int n_mel, int T, hipStream_t s);
+                        int n_mel, int T, hipStream_t s, int t_valid = -1);
 // in place: x = (max(x, clipmax[b] - 8) + 4) / 4
 void launch_mel_normalize(float* logmel, const unsigned* clip_max, int batch, int n_mel, int T,
                           hipStream_t s);
