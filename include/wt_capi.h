@@ -85,8 +85,7 @@ int wt_engine_dims(const wt_engine* h, wt_dims* out);
  * blocks per CU; 10, 13..16 = three bf16 planes, full fp32 operand range; 0..9 = fp32-MFMA tile
  * shapes; 11 = operands rounded to bf16), "attn_variant" (4 = default, two fp16 planes; 1, 2 = three
  * bf16 planes with 128 / 256 queries per block; 0 = fp32 MFMA; 3 = operands rounded to bf16),
- * "resid_waves" (4, 8, 16 wavefronts per block of the decoder's residual
- * GEMMs), "fc2_ksplit" (2 = default: the decoder's fc2 GEMM over twice the blocks, halves added by the
+ * "fc2_ksplit" (2 = default: the decoder's fc2 GEMM over twice the blocks, halves added by the
  * consumer; 1 = one block per column tile), "use_graphs" (1 = default: the decoder's launch sequence is replayed from a hipGraph).
  * Read-only (wt_engine_get_option): "f16_fallbacks" = contractions that were given the full-range bf16
  * three-plane kernels at load time because an operand's weight-derived bound lies more than 2^12 above its

@@ -14,8 +14,8 @@ int wt_dbg_gemm(wt_engine* h, int M, int N, int K, const float* A, const float* 
 /* times `iters` back-to-back launches of the encoder GEMM on random operands (HIP events on the
  * engine's stream); variant selects the tile shape (k_gemm.hip) */
 int wt_dbg_gemm_bench(wt_engine* h, int M, int N, int K, int epi, int variant, int iters, float* avg_ms);
-/* times back-to-back launches of a decoder GEMM: kind 0 residual, 1 LayerNorm-fused, 2 combine +
- * residual; waves = wavefronts per block of the residual forms (4, 8, 16) */
+/* (wt_dbg_dec_gemm_bench, below) times back-to-back launches of a decoder GEMM: kind 0 residual, 1 LayerNorm-fused,
+ * 2 combine + residual; rows = B x positions in the pass (<= 128) */
 /* Interference probe: enqueues `n_enc` encoder passes over d_mel [batch][80][3000] on the encoder
  * stream and, concurrently, a chain of `chain_len` dependent trivial launches (`blocks` x 64
  * threads) on a decoder stream; returns the device time of each. */
@@ -26,8 +26,8 @@ int wt_dbg_interference(wt_engine* h, const float* d_mel, int batch, int n_enc, 
  * earlier batches so that every slot is populated. dec_ms[n_dec], enc_ms[1] = device times. */
 int wt_dbg_concurrency(wt_engine* h, const float* d_mel, int batch, int n_dec, int n_enc, float* dec_ms,
                        float* enc_ms);
-int wt_dbg_dec_gemm_bench(wt_engine* h, int kind, int B, int N, int K, int waves, int iters, float* avg_us);
-/* decoder-step GEMM (k_decoder.hip), plain input X[B][K], W[N][K] (tiled internally):
+int wt_dbg_dec_gemm_bench(wt_engine* h, int kind, int B, int N, int K, int rows, int iters, float* avg_us);
+/* decoder-step GEMM (k_decoder.hip), plain input X[B][K] (B <= 128 rows), W[N][K] (split into fp16 planes and tiled internally):
  * mode 0: Y = X.W^T + bias   1: gelu(...)   2: Y = R + bias + X.W^T (in-place residual form)
  * mode 3: Y = X.W^T and argmax_out[B] = last maximal column (reference tie rule) */
 int wt_dbg_dec_gemm(wt_engine* h, int mode, int B, int N, int K, const float* X, const float* W,
@@ -41,11 +41,13 @@ int wt_dbg_dec_ln_gemm(wt_engine* h, int B, int N, int K, const float* xin, cons
 int wt_dbg_layernorm(wt_engine* h, int M, int d, const float* x, const float* g, const float* b, float* y);
 /* qkv [B*T][3*heads*64] -> out [B*T][heads*64] */
 int wt_dbg_encoder_attention(wt_engine* h, int batch, int T, int heads, const float* qkv, float* out);
-/* q [B][heads*64], kc/vc [B][heads][T][64] -> out [B][heads*64] */
-int wt_dbg_cross_attention(wt_engine* h, int batch, int heads, int T, int chunks, const float* q,
-                           const float* kc, const float* vc, float* out);
-/* qkv [B][3d]; caches [B][cap][d] updated in place at row pos; out [B][d] */
-int wt_dbg_self_attention(wt_engine* h, int batch, int heads, int cap, int pos, const float* qkv,
+/* decoder cross attention with its fused query projection: x [nq*B][d] residual rows (row = p * B + b),
+ * q = LayerNorm(x; ln_g, ln_b) . wq^T + bq (wq [d][d] row-major), kc/vc [B][heads][T][64] -> out [nq*B][d] */
+int wt_dbg_cross_attention(wt_engine* h, int batch, int heads, int T, int chunks, int nq, const float* x,
+                           const float* ln_g, const float* ln_b, const float* wq, const float* bq, const float* kc,
+                           const float* vc, float* out);
+/* qkv [npos*B][3d] (row = p * B + b); caches [B][cap][d] updated in place at rows pos .. pos+npos-1; out [npos*B][d] */
+int wt_dbg_self_attention(wt_engine* h, int batch, int heads, int cap, int pos, int npos, const float* qkv,
                           float* kcache, float* vcache, float* out);
 #ifdef __cplusplus
 }

@@ -55,3 +55,23 @@ def synth_pcm(kind, n, seed):
 def argmax_last(x):
     x = np.asarray(x)
     return int(len(x) - 1 - np.argmax(x[::-1]))
+
+
+class DevBuf:
+    """Caller-owned device buffer for the *_dev entry points (what bench.py gets from torch).  Plain HIP through
+    ctypes: torch's bundled HIP runtime cannot be initialised in a process where the engine's libamdhip64 is
+    already live, so GPU tests never touch torch.cuda."""
+
+    _hip = None
+
+    def __init__(self, a):
+        import ctypes
+        if DevBuf._hip is None:
+            DevBuf._hip = ctypes.CDLL("libamdhip64.so")
+        a = np.ascontiguousarray(a)
+        self.p = ctypes.c_void_p()
+        assert DevBuf._hip.hipMalloc(ctypes.byref(self.p), ctypes.c_size_t(max(a.nbytes, 4))) == 0
+        assert DevBuf._hip.hipMemcpy(self.p, a.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(a.nbytes), 1) == 0
+
+    def data_ptr(self):
+        return self.p.value

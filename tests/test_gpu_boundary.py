@@ -19,7 +19,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import GOLD, ROOT, synth_pcm
+from conftest import GOLD, ROOT, DevBuf, synth_pcm
 
 pytestmark = pytest.mark.gpu
 
@@ -233,7 +233,6 @@ def test_sync_call_with_batches_in_flight_is_refused_before_any_work(pkg, assets
     the oldest uncollected slot, overwriting that batch — and throw only at decode().  Now every synchronous entry
     point checks first: error, nothing enqueued, and the later collects return the ORIGINAL ids (also when the
     refused call carried a larger batch than the submitted ones)."""
-    import torch
     prefix, vocab = assets("micro")
     e = pkg.Engine(prefix, vocab, True)
     e.set_option("stop_at_eot", 0)
@@ -243,10 +242,9 @@ def test_sync_call_with_batches_in_flight_is_refused_before_any_work(pkg, assets
     big = rng.uniform(-1.0, 1.5, size=(9,) + e.mel_shape).astype(np.float32)
     want = [e.encdec_tokens_batch(m) for m in mels]
     e.encdec_tokens_batch(big)  # grows the workspace now, not while batches are in flight
-    dev = [torch.from_numpy(m).cuda() for m in mels]
-    d_big = torch.from_numpy(big).cuda()
-    pcm = torch.zeros(9, e.pcm_len, device="cuda")
-    torch.cuda.synchronize()
+    dev = [DevBuf(m) for m in mels]
+    d_big = DevBuf(big)
+    pcm = DevBuf(np.zeros((9, e.pcm_len), np.float32))
     for d in dev:
         e.pipeline_submit_dev(d.data_ptr(), 3)
     assert e.get_option("in_flight") == 6

@@ -134,7 +134,8 @@ def test_gemm_epilogues(eng, epi):
     assert rel_err(C, ref) < 3e-6
 
 
-@pytest.mark.parametrize("B,N,K", [(32, 384, 384), (32, 128, 512), (7, 1536, 384), (64, 384, 1536), (33, 1000, 128), (32, 51865, 384)])
+@pytest.mark.parametrize("B,N,K", [(32, 384, 384), (32, 128, 512), (7, 1536, 384), (64, 384, 1536), (33, 1000, 128), (32, 51865, 384),
+                                   (128, 1152, 384), (100, 512, 512), (128, 96, 128)])
 def test_decoder_gemm_and_argmax(eng, B, N, K):
     rng = np.random.default_rng(B + N + K)
     X = rng.standard_normal((B, K)).astype(np.float32)
@@ -149,7 +150,7 @@ def test_decoder_gemm_and_argmax(eng, B, N, K):
     assert list(am) == [int(N - 1 - np.argmax(Y[b][::-1])) for b in range(B)]
 
 
-@pytest.mark.parametrize("B,N,K", [(32, 384, 384), (32, 384, 1536), (5, 128, 128), (64, 512, 2048)])
+@pytest.mark.parametrize("B,N,K", [(32, 384, 384), (32, 384, 1536), (5, 128, 128), (64, 512, 2048), (128, 384, 384), (128, 384, 1536)])
 def test_decoder_gemm_residual_in_place(eng, B, N, K):
     rng = np.random.default_rng(B * N + K)
     X = rng.standard_normal((B, K)).astype(np.float32)
@@ -159,6 +160,26 @@ def test_decoder_gemm_residual_in_place(eng, B, N, K):
     Y = eng.dbg_dec_gemm(X, W, bias, mode=2, R=R)
     assert rel_err(Y, R + bias + X.astype(np.float64) @ W.astype(np.float64).T) < 3e-6
     assert np.array_equal(Y, eng.dbg_dec_gemm(X, W, bias, mode=2, R=R))  # fixed reduction order, no atomics
+
+
+def test_decoder_gemm_dynamic_scale_covers_any_magnitude(eng):
+    """The activation planes take a power-of-two scale per (row, k-slice) from the data: rows of magnitude 1e-6 next
+    to rows of 1e+6, a row that is zero in one k-slice, and 12 decades inside a row stay at fp32-level error
+    (relative to sum |x||w|, the fp32 error scale)."""
+    rng = np.random.default_rng(17)
+    B, N, K = 32, 384, 384
+    X = rng.standard_normal((B, K)).astype(np.float32)
+    X[0] *= 1e-6
+    X[1] *= 1e6
+    X[2, :96] = 0.0
+    X[3] = (rng.standard_normal(K) * 10.0 ** rng.uniform(-6, 6, K)).astype(np.float32)
+    X[4] = 0.0
+    W = (rng.standard_normal((N, K)) / 16 * 10.0 ** rng.uniform(-2, 2, (N, 1))).astype(np.float32)
+    Y = eng.dbg_dec_gemm(X, W, np.zeros(N, np.float32), mode=0)
+    ref = X.astype(np.float64) @ W.astype(np.float64).T
+    bound = np.abs(X.astype(np.float64)) @ np.abs(W.astype(np.float64)).T + 1e-300
+    assert (np.abs(Y - ref) / bound).max() < 1.5e-6
+    assert np.all(Y[4] == 0.0)
 
 
 def test_decoder_argmax_tie_rule(eng):
@@ -271,17 +292,32 @@ def test_encoder_attention_forces_rescale(eng, attn_variant):
     assert np.abs(out - ref).max() < 2e-5
 
 
-@pytest.mark.parametrize("B,H,T,chunks", [(2, 2, 100, 4), (3, 6, 1500, 4), (1, 2, 1500, 1), (2, 2, 37, 8)])
-def test_cross_attention(eng, B, H, T, chunks):
-    rng = np.random.default_rng(B + H + T + chunks)
-    q = rng.standard_normal((B, H * 64)).astype(np.float32)
+def _ln64(x, g, b):
+    x = x.astype(np.float64)
+    return (x - x.mean(1, keepdims=True)) / np.sqrt(x.var(1, keepdims=True) + 1e-5) * g + b
+
+
+@pytest.mark.parametrize("B,H,T,chunks,nq", [(2, 2, 100, 4, 1), (3, 6, 1500, 2, 1), (1, 2, 1500, 1, 1), (2, 2, 37, 8, 1),
+                                             (32, 6, 1500, 2, 4), (5, 8, 200, 2, 3), (3, 2, 64, 4, 2)])
+def test_cross_attention_with_fused_query_projection(eng, B, H, T, chunks, nq):
+    """cross_attention_step makes its own queries: q = LayerNorm(x[row]) . Wq^T + bq per (clip, head), nq rows per clip
+    (row = p * B + b: the prompt positions of the first decoder pass share one sweep of the cache)."""
+    rng = np.random.default_rng(B + H + T + chunks + nq)
+    d = H * 64
+    x = (rng.standard_normal((nq * B, d)) * 2 + 0.3).astype(np.float32)
+    g_, b_ = (1 + 0.2 * rng.standard_normal(d)).astype(np.float32), (0.1 * rng.standard_normal(d)).astype(np.float32)
+    wq = (rng.standard_normal((d, d)) / np.sqrt(d)).astype(np.float32)
+    bq = (0.1 * rng.standard_normal(d)).astype(np.float32)
     kc = rng.standard_normal((B, H, T, 64)).astype(np.float32)
     vc = rng.standard_normal((B, H, T, 64)).astype(np.float32)
-    out = eng.dbg_cross_attention(q, kc, vc, chunks)
-    for b in range(B):
-        for h in range(H):
-            ref = attn_ref(q[b, h * 64:(h + 1) * 64].astype(np.float64)[None], kc[b, h].astype(np.float64), vc[b, h].astype(np.float64))[0]
-            assert np.abs(out[b, h * 64:(h + 1) * 64] - ref).max() < 1e-5
+    out = eng.dbg_cross_attention(x, g_, b_, wq, bq, kc, vc, chunks, nq)
+    q = _ln64(x, g_, b_) @ wq.astype(np.float64).T + bq
+    for p in range(nq):
+        for b in range(B if B <= 5 else 3):
+            for h in range(H):
+                sl = slice(h * 64, (h + 1) * 64)
+                ref = attn_ref(q[p * B + b, sl][None], kc[b, h].astype(np.float64), vc[b, h].astype(np.float64))[0]
+                assert np.abs(out[p * B + b, sl] - ref).max() < 2e-5, (p, b, h)
 
 
 def test_self_attention_appends_and_attends(eng):
@@ -302,3 +338,29 @@ def test_self_attention_appends_and_attends(eng):
                 ref = attn_ref(qkv[b, sl].astype(np.float64)[None], kc[b, :pos + 1, sl].astype(np.float64),
                                vc[b, :pos + 1, sl].astype(np.float64))[0]
                 assert np.abs(out[b, sl] - ref).max() < 1e-5
+
+
+@pytest.mark.parametrize("pos0,npos", [(0, 4), (0, 2), (3, 3), (28, 4)])
+def test_self_attention_several_positions_in_one_pass(eng, pos0, npos):
+    """The prompt pass: npos new positions per clip (rows p * B + b), causal among themselves and over the cache."""
+    rng = np.random.default_rng(pos0 * 10 + npos)
+    B, H, cap = 5, 2, 32
+    d = 64 * H
+    kc = np.zeros((B, cap, d), np.float32)
+    vc = np.zeros((B, cap, d), np.float32)
+    kc[:, :pos0] = rng.standard_normal((B, pos0, d))
+    vc[:, :pos0] = rng.standard_normal((B, pos0, d))
+    qkv = rng.standard_normal((npos * B, 3 * d)).astype(np.float32)
+    out, kc2, vc2 = eng.dbg_self_attention(qkv, kc, vc, pos0, npos)
+    for p in range(npos):
+        kc[:, pos0 + p] = qkv[p * B:(p + 1) * B, d:2 * d]
+        vc[:, pos0 + p] = qkv[p * B:(p + 1) * B, 2 * d:]
+    assert np.array_equal(kc2, kc) and np.array_equal(vc2, vc)
+    for p in range(npos):
+        for b in range(B):
+            for h in range(H):
+                sl = slice(h * 64, (h + 1) * 64)
+                n = pos0 + p + 1
+                ref = attn_ref(qkv[p * B + b, sl].astype(np.float64)[None], kc[b, :n, sl].astype(np.float64),
+                               vc[b, :n, sl].astype(np.float64))[0]
+                assert np.abs(out[p * B + b, sl] - ref).max() < 1e-5, (p, b, h)

@@ -142,8 +142,8 @@ def lib() -> ctypes.CDLL:
                                          c_int, c_int, fp, fp, fp, fp, c_int, fp, fp]
         L.wt_dbg_layernorm.argtypes = [c_void_p, c_int, c_int, fp, fp, fp, fp]
         L.wt_dbg_encoder_attention.argtypes = [c_void_p, c_int, c_int, c_int, fp, fp]
-        L.wt_dbg_cross_attention.argtypes = [c_void_p, c_int, c_int, c_int, c_int, fp, fp, fp, fp]
-        L.wt_dbg_self_attention.argtypes = [c_void_p, c_int, c_int, c_int, c_int, fp, fp, fp, fp]
+        L.wt_dbg_cross_attention.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, fp, fp, fp, fp, fp, fp, fp, fp]
+        L.wt_dbg_self_attention.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, fp, fp, fp, fp]
         _lib = L
     return _lib
 
@@ -458,9 +458,9 @@ class Engine:
         self._check(lib().wt_dbg_gemm_bench(self._h, M, N, K, epi, variant, iters, byref(ms)))
         return ms.value
 
-    def dbg_dec_gemm_bench(self, kind, B, N, K, waves=16, iters=200) -> float:
+    def dbg_dec_gemm_bench(self, kind, B, N, K, rows=None, iters=200) -> float:
         us = c_float(0)
-        self._check(lib().wt_dbg_dec_gemm_bench(self._h, kind, B, N, K, waves, iters, byref(us)))
+        self._check(lib().wt_dbg_dec_gemm_bench(self._h, kind, B, N, K, rows or B, iters, byref(us)))
         return us.value
 
     def dbg_dec_gemm(self, X, W, bias=None, mode=0, R=None):
@@ -506,18 +506,21 @@ class Engine:
         self._check(lib().wt_dbg_encoder_attention(self._h, batch, T, heads, _fp(qkv), _fp(out)))
         return out
 
-    def dbg_cross_attention(self, q, kc, vc, chunks=4):
-        q, kc, vc = _f32(q), _f32(kc), _f32(vc)
+    def dbg_cross_attention(self, x, ln_g, ln_b, wq, bq, kc, vc, chunks=2, nq=1):
+        """x [nq*B][d] residual rows (row = p * B + b) -> attention output [nq*B][d]; the query projection
+        q = LayerNorm(x) . wq^T + bq runs inside the kernel."""
+        x, ln_g, ln_b, wq, bq, kc, vc = (_f32(a) for a in (x, ln_g, ln_b, wq, bq, kc, vc))
         B, H, T, _ = kc.shape
-        out = np.zeros((B, H * 64), np.float32)
-        self._check(lib().wt_dbg_cross_attention(self._h, B, H, T, chunks, _fp(q), _fp(kc), _fp(vc), _fp(out)))
+        out = np.zeros((nq * B, H * 64), np.float32)
+        self._check(lib().wt_dbg_cross_attention(self._h, B, H, T, chunks, nq, _fp(x), _fp(ln_g), _fp(ln_b), _fp(wq),
+                                                 _fp(bq), _fp(kc), _fp(vc), _fp(out)))
         return out
 
-    def dbg_self_attention(self, qkv, kcache, vcache, pos):
+    def dbg_self_attention(self, qkv, kcache, vcache, pos, npos=1):
         qkv, kcache, vcache = _f32(qkv), _f32(kcache).copy(), _f32(vcache).copy()
         B, cap, d = kcache.shape
-        out = np.zeros((B, d), np.float32)
-        self._check(lib().wt_dbg_self_attention(self._h, B, d // 64, cap, pos, _fp(qkv), _fp(kcache),
+        out = np.zeros((npos * B, d), np.float32)
+        self._check(lib().wt_dbg_self_attention(self._h, B, d // 64, cap, pos, npos, _fp(qkv), _fp(kcache),
                                                 _fp(vcache), _fp(out)))
         return out, kcache, vcache
 

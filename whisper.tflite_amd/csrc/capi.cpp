@@ -129,9 +129,6 @@ int wt_engine_set_option(wt_engine* h, const char* key, long value) {
   } else if (k == "attn_variant") {
     if (value < 0 || value > 4) return fail(h, WT_ERR_INVALID_ARG, "attn_variant must be 0 (fp32 MFMA), 1 or 2 (bf16 x3 split, 128 / 256 queries per block), 3 (bf16 operands) or 4 (fp16 x2 split)");
     e.attn_variant = value;
-  } else if (k == "resid_waves") {
-    if (value != 4 && value != 8 && value != 16) return fail(h, WT_ERR_INVALID_ARG, "resid_waves must be 4, 8 or 16");
-    e.resid_waves = value;
   } else if (k == "fc2_ksplit") {
     if (value != 1 && value != 2) return fail(h, WT_ERR_INVALID_ARG, "fc2_ksplit must be 1 or 2");
     e.fc2_ksplit = value;
@@ -166,7 +163,6 @@ int wt_engine_get_option(const wt_engine* h, const char* key, long* value) {
   else if (k == "gemm_variant") *value = e.gemm_variant;
   else if (k == "use_graphs") *value = e.use_graphs;
   else if (k == "fc2_ksplit") *value = e.fc2_ksplit;
-  else if (k == "resid_waves") *value = e.resid_waves;
   else if (k == "attn_variant") *value = e.attn_variant;
   else if (k == "f16_fallbacks") *value = e.f16_fallbacks();  // read-only
   else if (k == "in_flight") *value = e.in_flight();          // read-only
@@ -607,6 +603,21 @@ struct DevBuf {
 };
 }  // namespace
 
+namespace {
+// W [N][K] as device-resident fp16 planes in the decoder GEMM's fragment order
+struct DevTiled {
+  void* p = nullptr;
+  float scale = 1.0f;
+  DevTiled(const float* W, int N, int K) {
+    const std::vector<unsigned short> planes = wt::tile_weights_f16(W, N, K, &scale);
+    hipchk(hipMalloc(&p, std::max<size_t>(planes.size(), 1) * 2), "hipMalloc");
+    hipchk(hipMemcpy(p, planes.data(), planes.size() * 2, hipMemcpyHostToDevice), "H2D");
+  }
+  ~DevTiled() { (void)hipFree(p); }
+  const unsigned short* w() const { return static_cast<const unsigned short*>(p); }
+};
+}  // namespace
+
 int wt_dbg_gemm(wt_engine* h, int M, int N, int K, const float* A, const float* W, const float* bias,
                 const float* R, const float* pos, int pos_period, int epi, float* C) {
   if (!h || N % 128 || K % 32) return WT_ERR_INVALID_ARG;
@@ -697,24 +708,24 @@ int wt_dbg_concurrency(wt_engine* h, const float* d_mel, int batch, int n_dec, i
   return guarded(h, [&] { h->impl->debug_concurrency(d_mel, batch, n_dec, n_enc, dec_ms, enc_ms); });
 }
 
-int wt_dbg_dec_gemm_bench(wt_engine* h, int kind, int B, int N, int K, int waves, int iters, float* avg_us) {
-  if (!h || !avg_us || B < 1 || B > 64 || iters < 1) return WT_ERR_INVALID_ARG;
+int wt_dbg_dec_gemm_bench(wt_engine* h, int kind, int B, int N, int K, int rows, int iters, float* avg_us) {
+  if (!h || !avg_us || B < 1 || B > 64 || iters < 1 || rows < B || rows % B != 0) return WT_ERR_INVALID_ARG;
   return guarded(h, [&] {
     // kind 0: residual GEMM, 1: LayerNorm-fused GEMM (+bias), 2: combine + residual GEMM
-    std::vector<float> hostW(size_t(N) * K), hostX(size_t(B) * std::max(K, N));
+    std::vector<float> hostW(size_t(N) * K), hostX(size_t(rows) * std::max(K, N));
     uint64_t x = 88172645463325252ull;
     auto rnd = [&x] { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return float(int64_t(x % 2000001) - 1000000) * 1e-6f; };
     for (auto& v : hostW) v = rnd() * 0.05f;
     for (auto& v : hostX) v = rnd();
-    const std::vector<float> tiled = wt::tile_weights(hostW.data(), N, K);
-    const int heads = K / 64, chunks = 4;
-    DevBuf dW(tiled.data(), tiled.size()), dX(hostX.data(), size_t(B) * K), dB(hostX.data(), N), dG(hostX.data(), K);
-    DevBuf dY(hostX.data(), size_t(B) * N), dWs(size_t(B) * heads * chunks * 68);
-    std::vector<float> ws(size_t(B) * heads * chunks * 68);
+    const DevTiled dW(hostW.data(), N, K);
+    const int heads = K / 64, chunks = 2;
+    DevBuf dX(hostX.data(), size_t(rows) * K), dB(hostX.data(), N), dG(hostX.data(), K);
+    DevBuf dY(hostX.data(), size_t(rows) * N), dWs(size_t(rows) * heads * chunks * 68);
+    std::vector<float> ws(size_t(rows) * heads * chunks * 68);
     for (auto& v : ws) v = rnd();
     hipchk(hipMemcpy(dWs.p, ws.data(), ws.size() * 4, hipMemcpyHostToDevice), "H2D");
     wt::DecGemmArgs g;
-    g.Wt = dW.p; g.N = N; g.K = K; g.B = B; g.bias = dB.p; g.Y = dY.p; g.ldy = N; g.resid_waves = waves;
+    g.Wt = dW.w(); g.w_scale = dW.scale; g.N = N; g.K = K; g.B = B; g.M = rows; g.bias = dB.p; g.Y = dY.p; g.ldy = N;
     int pro = wt::kProNone, epi = wt::kDecResid;
     if (kind == 0) { g.X = dX.p; g.ldx = K; g.R = dY.p; }
     if (kind == 1) { pro = wt::kProLn; epi = wt::kDecBias; g.xin = dX.p; g.ln_g = dG.p; g.ln_b = dG.p; }
@@ -738,18 +749,21 @@ int wt_dbg_dec_gemm_bench(wt_engine* h, int kind, int B, int N, int K, int waves
 
 int wt_dbg_dec_gemm(wt_engine* h, int mode, int B, int N, int K, const float* X, const float* W,
                     const float* bias, const float* R, float* Y, int64_t* argmax_out) {
-  if (!h || mode < 0 || mode > 3 || B < 1 || B > 64 || K % 32 != 0 || (mode == 2 && !R)) {
+  if (!h || mode < 0 || mode > 3 || B < 1 || B > 128 || (mode == 2 && !R)) {
     return WT_ERR_INVALID_ARG;
   }
+  // B rows in all; more than 64 rows are presented as positions x clips (the kernels' row = p * B + b)
+  const int rows_per = B > 64 ? (B % 4 == 0 ? B / 4 : (B % 2 == 0 ? B / 2 : 0)) : B;
+  if (rows_per == 0) return WT_ERR_INVALID_ARG;
   return guarded(h, [&] {
-    const std::vector<float> tiled = wt::tile_weights(W, N, K);
+    const DevTiled dW(W, N, K);
     const int n_tiles = (N + 31) / 32;
-    DevBuf dX(X, size_t(B) * K), dW(tiled.data(), tiled.size()), dB(bias, N);
+    DevBuf dX(X, size_t(B) * K), dB(bias, N);
     DevBuf dY(mode == 2 ? R : nullptr, size_t(B) * N);
     DevBuf dBest(size_t(B) * 2 * n_tiles);
     hipchk(hipMemset(dBest.p, 0, size_t(B) * 8 * n_tiles), "memset");
     wt::DecGemmArgs g;
-    g.Wt = dW.p; g.N = N; g.K = K; g.B = B; g.X = dX.p; g.ldx = K;
+    g.Wt = dW.w(); g.w_scale = dW.scale; g.N = N; g.K = K; g.B = rows_per > 0 ? rows_per : B; g.M = B; g.X = dX.p; g.ldx = K;
     g.bias = dB.p; g.R = dY.p; g.Y = dY.p; g.ldy = N;  // residual in place, as the engine does
     g.best = reinterpret_cast<unsigned long long*>(dBest.p);
     const int epi = mode == 0 ? wt::kDecBias : mode == 1 ? wt::kDecBiasGelu : mode == 2 ? wt::kDecResid : wt::kDecLogits;
@@ -773,21 +787,25 @@ int wt_dbg_dec_ln_gemm(wt_engine* h, int B, int N, int K, const float* xin, cons
                        const float* tok_emb, const float* pos_emb, int n_vocab, int n_pos,
                        const float* ln_g, const float* ln_b, const float* W, const float* bias,
                        int gelu, float* Y, float* xout) {
-  if (!h || B < 1 || B > 64 || (K != 128 && K != 384 && K != 512) || (!xin && !ids)) return WT_ERR_INVALID_ARG;
+  if (!h || B < 1 || B > 64 || (K != 128 && K != 384 && K != 512) || (!xin && !ids) || pos < 0 || (ids && pos >= n_pos)) return WT_ERR_INVALID_ARG;
   return guarded(h, [&] {
-    const std::vector<float> tiled = wt::tile_weights(W, N, K);
+    const DevTiled dW(W, N, K);
     DevBuf dxin(xin, xin ? size_t(B) * K : 0);
     DevBuf dtok(tok_emb, ids ? size_t(n_vocab) * K : 0), dpos(pos_emb, ids ? size_t(n_pos) * K : 0);
-    DevBuf dg(ln_g, K), db(ln_b, K), dW(tiled.data(), tiled.size()), dB(bias, N), dY(size_t(B) * N), dxo(size_t(B) * K);
-    DevBuf dids(size_t(B) * 2);
-    if (ids) hipchk(hipMemcpy(dids.p, ids, size_t(B) * 8, hipMemcpyHostToDevice), "H2D ids");
+    DevBuf dg(ln_g, K), db(ln_b, K), dB(bias, N), dY(size_t(B) * N), dxo(size_t(B) * K);
+    // the kernel reads ids[b][pos]: one row of pos + 1 ids per clip, the given id in its last column
+    std::vector<long long> idrows(size_t(B) * (pos + 1), 0);
+    if (ids)
+      for (int b = 0; b < B; ++b) idrows[size_t(b) * (pos + 1) + pos] = ids[b];
+    DevBuf dids(idrows.size() * 2);
+    hipchk(hipMemcpy(dids.p, idrows.data(), idrows.size() * 8, hipMemcpyHostToDevice), "H2D ids");
     hipchk(hipMemset(dxo.p, 0, size_t(B) * K * 4), "memset");
     wt::DecGemmArgs g;
-    g.Wt = dW.p; g.N = N; g.K = K; g.B = B;
+    g.Wt = dW.w(); g.w_scale = dW.scale; g.N = N; g.K = K; g.B = B;
     g.xin = dxin.p; g.xout = dxo.p; g.ln_g = dg.p; g.ln_b = db.p;
     if (ids) {
-      g.ids = reinterpret_cast<const long long*>(dids.p); g.ids_stride = 1; g.pos = 0;
-      g.tok_emb = dtok.p; g.pos_emb = dpos.p + size_t(pos) * K; g.n_vocab = n_vocab;
+      g.ids = reinterpret_cast<const long long*>(dids.p); g.ids_stride = pos + 1; g.pos = pos;
+      g.tok_emb = dtok.p; g.pos_emb = dpos.p; g.n_vocab = n_vocab;
     }
     g.bias = dB.p; g.Y = dY.p; g.ldy = N;
     wt::launch_dec_gemm(g, wt::kProLn, gelu ? wt::kDecBiasGelu : wt::kDecBias, h->impl->stream());
@@ -829,42 +847,49 @@ int wt_dbg_encoder_attention(wt_engine* h, int batch, int T, int heads, const fl
   });
 }
 
-int wt_dbg_cross_attention(wt_engine* h, int batch, int heads, int T, int chunks, const float* q,
-                           const float* kc, const float* vc, float* out) {
-  if (!h || (chunks != 1 && chunks != 2 && chunks != 4 && chunks != 8) || batch > 64 || heads % 2 != 0) return WT_ERR_INVALID_ARG;
+int wt_dbg_cross_attention(wt_engine* h, int batch, int heads, int T, int chunks, int nq, const float* x,
+                           const float* ln_g, const float* ln_b, const float* wq, const float* bq, const float* kc,
+                           const float* vc, float* out) {
+  if (!h || (chunks != 1 && chunks != 2 && chunks != 4 && chunks != 8) || batch < 1 || nq < 1 || nq * batch > 128 ||
+      !x || !ln_g || !ln_b || !wq || !bq || !kc || !vc || !out)
+    return WT_ERR_INVALID_ARG;
   return guarded(h, [&] {
-    const size_t d = size_t(heads) * 64;
-    DevBuf dq(q, size_t(batch) * d), dk(kc, size_t(batch) * T * d), dv(vc, size_t(batch) * T * d);
-    DevBuf dws(size_t(batch) * heads * chunks * 68), dout(size_t(batch) * d), dzero(d);
-    hipchk(hipMemset(dout.p, 0, size_t(batch) * d * 4), "memset");
+    const size_t d = size_t(heads) * 64, rows = size_t(nq) * batch;
+    DevBuf dx(x, rows * d), dg(ln_g, d), db(ln_b, d), dbq(bq, d), dk(kc, size_t(batch) * T * d), dv(vc, size_t(batch) * T * d);
+    const std::vector<float> wqt = wt::cross_q_layout(wq, int(d));
+    DevBuf dwq(wqt.data(), wqt.size());
+    DevBuf dws(rows * heads * chunks * 68), dout(rows * d), dzero(d);
+    hipchk(hipMemset(dout.p, 0, rows * d * 4), "memset");
     hipchk(hipMemset(dzero.p, 0, d * 4), "memset");
     // the product combines the chunk partials in the out-projection's prologue; an identity
     // projection onto a zero residual exposes exactly that combined row
     std::vector<float> eye(d * d, 0.0f);
     for (size_t i = 0; i < d; ++i) eye[i * d + i] = 1.0f;
-    const std::vector<float> tiled = wt::tile_weights(eye.data(), int(d), int(d));
-    DevBuf dW(tiled.data(), tiled.size());
-    wt::launch_cross_attention(dq.p, dk.p, dv.p, dws.p, batch, heads, T, chunks, h->impl->stream());
+    const DevTiled dW(eye.data(), int(d), int(d));
+    wt::CrossAttnArgs ca;
+    ca.x = dx.p; ca.ln_g = dg.p; ca.ln_b = db.p; ca.wq_t = dwq.p; ca.bq = dbq.p; ca.kc = dk.p; ca.vc = dv.p;
+    ca.ws = dws.p; ca.batch = batch; ca.heads = heads; ca.T = T; ca.chunks = chunks; ca.nq = nq;
+    wt::launch_cross_attention(ca, h->impl->stream());
     wt::DecGemmArgs g;
-    g.Wt = dW.p; g.N = int(d); g.K = int(d); g.B = batch;
+    g.Wt = dW.w(); g.w_scale = dW.scale; g.N = int(d); g.K = int(d); g.B = batch; g.M = int(rows);
     g.cross_ws = dws.p; g.heads = heads; g.chunks = chunks;
     g.bias = dzero.p; g.R = dout.p; g.Y = dout.p; g.ldy = int(d);
     wt::launch_dec_gemm(g, wt::kProCombine, wt::kDecResid, h->impl->stream());
     h->impl->sync();
-    dout.to_host(out, size_t(batch) * d);
+    dout.to_host(out, rows * d);
   });
 }
 
-int wt_dbg_self_attention(wt_engine* h, int batch, int heads, int cap, int pos, const float* qkv,
+int wt_dbg_self_attention(wt_engine* h, int batch, int heads, int cap, int pos, int npos, const float* qkv,
                           float* kcache, float* vcache, float* out) {
-  if (!h || pos >= cap || cap > 64) return WT_ERR_INVALID_ARG;
+  if (!h || npos < 1 || pos < 0 || pos + npos > cap || cap > 64) return WT_ERR_INVALID_ARG;
   return guarded(h, [&] {
-    const size_t d = size_t(heads) * 64;
-    DevBuf dq(qkv, size_t(batch) * 3 * d), dk(kcache, size_t(batch) * cap * d), dv(vcache, size_t(batch) * cap * d),
-        dout(size_t(batch) * d);
-    wt::launch_self_attention(dq.p, dk.p, dv.p, cap, pos, dout.p, batch, heads, h->impl->stream());
+    const size_t d = size_t(heads) * 64, rows = size_t(npos) * batch;
+    DevBuf dq(qkv, rows * 3 * d), dk(kcache, size_t(batch) * cap * d), dv(vcache, size_t(batch) * cap * d),
+        dout(rows * d);
+    wt::launch_self_attention(dq.p, dk.p, dv.p, cap, pos, npos, dout.p, batch, heads, h->impl->stream());
     h->impl->sync();
-    dout.to_host(out, size_t(batch) * d);
+    dout.to_host(out, rows * d);
     dk.to_host(kcache, size_t(batch) * cap * d);
     dv.to_host(vcache, size_t(batch) * cap * d);
   });

@@ -29,22 +29,58 @@ size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
 
 // ------------------------------------------------------------ weights ---
 
-// W [N][K] -> MFMA-fragment order [ceil(N/32)][K/8][64 lanes][4] (rows past N are zero): lane
-// (l & 31, l >> 5) of tile t, chunk c holds W[32t + (l & 31)][8c + 4(l >> 5) .. +3], so one
-// wave-instruction of the decoder GEMM reads 1 KiB contiguous.
-std::vector<float> tile_weights(const float* W, int N, int K) {
-  const int n_tiles = (N + 31) / 32, chunks = K / 8;
-  std::vector<float> out(size_t(n_tiles) * chunks * 256, 0.0f);
+// W [N][K] -> two fp16 planes in MFMA-fragment order [ceil(N/32)][K/16][plane][64 lanes][8] (rows past N zero):
+// lane (l & 31, l >> 5) of tile t, k-step s holds W[32t + (l & 31)][16s + 8(l >> 5) .. +7], so one wave-instruction
+// of the decoder GEMM reads 1 KiB contiguous.  The planes are hi = fp16(w * scale), lo = fp16(w * scale - hi) with
+// scale the power of two that puts max |W| into (8192, 16384]: 22 significand bits, same bytes as fp32.
+std::vector<unsigned short> tile_weights_f16(const float* W, int N, int K, float* scale) {
+  float mx = 0.0f;
+  for (size_t i = 0; i < size_t(N) * K; ++i) mx = std::max(mx, std::fabs(W[i]));
+  const float sc = f16_scale_for(mx);
+  *scale = sc;
+  const int n_tiles = (N + 31) / 32, steps = K / 16;
+  std::vector<unsigned short> out(size_t(n_tiles) * steps * 1024, 0);
   for (int t = 0; t < n_tiles; ++t)
-    for (int c = 0; c < chunks; ++c)
+    for (int s = 0; s < steps; ++s)
       for (int lane = 0; lane < 64; ++lane) {
         const int n = t * 32 + (lane & 31);
         if (n >= N) continue;
-        const float* src = W + size_t(n) * K + 8 * c + 4 * (lane >> 5);
-        float* dst = out.data() + ((size_t(t) * chunks + c) * 64 + lane) * 4;
-        dst[0] = src[0], dst[1] = src[1], dst[2] = src[2], dst[3] = src[3];
+        const float* src = W + size_t(n) * K + 16 * s + 8 * (lane >> 5);
+        unsigned short* hi = out.data() + (size_t(t) * steps + s) * 1024 + lane * 8;
+        unsigned short* lo = hi + 512;
+        for (int e = 0; e < 8; ++e) {
+          const float v = src[e] * sc;
+          const _Float16 h = static_cast<_Float16>(v);
+          const _Float16 l = static_cast<_Float16>(v - static_cast<float>(h));
+          std::memcpy(hi + e, &h, 2);
+          std::memcpy(lo + e, &l, 2);
+        }
       }
   return out;
+}
+
+// Wq [d][d] (row = output) -> [head][d / 4][64 outputs of the head][4 k]: thread (output j, k-quarter) of
+// cross_attention_step reads 16 contiguous bytes per step and a wavefront 1 KiB
+std::vector<float> cross_q_layout(const float* Wq, int d) {
+  const int heads = d / 64, c4 = d / 4;
+  std::vector<float> out(size_t(d) * d);
+  for (int h = 0; h < heads; ++h)
+    for (int c = 0; c < c4; ++c)
+      for (int j = 0; j < 64; ++j)
+        for (int e = 0; e < 4; ++e)
+          out[((size_t(h) * c4 + c) * 64 + j) * 4 + e] = Wq[size_t(h * 64 + j) * d + 4 * c + e];
+  return out;
+}
+
+TiledW Engine::upload_tiled(const float* W, int N, int K) {
+  TiledW t;
+  const std::vector<unsigned short> planes = tile_weights_f16(W, N, K, &t.scale);
+  void* p = nullptr;
+  HIPCHK(hipMalloc(&p, std::max<size_t>(planes.size(), 1) * sizeof(unsigned short)));
+  allocations_.push_back(p);
+  HIPCHK(hipMemcpy(p, planes.data(), planes.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+  t.w = static_cast<const unsigned short*>(p);
+  return t;
 }
 
 float* Engine::upload(const std::vector<float>& host) {
@@ -160,29 +196,15 @@ void Engine::upload_weights(const std::string& path) {
   }
   enc_pos = up("encoder.positional_embedding", size_t(c.n_audio_ctx) * d);
 
-  auto up_tiled = [&](const std::string& n, int N, int K) -> const float* {
-    return upload(tile_weights(H(n, size_t(N) * K), N, K));
-  };
-  auto fused_qkv = [&](const std::string& p, AttnWeights* a, bool tiled) {
+  auto fused_qkv = [&](const std::string& p, std::vector<float>* w, std::vector<float>* b) {
     const size_t dd = size_t(d) * d;
-    std::vector<float> w(3 * dd), b(3 * size_t(d), 0.0f);
-    std::memcpy(w.data(), H(p + ".query.weight", dd), dd * 4);
-    std::memcpy(w.data() + dd, H(p + ".key.weight", dd), dd * 4);
-    std::memcpy(w.data() + 2 * dd, H(p + ".value.weight", dd), dd * 4);
-    std::memcpy(b.data(), H(p + ".query.bias", d), size_t(d) * 4);
-    std::memcpy(b.data() + 2 * size_t(d), H(p + ".value.bias", d), size_t(d) * 4);  // key has no bias
-    a->wqkv = tiled ? upload(tile_weights(w.data(), 3 * d, d)) : upload(w);
-    a->bqkv = upload(b);
-    a->wo = tiled ? up_tiled(p + ".out.weight", d, d) : up(p + ".out.weight", dd);
-    a->bo = up(p + ".out.bias", d);
-  };
-  auto mlp_ln = [&](const std::string& blk, BlockWeights* bw, bool tiled) {
-    bw->mlp_ln_g = up(blk + ".mlp_ln.weight", d);
-    bw->mlp_ln_b = up(blk + ".mlp_ln.bias", d);
-    bw->w1 = tiled ? up_tiled(blk + ".mlp.0.weight", 4 * d, d) : up(blk + ".mlp.0.weight", size_t(4) * d * d);
-    bw->b1 = up(blk + ".mlp.0.bias", size_t(4) * d);
-    bw->w2 = tiled ? up_tiled(blk + ".mlp.2.weight", d, 4 * d) : up(blk + ".mlp.2.weight", size_t(4) * d * d);
-    bw->b2 = up(blk + ".mlp.2.bias", d);
+    w->assign(3 * dd, 0.0f);
+    b->assign(3 * size_t(d), 0.0f);
+    std::memcpy(w->data(), H(p + ".query.weight", dd), dd * 4);
+    std::memcpy(w->data() + dd, H(p + ".key.weight", dd), dd * 4);
+    std::memcpy(w->data() + 2 * dd, H(p + ".value.weight", dd), dd * 4);
+    std::memcpy(b->data(), H(p + ".query.bias", d), size_t(d) * 4);
+    std::memcpy(b->data() + 2 * size_t(d), H(p + ".value.bias", d), size_t(d) * 4);  // key has no bias
   };
   enc_blocks_.resize(c.n_audio_layer);
   for (int l = 0; l < c.n_audio_layer; ++l) {
@@ -190,35 +212,55 @@ void Engine::upload_weights(const std::string& path) {
     BlockWeights& bw = enc_blocks_[l];
     bw.attn_ln_g = up(blk + ".attn_ln.weight", d);
     bw.attn_ln_b = up(blk + ".attn_ln.bias", d);
-    fused_qkv(blk + ".attn", &bw.attn, false);
-    mlp_ln(blk, &bw, false);
+    std::vector<float> wqkv, bqkv;
+    fused_qkv(blk + ".attn", &wqkv, &bqkv);
+    bw.attn.wqkv = upload(wqkv);
+    bw.attn.bqkv = upload(bqkv);
+    bw.attn.wo = up(blk + ".attn.out.weight", size_t(d) * d);
+    bw.attn.bo = up(blk + ".attn.out.bias", d);
+    bw.mlp_ln_g = up(blk + ".mlp_ln.weight", d);
+    bw.mlp_ln_b = up(blk + ".mlp_ln.bias", d);
+    bw.w1 = up(blk + ".mlp.0.weight", size_t(4) * d * d);
+    bw.b1 = up(blk + ".mlp.0.bias", size_t(4) * d);
+    bw.w2 = up(blk + ".mlp.2.weight", size_t(4) * d * d);
+    bw.b2 = up(blk + ".mlp.2.bias", d);
   }
   enc_ln_post_g = up("encoder.ln_post.weight", d);
   enc_ln_post_b = up("encoder.ln_post.bias", d);
 
   tok_emb = up("decoder.token_embedding.weight", size_t(c.n_vocab) * d);  // row lookup
-  tok_emb_tiled = up_tiled("decoder.token_embedding.weight", c.n_vocab, d);  // logits GEMM
+  tok_emb_tiled = upload_tiled(H("decoder.token_embedding.weight", size_t(c.n_vocab) * d), c.n_vocab, d);  // logits GEMM
   dec_pos = up("decoder.positional_embedding", size_t(c.n_text_ctx) * d);
   dec_blocks_.resize(c.n_text_layer);
   const size_t dd = size_t(d) * d;
   std::vector<float> ckv_w(size_t(c.n_text_layer) * 2 * dd), ckv_b(size_t(c.n_text_layer) * 2 * d, 0.0f);
   for (int l = 0; l < c.n_text_layer; ++l) {
     const std::string blk = "decoder.blocks." + std::to_string(l);
-    BlockWeights& bw = dec_blocks_[l];
+    DecBlockWeights& bw = dec_blocks_[l];
     bw.attn_ln_g = up(blk + ".attn_ln.weight", d);
     bw.attn_ln_b = up(blk + ".attn_ln.bias", d);
-    fused_qkv(blk + ".attn", &bw.attn, true);  // decoder Linears: MFMA-fragment order
+    std::vector<float> wqkv, bqkv;
+    fused_qkv(blk + ".attn", &wqkv, &bqkv);
+    bw.wqkv = upload_tiled(wqkv.data(), 3 * d, d);  // decoder Linears: fp16 planes in MFMA-fragment order
+    bw.bqkv = upload(bqkv);
+    bw.wo = upload_tiled(H(blk + ".attn.out.weight", dd), d, d);
+    bw.bo = up(blk + ".attn.out.bias", d);
     bw.cross_ln_g = up(blk + ".cross_attn_ln.weight", d);
     bw.cross_ln_b = up(blk + ".cross_attn_ln.bias", d);
-    bw.cross.wq = up_tiled(blk + ".cross_attn.query.weight", d, d);
-    bw.cross.bq = up(blk + ".cross_attn.query.bias", d);
-    bw.cross.wo = up_tiled(blk + ".cross_attn.out.weight", d, d);
-    bw.cross.bo = up(blk + ".cross_attn.out.bias", d);
+    bw.cross_wq_t = upload(cross_q_layout(H(blk + ".cross_attn.query.weight", dd), d));
+    bw.cross_bq = up(blk + ".cross_attn.query.bias", d);
+    bw.cross_wo = upload_tiled(H(blk + ".cross_attn.out.weight", dd), d, d);
+    bw.cross_bo = up(blk + ".cross_attn.out.bias", d);
     // all layers' cross K/V projections act on the same encoder output: one GEMM
     std::memcpy(ckv_w.data() + (size_t(l) * 2 + 0) * dd, H(blk + ".cross_attn.key.weight", dd), dd * 4);
     std::memcpy(ckv_w.data() + (size_t(l) * 2 + 1) * dd, H(blk + ".cross_attn.value.weight", dd), dd * 4);
     std::memcpy(ckv_b.data() + (size_t(l) * 2 + 1) * d, H(blk + ".cross_attn.value.bias", d), size_t(d) * 4);
-    mlp_ln(blk, &bw, true);
+    bw.mlp_ln_g = up(blk + ".mlp_ln.weight", d);
+    bw.mlp_ln_b = up(blk + ".mlp_ln.bias", d);
+    bw.w1 = upload_tiled(H(blk + ".mlp.0.weight", 4 * dd), 4 * d, d);
+    bw.b1 = up(blk + ".mlp.0.bias", size_t(4) * d);
+    bw.w2 = upload_tiled(H(blk + ".mlp.2.weight", 4 * dd), d, 4 * d);
+    bw.b2 = up(blk + ".mlp.2.bias", d);
   }
   cross_kv_w = upload(ckv_w);
   cross_kv_b = upload(ckv_b);
@@ -613,16 +655,17 @@ void Engine::ensure_batch(int batch) {
     sl.cross_kv = alloc(size_t(c.n_text_layer) * 2 * B * T * d, false);
     sl.used = false;
   }
+  // decoder rows: one position of the batch, or all prompt positions of a <= 32-clip batch in one pass
+  const size_t R = std::max<size_t>(B, kDecRowsMax);
   for (DecWorkspace& dw : dws_) {
-    dw.xd = alloc(B * d, false);
-    dw.xb = alloc(B * d, false);
-    dw.xpart = alloc(B * d, false);
+    dw.xd = alloc(R * d, false);
+    dw.xb = alloc(R * d, false);
+    dw.xpart = alloc(R * d, false);
     dw.lnd = alloc(B * d, false);
-    dw.qkvd = alloc(B * 3 * d, false);
-    dw.attd = alloc(B * d, false);
-    dw.qd = alloc(B * d, false);
-    dw.hd = alloc(B * 4 * d, false);
-    dw.cross_ws = alloc(B * c.n_text_head * 64 * 68, false);
+    dw.qkvd = alloc(R * 3 * d, false);
+    dw.attd = alloc(R * d, false);
+    dw.hd = alloc(R * 4 * d, false);
+    dw.cross_ws = alloc(R * c.n_text_head * 8 * 68, false);
     dw.self_kv = alloc(size_t(c.n_text_layer) * 2 * B * self_cap_ * d, true);
     dw.logits = alloc(B * c.n_vocab, false);
     dw.best = reinterpret_cast<unsigned long long*>(alloc(B * 2 * size_t((c.n_vocab + 31) / 32), true));
@@ -978,6 +1021,7 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
       CALL;                                                                   \
     }                                                                         \
   } while (0)
+  (void)dw;
   auto enqueue_all = [&](int si) {
     Slot& slot = slots_[si];
     DecWorkspace& dw = dws_[si % n_dec_streams_];
@@ -992,66 +1036,70 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
 
     const size_t kv_slab = size_t(batch) * T * d;  // one (layer, k|v) slab of the cross cache
     const size_t self_slab = size_t(batch) * self_cap_ * d;
-    float* const x = dw.xd;  // residual stream [B][d], updated in place by the residual GEMMs
-    // fc2 (K = 4 d) runs over twice the blocks when its K splits evenly over 2 x waves x 8
-    const bool split = fc2_ksplit == 2 && (4 * d) % (16 * int(resid_waves)) == 0;
-    for (int pos = 0; pos < max_pos; ++pos) {
+    float* const x = dw.xd;  // residual stream [rows][d], updated in place by the residual GEMMs
+    // fc2 (K = 4 d) runs over twice the blocks when its K splits evenly over 2 x 8 waves x 16
+    const bool split = fc2_ksplit == 2 && (4 * d) % 256 == 0;
+    // Passes.  The prompt positions of every clip go through the layers TOGETHER when they fit one pass (rows =
+    // positions x clips <= 128, at most 4 positions: causal self-attention inside the pass, one sweep of the
+    // cross-KV cache for all of them); the reference feeds the same prefix to its graph at once, whisper.cpp:367-375.
+    // Every later position is one pass of `batch` rows.
+    const int first = (n_prompt <= 4 && n_prompt * batch <= kDecRowsMax) ? std::min(n_prompt, max_pos) : 1;
+    for (int pos0 = 0, np = first; pos0 < max_pos; pos0 += np, np = 1) {
+      const int M = np * batch, last = pos0 + np - 1;
       for (int l = 0; l < c.n_text_layer; ++l) {
-        const BlockWeights& w = dec_blocks_[l];
+        const DecBlockWeights& w = dec_blocks_[l];
         DecGemmArgs q;  // LN + fused q|k|v projection (+ token/positional embedding at layer 0)
-        q.Wt = w.attn.wqkv; q.N = 3 * d; q.K = d; q.B = batch;
+        q.Wt = w.wqkv.w; q.w_scale = w.wqkv.scale; q.N = 3 * d; q.K = d; q.B = batch; q.M = M;
         q.xin = x; q.ln_g = w.attn_ln_g; q.ln_b = w.attn_ln_b;
         if (l > 0 && split) {  // the previous layer's fc2 left x in two halves: sum them, block 0 completes x
           q.xin = dw.xb; q.xpart = dw.xpart; q.xout = x;
         }
         if (l == 0) {
-          q.ids = dw.ids; q.ids_stride = stride; q.pos = pos; q.tok_emb = tok_emb; q.pos_emb = dec_pos;
+          q.ids = dw.ids; q.ids_stride = stride; q.pos = pos0; q.tok_emb = tok_emb; q.pos_emb = dec_pos;
           q.n_vocab = V; q.xout = x;
         }
-        q.bias = w.attn.bqkv; q.Y = dw.qkvd; q.ldy = 3 * d;
+        q.bias = w.bqkv; q.Y = dw.qkvd; q.ldy = 3 * d;
         DT(0, launch_dec_gemm(q, kProLn, kDecBias, stream_));
         DT(1, launch_self_attention(dw.qkvd, dw.self_kv + (size_t(l) * 2 + 0) * self_slab,
-                              dw.self_kv + (size_t(l) * 2 + 1) * self_slab, self_cap_, pos, dw.attd,
-                              batch, H, stream_));
+                                    dw.self_kv + (size_t(l) * 2 + 1) * self_slab, self_cap_, pos0, np, dw.attd,
+                                    batch, H, stream_));
         DecGemmArgs o;  // x += attn . Wo^T + bo
-        o.Wt = w.attn.wo; o.N = d; o.K = d; o.B = batch; o.X = dw.attd; o.ldx = d;
-        o.bias = w.attn.bo; o.R = x; o.Y = x; o.ldy = d; o.resid_waves = int(resid_waves);
+        o.Wt = w.wo.w; o.w_scale = w.wo.scale; o.N = d; o.K = d; o.B = batch; o.M = M; o.X = dw.attd; o.ldx = d;
+        o.bias = w.bo; o.R = x; o.Y = x; o.ldy = d;
         DT(2, launch_dec_gemm(o, kProNone, kDecResid, stream_));
 
-        DecGemmArgs cq;  // LN + cross-attention query projection
-        cq.Wt = w.cross.wq; cq.N = d; cq.K = d; cq.B = batch;
-        cq.xin = x; cq.ln_g = w.cross_ln_g; cq.ln_b = w.cross_ln_b;
-        cq.bias = w.cross.bq; cq.Y = dw.qd; cq.ldy = d;
-        DT(3, launch_dec_gemm(cq, kProLn, kDecBias, stream_));
-        DT(4, launch_cross_attention(dw.qd, slot.cross_kv + (size_t(l) * 2 + 0) * kv_slab,
-                               slot.cross_kv + (size_t(l) * 2 + 1) * kv_slab, dw.cross_ws, batch, H, T,
-                               chunks, stream_));
+        CrossAttnArgs ca;  // LN + query projection + attention over the cached encoder keys, per key chunk
+        ca.x = x; ca.ln_g = w.cross_ln_g; ca.ln_b = w.cross_ln_b; ca.wq_t = w.cross_wq_t; ca.bq = w.cross_bq;
+        ca.kc = slot.cross_kv + (size_t(l) * 2 + 0) * kv_slab; ca.vc = slot.cross_kv + (size_t(l) * 2 + 1) * kv_slab;
+        ca.ws = dw.cross_ws; ca.batch = batch; ca.heads = H; ca.T = T; ca.chunks = chunks; ca.nq = np;
+        DT(4, launch_cross_attention(ca, stream_));
         DecGemmArgs co;  // x += combine(chunks) . Wco^T + bco
-        co.Wt = w.cross.wo; co.N = d; co.K = d; co.B = batch;
+        co.Wt = w.cross_wo.w; co.w_scale = w.cross_wo.scale; co.N = d; co.K = d; co.B = batch; co.M = M;
         co.cross_ws = dw.cross_ws; co.heads = H; co.chunks = chunks;
-        co.bias = w.cross.bo; co.R = x; co.Y = x; co.ldy = d; co.resid_waves = int(resid_waves);
+        co.bias = w.cross_bo; co.R = x; co.Y = x; co.ldy = d;
         DT(5, launch_dec_gemm(co, kProCombine, kDecResid, stream_));
 
         DecGemmArgs f1;  // LN + fc1 + GELU
-        f1.Wt = w.w1; f1.N = 4 * d; f1.K = d; f1.B = batch;
+        f1.Wt = w.w1.w; f1.w_scale = w.w1.scale; f1.N = 4 * d; f1.K = d; f1.B = batch; f1.M = M;
         f1.xin = x; f1.ln_g = w.mlp_ln_g; f1.ln_b = w.mlp_ln_b;
         f1.bias = w.b1; f1.Y = dw.hd; f1.ldy = 4 * d;
         DT(6, launch_dec_gemm(f1, kProLn, kDecBiasGelu, stream_));
         DecGemmArgs f2;  // x += h . W2^T + b2
-        f2.Wt = w.w2; f2.N = d; f2.K = 4 * d; f2.B = batch; f2.X = dw.hd; f2.ldx = 4 * d;
-        f2.bias = w.b2; f2.R = x; f2.Y = x; f2.ldy = d; f2.resid_waves = int(resid_waves);
+        f2.Wt = w.w2.w; f2.w_scale = w.w2.scale; f2.N = d; f2.K = 4 * d; f2.B = batch; f2.M = M; f2.X = dw.hd; f2.ldx = 4 * d;
+        f2.bias = w.b2; f2.R = x; f2.Y = x; f2.ldy = d;
         if (split) {
           f2.Y = dw.xb; f2.ksplit = 2; f2.part = dw.xpart;
         }
         DT(7, launch_dec_gemm(f2, kProNone, kDecResid, stream_));
       }
-      if (pos >= n_prompt - 1) {
+      if (last >= n_prompt - 1) {
         // logits against the tied embedding + greedy argmax (whisper.cpp:379-399); only the
-        // last position's row exists here, the reference computes and drops the others
-        DT(8, launch_dec_finalize_ln(split ? dw.xb : x, dec_ln_g, dec_ln_b, dw.lnd, batch, d, stream_,
-                                     split ? dw.xpart : nullptr));
+        // last position's rows exist here, the reference computes and drops the others
+        const size_t off = size_t(np - 1) * batch * d;
+        DT(8, launch_dec_finalize_ln((split ? dw.xb : x) + off, dec_ln_g, dec_ln_b, dw.lnd, batch, d, stream_,
+                                     split ? dw.xpart + off : nullptr));
         DecGemmArgs lg;
-        lg.Wt = tok_emb_tiled; lg.N = V; lg.K = d; lg.B = batch; lg.X = dw.lnd; lg.ldx = d;
+        lg.Wt = tok_emb_tiled.w; lg.w_scale = tok_emb_tiled.scale; lg.N = V; lg.K = d; lg.B = batch; lg.X = dw.lnd; lg.ldx = d;
         lg.Y = logits_host ? dw.logits : nullptr; lg.ldy = V; lg.best = dw.best;
         DT(9, launch_dec_gemm(lg, kProNone, kDecLogits, stream_));
         if (logits_host && steps < logits_steps_cap) {
@@ -1059,7 +1107,7 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
                                   dw.logits, size_t(V) * sizeof(float), size_t(V) * sizeof(float), batch,
                                   hipMemcpyDeviceToHost, stream_));
         }
-        DT(10, launch_select_token(dw.best, (V + 31) / 32, dw.ids, stride, pos, dw.n_ids, dw.finished,
+        DT(10, launch_select_token(dw.best, (V + 31) / 32, dw.ids, stride, last, dw.n_ids, dw.finished,
                             vocab_.token_eot, int(stop_at_eot), batch, stream_));
         ++steps;
       }
@@ -1073,7 +1121,7 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
   // kernels' one-time attribute set-up) and then captures one hipGraph per slot; later calls
   // replay the slot's graph: one host call instead of ~1100. The logits tap stays eager.
   auto key_of = [&](int si) {
-    return std::vector<long long>{si, batch, max_pos, n_prompt, chunks, long(stop_at_eot), resid_waves, fc2_ksplit};
+    return std::vector<long long>{si, batch, max_pos, n_prompt, chunks, long(stop_at_eot), fc2_ksplit};
   };
   hipGraphExec_t exec = nullptr;
   if (use_graphs && !logits_host) {

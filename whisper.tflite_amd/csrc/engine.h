@@ -33,18 +33,26 @@ enum KernelClass { kKcGemm = 0, kKcEncAttn, kKcLayerNorm, kKcTranspose, kKcCount
 
 struct AttnWeights {
   const float *wqkv = nullptr, *bqkv = nullptr;  // fused [3d][d] (self attention)
-  const float *wq = nullptr, *bq = nullptr;      // cross attention query
   const float *wo = nullptr, *bo = nullptr;
 };
-struct BlockWeights {
+struct BlockWeights {  // encoder layer: fp32 row-major [N][K]
   const float *attn_ln_g, *attn_ln_b;
   AttnWeights attn;
-  const float *cross_ln_g = nullptr, *cross_ln_b = nullptr;
-  AttnWeights cross;
   const float *mlp_ln_g, *mlp_ln_b, *w1, *b1, *w2, *b2;
 };
-
-std::vector<float> tile_weights(const float* W, int N, int K);
+// decoder Linear weights: two fp16 planes in MFMA-fragment order (kernels.h tile_weights_f16) + their scale
+struct TiledW {
+  const unsigned short* w = nullptr;
+  float scale = 1.0f;
+};
+struct DecBlockWeights {
+  const float *attn_ln_g, *attn_ln_b, *bqkv, *bo;
+  TiledW wqkv, wo;
+  const float *cross_ln_g, *cross_ln_b, *cross_wq_t, *cross_bq, *cross_bo;  // cross_wq_t: cross_q_layout()
+  TiledW cross_wo;
+  const float *mlp_ln_g, *mlp_ln_b, *b1, *b2;
+  TiledW w1, w2;
+};
 
 class Engine {
  public:
@@ -73,7 +81,6 @@ class Engine {
   long verbose = 0;
   long cross_chunks = 2;  // key chunks per (clip, head) of the decoder cross-attention (measured: 2 beats 4 by 6 % alone)
   long attn_variant = 4;  // encoder attention: 0 = fp32 MFMA, 1/2 = bf16 x3 split, 3 = bf16 operands, 4 = fp16 x2 split
-  long resid_waves = 8;   // wavefronts per block of the decoder's residual GEMMs (4, 8, 16)
   long fc2_ksplit = 2;  // decoder fc2 (K = 4 d_model) over twice the blocks, halves summed by the consumer
   long use_graphs = 1;  // replay the decoder's launch sequence from a captured hipGraph
   long gemm_variant = -1;  // encoder GEMM tile variant (k_gemm.hip); -1 = per-shape choice
@@ -134,6 +141,7 @@ class Engine {
   void upload_weights(const std::string& path);
   const float* dev(const std::string& name) const;
   float* upload(const std::vector<float>& host);
+  TiledW upload_tiled(const float* W, int N, int K);
   void build_frontend_tables();
 
   void decode_enqueue(int batch, int slot, float* logits_host, int logits_steps_cap);
@@ -191,7 +199,8 @@ class Engine {
   const float *conv1_w = nullptr, *conv1_b = nullptr, *conv2_w = nullptr, *conv2_b = nullptr;
   int conv1_kpad = 0;
   const float* enc_pos = nullptr;
-  std::vector<BlockWeights> enc_blocks_, dec_blocks_;
+  std::vector<BlockWeights> enc_blocks_;
+  std::vector<DecBlockWeights> dec_blocks_;
   // Operand scales of the two-plane fp16 encoder kernels (powers of two, f16_scale_for): derived at load
   // time from weight-only upper bounds of every contraction operand (LayerNorm output <= |g| sqrt(d-1) + |b|,
   // Linear output <= sum |W| * input bound + |bias|, GELU(x) <= max(x, 0.17), attention output <= V bound),
@@ -217,7 +226,8 @@ class Engine {
   std::vector<EncLayerScales> sc_layers_;
   const float *enc_ln_post_g = nullptr, *enc_ln_post_b = nullptr;
   const float *cross_kv_w = nullptr, *cross_kv_b = nullptr;  // [L*2*d][d], [L*2*d]
-  const float *tok_emb = nullptr, *tok_emb_tiled = nullptr, *dec_pos = nullptr, *dec_ln_g = nullptr, *dec_ln_b = nullptr;
+  const float *tok_emb = nullptr, *dec_pos = nullptr, *dec_ln_g = nullptr, *dec_ln_b = nullptr;
+  TiledW tok_emb_tiled;  // logits GEMM against the tied embedding
   // front end
   const float* dft_basis = nullptr;  // [dft_n][dft_k]  windowed cos | sin rows
   const float* mel_w = nullptr;      // [mel_n][mel_k]
@@ -225,7 +235,7 @@ class Engine {
 
   struct DecWorkspace {  // one per decoder stream
     float *xb = nullptr, *xpart = nullptr;  // fc2's K-split: first-half result / second-half partial
-    float *xd = nullptr, *lnd = nullptr, *qkvd = nullptr, *attd = nullptr, *qd = nullptr,
+    float *xd = nullptr, *lnd = nullptr, *qkvd = nullptr, *attd = nullptr,
           *hd = nullptr, *cross_ws = nullptr, *self_kv = nullptr, *logits = nullptr;
     unsigned long long* best = nullptr;
     long long* ids = nullptr;
@@ -250,6 +260,7 @@ class Engine {
                                   {"layernorm_rows", 0, 0, 0, 0},
                                   {"mel_transpose", 0, 0, 0, 0}};
   int self_cap_ = 32;
+  static constexpr int kDecRowsMax = 128;  // rows of one decoder pass (k_decoder.hip: up to four 32-row tiles)
 };
 
 }  // namespace wt

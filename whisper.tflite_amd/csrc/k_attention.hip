@@ -455,149 +455,259 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void encoder_attention_sp
 #undef WT_MM16
 
 // ------------------------------------------------- decoder self attention ---
-// One block per clip, one wavefront per head.  Appends this position's k, v to the
-// cache, then lane j scores position j (pos < 64), and lane d accumulates output d.
+// One block = one wavefront per (clip, head).  Appends the k, v of `npos` new positions (pos0 .. pos0 + npos - 1;
+// npos = 1 for a generated position, the whole prompt in the first pass) to the cache, then for each new position
+// lane j scores cached position j and lane d accumulates output d.  qkv / out rows: row(p) = p * B + b.
 __global__ void self_attention_step(const float* __restrict__ qkv, float* __restrict__ kcache,
-                                    float* __restrict__ vcache, int cap, int pos,
+                                    float* __restrict__ vcache, int cap, int pos0, int npos, int B,
                                     float* __restrict__ out, int heads) {
-  // Everything this (clip, head) needs is requested in one batch of independent loads — the new
-  // q/k/v row and the cached K and V rows of positions < pos (16 lanes x 16 B per row) — and staged
-  // in LDS; scores, softmax and the weighted sum then run out of LDS.  One round trip to memory
-  // instead of one per unrolled group of the old per-lane row walk.
-  // one wavefront per (clip, head): 17 KB of LDS per block
+  // Everything this (clip, head) needs is requested in one batch of independent loads — the new q/k/v rows and the
+  // cached K and V rows of positions < pos0 (16 lanes x 16 B per row) — and staged in LDS; scores, softmax and the
+  // weighted sum then run out of LDS.  One round trip to memory.
   const int b = blockIdx.x / heads, h = blockIdx.x % heads, lane = threadIdx.x;
   const int d = heads * 64;
-  const float* row = qkv + (long)b * 3 * d;
   float* kc = kcache + ((long)b * cap) * d + h * 64;
   float* vc = vcache + ((long)b * cap) * d + h * 64;
   __shared__ __attribute__((aligned(16))) float Ks[32][68];
   __shared__ __attribute__((aligned(16))) float Vs[32][64];
   __shared__ float qs[64];
   __shared__ float ps[64];
-  const float q = row[h * 64 + lane] * 0.125f;
-  const float knew = row[d + h * 64 + lane];
-  const float vnew = row[2 * d + h * 64 + lane];
   const int r16 = lane >> 4, c4 = (lane & 15) * 4;
   f32x4 kr[8], vr[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {  // rows 4i + r16 < pos (pos <= 31); rows past pos re-read row 0
+  for (int i = 0; i < 8; ++i) {  // rows 4i + r16 < pos0 (pos0 <= 31); rows past pos0 re-read row 0
     const int j = 4 * i + r16;
-    const int jj = j < pos ? j : 0;
+    const int jj = j < pos0 ? j : 0;
     kr[i] = *reinterpret_cast<const f32x4*>(kc + (long)jj * d + c4);
     vr[i] = *reinterpret_cast<const f32x4*>(vc + (long)jj * d + c4);
   }
-  kc[(long)pos * d + lane] = knew;
-  vc[(long)pos * d + lane] = vnew;
-  qs[lane] = q;
-  Ks[pos][lane] = knew;
-  Vs[pos][lane] = vnew;
+  for (int p = 0; p < npos; ++p) {
+    const float* row = qkv + ((long)p * B + b) * 3 * d;
+    const float knew = row[d + h * 64 + lane];
+    const float vnew = row[2 * d + h * 64 + lane];
+    kc[(long)(pos0 + p) * d + lane] = knew;
+    vc[(long)(pos0 + p) * d + lane] = vnew;
+    Ks[pos0 + p][lane] = knew;
+    Vs[pos0 + p][lane] = vnew;
+  }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int j = 4 * i + r16;
-    if (j < pos) {
+    if (j < pos0) {
       *reinterpret_cast<f32x4*>(&Ks[j][c4]) = kr[i];
       *reinterpret_cast<f32x4*>(&Vs[j][c4]) = vr[i];
     }
   }
-  __syncthreads();
-  const int n = pos + 1;
-  float s = -1e30f;
-  if (lane < n) {
-    float acc = 0.0f;
+  for (int p = 0; p < npos; ++p) {
+    const long r = (long)p * B + b;
+    __syncthreads();  // staging complete / the previous position is done with qs and ps
+    qs[lane] = qkv[r * 3 * d + h * 64 + lane] * 0.125f;
+    __syncthreads();
+    const int n = pos0 + p + 1;  // causal: keys 0 .. pos0 + p
+    float s = -1e30f;
+    if (lane < n) {
+      float acc = 0.0f;
 #pragma unroll 8
-    for (int c = 0; c < 64; ++c) acc += qs[c] * Ks[lane][c];
-    s = acc;
+      for (int c = 0; c < 64; ++c) acc += qs[c] * Ks[lane][c];
+      s = acc;
+    }
+    float mx = s;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    const float pe = lane < n ? __expf(s - mx) : 0.0f;
+    float sum = pe;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    ps[lane] = pe / sum;
+    __syncthreads();
+    float o = 0.0f;
+    for (int j = 0; j < n; ++j) o += ps[j] * Vs[j][lane];
+    out[r * d + h * 64 + lane] = o;
   }
-  float mx = s;
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-  const float p = lane < n ? __expf(s - mx) : 0.0f;
-  float sum = p;
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
-  ps[lane] = p / sum;
-  __syncthreads();
-  float o = 0.0f;
-  for (int j = 0; j < n; ++j) o += ps[j] * Vs[j][lane];
-  out[(long)b * d + h * 64 + lane] = o;
 }
 
 // ------------------------------------------------ decoder cross attention ---
-// One block per (clip, head, key chunk).  The chunk's K and V slabs ([keys][64] floats,
-// 256 B per key, contiguous) are streamed ONCE in a single pass: 16 lanes own a key row
-// (16-byte loads), each 16-lane group runs an online softmax over its keys (4 keys = 8 loads of
-// 16 B per lane in flight), and the 16 group partials are merged through LDS at the end.
-// Output per block: o[64] (unnormalised), m (running max, natural-log units), l (sum).
-__global__ __launch_bounds__(256) void cross_attention_step(const float* __restrict__ q,
-                                                            const float* __restrict__ kc,
-                                                            const float* __restrict__ vc,
-                                                            float* __restrict__ ws, int heads,
-                                                            int T, int chunks) {
-  __shared__ __attribute__((aligned(16))) float go[16 * 64];
-  __shared__ float gm[16], gl[16];
+// One block per (clip, head, key chunk), NQ query rows (NQ = 1 for a generated position; the prompt positions of
+// the first pass share one sweep of the cache).  The block first makes its own queries — q = LayerNorm(x[row]) .
+// Wq[head slice]^T + bq, a 64 x DM matrix-vector product per row, 98 KB of weights from L2 — so the separate
+// "LayerNorm + query projection" launch of every layer is gone; the first K/V rows are requested before that, and
+// the chunk's K and V slabs ([keys][64] floats, 256 B per key, contiguous) are then streamed ONCE in a single pass:
+// 16 lanes own a key row (16-byte loads), each 16-lane group runs an online softmax over its keys (4 keys = 8
+// loads of 16 B per lane in flight), and the 16 group partials are merged through LDS at the end.
+// Output per (row, head, chunk): o[64] (unnormalised), m (running max, natural-log units), l (sum).
+// Wq_t: the query projection re-laid-out for this product: [head][DM / 4][64 outputs][4 k] (cross_q_layout()).
+template <int NQ, int DM>
+__global__ __launch_bounds__(256) void cross_attention_step(const float* __restrict__ x, const float* __restrict__ ln_g,
+                                                            const float* __restrict__ ln_b,
+                                                            const float* __restrict__ Wq_t, const float* __restrict__ bq,
+                                                            const float* __restrict__ kc, const float* __restrict__ vc,
+                                                            float* __restrict__ ws, int B, int heads, int T,
+                                                            int chunks) {
+  __shared__ __attribute__((aligned(16))) float lnx[NQ][DM];
+  __shared__ __attribute__((aligned(16))) float qpart[4][NQ][64];
+  __shared__ __attribute__((aligned(16))) float qs[NQ][64];
+  __shared__ __attribute__((aligned(16))) float go[NQ][16 * 64];
+  __shared__ float gm[NQ][16], gl[NQ][16];
+  __shared__ float red[4][NQ];
   const int chunk = blockIdx.x % chunks, bh = blockIdx.x / chunks;
   const int b = bh / heads, h = bh % heads;
   const int per = (T + chunks - 1) / chunks;
   const int k_begin = chunk * per, k_end = min(T, k_begin + per), nk = k_end - k_begin;
-  const int tid = threadIdx.x, grp = tid >> 4, gl16 = tid & 15;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, grp = tid >> 4, gl16 = tid & 15;
   constexpr float kLog2e = 1.44269504088896340736f;
   constexpr int U = 4;
+  constexpr int C4 = DM / 4;    // float4 per row
+  constexpr int CW = DM / 16;   // float4 of the k-quarter one wavefront contracts
 
-  // q is requested together with the first K/V rows: nothing touches it before they are in flight
-  // (scaling q here would make every K/V load wait for q's round trip to memory)
-  const f32x4 qv = *reinterpret_cast<const f32x4*>(q + ((long)b * heads + h) * 64 + gl16 * 4);
-  constexpr float kScale = 0.125f * kLog2e;  // scores in log2 units: p = exp2(s - m)
+  // (0) the first K/V rows: nothing below touches them before the queries exist
   const float* kb = kc + ((long)bh * T + k_begin) * 64 + gl16 * 4;
   const float* vb = vc + ((long)bh * T + k_begin) * 64 + gl16 * 4;
-
-  float m = -1e30f, l = 0.0f;
-  f32x4 o = {0, 0, 0, 0};
-  for (int k0 = grp; k0 < nk; k0 += 16 * U) {
-    f32x4 kv[U], vv[U];
+  f32x4 kv[U], vv[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {  // unguarded loads: keys past the chunk re-read its last row
-      const int k = k0 + 16 * u;
-      const int kk = k < nk ? k : nk - 1;
-      kv[u] = *reinterpret_cast<const f32x4*>(kb + (long)kk * 64);
-      vv[u] = *reinterpret_cast<const f32x4*>(vb + (long)kk * 64);
+  for (int u = 0; u < U; ++u) {  // unguarded loads: keys past the chunk re-read its last row
+    const int k = grp + 16 * u;
+    const int kk = k < nk ? k : nk - 1;
+    kv[u] = *reinterpret_cast<const f32x4*>(kb + (long)kk * 64);
+    vv[u] = *reinterpret_cast<const f32x4*>(vb + (long)kk * 64);
+  }
+  // (1) query-projection weights of this head, k-quarter `wid`, output `lane`: CW independent 16-byte loads
+  f32x4 wq[CW];
+  const float* wqp = Wq_t + (((long)h * C4 + wid * CW) * 64 + lane) * 4;
+#pragma unroll
+  for (int c = 0; c < CW; ++c) wq[c] = *reinterpret_cast<const f32x4*>(wqp + (long)c * 256);
+  // (2) LayerNorm of the NQ residual rows (two-pass statistics, eps 1e-5, as the LN-fused GEMMs)
+  const int c4 = tid < C4 ? tid : C4 - 1;
+  f32x4 xv[NQ];
+#pragma unroll
+  for (int p = 0; p < NQ; ++p) xv[p] = *reinterpret_cast<const f32x4*>(x + ((long)p * B + b) * DM + c4 * 4);
+  const f32x4 gg = *reinterpret_cast<const f32x4*>(ln_g + c4 * 4), bb = *reinterpret_cast<const f32x4*>(ln_b + c4 * 4);
+  const bool own = tid < C4;
+  float mean[NQ], rstd[NQ];
+#pragma unroll
+  for (int p = 0; p < NQ; ++p) {
+    float s = own ? (xv[p][0] + xv[p][1]) + (xv[p][2] + xv[p][3]) : 0.0f;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) red[wid][p] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < NQ; ++p) mean[p] = ((red[0][p] + red[1][p]) + (red[2][p] + red[3][p])) / (float)DM;
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < NQ; ++p) {
+    float q = 0.0f;
+    if (own) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float t = xv[p][e] - mean[p];
+        q += t * t;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off, 64);
+    if (lane == 0) red[wid][p] = q;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < NQ; ++p) {
+    rstd[p] = rsqrtf(((red[0][p] + red[1][p]) + (red[2][p] + red[3][p])) / (float)DM + 1e-5f);
+    if (own) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (xv[p][e] - mean[p]) * rstd[p] * gg[e] + bb[e];
+      *reinterpret_cast<f32x4*>(&lnx[p][c4 * 4]) = o;
+    }
+  }
+  __syncthreads();
+  // (3) q[p][lane] partial over this wavefront's k-quarter; LDS reads of lnx are wave-uniform (broadcast)
+  float qa[NQ];
+#pragma unroll
+  for (int p = 0; p < NQ; ++p) qa[p] = 0.0f;
+#pragma unroll
+  for (int c = 0; c < CW; ++c) {
+#pragma unroll
+    for (int p = 0; p < NQ; ++p) {
+      const f32x4 l4 = *reinterpret_cast<const f32x4*>(&lnx[p][(wid * CW + c) * 4]);
+      qa[p] += (wq[c][0] * l4[0] + wq[c][1] * l4[1]) + (wq[c][2] * l4[2] + wq[c][3] * l4[3]);
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < NQ; ++p) qpart[wid][p][lane] = qa[p];
+  __syncthreads();
+  constexpr float kScale = 0.125f * kLog2e;  // scores in log2 units: p = exp2(s - m)
+  if (tid < NQ * 64) {
+    const int p = tid >> 6;
+    qs[p][lane] = (((qpart[0][p][lane] + qpart[1][p][lane]) + (qpart[2][p][lane] + qpart[3][p][lane])) + bq[h * 64 + lane]) * kScale;
+  }
+  __syncthreads();
+  f32x4 qv[NQ];
+#pragma unroll
+  for (int p = 0; p < NQ; ++p) qv[p] = *reinterpret_cast<const f32x4*>(&qs[p][gl16 * 4]);
+
+  // (4) one sweep of the chunk's keys
+  float m[NQ], l[NQ];
+  f32x4 o[NQ];
+#pragma unroll
+  for (int p = 0; p < NQ; ++p) {
+    m[p] = -1e30f;
+    l[p] = 0.0f;
+    o[p] = f32x4{0, 0, 0, 0};
+  }
+  for (int k0 = grp; k0 < nk; k0 += 16 * U) {
+    if (k0 != grp) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = k0 + 16 * u;
+        const int kk = k < nk ? k : nk - 1;
+        kv[u] = *reinterpret_cast<const f32x4*>(kb + (long)(kk - grp) * 64);
+        vv[u] = *reinterpret_cast<const f32x4*>(vb + (long)(kk - grp) * 64);
+      }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      float s = kv[u][0] * qv[0] + kv[u][1] * qv[1] + kv[u][2] * qv[2] + kv[u][3] * qv[3];
-      s += __shfl_xor(s, 8, 64);
-      s += __shfl_xor(s, 4, 64);
-      s += __shfl_xor(s, 2, 64);
-      s += __shfl_xor(s, 1, 64);
-      s *= kScale;
-      if (k0 + 16 * u >= nk) s = -1e30f;
-      const float mn = fmaxf(m, s);
-      const float a = exp2f(m - mn), p = exp2f(s - mn);
-      l = l * a + p;
+      const bool past = k0 + 16 * u >= nk;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = o[j] * a + p * vv[u][j];
-      m = mn;
+      for (int p = 0; p < NQ; ++p) {
+        float s = kv[u][0] * qv[p][0] + kv[u][1] * qv[p][1] + kv[u][2] * qv[p][2] + kv[u][3] * qv[p][3];
+        s += __shfl_xor(s, 8, 64);
+        s += __shfl_xor(s, 4, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 1, 64);
+        if (past) s = -1e30f;
+        const float mn = fmaxf(m[p], s);
+        const float a = exp2f(m[p] - mn), pr = exp2f(s - mn);
+        l[p] = l[p] * a + pr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[p][j] = o[p][j] * a + pr * vv[u][j];
+        m[p] = mn;
+      }
     }
   }
-  *reinterpret_cast<f32x4*>(&go[grp * 64 + gl16 * 4]) = o;
-  if (gl16 == 0) {
-    gm[grp] = m;
-    gl[grp] = l;
+#pragma unroll
+  for (int p = 0; p < NQ; ++p) {
+    *reinterpret_cast<f32x4*>(&go[p][grp * 64 + gl16 * 4]) = o[p];
+    if (gl16 == 0) {
+      gm[p][grp] = m[p];
+      gl[p][grp] = l[p];
+    }
   }
   __syncthreads();
-  if (tid < 64) {
-    float mx = gm[0];
+  if (tid < NQ * 64) {
+    const int p = tid >> 6;
+    float mx = gm[p][0];
 #pragma unroll
-    for (int gI = 1; gI < 16; ++gI) mx = fmaxf(mx, gm[gI]);
+    for (int gI = 1; gI < 16; ++gI) mx = fmaxf(mx, gm[p][gI]);
     float acc = 0.0f, lsum = 0.0f;
 #pragma unroll
     for (int gI = 0; gI < 16; ++gI) {
-      const float w = exp2f(gm[gI] - mx);
-      acc += w * go[gI * 64 + tid];
-      lsum += w * gl[gI];
+      const float w = exp2f(gm[p][gI] - mx);
+      acc += w * go[p][gI * 64 + lane];
+      lsum += w * gl[p][gI];
     }
-    float* dst = ws + ((long)bh * chunks + chunk) * 68;
-    dst[tid] = acc;
-    if (tid == 0) {
+    float* dst = ws + ((((long)p * B + b) * heads + h) * chunks + chunk) * 68;
+    dst[lane] = acc;
+    if (lane == 0) {
       dst[64] = mx * (1.0f / kLog2e);  // natural-log units for the combine prologue
       dst[65] = lsum;
     }
@@ -626,18 +736,36 @@ void launch_encoder_attention(const float* qkv, float* out, int batch, int T, in
   }
 }
 
-void launch_self_attention(const float* qkv, float* kcache, float* vcache, int cap, int pos,
-                           float* out, int batch, int heads, hipStream_t s) {
+void launch_self_attention(const float* qkv, float* kcache, float* vcache, int cap, int pos0, int npos, float* out,
+                           int batch, int heads, hipStream_t s) {
   // the kernel stages at most 32 cached rows in LDS
-  if (pos < 0 || pos > 31 || pos >= cap) throw Error(kErrInvalidArg, "decoder self-attention: position outside [0, 31]");
-  hipLaunchKernelGGL(self_attention_step, dim3(batch * heads), dim3(64), 0, s, qkv, kcache, vcache,
-                     cap, pos, out, heads);
+  if (pos0 < 0 || npos < 1 || pos0 + npos > 32 || pos0 + npos > cap) {
+    throw Error(kErrInvalidArg, "decoder self-attention: positions outside [0, 31]");
+  }
+  hipLaunchKernelGGL(self_attention_step, dim3(batch * heads), dim3(64), 0, s, qkv, kcache, vcache, cap, pos0, npos,
+                     batch, out, heads);
 }
 
-void launch_cross_attention(const float* q, const float* kc, const float* vc, float* ws, int batch,
-                            int heads, int T, int chunks, hipStream_t s) {
-  hipLaunchKernelGGL(cross_attention_step, dim3(batch * heads * chunks), dim3(256), 0, s, q, kc, vc,
-                     ws, heads, T, chunks);
+template <int NQ>
+static void launch_cross_nq(const CrossAttnArgs& a, hipStream_t s) {
+  const dim3 grid(a.batch * a.heads * a.chunks);
+  switch (a.heads * 64) {
+    case 128: hipLaunchKernelGGL((cross_attention_step<NQ, 128>), grid, dim3(256), 0, s, a.x, a.ln_g, a.ln_b, a.wq_t, a.bq, a.kc, a.vc, a.ws, a.batch, a.heads, a.T, a.chunks); break;
+    case 384: hipLaunchKernelGGL((cross_attention_step<NQ, 384>), grid, dim3(256), 0, s, a.x, a.ln_g, a.ln_b, a.wq_t, a.bq, a.kc, a.vc, a.ws, a.batch, a.heads, a.T, a.chunks); break;
+    case 512: hipLaunchKernelGGL((cross_attention_step<NQ, 512>), grid, dim3(256), 0, s, a.x, a.ln_g, a.ln_b, a.wq_t, a.bq, a.kc, a.vc, a.ws, a.batch, a.heads, a.T, a.chunks); break;
+    default: throw Error(kErrFormat, "decoder kernels support d_model 128, 384 or 512");
+  }
+}
+
+void launch_cross_attention(const CrossAttnArgs& a, hipStream_t s) {
+  if (a.batch < 1 || a.T < 1 || a.chunks < 1 || a.chunks > a.T) throw Error(kErrInvalidArg, "cross attention: bad shape");
+  switch (a.nq) {
+    case 1: launch_cross_nq<1>(a, s); break;
+    case 2: launch_cross_nq<2>(a, s); break;
+    case 3: launch_cross_nq<3>(a, s); break;
+    case 4: launch_cross_nq<4>(a, s); break;
+    default: throw Error(kErrInvalidArg, "cross attention: 1..4 query rows per clip");
+  }
 }
 
 }  // namespace wt

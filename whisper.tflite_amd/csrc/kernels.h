@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <vector>
 
 #include "error.h"
 
@@ -58,10 +59,11 @@ int gemm_occupancy(int variant);
 // variants launch_gemm accepts: 0 fp32 MFMA, 11 bf16 operands, 13/16 three bf16 planes, 17/18 two fp16 planes
 bool gemm_variant_supported(int variant);
 
-// Decoder-step GEMM: out[B][N] = epi(pro(x)[B][K] . W[N][K]^T), B <= 64 (k_decoder.hip).
-// Wt is W pre-tiled by tile_weights(): [ceil(N/32)][K/8][64 lanes][4].
+// Decoder-step GEMM: out[M][N] = epi(pro(x)[M][K] . W[N][K]^T), M = positions x B clips <= 128 rows (row =
+// p * B + b), k_decoder.hip.  Wt is W as two fp16 planes in MFMA-fragment order, made by tile_weights_f16():
+// [ceil(N/32)][K/16][plane hi|lo][64 lanes][8], scaled by w_scale.
 enum DecPro : int {
-  kProNone = 0,    // A operand = X [B][K] (ldx) from global memory
+  kProNone = 0,    // A operand = X [M][K] (ldx) from global memory
   kProLn = 1,      // A = LayerNorm(x) * ln_g + ln_b with x = xin, or (ids != nullptr) the token +
                    // positional embedding, which block 0 also stores to xout
   kProCombine = 2  // A = combine of the cross-attention key-chunk partials cross_ws
@@ -70,21 +72,23 @@ enum DecEpi : int {
   kDecResid = 0,     // Y = R + bias + acc   (R may alias Y: the residual stream, in place)
   kDecBias = 1,      // Y = acc + bias
   kDecBiasGelu = 2,  // Y = gelu(acc + bias)
-  kDecLogits = 3     // (optional Y = acc) + per-tile argmax records best[b][tile], reference tie rule
+  kDecLogits = 3     // (optional Y = acc) + per-tile argmax records best[m][tile], reference tie rule
 };
 struct DecGemmArgs {
-  const float* Wt = nullptr;
+  const unsigned short* Wt = nullptr;
+  float w_scale = 1.0f;  // power of two the planes were scaled by (tile_weights_f16)
   int N = 0, K = 0, B = 0;
+  int M = 0;  // rows; 0 = B (one position)
   const float* X = nullptr;
   int ldx = 0;
   const float* xin = nullptr;
   float* xout = nullptr;
   const float* ln_g = nullptr;
   const float* ln_b = nullptr;
-  const long long* ids = nullptr;
+  const long long* ids = nullptr;  // kProLn embedding rows: row p * B + b = tok_emb[ids[b][pos + p]] + pos_emb[pos + p]
   int ids_stride = 0, pos = 0;
   const float* tok_emb = nullptr;
-  const float* pos_emb = nullptr;
+  const float* pos_emb = nullptr;  // the whole table [n_text_ctx][K]
   int n_vocab = 0;
   const float* cross_ws = nullptr;
   int heads = 0, chunks = 0;
@@ -93,10 +97,10 @@ struct DecGemmArgs {
   float* Y = nullptr;
   int ldy = 0;
   unsigned long long* best = nullptr;
-  int resid_waves = 16;  // wavefronts per block of the kDecResid GEMMs (4, 8 or 16)
+  int best_stride = 0;  // records per row; 0 = ceil(N / 32)
   // kProNone + kDecResid with ksplit = 2: twice the blocks, each over half of K (a K = 1536 GEMM on 12 column
   // tiles is bound by what one CU can stream).  Blocks of the first half write Y = R + bias + partial, blocks
-  // of the second half write their raw partial to `part` [B][ldy]; the consumer adds the two (xpart below).
+  // of the second half write their raw partial to `part` [M][ldy]; the consumer adds the two (xpart below).
   int ksplit = 1;
   float* part = nullptr;
   // kProLn: rows = xin + xpart (the pending second half of the previous residual GEMM); block 0 stores the
@@ -142,19 +146,34 @@ void launch_mel_normalize(float* logmel, const unsigned* clip_max, int batch, in
                           hipStream_t s);
 
 // --------------------------------------------------------------- decoder ---
-// Appends k,v of position `pos` (from qkv [B][3d]) to the self-attention cache
-// [2][B][cap][d] and attends q over positions 0..pos.  out [B][d].
-void launch_self_attention(const float* qkv, float* kcache, float* vcache, int cap, int pos,
-                           float* out, int batch, int heads, hipStream_t s);
-// Cross attention of one query row per clip over T cached keys.
-// q [B][d]; kc, vc [B][heads][T][64]; partial results per key chunk in ws
-// [B][heads][chunks][68] (o[64], m, l, pad), combined by the out-projection's prologue (kProCombine).
-void launch_cross_attention(const float* q, const float* kc, const float* vc, float* ws, int batch,
-                            int heads, int T, int chunks, hipStream_t s);
+// Appends k, v of positions pos0 .. pos0 + npos - 1 (from qkv rows p * B + b, [.][3d]) to the self-attention
+// cache [2][B][cap][d] and attends each new position's q causally over positions 0 .. pos0 + p.  out rows likewise.
+void launch_self_attention(const float* qkv, float* kcache, float* vcache, int cap, int pos0, int npos, float* out,
+                           int batch, int heads, hipStream_t s);
+// Cross attention of nq (1..4) query rows per clip over T cached keys, the query projection included:
+// q = LayerNorm(x[row]) . Wq^T + bq with x the residual stream [nq * B][d], rows p * B + b.  wq_t = Wq in the
+// layout of cross_q_layout(); kc, vc [B][heads][T][64]; partial results per key chunk in ws
+// [row][heads][chunks][68] (o[64], m, l, pad), combined by the out-projection's prologue (kProCombine).
+struct CrossAttnArgs {
+  const float* x = nullptr;
+  const float *ln_g = nullptr, *ln_b = nullptr, *wq_t = nullptr, *bq = nullptr;
+  const float *kc = nullptr, *vc = nullptr;
+  float* ws = nullptr;
+  int batch = 0, heads = 0, T = 0, chunks = 1, nq = 1;
+};
+void launch_cross_attention(const CrossAttnArgs& a, hipStream_t s);
 // Greedy selection after the logits GEMM: reduces the per-tile (value, column) records
 // best[B][n_tiles], appends to ids and applies the EOT stop (reference whisper.cpp:397-399).
 void launch_select_token(const unsigned long long* best, int n_tiles, long long* ids, int ids_stride,
                          int pos, int* n_ids, int* finished, long long eot, int stop_at_eot, int batch,
                          hipStream_t s);
+
+// ---- load-time re-layouts of decoder weights (host) ----
+// W [N][K] fp32 -> two fp16 planes in MFMA-fragment order [ceil(N/32)][K/16][plane][64 lanes][8] (rows past N zero):
+// lane (l & 31, l >> 5) of tile t, step s holds W[32t + (l & 31)][16s + 8(l >> 5) .. +7] * scale as hi = fp16(v),
+// lo = fp16(v - hi).  *scale = f16_scale_for(max |W|).  K % 16 == 0.
+std::vector<unsigned short> tile_weights_f16(const float* W, int N, int K, float* scale);
+// Wq [d][d] -> [head][d / 4][64 outputs][4 k] for cross_attention_step's in-kernel query projection
+std::vector<float> cross_q_layout(const float* Wq, int d);
 
 }  // namespace wt
