@@ -727,7 +727,9 @@ int wt_dbg_dec_gemm_bench(wt_engine* h, int kind, int B, int N, int K, int rows,
     wt::DecGemmArgs g;
     g.Wt = dW.w(); g.w_scale = dW.scale; g.N = N; g.K = K; g.B = B; g.M = rows; g.bias = dB.p; g.Y = dY.p; g.ldy = N;
     int pro = wt::kProNone, epi = wt::kDecResid;
+    DevBuf dPart(size_t(rows) * N), dR(hostX.data(), size_t(rows) * N);
     if (kind == 0) { g.X = dX.p; g.ldx = K; g.R = dY.p; }
+    if (kind == 0 && K > 1024) { g.ksplit = 2; g.part = dPart.p; g.R = dR.p; }  // fc2: K split over twice the blocks
     if (kind == 1) { pro = wt::kProLn; epi = wt::kDecBias; g.xin = dX.p; g.ln_g = dG.p; g.ln_b = dG.p; }
     if (kind == 2) { pro = wt::kProCombine; g.cross_ws = dWs.p; g.heads = heads; g.chunks = chunks; g.R = dY.p; }
     hipStream_t st = h->impl->stream();

@@ -660,8 +660,8 @@ __global__ __launch_bounds__(256) void cross_attention_step(const float* __restr
       for (int u = 0; u < U; ++u) {
         const int k = k0 + 16 * u;
         const int kk = k < nk ? k : nk - 1;
-        kv[u] = *reinterpret_cast<const f32x4*>(kb + (long)(kk - grp) * 64);
-        vv[u] = *reinterpret_cast<const f32x4*>(vb + (long)(kk - grp) * 64);
+        kv[u] = *reinterpret_cast<const f32x4*>(kb + (long)kk * 64);
+        vv[u] = *reinterpret_cast<const f32x4*>(vb + (long)kk * 64);
       }
     }
 #pragma unroll

@@ -69,6 +69,7 @@ struct DecGemmDev {
   int ksplit;
   float* part;
   const float* xpart;
+  int lnp_off;  // float offset of the LayerNorm gain / shift staging area in LDS
 };
 
 // Row sources of the residual stream.  LNMODE 0: x = xin;  2: x = tok_emb[id] + pos_emb (row = p * B + b reads
@@ -144,9 +145,11 @@ __device__ __forceinline__ void row_stats(const f32x4 (&v)[NF4], int K, float* m
 template <int PRO, int EPI, int NF4, int LNMODE, int WAVES, int CH, int GT, int SMAX>
 __global__ __launch_bounds__(WAVES * 64) void dec_gemm(DecGemmDev g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  // [GT*32][K + 4] LayerNorm rows (kProLn) and, once they are dead, [WAVES][GT][16][64] split-K partials
+  // [GT*32][K + 4] LayerNorm rows (kProLn) and, once they are dead, [WAVES][GT][16][64] split-K partials; behind
+  // them (kProLn) the LayerNorm gain and shift, [2][K]
   float* const xs = smem;
   float* const red = smem;
+  float* const lnp = smem + g.lnp_off;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
   // ksplit = 2 (kProNone + kDecResid only): blocks [0, n_tiles) take the first half of K and finish the
@@ -158,10 +161,11 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm(DecGemmDev g) {
 
   const int kwave = (K / g.ksplit) / WAVES;  // a multiple of 16 (host-checked)
   const int k0 = khalf * (K / g.ksplit) + wid * kwave;
-  const int nsteps = kwave >> 4;             // <= SMAX (host-checked)
+  const int nsteps = kwave >> 4;             // rounds of SMAX steps
   // weights of this (tile, k-slice): [step][plane][lane][8 halfs]; the stream does not depend on the
   // prologue, so it goes in flight now and its HBM/L2 latency overlaps the LayerNorm / combine work below.
-  // Steps past nsteps re-read the last valid step (no branch around a load) and are never used.
+  // Steps past nsteps re-read the last valid step (no branch around a load) and are never used.  (With more than
+  // SMAX steps or several row groups the registers are refilled per round, below.)
   const unsigned short* wp = g.Wt + ((long)tile * (K >> 4) + (k0 >> 4)) * 1024 + lane * 8;
   u32x4_t wh[SMAX], wl[SMAX];
 #pragma unroll
@@ -169,6 +173,13 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm(DecGemmDev g) {
     const int ss = s < nsteps ? s : nsteps - 1;
     wh[s] = *reinterpret_cast<const u32x4_t*>(wp + (long)ss * 1024);
     wl[s] = *reinterpret_cast<const u32x4_t*>(wp + (long)ss * 1024 + 512);
+  }
+  // LayerNorm gain / shift are row-independent: requested now (one 16-byte load per thread), parked in LDS while
+  // the rows are in flight, read back after the row statistics — not a second dependent trip to memory
+  f32x4 lnreg = {0, 0, 0, 0};
+  if (PRO == kProLn) {
+    const int c4n = K >> 2;  // float4 per vector (<= 128)
+    if (tid < 2 * c4n) lnreg = *reinterpret_cast<const f32x4*>((tid < c4n ? g.ln_g : g.ln_b - K) + tid * 4);
   }
   // the epilogue's column operand does not depend on the product either
   const int n_epi = tile * 32 + l31;
@@ -190,8 +201,12 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm(DecGemmDev g) {
       for (int pass = 0; pass < GT; ++pass) {
         const int lrow = pass * 32 + wid * 8 + r8, row = g0 * 32 + lrow;
         f32x4 v[NV];
+        if (row < M) load_row<NV, LNMODE>(v, src, row < M ? row : M - 1, sub, K);
+        if (g0 == 0 && pass == 0) {
+          if (tid < 2 * (K >> 2)) *reinterpret_cast<f32x4*>(&lnp[tid * 4]) = lnreg;
+          __syncthreads();
+        }
         if (row < M) {
-          load_row<NV, LNMODE>(v, src, row, sub, K);
           if (writer) {
 #pragma unroll
             for (int j = 0; j < NV; ++j)
@@ -202,8 +217,8 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm(DecGemmDev g) {
 #pragma unroll
           for (int j = 0; j < NV; ++j) {
             const int c = (sub + 8 * j) * 4;
-            const f32x4 gg = *reinterpret_cast<const f32x4*>(g.ln_g + c);
-            const f32x4 bb = *reinterpret_cast<const f32x4*>(g.ln_b + c);
+            const f32x4 gg = *reinterpret_cast<const f32x4*>(&lnp[c]);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(&lnp[K + c]);
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (v[j][e] - mean) * rstd * gg[e] + bb[e];
@@ -218,94 +233,123 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm(DecGemmDev g) {
       __syncthreads();
     }
 
+    // the residual rows of the tile this wave will finish do not depend on the product: requested before the
+    // contraction instead of after the split-K combine (one dependent round trip less per launch)
+    float r_pre[EPI == kDecResid ? 16 : 1];
+    if (EPI == kDecResid && khalf == 0 && wid < GT && g0 + wid < m_tiles) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = (g0 + wid) * 32 + crow(r, lh);
+        r_pre[r] = g.R[(long)(m < M ? m : M - 1) * g.ldy + (n_ok ? n_epi : 0)];
+      }
+    }
     f32x16 acc[GT];
 #pragma unroll
-    for (int t = 0; t < GT; ++t) {
+    for (int t = 0; t < GT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-      if (g0 + t >= m_tiles) continue;  // block-uniform
-      const int rowl = t * 32 + l31;
-      int row = (g0 + t) * 32 + l31;
-      row = row < M ? row : M - 1;  // clamped: rows past M are computed and discarded
-      // A fragments of this wave's k-slice: lane (row l31, half lh) holds x[row][k0 + 16 s + 8 lh .. + 7]
-      float xa[SMAX][8];
-      if (PRO == kProCombine) {
-        // the A fragment is the combine of the cross-attention key-chunk partials (o[64], m, l, pad; 68-float
-        // records), computed by the lane that consumes it — no LDS, every load independent
+    // k-slices deeper than SMAX steps (K = 4 d_model without the K split) take several rounds of SMAX steps; each
+    // round has its own activation scale and is scaled back before it is added
+    for (int c0 = 0; c0 < nsteps; c0 += SMAX) {
+      if (c0 > 0 || g0 > 0) {
+        if (nsteps > SMAX) {  // the weight registers hold one round at a time
 #pragma unroll
-        for (int s = 0; s < SMAX; ++s) {
-          const int ss = s < nsteps ? s : nsteps - 1;
-          const int col = k0 + 16 * ss + 8 * lh;
-          const int hh = col >> 6, dd = col & 63;
-          const float* p = g.cross_ws + ((long)(row * g.heads + hh) * CH) * 68;
-          float mc[CH], lc[CH];
-          f32x4 pv0[CH], pv1[CH];
-#pragma unroll
-          for (int c = 0; c < CH; ++c) {  // all loads first: CH is a compile-time constant
-            mc[c] = p[c * 68 + 64];
-            lc[c] = p[c * 68 + 65];
-            pv0[c] = *reinterpret_cast<const f32x4*>(p + c * 68 + dd);
-            pv1[c] = *reinterpret_cast<const f32x4*>(p + c * 68 + dd + 4);
-          }
-          float mxc = mc[0];
-#pragma unroll
-          for (int c = 1; c < CH; ++c) mxc = fmaxf(mxc, mc[c]);
-          float l = 0.0f;
-          f32x4 o0 = {0, 0, 0, 0}, o1 = {0, 0, 0, 0};
-#pragma unroll
-          for (int c = 0; c < CH; ++c) {
-            const float wgt = __expf(mc[c] - mxc);
-            o0 += wgt * pv0[c];
-            o1 += wgt * pv1[c];
-            l += wgt * lc[c];
-          }
-          const float linv = 1.0f / l;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            xa[s][e] = o0[e] * linv;
-            xa[s][4 + e] = o1[e] * linv;
-          }
-        }
-      } else {
-        const float* xp = (PRO == kProLn ? xs + rowl * xld : g.X + (long)row * g.ldx) + k0 + 8 * lh;
-#pragma unroll
-        for (int s = 0; s < SMAX; ++s) {
-          const int ss = s < nsteps ? s : nsteps - 1;
-          const f32x4 a = *reinterpret_cast<const f32x4*>(xp + 16 * ss);
-          const f32x4 b = *reinterpret_cast<const f32x4*>(xp + 16 * ss + 4);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            xa[s][e] = a[e];
-            xa[s][4 + e] = b[e];
+          for (int s = 0; s < SMAX; ++s) {
+            const int ss = c0 + s < nsteps ? c0 + s : nsteps - 1;
+            wh[s] = *reinterpret_cast<const u32x4_t*>(wp + (long)ss * 1024);
+            wl[s] = *reinterpret_cast<const u32x4_t*>(wp + (long)ss * 1024 + 512);
           }
         }
       }
-      // dynamic scale of this (row, k-slice): the largest element goes to [2^14, 2^15), inside fp16's range
-      float mx = 0.0f;
 #pragma unroll
-      for (int s = 0; s < SMAX; ++s)
+      for (int t = 0; t < GT; ++t) {
+        if (g0 + t >= m_tiles) continue;  // block-uniform
+        const int rowl = t * 32 + l31;
+        int row = (g0 + t) * 32 + l31;
+        row = row < M ? row : M - 1;  // clamped: rows past M are computed and discarded
+        // A fragments of this wave's k-slice: lane (row l31, half lh) holds x[row][k0 + 16 s + 8 lh .. + 7]
+        float xa[SMAX][8];
+        if (PRO == kProCombine) {
+          // the A fragment is the combine of the cross-attention key-chunk partials (o[64], m, l, pad; 68-float
+          // records), computed by the lane that consumes it — no LDS, every load independent
 #pragma unroll
-        for (int e = 0; e < 8; ++e) mx = fmaxf(mx, fabsf(xa[s][e]));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const unsigned ex = (__float_as_uint(mx) >> 23) & 0xFFu;
-      const float sc = ex < 32u ? 1.0f : __uint_as_float((268u - ex) << 23);   // 2^(14 - (ex - 127))
-      const float inv = ex < 32u ? 1.0f : __uint_as_float((ex - 14u) << 23);   // 1 / sc
+          for (int s = 0; s < SMAX; ++s) {
+            const int ss = c0 + s < nsteps ? c0 + s : nsteps - 1;
+            const int col = k0 + 16 * ss + 8 * lh;
+            const int hh = col >> 6, dd = col & 63;
+            const float* p = g.cross_ws + ((long)(row * g.heads + hh) * CH) * 68;
+            float mc[CH], lc[CH];
+            f32x4 pv0[CH], pv1[CH];
 #pragma unroll
-      for (int s = 0; s < SMAX; ++s) {
-        if (s < nsteps) {
-          u32x4_t pl[3];
-          split8_f16x2(xa[s], sc, pl);
-          const half8 ah = __builtin_bit_cast(half8, pl[0]), al = __builtin_bit_cast(half8, pl[1]);
-          const half8 bh = __builtin_bit_cast(half8, wh[s]), bl = __builtin_bit_cast(half8, wl[s]);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
+            for (int c = 0; c < CH; ++c) {  // all loads first: CH is a compile-time constant
+              mc[c] = p[c * 68 + 64];
+              lc[c] = p[c * 68 + 65];
+              pv0[c] = *reinterpret_cast<const f32x4*>(p + c * 68 + dd);
+              pv1[c] = *reinterpret_cast<const f32x4*>(p + c * 68 + dd + 4);
+            }
+            float mxc = mc[0];
+#pragma unroll
+            for (int c = 1; c < CH; ++c) mxc = fmaxf(mxc, mc[c]);
+            float l = 0.0f;
+            f32x4 o0 = {0, 0, 0, 0}, o1 = {0, 0, 0, 0};
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+              const float wgt = __expf(mc[c] - mxc);
+              o0 += wgt * pv0[c];
+              o1 += wgt * pv1[c];
+              l += wgt * lc[c];
+            }
+            const float linv = 1.0f / l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              xa[s][e] = o0[e] * linv;
+              xa[s][4 + e] = o1[e] * linv;
+            }
+          }
+        } else {
+          const float* xp = (PRO == kProLn ? xs + rowl * xld : g.X + (long)row * g.ldx) + k0 + 8 * lh;
+#pragma unroll
+          for (int s = 0; s < SMAX; ++s) {
+            const int ss = c0 + s < nsteps ? c0 + s : nsteps - 1;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(xp + 16 * ss);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(xp + 16 * ss + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              xa[s][e] = a[e];
+              xa[s][4 + e] = b[e];
+            }
+          }
         }
-      }
-      // scale back per row: accumulator register r of this lane belongs to row crow(r, lh), whose scale is
-      // held by lane crow(r, lh)
+        // dynamic scale of this (row, k-round): the largest element goes to [2^14, 2^15), inside fp16's range
+        float mx = 0.0f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][r] *= __shfl(inv, crow(r, lh), 64) * g.w_descale;
+        for (int s = 0; s < SMAX; ++s)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) mx = fmaxf(mx, fabsf(xa[s][e]));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const unsigned ex = (__float_as_uint(mx) >> 23) & 0xFFu;
+        const float sc = ex < 32u ? 1.0f : __uint_as_float((268u - ex) << 23);   // 2^(14 - (ex - 127))
+        const float inv = ex < 32u ? 1.0f : __uint_as_float((ex - 14u) << 23);   // 1 / sc
+        f32x16 part;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[r] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < SMAX; ++s) {
+          if (c0 + s < nsteps) {
+            u32x4_t pl[3];
+            split8_f16x2(xa[s], sc, pl);
+            const half8 ah = __builtin_bit_cast(half8, pl[0]), al = __builtin_bit_cast(half8, pl[1]);
+            const half8 bh = __builtin_bit_cast(half8, wh[s]), bl = __builtin_bit_cast(half8, wl[s]);
+            part = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, part, 0, 0, 0);
+            part = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, part, 0, 0, 0);
+            part = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, part, 0, 0, 0);
+          }
+        }
+        // scale back per row: accumulator register r of this lane belongs to row crow(r, lh), whose scale is
+        // held by lane crow(r, lh)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] += part[r] * (__shfl(inv, crow(r, lh), 64) * g.w_descale);
+      }
     }
 
     // split-K combine through LDS, fixed order; tile t of the group is finished by wave t
@@ -339,7 +383,7 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm(DecGemmDev g) {
           continue;
         }
         // R may alias Y: each element is read and written by the same thread
-        if (EPI == kDecResid && ok) v += g.R[(long)m * g.ldy + n_epi];
+        if (EPI == kDecResid && ok) v += r_pre[EPI == kDecResid ? r : 0];
         if (ok && g.Y) g.Y[(long)m * g.ldy + n_epi] = v;
         if (EPI == kDecLogits) {
           // fold (value, column): larger value wins, then the larger column — the reference's
@@ -398,24 +442,32 @@ void launch_one(const DecGemmDev& g, size_t smem, dim3 grid, hipStream_t s) {
   hipLaunchKernelGGL((dec_gemm<PRO, EPI, NF4, LNMODE, WAVES, CH, GT, SMAX>), grid, dim3(WAVES * 64), smem, s, g);
 }
 
-template <int PRO, int EPI, int NF4, int LNMODE, int WAVES, int CH>
-void launch_gt(const DecGemmDev& g, hipStream_t s) {
+template <int PRO, int EPI, int NF4, int LNMODE, int WAVES, int CH, int GT>
+void launch_steps(DecGemmDev g, hipStream_t s) {
   const int n_tiles = (g.N + 31) / 32;
   const dim3 grid(n_tiles * (PRO == kProNone && EPI == kDecResid ? g.ksplit : 1));
-  // row groups of two tiles while the LayerNorm rows of a group fit in LDS (K <= 384: 64 x 388 x 4 B = 99 KB);
-  // one tile per group for K = 512
-  const bool two = !(PRO == kProLn && g.K > 384);
-  const int GT = two ? 2 : 1;
   const size_t red_bytes = (size_t)WAVES * GT * 16 * 64 * sizeof(float);
   const size_t xs_bytes = PRO == kProLn ? (size_t)GT * 32 * (g.K + 4) * sizeof(float) : 0;
-  const size_t smem = red_bytes > xs_bytes ? red_bytes : xs_bytes;
-  const int nsteps = (g.K / g.ksplit) / WAVES / 16;
+  const size_t body = red_bytes > xs_bytes ? red_bytes : xs_bytes;
+  g.lnp_off = (int)(body / sizeof(float));
+  const size_t smem = body + (PRO == kProLn ? (size_t)2 * g.K * sizeof(float) : 0);
+  const int nsteps = (g.K / g.ksplit) / WAVES / 16;  // k-steps per wavefront; deeper slices run in rounds of 8
+  if (nsteps <= 2) launch_one<PRO, EPI, NF4, LNMODE, WAVES, CH, GT, 2>(g, smem, grid, s);
+  else if (nsteps == 3) launch_one<PRO, EPI, NF4, LNMODE, WAVES, CH, GT, 3>(g, smem, grid, s);
+  else if (nsteps == 4) launch_one<PRO, EPI, NF4, LNMODE, WAVES, CH, GT, 4>(g, smem, grid, s);
+  else if (nsteps <= 6) launch_one<PRO, EPI, NF4, LNMODE, WAVES, CH, GT, 6>(g, smem, grid, s);
+  else launch_one<PRO, EPI, NF4, LNMODE, WAVES, CH, GT, 8>(g, smem, grid, s);
+}
+
+template <int PRO, int EPI, int NF4, int LNMODE, int WAVES, int CH>
+void launch_gt(const DecGemmDev& g, hipStream_t s) {
+  // row groups of two 32-row tiles when there is more than one tile, while the LayerNorm rows of a group fit in LDS
+  // (K <= 384: 64 x 388 x 4 B = 99 KB); one tile per group otherwise
+  const bool two = g.M > 32 && !(PRO == kProLn && g.K > 384);
   if (two) {
-    if (nsteps <= 2) launch_one<PRO, EPI, NF4, LNMODE, WAVES, CH, 2, 2>(g, smem, grid, s);
-    else if (nsteps <= 4) launch_one<PRO, EPI, NF4, LNMODE, WAVES, CH, 2, 4>(g, smem, grid, s);
-    else launch_one<PRO, EPI, NF4, LNMODE, WAVES, CH, 2, 8>(g, smem, grid, s);
+    launch_steps<PRO, EPI, NF4, LNMODE, WAVES, CH, 2>(g, s);
   } else {
-    launch_one<PRO, EPI, NF4, LNMODE, WAVES, CH, 1, 8>(g, smem, grid, s);
+    launch_steps<PRO, EPI, NF4, LNMODE, WAVES, CH, 1>(g, s);
   }
 }
 
@@ -439,13 +491,13 @@ void launch_dec_gemm(const DecGemmArgs& a, int pro, int epi, hipStream_t s) {
   DecGemmDev g{a.Wt,      1.0f / a.w_scale, a.N,  a.K,       M,         a.B,     a.X,     a.ldx,   a.xin,  a.xout,
                a.ln_g,    a.ln_b,    a.ids,      a.ids_stride, a.pos,   a.tok_emb, a.pos_emb, a.n_vocab,
                a.cross_ws, a.heads,  a.chunks,   a.bias,    gelu,      a.R,     a.Y,     a.ldy,   a.best,
-               a.best_stride > 0 ? a.best_stride : (a.N + 31) / 32, ksplit, a.part,  a.xpart};
+               a.best_stride > 0 ? a.best_stride : (a.N + 31) / 32, ksplit, a.part,  a.xpart, 0};
   // host-side shape contract: operands must match what the kernel indexes
   const bool resid = epi == kDecResid;  // N = d_model: 8 wavefronts split K
   const int waves = resid ? 8 : 4;
   const int kblock = a.K / ksplit;
   if (!a.Wt || a.B < 1 || M < a.B || M > 128 || M % a.B != 0 || a.K > 2048 || a.K % 16 != 0 || !(a.w_scale > 0.0f) ||
-      ksplit > 2 || kblock % (16 * waves) != 0 || kblock / (16 * waves) > 8 ||
+      ksplit > 2 || kblock % (16 * waves) != 0 ||
       (pro == kProCombine && a.K != a.heads * 64) || (resid && (!a.R || !a.Y))) {
     throw Error(kErrInvalidArg, "decoder GEMM shape outside the kernel contract");
   }

@@ -148,34 +148,41 @@ bool dims_by_name(const char* name, Dims* out) {
   return true;
 }
 
-int write_synthetic(const char* path, const Dims& dims, uint64_t seed, std::string* err) {
-  if (dims.n_audio_state % dims.n_audio_head != 0 || dims.n_text_state % dims.n_text_head != 0 ||
-      dims.n_audio_state != dims.n_text_state) {
-    if (err) *err = "inconsistent dims";
-    return 1;
+std::vector<NamedTensor> tensor_specs(const Dims& dims) {
+  std::vector<NamedTensor> out;
+  for (const Spec& s : build_specs(dims)) out.push_back(NamedTensor{s.name, s.shape, {}});
+  return out;
+}
+
+int write_tensors(const char* path, const Dims& dims, const std::vector<NamedTensor>& tensors, uint64_t seed,
+                  std::string* err) {
+  for (const NamedTensor& t : tensors) {
+    if (t.shape.empty() || t.shape.size() > 4 || t.name.size() >= sizeof(WtwTensor::name) || numel(t.shape) != t.data.size()) {
+      if (err) *err = "bad tensor " + t.name;
+      return 1;
+    }
   }
-  const std::vector<Spec> specs = build_specs(dims);
   WtwHeader hdr;
   std::memset(&hdr, 0, sizeof(hdr));
   hdr.magic = kMagic;
   hdr.version = kVersion;
-  hdr.n_tensors = static_cast<uint32_t>(specs.size());
+  hdr.n_tensors = static_cast<uint32_t>(tensors.size());
   hdr.table_offset = sizeof(WtwHeader);
   hdr.dims = dims;
   hdr.seed = seed;
-  std::vector<WtwTensor> table(specs.size());
-  uint64_t off = sizeof(WtwHeader) + sizeof(WtwTensor) * specs.size();
+  std::vector<WtwTensor> table(tensors.size());
+  uint64_t off = sizeof(WtwHeader) + sizeof(WtwTensor) * tensors.size();
   off = (off + kAlign - 1) / kAlign * kAlign;
   hdr.payload_offset = off;
-  for (size_t i = 0; i < specs.size(); ++i) {
+  for (size_t i = 0; i < tensors.size(); ++i) {
     WtwTensor& t = table[i];
     std::memset(&t, 0, sizeof(t));
-    std::snprintf(t.name, sizeof(t.name), "%s", specs[i].name.c_str());
+    std::snprintf(t.name, sizeof(t.name), "%s", tensors[i].name.c_str());
     t.dtype = 0;
-    t.ndim = static_cast<uint32_t>(specs[i].shape.size());
-    for (size_t k = 0; k < specs[i].shape.size(); ++k) t.shape[k] = specs[i].shape[k];
+    t.ndim = static_cast<uint32_t>(tensors[i].shape.size());
+    for (size_t k = 0; k < tensors[i].shape.size(); ++k) t.shape[k] = tensors[i].shape[k];
     t.offset = off;
-    t.nbytes = numel(specs[i].shape) * sizeof(float);
+    t.nbytes = tensors[i].data.size() * sizeof(float);
     off += (t.nbytes + kAlign - 1) / kAlign * kAlign;
   }
   hdr.file_bytes = off;
@@ -186,40 +193,55 @@ int write_synthetic(const char* path, const Dims& dims, uint64_t seed, std::stri
     return 2;
   }
   bool ok = std::fwrite(&hdr, sizeof(hdr), 1, f) == 1;
-  ok = ok && std::fwrite(table.data(), sizeof(WtwTensor), table.size(), f) == table.size();
-  std::vector<float> buf;
-  uint64_t pos = sizeof(WtwHeader) + sizeof(WtwTensor) * specs.size();
+  ok = ok && (table.empty() || std::fwrite(table.data(), sizeof(WtwTensor), table.size(), f) == table.size());
+  uint64_t pos = sizeof(WtwHeader) + sizeof(WtwTensor) * tensors.size();
   static const char zeros[kAlign] = {0};
-  for (size_t i = 0; ok && i < specs.size(); ++i) {
-    while (pos < table[i].offset) {
-      const uint64_t n = std::min<uint64_t>(kAlign, table[i].offset - pos);
+  auto pad_to = [&](uint64_t target) {
+    while (ok && pos < target) {
+      const uint64_t n = std::min<uint64_t>(kAlign, target - pos);
       ok = ok && std::fwrite(zeros, 1, n, f) == n;
       pos += n;
     }
-    const uint64_t n = numel(specs[i].shape);
-    buf.resize(n);
-    if (specs[i].init == Init::Sinusoid) {
-      fill_sinusoid(buf.data(), specs[i].shape[0], specs[i].shape[1]);
-    } else {
-      const uint64_t key = splitmix64(seed ^ fnv1a(specs[i].name.c_str()));
-      const float sd = static_cast<float>(specs[i].std);
-      const float base = specs[i].init == Init::OnePlusNormal ? 1.0f : 0.0f;
-      for (uint64_t e = 0; e < n; ++e) buf[e] = base + sd * unit_normal(key, e);
-    }
-    ok = ok && std::fwrite(buf.data(), sizeof(float), n, f) == n;
+  };
+  for (size_t i = 0; ok && i < tensors.size(); ++i) {
+    pad_to(table[i].offset);
+    const size_t n = tensors[i].data.size();
+    ok = ok && std::fwrite(tensors[i].data.data(), sizeof(float), n, f) == n;
     pos += n * sizeof(float);
   }
-  while (ok && pos < hdr.file_bytes) {
-    const uint64_t n = std::min<uint64_t>(kAlign, hdr.file_bytes - pos);
-    ok = ok && std::fwrite(zeros, 1, n, f) == n;
-    pos += n;
-  }
+  pad_to(hdr.file_bytes);
   ok = (std::fclose(f) == 0) && ok;
   if (!ok) {
     if (err) *err = std::string("short write: ") + path;
     return 2;
   }
   return 0;
+}
+
+int write_synthetic(const char* path, const Dims& dims, uint64_t seed, std::string* err) {
+  if (dims.n_audio_state % dims.n_audio_head != 0 || dims.n_text_state % dims.n_text_head != 0 ||
+      dims.n_audio_state != dims.n_text_state) {
+    if (err) *err = "inconsistent dims";
+    return 1;
+  }
+  const std::vector<Spec> specs = build_specs(dims);
+  std::vector<NamedTensor> tensors;
+  tensors.reserve(specs.size());
+  for (const Spec& sp : specs) {
+    NamedTensor t{sp.name, sp.shape, {}};
+    const uint64_t n = numel(sp.shape);
+    t.data.resize(n);
+    if (sp.init == Init::Sinusoid) {
+      fill_sinusoid(t.data.data(), sp.shape[0], sp.shape[1]);
+    } else {
+      const uint64_t key = splitmix64(seed ^ fnv1a(sp.name.c_str()));
+      const float sd = static_cast<float>(sp.std);
+      const float base = sp.init == Init::OnePlusNormal ? 1.0f : 0.0f;
+      for (uint64_t e = 0; e < n; ++e) t.data[e] = base + sd * unit_normal(key, e);
+    }
+    tensors.push_back(std::move(t));
+  }
+  return write_tensors(path, dims, tensors, seed, err);
 }
 
 }  // namespace wtw
