@@ -11,6 +11,15 @@ extern "C" {
 /* C[M][N] = epi(A[M][K] . W[N][K]^T); needs N % 128 == 0, K % 32 == 0 */
 int wt_dbg_gemm(wt_engine* h, int M, int N, int K, const float* A, const float* W, const float* bias,
                 const float* R, const float* pos, int pos_period, int epi, float* C);
+/* the default encoder GEMM on fp16 planes (k_gemm_planes.hip): A and W are split on the host with scales from the data;
+ * planes_out != 0 returns the plane output reconstructed as (hi + lo) / scale; iters > 0 also times the launch */
+int wt_dbg_gemm_planes(wt_engine* h, int M, int N, int K, const float* A, const float* W, const float* bias,
+                       const float* R, const float* pos, int pos_period, int epi, int planes_out, int iters, float* C,
+                       float* avg_ms);
+/* encoder attention on planes (k_attention_planes.hip): qkv fp32 [B*T][3*heads*64] is split on the host the way the
+ * qkv GEMM's epilogue writes it; out [B*T][heads*64] reconstructed from the output planes */
+int wt_dbg_encoder_attention_planes(wt_engine* h, int batch, int T, int heads, const float* qkv, int iters, float* out,
+                                    float* avg_ms);
 /* times `iters` back-to-back launches of the encoder GEMM on random operands (HIP events on the
  * engine's stream); variant selects the tile shape (k_gemm.hip) */
 int wt_dbg_gemm_bench(wt_engine* h, int M, int N, int K, int epi, int variant, int iters, float* avg_ms);

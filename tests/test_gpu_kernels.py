@@ -73,6 +73,51 @@ def test_gemm_variants_have_fp32_error(eng, gemm_variant, variant):
     assert (np.abs(eng.dbg_gemm(A, W) - ref) / bound).max() < 1.5e-6, variant  # fp32 accumulation over K = 256
 
 
+@pytest.mark.parametrize("M,N,K", [(192, 128, 32), (300, 256, 96), (1, 128, 64), (257, 384, 416), (1500, 384, 1152), (3000, 1152, 384)])
+def test_plane_gemm_plain_and_plane_output(eng, M, N, K):
+    """The default encoder GEMM: operands as two fp16 planes (split on the host here, by the producing kernels in the
+    engine), three f16 MFMA products, fp32 accumulation.  Same fp32 error budget as the fp32-MFMA kernel; the plane
+    OUTPUT (what the next contraction reads) reconstructs the result to 22 bits."""
+    rng = np.random.default_rng(M * 7 + N + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    ref = A.astype(np.float64) @ W.astype(np.float64).T + bias
+    assert rel_err(eng.dbg_gemm_planes(A, W, bias, epi=1), ref) < 2e-6
+    assert rel_err(eng.dbg_gemm_planes(A, W, bias, epi=3, planes_out=True), gelu(ref)) < 4e-6  # output scale is a loose bound here
+
+
+@pytest.mark.parametrize("epi", [1, 5, 11])
+def test_plane_gemm_epilogues(eng, epi):
+    rng = np.random.default_rng(epi)
+    M, N, K, P = 400, 256, 64, 100
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / 8).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    R = rng.standard_normal((M, N)).astype(np.float32)
+    pos = rng.standard_normal((P, N)).astype(np.float32)
+    C = eng.dbg_gemm_planes(A, W, bias=bias, R=R if epi & 4 else None, pos=pos if epi & 8 else None, epi=epi)
+    ref = A.astype(np.float64) @ W.astype(np.float64).T + bias
+    if epi & 2:
+        ref = gelu(ref)
+    if epi & 8:
+        ref = ref + pos[np.arange(M) % P]
+    if epi & 4:
+        ref = ref + R
+    assert rel_err(C, ref) < 3e-6
+
+
+def test_plane_gemm_is_exact_on_integers(eng):
+    """A = I (padded) against an ASYMMETRIC integer W catches a swapped C/D row-col map or a wrong LDS swizzle."""
+    K, N = 128, 256
+    W = ((np.arange(N)[:, None] * 3 + np.arange(K)[None, :] * 7) % 251).astype(np.float32)
+    A = np.zeros((K + 70, K), np.float32)
+    A[np.arange(K), np.arange(K)] = 1.0
+    A[K:, :] = (np.arange(70)[:, None] % 5 - 2 + (np.arange(K)[None, :] % 3)).astype(np.float32)
+    C = eng.dbg_gemm_planes(A, W, epi=1)
+    assert np.array_equal(C, (A.astype(np.float64) @ W.astype(np.float64).T).astype(np.float32))
+
+
 def test_gemm_split_and_fp32_mfma_agree_to_rounding(eng, gemm_variant):
     """The split kernel and the fp32-MFMA kernel differ only by accumulation-order rounding."""
     rng = np.random.default_rng(99)
@@ -256,6 +301,32 @@ def test_encoder_attention(eng, B, T, H, attn_variant):
             ref = attn_ref(q64[b, :, 0, h], q64[b, :, 1, h], q64[b, :, 2, h])
             got = out.reshape(B, T, H, 64)[b, :, h]
             assert np.abs(got - ref).max() < 2e-5, (b, h)
+
+
+@pytest.mark.parametrize("B,T,H", [(1, 64, 1), (2, 100, 2), (1, 1500, 6), (3, 333, 2), (1, 128, 1)])
+def test_encoder_attention_planes(eng, B, T, H):
+    """The default encoder attention: q, k, v as fp16 planes, V^T fragments by ds_read_b64_tr_b16."""
+    rng = np.random.default_rng(B * 1000 + T + H)
+    d = 64 * H
+    qkv = rng.standard_normal((B * T, 3 * d)).astype(np.float32)
+    out = eng.dbg_encoder_attention_planes(qkv, B, T, H)
+    q = qkv.astype(np.float64).reshape(B, T, 3 * d)
+    for b in range(B):
+        for h in range(H):
+            ref = attn_ref(q[b, :, h * 64:(h + 1) * 64], q[b, :, d + h * 64:d + (h + 1) * 64], q[b, :, 2 * d + h * 64:2 * d + (h + 1) * 64])
+            assert np.abs(out.reshape(B, T, d)[b, :, h * 64:(h + 1) * 64] - ref).max() < 2e-5, (b, h)
+
+
+def test_encoder_attention_planes_forces_rescale(eng):
+    """A key far above the others late in the sequence forces the running-max rescale branch."""
+    rng = np.random.default_rng(4)
+    T, d = 300, 64
+    qkv = rng.standard_normal((T, 3 * d)).astype(np.float32)
+    qkv[250, d:2 * d] = qkv[7, 0:d] * 6.0  # key 250 aligned with query 7: its score dwarfs the earlier ones
+    out = eng.dbg_encoder_attention_planes(qkv, 1, T, 1)
+    q = qkv.astype(np.float64)
+    ref = attn_ref(q[:, 0:64], q[:, 64:128], q[:, 128:192])
+    assert np.abs(out - ref).max() < 2e-5
 
 
 def test_encoder_attention_bf16_mode(eng):

@@ -48,6 +48,7 @@ CAPI_SYMBOLS = [
 DEBUG_SYMBOLS = [
     "wt_dbg_gemm", "wt_dbg_gemm_bench", "wt_dbg_dec_gemm_bench", "wt_dbg_dec_gemm", "wt_dbg_dec_ln_gemm", "wt_dbg_layernorm", "wt_dbg_encoder_attention",
     "wt_dbg_cross_attention", "wt_dbg_self_attention", "wt_dbg_interference", "wt_dbg_concurrency",
+    "wt_dbg_gemm_planes", "wt_dbg_encoder_attention_planes",
 ]
 
 
@@ -135,6 +136,9 @@ def lib() -> ctypes.CDLL:
         L.wt_log_mel_spectrogram.argtypes = [fp, c_int, fp, c_int, c_int, c_int, fp, c_size_t, POINTER(c_int)]
         L.wt_convert_tflite.argtypes = [c_char_p, c_char_p]
         L.wt_dbg_gemm.argtypes = [c_void_p, c_int, c_int, c_int, fp, fp, fp, fp, fp, c_int, c_int, fp]
+        L.wt_dbg_gemm_planes.argtypes = [c_void_p, c_int, c_int, c_int, fp, fp, fp, fp, fp, c_int, c_int, c_int, c_int, fp,
+                                         POINTER(c_float)]
+        L.wt_dbg_encoder_attention_planes.argtypes = [c_void_p, c_int, c_int, c_int, fp, c_int, fp, POINTER(c_float)]
         L.wt_dbg_gemm_bench.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_float)]
         L.wt_dbg_dec_gemm_bench.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_float)]
         L.wt_dbg_dec_gemm.argtypes = [c_void_p, c_int, c_int, c_int, c_int, fp, fp, fp, fp, fp, ip64]
@@ -452,6 +456,28 @@ class Engine:
         self._check(lib().wt_dbg_gemm(self._h, M, N, K, _fp(A), _fp(W), _fp(bias), _fp(R), _fp(pos),
                                       pos.shape[0] if pos is not None else 0, epi, _fp(C)))
         return C
+
+    def dbg_gemm_planes(self, A, W, bias=None, R=None, pos=None, epi=1, planes_out=False, iters=0):
+        """The default encoder GEMM (fp16 planes).  Returns C, or (C, ms per launch) when iters > 0."""
+        A, W = _f32(A), _f32(W)
+        M, K = A.shape
+        N = W.shape[0]
+        C = np.zeros((M, N), np.float32)
+        bias = _f32(bias) if bias is not None else np.zeros(N, np.float32)
+        R = _f32(R) if R is not None else None
+        pos = _f32(pos) if pos is not None else None
+        ms = c_float(0)
+        self._check(lib().wt_dbg_gemm_planes(self._h, M, N, K, _fp(A), _fp(W), _fp(bias), _fp(R), _fp(pos),
+                                             pos.shape[0] if pos is not None else 0, epi, int(planes_out), iters, _fp(C),
+                                             byref(ms)))
+        return (C, ms.value) if iters > 0 else C
+
+    def dbg_encoder_attention_planes(self, qkv, batch, T, heads, iters=0):
+        qkv = _f32(qkv)
+        out = np.zeros((batch * T, heads * 64), np.float32)
+        ms = c_float(0)
+        self._check(lib().wt_dbg_encoder_attention_planes(self._h, batch, T, heads, _fp(qkv), iters, _fp(out), byref(ms)))
+        return (out, ms.value) if iters > 0 else out
 
     def dbg_gemm_bench(self, M, N, K, epi=1, variant=0, iters=10) -> float:
         ms = c_float(0)

@@ -641,6 +641,128 @@ int wt_dbg_gemm(wt_engine* h, int M, int N, int K, const float* A, const float* 
   });
 }
 
+namespace {
+// fp32 [n] -> device planes: hi [n] then lo [n] halfs of x * scale
+struct DevPlanes {
+  void* p = nullptr;
+  long plane = 0;
+  DevPlanes(const float* x, size_t n, float scale, size_t pad = 64) : plane(long(n + pad)) {
+    std::vector<unsigned short> host(2 * (n + pad), 0);
+    for (size_t i = 0; x && i < n; ++i) {
+      const float v = x[i] * scale;
+      const _Float16 hi = static_cast<_Float16>(v), lo = static_cast<_Float16>(v - static_cast<float>(hi));
+      std::memcpy(&host[i], &hi, 2);
+      std::memcpy(&host[n + pad + i], &lo, 2);
+    }
+    hipchk(hipMalloc(&p, host.size() * 2), "hipMalloc");
+    hipchk(hipMemcpy(p, host.data(), host.size() * 2, hipMemcpyHostToDevice), "H2D");
+  }
+  ~DevPlanes() { (void)hipFree(p); }
+  unsigned short* ptr() const { return static_cast<unsigned short*>(p); }
+  // device planes -> fp32 (hi + lo) / scale
+  void to_host(float* out, size_t n, float scale) const {
+    std::vector<unsigned short> host(size_t(2) * plane);
+    hipchk(hipMemcpy(host.data(), p, host.size() * 2, hipMemcpyDeviceToHost), "D2H");
+    for (size_t i = 0; i < n; ++i) {
+      _Float16 hi, lo;
+      std::memcpy(&hi, &host[i], 2);
+      std::memcpy(&lo, &host[size_t(plane) + i], 2);
+      out[i] = (static_cast<float>(hi) + static_cast<float>(lo)) / scale;
+    }
+  }
+};
+float max_abs(const float* x, size_t n) {
+  float m = 0.0f;
+  for (size_t i = 0; i < n; ++i) m = std::max(m, std::fabs(x[i]));
+  return m;
+}
+}  // namespace
+
+int wt_dbg_gemm_planes(wt_engine* h, int M, int N, int K, const float* A, const float* W, const float* bias,
+                       const float* R, const float* pos, int pos_period, int epi, int planes_out, int iters, float* C,
+                       float* avg_ms) {
+  if (!h || !A || !W || !C || N % 128 || K % 32 || M < 1) return WT_ERR_INVALID_ARG;
+  return guarded(h, [&] {
+    const float sa = wt::f16_scale_for(max_abs(A, size_t(M) * K)), sw = wt::f16_scale_for(max_abs(W, size_t(N) * K));
+    const DevPlanes dA(A, size_t(M) * K, sa), dW(W, size_t(N) * K, sw);
+    DevBuf dB(bias, N), dC(R ? R : nullptr, size_t(M) * N), dP(pos, pos ? size_t(pos_period) * N : 0);
+    // plane output: scale from the fp64-free bound sum |a||w| is overkill for a test tap; 2^10 / max |bias| + ... is not
+    // known here, so the caller's outputs are assumed O(max|A| max|W| K): use a conservative power of two
+    const float out_bound = max_abs(A, size_t(M) * K) * max_abs(W, size_t(N) * K) * float(K) + (bias ? max_abs(bias, N) : 0.0f);
+    const float so = wt::f16_scale_for(out_bound);
+    DevPlanes dO(nullptr, size_t(M) * N, 1.0f);
+    wt::PlaneGemmArgs g;
+    g.A = dA.ptr(); g.a_plane = dA.plane; g.lda = K; g.W = dW.ptr(); g.w_plane = dW.plane; g.bias = dB.p;
+    g.C = dC.p; g.R = dC.p; g.ldc = N; g.pos = dP.p; g.pos_period = pos_period > 0 ? pos_period : 1;
+    g.M = M; g.N = N; g.K = K; g.a_scale = sa; g.w_scale = sw;
+    if (planes_out) { g.P = dO.ptr(); g.p_plane = dO.plane; g.out_scale[0] = so; }
+    hipStream_t st = h->impl->stream();
+    wt::launch_gemm_planes(g, epi, st);
+    h->impl->sync();
+    if (planes_out) dO.to_host(C, size_t(M) * N, so); else dC.to_host(C, size_t(M) * N);
+    if (avg_ms && iters > 0 && !(epi & wt::kEpiResidual)) {
+      hipEvent_t e0, e1;
+      hipchk(hipEventCreate(&e0), "event");
+      hipchk(hipEventCreate(&e1), "event");
+      for (int i = 0; i < 3; ++i) wt::launch_gemm_planes(g, epi, st);
+      hipchk(hipEventRecord(e0, st), "record");
+      for (int i = 0; i < iters; ++i) wt::launch_gemm_planes(g, epi, st);
+      hipchk(hipEventRecord(e1, st), "record");
+      hipchk(hipEventSynchronize(e1), "sync");
+      float ms = 0;
+      hipchk(hipEventElapsedTime(&ms, e0, e1), "elapsed");
+      *avg_ms = ms / iters;
+      (void)hipEventDestroy(e0);
+      (void)hipEventDestroy(e1);
+    }
+  });
+}
+
+int wt_dbg_encoder_attention_planes(wt_engine* h, int batch, int T, int heads, const float* qkv, int iters, float* out,
+                                    float* avg_ms) {
+  if (!h || !qkv || !out) return WT_ERR_INVALID_ARG;
+  return guarded(h, [&] {
+    const size_t d = size_t(heads) * 64, rows = size_t(batch) * T;
+    float mq = 0.0f, mk = 0.0f, mv = 0.0f;
+    for (size_t r = 0; r < rows; ++r) {
+      const float* row = qkv + r * 3 * d;
+      for (size_t c = 0; c < d; ++c) {
+        mq = std::max(mq, std::fabs(row[c]));
+        mk = std::max(mk, std::fabs(row[d + c]));
+        mv = std::max(mv, std::fabs(row[2 * d + c]));
+      }
+    }
+    constexpr float kQ = 0.125f * 1.44269504088896340736f;
+    const float sq = wt::f16_scale_for(mq * kQ), sk = wt::f16_scale_for(mk), sv = wt::f16_scale_for(mv), so = wt::f16_scale_for(mv);
+    // planes as the qkv GEMM's epilogue writes them: q * kQ * sq | k * sk | v * sv
+    std::vector<float> scaled(rows * 3 * d);
+    for (size_t r = 0; r < rows; ++r)
+      for (size_t c = 0; c < 3 * d; ++c)
+        scaled[r * 3 * d + c] = qkv[r * 3 * d + c] * (c < d ? kQ * sq : c < 2 * d ? sk : sv);
+    const DevPlanes dQ(scaled.data(), scaled.size(), 1.0f);
+    DevPlanes dO(nullptr, rows * d, 1.0f);
+    hipStream_t st = h->impl->stream();
+    wt::launch_encoder_attention_planes(dQ.ptr(), dQ.plane, dO.ptr(), dO.plane, batch, T, heads, sq, sk, sv, so, st);
+    h->impl->sync();
+    dO.to_host(out, rows * d, so);
+    if (avg_ms && iters > 0) {
+      hipEvent_t e0, e1;
+      hipchk(hipEventCreate(&e0), "event");
+      hipchk(hipEventCreate(&e1), "event");
+      hipchk(hipEventRecord(e0, st), "record");
+      for (int i = 0; i < iters; ++i)
+        wt::launch_encoder_attention_planes(dQ.ptr(), dQ.plane, dO.ptr(), dO.plane, batch, T, heads, sq, sk, sv, so, st);
+      hipchk(hipEventRecord(e1, st), "record");
+      hipchk(hipEventSynchronize(e1), "sync");
+      float ms = 0;
+      hipchk(hipEventElapsedTime(&ms, e0, e1), "elapsed");
+      *avg_ms = ms / iters;
+      (void)hipEventDestroy(e0);
+      (void)hipEventDestroy(e1);
+    }
+  });
+}
+
 int wt_dbg_gemm_bench(wt_engine* h, int M, int N, int K, int epi, int variant, int iters, float* avg_ms) {
   if (!h || N % 128 || K % 32 || iters < 1 || !avg_ms) return WT_ERR_INVALID_ARG;
   return guarded(h, [&] {

@@ -72,6 +72,31 @@ std::vector<float> cross_q_layout(const float* Wq, int d) {
   return out;
 }
 
+// W [N][K] fp32 -> hi plane [N][Kpad], then lo plane [N][Kpad]: fp16(w * scale), fp16(w * scale - hi)
+std::vector<unsigned short> split_weight_planes(const float* W, int N, int K, int Kpad, float scale) {
+  std::vector<unsigned short> out(size_t(2) * N * Kpad, 0);
+  unsigned short* hi = out.data();
+  unsigned short* lo = out.data() + size_t(N) * Kpad;
+  for (int n = 0; n < N; ++n)
+    for (int k = 0; k < K; ++k) {
+      const float v = W[size_t(n) * K + k] * scale;
+      const _Float16 h = static_cast<_Float16>(v);
+      const _Float16 l = static_cast<_Float16>(v - static_cast<float>(h));
+      std::memcpy(hi + size_t(n) * Kpad + k, &h, 2);
+      std::memcpy(lo + size_t(n) * Kpad + k, &l, 2);
+    }
+  return out;
+}
+
+Engine::PlaneW Engine::upload_planes(const float* W, int N, int K, int Kpad, float scale) {
+  const std::vector<unsigned short> planes = split_weight_planes(W, N, K, Kpad, scale);
+  void* p = nullptr;
+  HIPCHK(hipMalloc(&p, planes.size() * sizeof(unsigned short) + 256));
+  allocations_.push_back(p);
+  HIPCHK(hipMemcpy(p, planes.data(), planes.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+  return PlaneW{static_cast<const unsigned short*>(p), long(N) * Kpad};
+}
+
 TiledW Engine::upload_tiled(const float* W, int N, int K) {
   TiledW t;
   const std::vector<unsigned short> planes = tile_weights_f16(W, N, K, &t.scale);
@@ -369,6 +394,34 @@ void Engine::upload_weights(const std::string& path) {
     sc_cross_kv_ = GemmScale{f16_scale_for(vmax(lnp.bound)), f16_scale_for(maxabs(ckv_w.data(), ckv_w.size())), slack_ok(lnp)};
     if (!sc_cross_kv_.f16_ok) ++n_f16_fallbacks_;
   }
+  // ---- encoder weights as fp16 planes (k_gemm_planes.hip): split once, here ----
+  {
+    conv1_kpad_p_ = int(round_up(size_t(3) * nm, 32));
+    std::vector<float> r(size_t(d) * 3 * nm);
+    const float* w = H("encoder.conv1.weight", size_t(d) * nm * 3);
+    for (int co = 0; co < d; ++co)
+      for (int ci = 0; ci < nm; ++ci)
+        for (int kk = 0; kk < 3; ++kk) r[size_t(co) * 3 * nm + kk * nm + ci] = w[(size_t(co) * nm + ci) * 3 + kk];
+    conv1_p_ = upload_planes(r.data(), d, 3 * nm, conv1_kpad_p_, sc_conv1_.w);
+    std::vector<float> r2(size_t(d) * 3 * d);
+    const float* w2 = H("encoder.conv2.weight", size_t(d) * d * 3);
+    for (int co = 0; co < d; ++co)
+      for (int ci = 0; ci < d; ++ci)
+        for (int kk = 0; kk < 3; ++kk) r2[size_t(co) * 3 * d + kk * d + ci] = w2[(size_t(co) * d + ci) * 3 + kk];
+    conv2_p_ = upload_planes(r2.data(), d, 3 * d, 3 * d, sc_conv2_.w);
+    enc_planes_.resize(c.n_audio_layer);
+    const size_t dd3 = size_t(d) * d;
+    for (int l = 0; l < c.n_audio_layer; ++l) {
+      const std::string blk = "encoder.blocks." + std::to_string(l);
+      std::vector<float> wqkv, bqkv;
+      fused_qkv(blk + ".attn", &wqkv, &bqkv);
+      enc_planes_[l].qkv = upload_planes(wqkv.data(), 3 * d, d, d, sc_layers_[l].qkv.w);
+      enc_planes_[l].out = upload_planes(H(blk + ".attn.out.weight", dd3), d, d, d, sc_layers_[l].out.w);
+      enc_planes_[l].fc1 = upload_planes(H(blk + ".mlp.0.weight", 4 * dd3), 4 * d, d, d, sc_layers_[l].fc1.w);
+      enc_planes_[l].fc2 = upload_planes(H(blk + ".mlp.2.weight", 4 * dd3), d, 4 * d, 4 * d, sc_layers_[l].fc2.w);
+    }
+    cross_kv_p_ = upload_planes(ckv_w.data(), c.n_text_layer * 2 * d, d, d, sc_cross_kv_.w);
+  }
 
 }
 
@@ -645,6 +698,8 @@ void Engine::ensure_batch(int batch) {
   }
   ws_.melT = alloc(B * (T0 + 2) * c.n_mels + 256, true);
   ws_.h1p = alloc(B * (T0 + 2) * d + 256, true);
+  ws_.melTp = reinterpret_cast<unsigned short*>(alloc(B * (T0 + 2) * c.n_mels + 256, true));  // 2 planes of halfs
+  ws_.h1pp = reinterpret_cast<unsigned short*>(alloc(B * (T0 + 2) * d + 256, true));
   ws_.x = alloc(B * T * d, false);
   ws_.ln = alloc(B * T * d, false);
   ws_.qkv = alloc(B * T * 3 * d, false);
@@ -777,8 +832,8 @@ void Engine::resolve_kernel_stats(int slot) {
   Slot& sl = slots_[slot];
   // class names = the kernels the current options select (what rocprofv3 lists)
   const long gv = gemm_variant;
-  kstats_[kKcGemm].name = gv < 0 || (gv >= 13 && gv <= 18) ? "gemm_split16_tile" : gv == 11 ? "gemm_bf16_tile" : "gemm_f32_tile";
-  kstats_[kKcEncAttn].name = attn_variant ? "encoder_attention_split" : "encoder_attention_f32";
+  kstats_[kKcGemm].name = use_planes() ? "gemm_planes_tile" : gv < 0 || (gv >= 13 && gv <= 18) ? "gemm_split16_tile" : gv == 11 ? "gemm_bf16_tile" : "gemm_f32_tile";
+  kstats_[kKcEncAttn].name = use_planes() ? "encoder_attention_planes" : attn_variant ? "encoder_attention_split" : "encoder_attention_f32";
   for (auto& k : kstats_) k.launches = 0, k.ms = 0, k.flops = 0, k.bytes = 0;
   for (size_t i = 0; i < sl.kt_cls.size(); ++i) {
     float ms = 0;
@@ -808,6 +863,10 @@ void Engine::encode(const float* d_mel, int batch) {
 void Engine::encode_enqueue(const float* d_mel, int batch) {
   if (dims_.n_audio_state == 0) throw Error(kErrUnsupported, "front-end-only engine: no model weights loaded");
   ensure_batch(batch);
+  if (use_planes()) {
+    encode_enqueue_planes(d_mel, batch);
+    return;
+  }
   const wtw::Dims& c = dims_;
   const int T0 = mel_frames(), T = c.n_audio_ctx, d = c.n_audio_state, M = batch * T;
   Slot& slot = slots_[enc_slot_];
@@ -917,6 +976,124 @@ void Engine::encode_enqueue(const float* d_mel, int batch) {
     g.c_rpb = T; g.kv_batch = batch; g.kv_heads = c.n_text_head; g.kv_dmodel = d;
     kt_begin(kKcGemm, 2.0 * g.M * g.N * g.K, 0);
     launch_gemm(g, kEpiBias | kEpiKvLayout, stream_);
+    kt_end();
+  }
+  HIPCHK(hipEventRecord(slot.enc_done, stream_));
+  slot.used = true;
+  last_enc_slot_ = enc_slot_;
+  enc_slot_ = (enc_slot_ + 1) % kSlots;
+}
+
+// The default encoder: every contraction operand travels as two fp16 planes (k_gemm_planes.hip,
+// k_attention_planes.hip); the residual stream x stays fp32.  Same graph, same scales, same event / timer protocol as
+// encode_enqueue above.
+void Engine::encode_enqueue_planes(const float* d_mel, int batch) {
+  const wtw::Dims& c = dims_;
+  const int T0 = mel_frames(), T = c.n_audio_ctx, d = c.n_audio_state, M = batch * T, nm = c.n_mels;
+  const long Bw = ws_.batch;  // plane strides follow the workspace, not the call
+  Slot& slot = slots_[enc_slot_];
+  if (slot.used) HIPCHK(hipStreamWaitEvent(stream_, slot.dec_done, 0));
+  slot.kt_cls.clear();
+  slot.kt_flops.clear();
+  slot.kt_bytes.clear();
+  slot.batch = batch;
+  if (!trace_base_ && getenv("WT_TRACE_PIPELINE")) {
+    HIPCHK(hipEventCreate(&trace_base_));
+    HIPCHK(hipEventRecord(trace_base_, stream_));
+  }
+  HIPCHK(hipMemsetAsync(slot.d_flag, 0, sizeof(int), stream_));
+  HIPCHK(hipEventRecord(slot.enc_begin, stream_));
+  unsigned short* const lnp = reinterpret_cast<unsigned short*>(ws_.ln);
+  unsigned short* const qkvp = reinterpret_cast<unsigned short*>(ws_.qkv);
+  unsigned short* const attp = reinterpret_cast<unsigned short*>(ws_.att);
+  unsigned short* const hidp = reinterpret_cast<unsigned short*>(ws_.hid);
+  const long melT_plane = Bw * (T0 + 2) * nm + 128, h1p_plane = Bw * (T0 + 2) * d + 128;
+  const long ln_plane = Bw * T * d, qkv_plane = Bw * T * 3 * d, hid_plane = Bw * T * 4 * d;
+
+  kt_begin(kKcTranspose, 0, 2.0 * batch * nm * T0 * 4);
+  launch_mel_transpose_planes(d_mel, ws_.melTp, melT_plane, sc_conv1_.a, batch, nm, T0, nm, stream_);
+  kt_end();
+  {
+    PlaneGemmArgs g;  // conv1 + GELU: rows (clip, t) read melT rows t..t+2 (input t-1..t+1)
+    g.A = ws_.melTp; g.a_plane = melT_plane; g.a_rpb = T0; g.a_bs = long(T0 + 2) * nm; g.lda = nm;
+    g.W = conv1_p_.w; g.w_plane = conv1_p_.plane; g.bias = conv1_b;
+    g.P = ws_.h1pp + d; g.p_plane = h1p_plane;  // row t lands at padded row t + 1
+    g.c_rpb = T0; g.c_bs = long(T0 + 2) * d; g.ldc = d;
+    g.M = batch * T0; g.N = d; g.K = conv1_kpad_p_;
+    g.a_scale = sc_conv1_.a; g.w_scale = sc_conv1_.w; g.out_scale[0] = sc_conv2_.a;
+    kt_begin(kKcGemm, 2.0 * g.M * g.N * (3.0 * nm), 0);
+    launch_gemm_planes(g, kEpiBias | kEpiGelu, stream_);
+    kt_end();
+  }
+  {
+    PlaneGemmArgs g;  // conv2 (stride 2) + GELU + positional embedding
+    g.A = ws_.h1pp; g.a_plane = h1p_plane; g.a_rpb = T; g.a_bs = long(T0 + 2) * d; g.lda = 2 * d;  // output t reads padded rows 2t..2t+2
+    g.W = conv2_p_.w; g.w_plane = conv2_p_.plane; g.bias = conv2_b; g.pos = enc_pos; g.pos_period = T;
+    g.C = ws_.x; g.ldc = d;
+    g.M = M; g.N = d; g.K = 3 * d;
+    g.a_scale = sc_conv2_.a; g.w_scale = sc_conv2_.w;
+    kt_begin(kKcGemm, 2.0 * g.M * g.N * g.K, 0);
+    launch_gemm_planes(g, kEpiBias | kEpiGelu | kEpiPos, stream_);
+    kt_end();
+  }
+  constexpr float kQScale = 0.125f * 1.44269504088896340736f;  // d_head^-1/2 * log2(e): softmax as exp2
+  for (int l = 0; l < c.n_audio_layer; ++l) {
+    const BlockWeights& w = enc_blocks_[l];
+    const EncLayerPlanes& wp = enc_planes_[l];
+    const EncLayerScales& sc = sc_layers_[l];
+    kt_begin(kKcLayerNorm, 0, 2.0 * M * d * 4);
+    launch_layernorm_planes(ws_.x, lnp, ln_plane, sc.qkv.a, nullptr, w.attn_ln_g, w.attn_ln_b, M, d, stream_);
+    kt_end();
+    PlaneGemmArgs q;  // q | k | v, written as the attention kernel's operand planes
+    q.A = lnp; q.a_plane = ln_plane; q.lda = d; q.W = wp.qkv.w; q.w_plane = wp.qkv.plane; q.bias = w.attn.bqkv;
+    q.P = qkvp; q.p_plane = qkv_plane; q.ldc = 3 * d; q.M = M; q.N = 3 * d; q.K = d;
+    q.a_scale = sc.qkv.a; q.w_scale = sc.qkv.w; q.seg = d;
+    q.out_scale[0] = kQScale * sc.q; q.out_scale[1] = sc.k; q.out_scale[2] = sc.v;
+    kt_begin(kKcGemm, 2.0 * q.M * q.N * q.K, 0);
+    launch_gemm_planes(q, kEpiBias, stream_);
+    kt_end();
+    kt_begin(kKcEncAttn, 4.0 * batch * c.n_audio_head * double(T) * T * 64, 0);
+    launch_encoder_attention_planes(qkvp, qkv_plane, attp, ln_plane, batch, T, c.n_audio_head, sc.q, sc.k, sc.v, sc.out.a,
+                                    stream_);
+    kt_end();
+    PlaneGemmArgs o;
+    o.A = attp; o.a_plane = ln_plane; o.lda = d; o.W = wp.out.w; o.w_plane = wp.out.plane; o.bias = w.attn.bo;
+    o.C = ws_.x; o.R = ws_.x; o.ldc = d; o.M = M; o.N = d; o.K = d; o.a_scale = sc.out.a; o.w_scale = sc.out.w;
+    kt_begin(kKcGemm, 2.0 * o.M * o.N * o.K, 0);
+    launch_gemm_planes(o, kEpiBias | kEpiResidual, stream_);
+    kt_end();
+    kt_begin(kKcLayerNorm, 0, 2.0 * M * d * 4);
+    launch_layernorm_planes(ws_.x, lnp, ln_plane, sc.fc1.a, nullptr, w.mlp_ln_g, w.mlp_ln_b, M, d, stream_);
+    kt_end();
+    PlaneGemmArgs f1;
+    f1.A = lnp; f1.a_plane = ln_plane; f1.lda = d; f1.W = wp.fc1.w; f1.w_plane = wp.fc1.plane; f1.bias = w.b1;
+    f1.P = hidp; f1.p_plane = hid_plane; f1.ldc = 4 * d; f1.M = M; f1.N = 4 * d; f1.K = d;
+    f1.a_scale = sc.fc1.a; f1.w_scale = sc.fc1.w; f1.out_scale[0] = sc.fc2.a;
+    kt_begin(kKcGemm, 2.0 * f1.M * f1.N * f1.K, 0);
+    launch_gemm_planes(f1, kEpiBias | kEpiGelu, stream_);
+    kt_end();
+    PlaneGemmArgs f2;
+    f2.A = hidp; f2.a_plane = hid_plane; f2.lda = 4 * d; f2.W = wp.fc2.w; f2.w_plane = wp.fc2.plane; f2.bias = w.b2;
+    f2.C = ws_.x; f2.R = ws_.x; f2.ldc = d; f2.M = M; f2.N = d; f2.K = 4 * d; f2.a_scale = sc.fc2.a; f2.w_scale = sc.fc2.w;
+    kt_begin(kKcGemm, 2.0 * f2.M * f2.N * f2.K, 0);
+    launch_gemm_planes(f2, kEpiBias | kEpiResidual, stream_);
+    kt_end();
+  }
+  kt_begin(kKcLayerNorm, 0, 2.0 * M * d * 4);
+  launch_layernorm_planes(ws_.x, lnp, ln_plane, sc_cross_kv_.a, ws_.enc_out, enc_ln_post_g, enc_ln_post_b, M, d, stream_,
+                          slot.d_flag);
+  HIPCHK(hipMemcpyAsync(slot.h_flag, slot.d_flag, sizeof(int), hipMemcpyDeviceToHost, stream_));
+  kt_end();
+  HIPCHK(hipEventRecord(slot.enc_mid, stream_));
+  {
+    // cross-attention K/V of every decoder layer, projected once per clip into the persistent cache
+    PlaneGemmArgs g;
+    g.A = lnp; g.a_plane = ln_plane; g.lda = d; g.W = cross_kv_p_.w; g.w_plane = cross_kv_p_.plane; g.bias = cross_kv_b;
+    g.C = slot.cross_kv; g.M = M; g.N = c.n_text_layer * 2 * d; g.K = d;
+    g.c_rpb = T; g.kv_batch = batch; g.kv_heads = c.n_text_head; g.kv_dmodel = d;
+    g.a_scale = sc_cross_kv_.a; g.w_scale = sc_cross_kv_.w;
+    kt_begin(kKcGemm, 2.0 * g.M * g.N * g.K, 0);
+    launch_gemm_planes(g, kEpiBias | kEpiKvLayout, stream_);
     kt_end();
   }
   HIPCHK(hipEventRecord(slot.enc_done, stream_));

@@ -198,6 +198,22 @@ class Engine {
   // derived, re-laid-out weights
   const float *conv1_w = nullptr, *conv1_b = nullptr, *conv2_w = nullptr, *conv2_b = nullptr;
   int conv1_kpad = 0;
+  // encoder weights as fp16 planes for the plane GEMM (hi plane, then lo plane at + N * K), scaled by GemmScale::w
+  struct PlaneW {
+    const unsigned short* w = nullptr;
+    long plane = 0;
+  };
+  PlaneW conv1_p_, conv2_p_, cross_kv_p_;
+  struct EncLayerPlanes {
+    PlaneW qkv, out, fc1, fc2;
+  };
+  std::vector<EncLayerPlanes> enc_planes_;
+  PlaneW upload_planes(const float* W, int N, int K, int Kpad, float scale);
+  int conv1_kpad_p_ = 0;  // conv1's K padded to the plane GEMM's k-tile
+  void encode_enqueue_planes(const float* d_mel, int batch);
+  // the plane kernels are the default encoder; an explicit gemm_variant / attn_variant, or a contraction the load-time
+  // slack check gave the full-range form, selects the fp32-storage kernels of k_gemm.hip / k_attention.hip
+  bool use_planes() const { return gemm_variant < 0 && attn_variant == 4 && n_f16_fallbacks_ == 0; }
   const float* enc_pos = nullptr;
   std::vector<BlockWeights> enc_blocks_;
   std::vector<DecBlockWeights> dec_blocks_;
@@ -245,6 +261,9 @@ class Engine {
     int batch = 0;
     float *melT = nullptr, *h1p = nullptr, *x = nullptr, *ln = nullptr, *qkv = nullptr,
           *att = nullptr, *hid = nullptr, *enc_out = nullptr;
+    // plane path (fp16 hi | lo planes; ln / qkv / att / hid reuse the fp32 buffers above, same bytes): the two
+    // zero-padded convolution inputs need buffers of their own (their pad rows sit elsewhere in the plane layout)
+    unsigned short *melTp = nullptr, *h1pp = nullptr;
     // front end
     float *pcm_pad = nullptr, *spec = nullptr, *pw = nullptr, *melacc = nullptr;
     unsigned* clip_max = nullptr;

@@ -1,0 +1,257 @@
+// Encoder self-attention on pre-split operands (gfx950): softmax(q k^T / 8) v per (clip, head), S = 1500, d_head 64,
+// non-causal, flash-style.  Same algorithm and block shape as encoder_attention_split<4, 2> (k_attention.hip) —
+// "swapped" products S^T = K . Q^T and O^T += V^T . P^T so that a softmax row sits on a lane, both contractions
+// as three v_mfma_f32_32x32x16_f16 plane products with fp32 accumulation — but q, k and v ARRIVE as two fp16
+// planes each (written by the qkv GEMM's epilogue, q already multiplied by d_head^-1/2 * log2(e)), so that
+//   * staging a K/V tile is a plain copy (16-byte global load -> ds_write_b128): round 1's kernel re-split every
+//     K and V element on the VALU in each of the 12 query blocks that stream it, and wrote the V^T image with
+//     scattered 4-byte LDS stores (the bank-conflict source rocprof showed: SQ_LDS_BANK_CONFLICT = LDS-active cycles);
+//   * V stays row-major [key][d] in LDS and its transposed MFMA fragments come from ds_read_b64_tr_b16, the hardware
+//     transpose read of gfx950 (each 16-lane group fetches a 4-key x 16-d block column-major);
+//   * both LDS images are XOR-swizzled in 16-byte chunks so that the fragment reads are conflict-free:
+//     K rows (128 B): chunk ^= (key >> 1) & 7 (ds_read_b128, 16-lane groups); V rows: chunk ^= ((key >> 1) & 1) << 2
+//     (a 32-lane half of the tr read covers 4 keys x 64 B = one 256-byte bank row);
+//   * the result leaves as two fp16 planes scaled for the out-projection GEMM.
+// Only the probabilities P = exp2(S^T - m) are split in registers (they are born there).
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace wt {
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using half8 = __attribute__((ext_vector_type(8))) _Float16;
+using half4 = __attribute__((ext_vector_type(4))) _Float16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+typedef short i16x4 __attribute__((__vector_size__(4 * sizeof(short))));
+
+constexpr int AK = 64;              // keys per tile
+constexpr int kPlaneBytes = AK * 128;  // one plane of a K or V tile in LDS
+
+__device__ __forceinline__ int crow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+#define WT_MM16(A, B, ACC) __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, ACC, 0, 0, 0)
+
+__global__ __launch_bounds__(256, 2) void encoder_attention_planes(const _Float16* __restrict__ qkv, long plane,
+                                                                   _Float16* __restrict__ out, long out_plane, int T,
+                                                                   int heads, float s_inv, float o_scale) {
+  // [K hi][K lo][V hi][V lo], 8 KB each
+  __shared__ __attribute__((aligned(16))) unsigned char lds[4 * kPlaneBytes];
+
+  const int d_model = heads * 64, ld = 3 * d_model;
+  const int q_blocks = (T + 127) / 128;
+  // consecutive blocks on one XCD (blockIdx % 8 equal) walk the q-blocks of one (clip, head), so its K/V stay in
+  // that XCD's L2
+  const int nb = gridDim.x, bid = blockIdx.x;
+  const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int bh = logical / q_blocks, qb = logical % q_blocks;
+  const int b = bh / heads, h = bh % heads;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const _Float16* base = qkv + (long)b * T * ld + h * 64;
+
+  // Q planes: lane (q = l31, half lh) holds Q[q][16c + 8lh + 0..7] for k-step c
+  const int q_row = qb * 128 + wid * 32 + l31;
+  const int q_ld = q_row < T ? q_row : T - 1;
+  half8 qh[4], ql[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    qh[c] = *reinterpret_cast<const half8*>(base + (long)q_ld * ld + 16 * c + 8 * lh);
+    ql[c] = *reinterpret_cast<const half8*>(base + plane + (long)q_ld * ld + 16 * c + 8 * lh);
+  }
+
+  f32x16 o0, o1;  // O^T tiles: d in [0,32) and [32,64)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.0f;
+  float m_run = -1e30f, l_run = 0.0f;
+
+  // staging: a tile is 4 planes x 64 rows x 8 chunks of 16 B = 2048 chunks, 8 per thread: thread = (row tid >> 2,
+  // chunk pair tid & 3) for each plane
+  const int srow = tid >> 2, sc0 = (tid & 3) * 2;
+  const _Float16* kbase = base + d_model + sc0 * 8;
+  const _Float16* vbase = base + 2 * d_model + sc0 * 8;
+  u32x4 st[8];
+  auto load_tile = [&](int kt) {
+    const int key = kt * AK + srow;
+    const long ro = (long)(key < T ? key : T - 1) * ld;  // rows past T re-read row T - 1; their scores are masked
+    st[0] = *reinterpret_cast<const u32x4*>(kbase + ro);
+    st[1] = *reinterpret_cast<const u32x4*>(kbase + ro + 8);
+    st[2] = *reinterpret_cast<const u32x4*>(kbase + plane + ro);
+    st[3] = *reinterpret_cast<const u32x4*>(kbase + plane + ro + 8);
+    st[4] = *reinterpret_cast<const u32x4*>(vbase + ro);
+    st[5] = *reinterpret_cast<const u32x4*>(vbase + ro + 8);
+    st[6] = *reinterpret_cast<const u32x4*>(vbase + plane + ro);
+    st[7] = *reinterpret_cast<const u32x4*>(vbase + plane + ro + 8);
+  };
+  const int kx = (srow >> 1) & 7, vx = ((srow >> 1) & 1) << 2;
+  auto store_tile = [&]() {
+    unsigned char* row = lds + srow * 128;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        *reinterpret_cast<u32x4*>(row + p * kPlaneBytes + (((sc0 + e) ^ kx) << 4)) = st[2 * p + e];
+        *reinterpret_cast<u32x4*>(row + (2 + p) * kPlaneBytes + (((sc0 + e) ^ vx) << 4)) = st[4 + 2 * p + e];
+      }
+    }
+  };
+  // fragment addresses.  K: lane (key l31 (+32), half lh), k-step c -> chunk 2c + lh of its row.
+  const int kfx = (l31 >> 1) & 7;
+  // V^T via transposed reads: 16-lane group gi = lane >> 4 covers d = 32 dt + 16 (gi & 1) + (lane & 15) and keys
+  // 16 s + 8 ri + 4 lh + 0..3; lane 4q + p of the group supplies the address of key row q, d columns 4p .. 4p + 3
+  const int vq = (lane >> 2) & 3, vp = lane & 3, vg = (lane >> 4) & 1;
+
+  const int n_tiles = (T + AK - 1) / AK;
+  load_tile(0);
+  for (int kt = 0; kt < n_tiles; ++kt) {
+    store_tile();
+    __syncthreads();
+    if (kt + 1 < n_tiles) load_tile(kt + 1);
+
+    // S^T for the two 32-key halves of the tile
+    f32x16 s0, s1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s0[r] = s1[r] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int slot = ((2 * c + lh) ^ kfx) << 4;
+      const half8 k0h = *reinterpret_cast<const half8*>(lds + l31 * 128 + slot);
+      const half8 k0l = *reinterpret_cast<const half8*>(lds + kPlaneBytes + l31 * 128 + slot);
+      const half8 k1h = *reinterpret_cast<const half8*>(lds + (32 + l31) * 128 + slot);
+      const half8 k1l = *reinterpret_cast<const half8*>(lds + kPlaneBytes + (32 + l31) * 128 + slot);
+      s0 = WT_MM16(k0h, ql[c], s0);
+      s0 = WT_MM16(k0l, qh[c], s0);
+      s0 = WT_MM16(k0h, qh[c], s0);
+      s1 = WT_MM16(k1h, ql[c], s1);
+      s1 = WT_MM16(k1l, qh[c], s1);
+      s1 = WT_MM16(k1h, qh[c], s1);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {  // the operand scales of the planes leave the scores
+      s0[r] *= s_inv;
+      s1[r] *= s_inv;
+    }
+    if ((kt + 1) * AK > T) {  // last tile: keys past T do not exist
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (kt * AK + crow(r, lh) >= T) s0[r] = -1e30f;
+        if (kt * AK + 32 + crow(r, lh) >= T) s1[r] = -1e30f;
+      }
+    }
+    // online softmax; the row (query) lives on lanes l and l ^ 32
+    float tmax = s0[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s0[r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s1[r]);
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m_run, tmax);
+    float psum = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s0[r] = __builtin_amdgcn_exp2f(s0[r] - m_new);
+      s1[r] = __builtin_amdgcn_exp2f(s1[r] - m_new);
+      psum += s0[r] + s1[r];
+    }
+    psum += __shfl_xor(psum, 32, 64);
+    if (__any(m_new != m_run)) {
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        o0[r] *= alpha;
+        o1[r] *= alpha;
+      }
+      m_run = m_new;
+    }
+    l_run += psum;
+    // O^T += V^T . P^T, 16 keys per step: registers 8 s2 .. 8 s2 + 7 of S^T are, unmoved, the B fragment
+    auto pv_half = [&](const f32x16& sp, const int hf) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        half8 ph, pl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float a = sp[8 * s2 + e] * 16384.0f;  // probabilities into fp16's normal range
+          const _Float16 hh = (_Float16)a;
+          ph[e] = hh;
+          pl[e] = (_Float16)(a - (float)hh);
+        }
+        // element j of lane half lh of that fragment is key 16 s2 + 8 (j >> 2) + 4 lh + (j & 3) (the C/D row map of
+        // the S^T accumulator): the V^T fragment takes its keys in the same order
+        const int key0 = hf * 32 + 16 * s2 + 4 * lh;
+        half8 v0h, v0l, v1h, v1l;
+#pragma unroll
+        for (int ri = 0; ri < 2; ++ri) {
+          const int key = key0 + 8 * ri + vq;
+          const int vsw = ((key >> 1) & 1) << 2;
+          // d tile 0: chunk = 2 vg + (vp >> 1) (+ 4 for d tile 1), byte 8 (vp & 1) inside the chunk
+          const unsigned char* r0 = lds + 2 * kPlaneBytes + key * 128 + ((vp & 1) << 3);
+          const int c0 = ((2 * vg + (vp >> 1)) ^ vsw) << 4, c1 = ((4 + 2 * vg + (vp >> 1)) ^ vsw) << 4;
+          const i16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(r0 + c0));
+          const i16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(r0 + kPlaneBytes + c0));
+          const i16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(r0 + c1));
+          const i16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(r0 + kPlaneBytes + c1));
+          const half4 a0h = __builtin_bit_cast(half4, a0), a1h = __builtin_bit_cast(half4, a1);
+          const half4 b0h = __builtin_bit_cast(half4, b0), b1h = __builtin_bit_cast(half4, b1);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v0h[4 * ri + e] = a0h[e];
+            v0l[4 * ri + e] = a1h[e];
+            v1h[4 * ri + e] = b0h[e];
+            v1l[4 * ri + e] = b1h[e];
+          }
+        }
+        o0 = WT_MM16(v0h, pl, o0);
+        o0 = WT_MM16(v0l, ph, o0);
+        o0 = WT_MM16(v0h, ph, o0);
+        o1 = WT_MM16(v1h, pl, o1);
+        o1 = WT_MM16(v1l, ph, o1);
+        o1 = WT_MM16(v1h, ph, o1);
+      }
+    };
+    pv_half(s0, 0);
+    pv_half(s1, 1);
+    __syncthreads();
+  }
+
+  if (q_row < T) {
+    const float inv = o_scale / l_run;  // o_scale = out_scale / (2^14 * v_scale)
+    _Float16* orow = out + ((long)b * T + q_row) * d_model + h * 64;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      half4 ah, al, ch, cl;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float a = o0[4 * g + j] * inv, c = o1[4 * g + j] * inv;
+        const _Float16 x = (_Float16)a, y = (_Float16)c;
+        ah[j] = x;
+        al[j] = (_Float16)(a - (float)x);
+        ch[j] = y;
+        cl[j] = (_Float16)(c - (float)y);
+      }
+      *reinterpret_cast<half4*>(orow + 8 * g + 4 * lh) = ah;
+      *reinterpret_cast<half4*>(orow + out_plane + 8 * g + 4 * lh) = al;
+      *reinterpret_cast<half4*>(orow + 32 + 8 * g + 4 * lh) = ch;
+      *reinterpret_cast<half4*>(orow + out_plane + 32 + 8 * g + 4 * lh) = cl;
+    }
+  }
+}
+#undef WT_MM16
+
+}  // namespace
+
+void launch_encoder_attention_planes(const unsigned short* qkv, long plane, unsigned short* out, long out_plane,
+                                     int batch, int T, int heads, float q_scale, float k_scale, float v_scale,
+                                     float out_scale, hipStream_t stream) {
+  if (batch < 1 || T < 1 || heads < 1 || (3 * heads * 64) % 8 != 0) throw Error(kErrInvalidArg, "encoder attention: bad shape");
+  const int q_blocks = (T + 127) / 128;
+  hipLaunchKernelGGL(encoder_attention_planes, dim3(batch * heads * q_blocks), dim3(256), 0, stream,
+                     reinterpret_cast<const _Float16*>(qkv), plane, reinterpret_cast<_Float16*>(out), out_plane, T, heads,
+                     1.0f / (q_scale * k_scale), out_scale / (16384.0f * v_scale));
+}
+
+}  // namespace wt

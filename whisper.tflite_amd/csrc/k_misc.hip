@@ -54,6 +54,79 @@ __global__ __launch_bounds__(256) void layernorm_rows(const float* __restrict__ 
   }
 }
 
+// LayerNorm rows written as two fp16 planes (hi, lo) of y * scale — the A operand format of the plane GEMM — and
+// optionally as fp32 too (the encoder's final LayerNorm feeds both the cross-KV GEMM and the debug tap).
+template <int PER>
+__global__ __launch_bounds__(256) void layernorm_rows_planes(const float* __restrict__ x, _Float16* __restrict__ yp,
+                                                             long plane, float scale, float* __restrict__ y32,
+                                                             const float* __restrict__ g, const float* __restrict__ b,
+                                                             int M, int d, int* __restrict__ nonfinite) {
+  using half2v = __attribute__((ext_vector_type(2))) _Float16;
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  // lane owns column pairs (2 lane + 128 i, + 1): 4-byte plane stores, 8-byte row loads
+  const float* xr = x + row * d;
+  float v0[PER], v1[PER];
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int c = 2 * lane + 128 * i;
+    const float2 t = c < d ? *reinterpret_cast<const float2*>(xr + c) : float2{0.0f, 0.0f};
+    v0[i] = t.x, v1[i] = t.y;
+    s += t.x + t.y;
+  }
+  const float mean = wave_sum(s) / (float)d;
+  float q = 0.0f;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int c = 2 * lane + 128 * i;
+    const float t0 = c < d ? v0[i] - mean : 0.0f, t1 = c < d ? v1[i] - mean : 0.0f;
+    q += t0 * t0 + t1 * t1;
+  }
+  const float var = wave_sum(q) / (float)d;
+  if (nonfinite != nullptr && lane == 0 && !(fabsf(mean) <= 3.0e38f && var <= 3.0e38f)) atomicOr(nonfinite, 1);
+  const float rstd = rsqrtf(var + 1e-5f);
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int c = 2 * lane + 128 * i;
+    if (c < d) {
+      const float y0 = (v0[i] - mean) * rstd * g[c] + b[c], y1 = (v1[i] - mean) * rstd * g[c + 1] + b[c + 1];
+      if (y32 != nullptr) *reinterpret_cast<float2*>(y32 + row * d + c) = float2{y0, y1};
+      const float a0 = y0 * scale, a1 = y1 * scale;
+      const _Float16 h0 = (_Float16)a0, h1 = (_Float16)a1;
+      *reinterpret_cast<half2v*>(yp + row * d + c) = half2v{h0, h1};
+      *reinterpret_cast<half2v*>(yp + plane + row * d + c) = half2v{(_Float16)(a0 - (float)h0), (_Float16)(a1 - (float)h1)};
+    }
+  }
+}
+
+// mel [B][C][T] -> fp16 planes of melT * scale, [B][T + 2][ld] (rows 1..T, columns < C).  32x32 LDS tile transpose.
+__global__ __launch_bounds__(256) void mel_transpose_planes(const float* __restrict__ mel, _Float16* __restrict__ out,
+                                                            long plane, float scale, int C, int T, int ld) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z, t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const float* src = mel + (long)b * C * T;
+  _Float16* dst = out + (long)b * (T + 2) * ld;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, t = t0 + tx;
+    tile[ty + 8 * i][tx] = (c < C && t < T) ? src[(long)c * T + t] : 0.0f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int t = t0 + ty + 8 * i, c = c0 + tx;
+    if (c < C && t < T) {
+      const float a = tile[tx][ty + 8 * i] * scale;
+      const _Float16 h = (_Float16)a;
+      dst[(long)(t + 1) * ld + c] = h;
+      dst[plane + (long)(t + 1) * ld + c] = (_Float16)(a - (float)h);
+    }
+  }
+}
+
 // mel [B][C][T] -> melT [B][T + 2][C] (rows 1..T).  32x32 LDS tile transpose.
 __global__ __launch_bounds__(256) void mel_transpose(const float* __restrict__ mel,
                                                      float* __restrict__ melT, int C, int T) {
@@ -199,6 +272,28 @@ void launch_layernorm(const float* x, float* y, const float* g, const float* b, 
   } else {
     throw Error(kErrFormat, "LayerNorm kernel supports rows of at most 512 elements");
   }
+}
+
+void launch_layernorm_planes(const float* x, unsigned short* yp, long plane, float scale, float* y32, const float* g,
+                             const float* b, int M, int d, hipStream_t s, int* nonfinite) {
+  const int blocks = (M + 3) / 4;
+  _Float16* y = reinterpret_cast<_Float16*>(yp);
+  if (d % 2 != 0) throw Error(kErrFormat, "LayerNorm plane kernel needs an even row length");
+  if (d <= 128) {
+    hipLaunchKernelGGL(layernorm_rows_planes<1>, dim3(blocks), dim3(256), 0, s, x, y, plane, scale, y32, g, b, M, d, nonfinite);
+  } else if (d <= 384) {
+    hipLaunchKernelGGL(layernorm_rows_planes<3>, dim3(blocks), dim3(256), 0, s, x, y, plane, scale, y32, g, b, M, d, nonfinite);
+  } else if (d <= 512) {
+    hipLaunchKernelGGL(layernorm_rows_planes<4>, dim3(blocks), dim3(256), 0, s, x, y, plane, scale, y32, g, b, M, d, nonfinite);
+  } else {
+    throw Error(kErrFormat, "LayerNorm kernel supports rows of at most 512 elements");
+  }
+}
+
+void launch_mel_transpose_planes(const float* mel, unsigned short* out, long plane, float scale, int batch, int n_mels,
+                                 int T, int ld, hipStream_t s) {
+  hipLaunchKernelGGL(mel_transpose_planes, dim3((T + 31) / 32, (n_mels + 31) / 32, batch), dim3(256), 0, s, mel,
+                     reinterpret_cast<_Float16*>(out), plane, scale, n_mels, T, ld);
 }
 
 __global__ void chain_probe(float* p) {

@@ -59,6 +59,41 @@ int gemm_occupancy(int variant);
 // variants launch_gemm accepts: 0 fp32 MFMA, 11 bf16 operands, 13/16 three bf16 planes, 17/18 two fp16 planes
 bool gemm_variant_supported(int variant);
 
+// ------------------------------------------------------- GEMM on fp16 planes ---
+// The default encoder GEMM (k_gemm_planes.hip): both operands are pairs of fp16 planes (hi = fp16(x * scale), lo =
+// fp16(x * scale - hi); 4 bytes per element like fp32).  A planes: hi at A, lo at A + a_plane (element offsets, same
+// row addressing as GemmArgs); W planes [N][K]: hi at W, lo at W + w_plane (split_weight_planes).  Output: fp32 C
+// (epilogues kEpiBias, | kEpiResidual, | kEpiGelu | kEpiPos, | kEpiKvLayout) or, when P != nullptr, planes of the
+// result for the next contraction (kEpiBias, | kEpiGelu): column n multiplied by out_scale[n / seg] before the split.
+// Requires N % 128 == 0, K % 32 == 0, lda / a_bs / ldc / c_bs multiples of 8 elements.
+struct PlaneGemmArgs {
+  const unsigned short* A = nullptr;
+  long a_plane = 0;
+  const unsigned short* W = nullptr;
+  long w_plane = 0;
+  float* C = nullptr;
+  unsigned short* P = nullptr;
+  long p_plane = 0;
+  const float* bias = nullptr;
+  const float* R = nullptr;
+  const float* pos = nullptr;
+  int M = 0, N = 0, K = 0;
+  int a_rpb = 1 << 30;
+  long a_bs = 0;
+  int lda = 0;
+  int c_rpb = 1 << 30;
+  long c_bs = 0;
+  int ldc = 0;
+  int pos_period = 1;
+  int kv_batch = 0, kv_heads = 0, kv_dmodel = 0;
+  float a_scale = 1.0f, w_scale = 1.0f;  // the powers of two baked into the A and W planes
+  float out_scale[3] = {1.0f, 1.0f, 1.0f};
+  int seg = 0;  // columns per out_scale segment (0 = one segment)
+};
+void launch_gemm_planes(const PlaneGemmArgs& a, int epi, hipStream_t s);
+// W [N][K] fp32 -> hi plane [N][Kpad] followed by lo plane [N][Kpad] (Kpad >= K, zero filled), scaled by `scale`
+std::vector<unsigned short> split_weight_planes(const float* W, int N, int K, int Kpad, float scale);
+
 // Decoder-step GEMM: out[M][N] = epi(pro(x)[M][K] . W[N][K]^T), M = positions x B clips <= 128 rows (row =
 // p * B + b), k_decoder.hip.  Wt is W as two fp16 planes in MFMA-fragment order, made by tile_weights_f16():
 // [ceil(N/32)][K/16][plane hi|lo][64 lanes][8], scaled by w_scale.
@@ -116,6 +151,10 @@ void launch_dec_finalize_ln(const float* xin, const float* g, const float* b, fl
 // y[m][:] = (x[m][:] - mean) * rstd * g + b, eps 1e-5, one wavefront per row.
 void launch_layernorm(const float* x, float* y, const float* g, const float* b, int M, int d,
                       hipStream_t s, int* nonfinite = nullptr);
+// Same rows, written as two fp16 planes of y * scale (hi at yp, lo at yp + plane) for the plane GEMM, and
+// optionally (y32 != nullptr) also as fp32.
+void launch_layernorm_planes(const float* x, unsigned short* yp, long plane, float scale, float* y32, const float* g,
+                             const float* b, int M, int d, hipStream_t s, int* nonfinite = nullptr);
 
 // ------------------------------------------------------ encoder attention ---
 // qkv [B*T][3*d] (q | k | v, heads of 64 inside each third) -> out [B*T][d].
@@ -124,6 +163,12 @@ void launch_layernorm(const float* x, float* y, const float* g, const float* b, 
 // q_scale, k_scale, v_scale: f16_scale_for() of the operands' bounds (variant 4 only)
 void launch_encoder_attention(const float* qkv, float* out, int batch, int T, int heads, int variant,
                               hipStream_t stream, float q_scale = 1.0f, float k_scale = 1.0f, float v_scale = 1.0f);
+// The same attention on pre-split operands (k_attention_planes.hip): qkv as fp16 planes [B*T][3d] (hi at qkv, lo at
+// qkv + plane), q already multiplied by d_head^-1/2 * log2(e) * q_scale, k by k_scale, v by v_scale (the plane GEMM's
+// out_scale); output planes of the attention result * out_scale, [B*T][d], hi at out, lo at out + out_plane.
+void launch_encoder_attention_planes(const unsigned short* qkv, long plane, unsigned short* out, long out_plane,
+                                     int batch, int T, int heads, float q_scale, float k_scale, float v_scale,
+                                     float out_scale, hipStream_t stream);
 
 // ------------------------------------------------------------- front end ---
 // mel [B][n_mels][T] -> melT [B][T + 2][n_mels] rows 1..T (rows 0 and T+1 stay zero).
@@ -131,6 +176,10 @@ void launch_encoder_attention(const float* qkv, float* out, int batch, int T, in
 void launch_chain_probe(float* p, int blocks, hipStream_t stream);
 void launch_mel_transpose(const float* mel, float* melT, int batch, int n_mels, int T,
                           hipStream_t s);
+// mel [B][n_mels][T] -> fp16 planes of melT * scale, [B][T + 2][ld] rows 1..T, columns [0, n_mels) (the rest and
+// rows 0, T + 1 stay zero): hi at out, lo at out + plane
+void launch_mel_transpose_planes(const float* mel, unsigned short* out, long plane, float scale, int batch, int n_mels,
+                                 int T, int ld, hipStream_t s);
 // spec [M][ld] holding re parts of all n_fft bins at columns [0,n_fft) and im parts at
 // [im_off, im_off+n_fft) -> pw [M][ldp]: |X[k]|^2 (+ |X[n_fft-k]|^2 for 0 < k < n_fft/2, the
 // reference's mirror fold) for k <= n_fft/2; columns above zeroed up to ldp.
