@@ -71,6 +71,18 @@ __device__ __forceinline__ void split2_f16x2(float lo, float hi, float scale, un
   o[1] = __builtin_bit_cast(unsigned, half2_t{la, lb});
 }
 
+// One value -> (hi, lo) fp16 planes.  `a` is first pinned to ONE fp32 value: where a is itself the result of a
+// multiply by something that is not a power of two (o * (1 / l) in the attention epilogue), hipcc is otherwise free to
+// make hi = fp16(a) with a fused multiply-convert (one rounding from the exact product) and to subtract the
+// fp32-rounded product for lo; near a rounding tie of the fp16 grid the two disagree about which way hi went and the
+// pair is off by one ulp of hi (measured: 1 element in ~10^4, error 2^-11 relative — tools/attn_diag.py).
+__device__ __forceinline__ void split_f16(float a, _Float16* hi, _Float16* lo) {
+  asm volatile("" : "+v"(a));
+  const _Float16 h = (_Float16)a;
+  *hi = h;
+  *lo = (_Float16)(a - (float)h);
+}
+
 // bf16 compute mode (BASELINE configs[3]): 8 values rounded to nearest-even bf16, one fragment
 __device__ __forceinline__ u32x4_t round8_bf16(const float (&x)[8]) {
   u32x4_t o;

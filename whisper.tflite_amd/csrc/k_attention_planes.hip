@@ -15,6 +15,7 @@
 // Only the probabilities P = exp2(S^T - m) are split in registers (they are born there).
 #include <hip/hip_runtime.h>
 
+#include "bf16_split.h"
 #include "kernels.h"
 
 namespace wt {
@@ -175,10 +176,10 @@ __global__ __launch_bounds__(256, 2) void encoder_attention_planes(const _Float1
         half8 ph, pl;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float a = sp[8 * s2 + e] * 16384.0f;  // probabilities into fp16's normal range
-          const _Float16 hh = (_Float16)a;
+          _Float16 hh, ll;
+          split_f16(sp[8 * s2 + e] * 16384.0f, &hh, &ll);  // probabilities into fp16's normal range
           ph[e] = hh;
-          pl[e] = (_Float16)(a - (float)hh);
+          pl[e] = ll;
         }
         // element j of lane half lh of that fragment is key 16 s2 + 8 (j >> 2) + 4 lh + (j & 3) (the C/D row map of
         // the S^T accumulator): the V^T fragment takes its keys in the same order
@@ -226,12 +227,13 @@ __global__ __launch_bounds__(256, 2) void encoder_attention_planes(const _Float1
       half4 ah, al, ch, cl;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float a = o0[4 * g + j] * inv, c = o1[4 * g + j] * inv;
-        const _Float16 x = (_Float16)a, y = (_Float16)c;
+        _Float16 x, xl, y, yl;
+        split_f16(o0[4 * g + j] * inv, &x, &xl);
+        split_f16(o1[4 * g + j] * inv, &y, &yl);
         ah[j] = x;
-        al[j] = (_Float16)(a - (float)x);
+        al[j] = xl;
         ch[j] = y;
-        cl[j] = (_Float16)(c - (float)y);
+        cl[j] = yl;
       }
       *reinterpret_cast<half4*>(orow + 8 * g + 4 * lh) = ah;
       *reinterpret_cast<half4*>(orow + out_plane + 8 * g + 4 * lh) = al;

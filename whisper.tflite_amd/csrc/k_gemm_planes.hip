@@ -16,6 +16,7 @@
 // group of a ds_read_b128 covers all 64 banks once.
 #include <hip/hip_runtime.h>
 
+#include "bf16_split.h"
 #include "kernels.h"
 
 namespace wt {
@@ -232,10 +233,10 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_tile(PlaneGemmDev g) {
           half8 hi, lo;
 #pragma unroll
           for (int e = 0; e < CPL; ++e) {
-            const float s = v[e] * oscale;
-            const _Float16 h = (_Float16)s;
+            _Float16 h, l;
+            split_f16(v[e] * oscale, &h, &l);
             hi[e] = h;
-            lo[e] = (_Float16)(s - (float)h);
+            lo[e] = l;
           }
           *reinterpret_cast<half8*>(g.P + o) = hi;
           *reinterpret_cast<half8*>(g.P + g.p_plane + o) = lo;

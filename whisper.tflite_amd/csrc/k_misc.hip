@@ -3,6 +3,7 @@
 // and the decoder's token embedding / greedy selection (whisper.cpp:346-361, :392-399).
 #include <hip/hip_runtime.h>
 
+#include "bf16_split.h"
 #include "kernels.h"
 
 namespace wt {
@@ -93,10 +94,11 @@ __global__ __launch_bounds__(256) void layernorm_rows_planes(const float* __rest
     if (c < d) {
       const float y0 = (v0[i] - mean) * rstd * g[c] + b[c], y1 = (v1[i] - mean) * rstd * g[c + 1] + b[c + 1];
       if (y32 != nullptr) *reinterpret_cast<float2*>(y32 + row * d + c) = float2{y0, y1};
-      const float a0 = y0 * scale, a1 = y1 * scale;
-      const _Float16 h0 = (_Float16)a0, h1 = (_Float16)a1;
+      _Float16 h0, l0, h1, l1;
+      split_f16(y0 * scale, &h0, &l0);
+      split_f16(y1 * scale, &h1, &l1);
       *reinterpret_cast<half2v*>(yp + row * d + c) = half2v{h0, h1};
-      *reinterpret_cast<half2v*>(yp + plane + row * d + c) = half2v{(_Float16)(a0 - (float)h0), (_Float16)(a1 - (float)h1)};
+      *reinterpret_cast<half2v*>(yp + plane + row * d + c) = half2v{l0, l1};
     }
   }
 }
@@ -119,10 +121,10 @@ __global__ __launch_bounds__(256) void mel_transpose_planes(const float* __restr
   for (int i = 0; i < 4; ++i) {
     const int t = t0 + ty + 8 * i, c = c0 + tx;
     if (c < C && t < T) {
-      const float a = tile[tx][ty + 8 * i] * scale;
-      const _Float16 h = (_Float16)a;
+      _Float16 h, l;
+      split_f16(tile[tx][ty + 8 * i] * scale, &h, &l);
       dst[(long)(t + 1) * ld + c] = h;
-      dst[plane + (long)(t + 1) * ld + c] = (_Float16)(a - (float)h);
+      dst[plane + (long)(t + 1) * ld + c] = l;
     }
   }
 }
