@@ -83,6 +83,33 @@ __device__ __forceinline__ void split_f16(float a, _Float16* hi, _Float16* lo) {
   *lo = (_Float16)(a - (float)h);
 }
 
+// erf for the GELU epilogues of the plane GEMM (one evaluation per output element: 73.7 M per fc1 launch).  The
+// library erff costs ~37 VALU instructions and a divergent branch per element there (measured in the ISA: the GELU
+// epilogue was as long as the K = 384 main loop).  Same two-interval minimax scheme, evaluated branch-free: both
+// polynomials, one raw v_exp_f32, one select.  Maximum absolute error 6e-8 against fp64 erf (tests/test_gpu_kernels.py
+// holds the GELU epilogue to the same bound as before), i.e. what 1 + erf(x) can resolve in fp32.
+__device__ __forceinline__ float erf_fast(float a) {
+  const float t = fabsf(a), s = a * a;
+  // |a| > 0.927734375: erf = sign(a) (1 - exp(p(t)))
+  float r = fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
+  const float u = fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
+  r = fmaf(r, s, u);
+  r = fmaf(r, t, -1.06777877e-1f);
+  r = fmaf(r, t, -6.34846687e-1f);
+  r = fmaf(r, t, -1.28717512e-1f);
+  r = fmaf(r, t, -t);
+  const float big = copysignf(1.0f - __builtin_amdgcn_exp2f(r * 1.44269504088896340736f), a);
+  // |a| <= 0.927734375: erf = a + a q(a^2)
+  float q = -5.96761703e-4f;
+  q = fmaf(q, s, 4.99119423e-3f);
+  q = fmaf(q, s, -2.67681349e-2f);
+  q = fmaf(q, s, 1.12819925e-1f);
+  q = fmaf(q, s, -3.76125336e-1f);
+  q = fmaf(q, s, 1.28379166e-1f);
+  const float small = fmaf(q, a, a);
+  return t > 0.927734375f ? big : small;
+}
+
 // bf16 compute mode (BASELINE configs[3]): 8 values rounded to nearest-even bf16, one fragment
 __device__ __forceinline__ u32x4_t round8_bf16(const float (&x)[8]) {
   u32x4_t o;

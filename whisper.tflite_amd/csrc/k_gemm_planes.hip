@@ -16,6 +16,8 @@
 // group of a ds_read_b128 covers all 64 banks once.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "bf16_split.h"
 #include "kernels.h"
 
@@ -28,16 +30,11 @@ using half8 = __attribute__((ext_vector_type(8))) _Float16;
 using half4 = __attribute__((ext_vector_type(4))) _Float16;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
-constexpr int BM = 192, BN = 128, BK = 32;
-constexpr int MI = 3, NI = 2;                       // MFMA tiles per wavefront (rows, columns)
-constexpr int kAPlane = BM * BK * 2;                // bytes of one A plane of a stage
-constexpr int kWPlane = BN * BK * 2;
-constexpr int kStage = 2 * kAPlane + 2 * kWPlane;   // 40960
-constexpr int kInstr = kStage / 1024;               // LDS-DMA wave-instructions per stage (40)
-constexpr int SLD = NI * 32 + 4;                    // epilogue staging row stride (floats)
+constexpr int BM = 192, BK = 32;
+constexpr int MI = 3;  // 32-row MFMA tiles per wavefront: two wavefront rows of 96
 
 __device__ __forceinline__ float gelu_erf(float x) {
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+  return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f));
 }
 
 struct PlaneGemmDev {
@@ -45,8 +42,8 @@ struct PlaneGemmDev {
   long a_plane;
   const _Float16* W;   // hi plane [N][K]; lo plane at W + w_plane
   long w_plane;
-  float* C;            // fp32 output (kOutF32)
-  _Float16* P;         // plane output (kOutPlanes): hi at P, lo at P + p_plane
+  float* C;            // fp32 output
+  _Float16* P;         // plane output: hi at P, lo at P + p_plane
   long p_plane;
   const float* bias;
   const float* R;
@@ -65,8 +62,21 @@ struct PlaneGemmDev {
   int seg;
 };
 
-template <int EPI, bool PLANES_OUT>
-__global__ __launch_bounds__(256, 2) void gemm_planes_tile(PlaneGemmDev g) {
+// Block tile 192 x BN with BN = WN * NI * 32: 2 x WN wavefronts, each owning 3 x NI MFMA tiles.
+//   WN 2, NI 2: 192 x 128, 4 wavefronts, 40 KB per stage, two blocks per CU (round 2's first shape);
+//   WN 4, NI 3: 192 x 384, 8 wavefronts, 72 KB per stage, one block per CU.  What bounds this kernel is the LDS-DMA
+//   round trip (one k-tile of prefetch distance, ~2 us under load) against the bytes a CU can hold in flight (LDS):
+//   the wide tile contracts 197 FLOP per staged byte instead of 118 and needs 24 ds_read_b128 per 54 MFMAs instead of
+//   20 per 36.  Every N of the encoder (384, 1152, 1536, 3072) is a multiple of 384, and 250 row tiles x {1, 3, 4, 8}
+//   column tiles fill 0.98 / 2.93 / 3.9 / 7.8 rounds of the 256 CUs.
+template <int EPI, bool PLANES_OUT, int WN, int NI>
+__global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 2) void gemm_planes_tile(PlaneGemmDev g) {
+  constexpr int BN = WN * NI * 32, NW = 2 * WN;
+  constexpr int kAPlane = BM * BK * 2, kWPlane = BN * BK * 2;  // bytes of one plane of a stage
+  constexpr int kStage = 2 * kAPlane + 2 * kWPlane;
+  constexpr int QA = BM / 16, QW = BN / 16;                   // LDS-DMA instructions per A / W plane (16 rows each)
+  constexpr int QT = 2 * QA + 2 * QW, QPW = QT / NW;          // per stage, per wavefront
+  static_assert(QT % NW == 0, "whole instructions per wavefront");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   // XCD-aware bijective remap: blocks with equal blockIdx % 8 share an XCD (speed only).
@@ -79,47 +89,38 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_tile(PlaneGemmDev g) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wid >> 1, wn = wid & 1;
+  const int wm = wid / WN, wn = wid % WN;
   const int l31 = lane & 31, lh = lane >> 5;
 
-  // ---- LDS-DMA source addresses.  Wave w issues instructions q = w, w + 4, ...: q in [0,12) A hi rows 16q..,
-  // [12,24) A lo, [24,32) W hi, [32,40) W lo.  Lane i writes LDS slot (row i >> 2, chunk i & 3) of its instruction
-  // and reads the global chunk (i & 3) ^ ((row >> 2) & 3) of that row.
+  // ---- LDS-DMA source addresses.  Instruction q of a stage copies 16 rows x 64 B: q in [0, QA) A hi, [QA, 2 QA) A lo,
+  // [2 QA, 2 QA + QW) W hi, then W lo; its LDS destination is the stage base + q * 1024 (lane-linear).  Wave w issues
+  // q = w, w + NW, ...  Lane i fills LDS slot (row i >> 2, chunk i & 3) of its instruction with the global chunk
+  // (i & 3) ^ ((row >> 2) & 3) of that row: the XOR swizzle lives on the SOURCE side.
   const int srow = lane >> 2;
-  const _Float16* a_src[3];
-  const _Float16* w_src[2];
+  const _Float16* src[QPW];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const int row = 16 * (wid + 4 * j) + srow;                      // row inside the A tile
-    int m = m0 + row;
-    m = m < g.M ? m : g.M - 1;                                      // clamp: rows past M are computed and discarded
+  for (int j = 0; j < QPW; ++j) {
+    const int q = wid + NW * j;
+    const bool is_a = q < 2 * QA;
+    const int qq = is_a ? (q < QA ? q : q - QA) : (q - 2 * QA < QW ? q - 2 * QA : q - 2 * QA - QW);
+    const bool lo = is_a ? q >= QA : q - 2 * QA >= QW;
+    const int row = 16 * qq + srow;
     const int chunk = (lane & 3) ^ ((row >> 2) & 3);
-    a_src[j] = g.A + (long)(m / g.a_rpb) * g.a_bs + (long)(m % g.a_rpb) * g.lda + chunk * 8;
-  }
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int row = 16 * (wid + 4 * j) + srow;                      // row inside the W tile
-    const int chunk = (lane & 3) ^ ((row >> 2) & 3);
-    w_src[j] = g.W + (long)(n0 + row) * g.K + chunk * 8;
+    if (is_a) {
+      int m = m0 + row;
+      m = m < g.M ? m : g.M - 1;  // clamp: rows past M are computed and discarded
+      src[j] = g.A + (lo ? g.a_plane : 0) + (long)(m / g.a_rpb) * g.a_bs + (long)(m % g.a_rpb) * g.lda + chunk * 8;
+    } else {
+      src[j] = g.W + (lo ? g.w_plane : 0) + (long)(n0 + row) * g.K + chunk * 8;
+    }
   }
   auto issue_stage = [&](int kt, int buf) {
     unsigned char* base = smem + buf * kStage;
     const int ko = kt * BK;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int q = wid + 4 * j;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[j] + ko),
-                                       (__attribute__((address_space(3))) void*)(base + q * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[j] + g.a_plane + ko),
-                                       (__attribute__((address_space(3))) void*)(base + kAPlane + q * 1024), 16, 0, 0);
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int q = wid + 4 * j;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[j] + ko),
-                                       (__attribute__((address_space(3))) void*)(base + 2 * kAPlane + q * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[j] + g.w_plane + ko),
-                                       (__attribute__((address_space(3))) void*)(base + 2 * kAPlane + kWPlane + q * 1024), 16, 0, 0);
+    for (int j = 0; j < QPW; ++j) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + ko),
+                                       (__attribute__((address_space(3))) void*)(base + (wid + NW * j) * 1024), 16, 0, 0);
     }
   };
 
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_tile(PlaneGemmDev g) {
 
   // fragment addresses: row = tile base (a multiple of 32) + l31, so the swizzle term depends on the lane only
   const int swz = (l31 >> 2) & 3;
-  const int a_off = (wm * 96 + l31) * 64, b_off = 2 * kAPlane + (wn * 64 + l31) * 64;
+  const int a_off = (wm * 96 + l31) * 64, b_off = 2 * kAPlane + (wn * NI * 32 + l31) * 64;
   auto compute = [&](int buf) {
     const unsigned char* base = smem + buf * kStage;
 #pragma unroll
@@ -169,102 +170,120 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_tile(PlaneGemmDev g) {
   const int nkt = g.K / BK;
   issue_stage(0, 0);
   for (int kt = 0; kt < nkt; ++kt) {
-    __syncthreads();  // k-tile kt has landed (every wave waited for its own LDS-DMA) and k-tile kt - 1 has been read
+    // k-tile kt has landed: every wave waits for its own LDS-DMA, the barrier for everybody else's; k-tile kt - 1 has
+    // been read by everyone, so its stage may be refilled
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     if (kt + 1 < nkt) issue_stage(kt + 1, (kt + 1) & 1);
     compute(kt & 1);
   }
   __syncthreads();  // the operand stages are dead: the epilogue reuses them
 
-  // ---- epilogue: each wavefront transposes 32-row slabs of its tile through a private LDS stage and moves 16 bytes
-  // per lane (whole row segments per 8 / 16 lanes)
+  // ---- epilogue: each wavefront transposes one 32 x 32 MFMA tile at a time through a private LDS stage and moves
+  // 16 bytes per lane (128-byte row segments per 8 lanes, or two 64-byte plane segments per 4)
+  constexpr int SLD = 36;  // staging row stride (floats)
   float* const stage = reinterpret_cast<float*>(smem) + wid * (32 * SLD);
   constexpr int CPL = PLANES_OUT ? 8 : 4;    // columns per lane
-  constexpr int LPR = NI * 32 / CPL;         // lanes per staged row
+  constexpr int LPR = 32 / CPL;              // lanes per staged row
   constexpr int RPS = 64 / LPR;              // rows per pass
   const int prow = lane / LPR, c0 = (lane % LPR) * CPL;
-  const int n = n0 + wn * (BN / 2) + c0;
-  float bias_v[CPL];
 #pragma unroll
-  for (int e = 0; e < CPL; ++e) bias_v[e] = (EPI & kEpiBias) ? g.bias[n + e] : 0.0f;
-  const float oscale = PLANES_OUT ? g.out_scale[n / g.seg] : 1.0f;  // CPL consecutive columns never straddle a segment
-  // kEpiKvLayout: the column decomposition does not depend on the row
-  const int slab = (EPI & kEpiKvLayout) ? n / g.kv_dmodel : 0, rem = (EPI & kEpiKvLayout) ? n % g.kv_dmodel : 0;
-  const int head = rem >> 6, dd = rem & 63;
+  for (int ni = 0; ni < NI; ++ni) {
+    const int n = n0 + (wn * NI + ni) * 32 + c0;
+    float bias_v[CPL];
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
+    for (int e = 0; e < CPL; ++e) bias_v[e] = (EPI & kEpiBias) ? g.bias[n + e] : 0.0f;
+    const float oscale = PLANES_OUT ? g.out_scale[n / g.seg] : 1.0f;  // CPL consecutive columns never straddle a segment
+    // kEpiKvLayout: the column decomposition does not depend on the row
+    const int slab = (EPI & kEpiKvLayout) ? n / g.kv_dmodel : 0, rem = (EPI & kEpiKvLayout) ? n % g.kv_dmodel : 0;
+    const int head = rem >> 6, dd = rem & 63;
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
+    for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        stage[((r & 3) + 8 * (r >> 2) + 4 * lh) * SLD + ni * 32 + l31] = acc[mi][ni][r] * g.descale;
-    // the stage is private to this wavefront and LDS executes a wave's operations in order.
-    // One division per 32-row slab: rows advance by at most 31 < c_rpb, pos_period (host-checked).
-    const int mbase = m0 + wm * 96 + mi * 32;
-    const int mb0 = mbase / g.c_rpb, mt0 = mbase % g.c_rpb;
-    const int mp0 = (EPI & kEpiPos) ? mbase % g.pos_period : 0;
+      for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * lh) * SLD + l31] = acc[mi][ni][r] * g.descale;
+      // the stage is private to this wavefront and LDS executes a wave's operations in order.
+      // One division per 32-row slab: rows advance by at most 31 < c_rpb, pos_period (host-checked).
+      const int mbase = m0 + wm * 96 + mi * 32;
+      const int mb0 = mbase / g.c_rpb, mt0 = mbase % g.c_rpb;
+      const int mp0 = (EPI & kEpiPos) ? mbase % g.pos_period : 0;
 #pragma unroll
-    for (int p = 0; p < 32 / RPS; ++p) {
-      const int row = p * RPS + prow;
-      float v[CPL];
+      for (int p = 0; p < 32 / RPS; ++p) {
+        const int row = p * RPS + prow;
+        float v[CPL];
 #pragma unroll
-      for (int e = 0; e < CPL; e += 4) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(&stage[row * SLD + c0 + e]);
-        v[e] = t[0], v[e + 1] = t[1], v[e + 2] = t[2], v[e + 3] = t[3];
-      }
-      if (mbase + row < g.M) {
-        int mb = mb0, mt = mt0 + row;
-        if (mt >= g.c_rpb) mt -= g.c_rpb, mb += 1;
-#pragma unroll
-        for (int e = 0; e < CPL; ++e) {
-          v[e] += bias_v[e];
-          if (EPI & kEpiGelu) v[e] = gelu_erf(v[e]);
+        for (int e = 0; e < CPL; e += 4) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(&stage[row * SLD + c0 + e]);
+          v[e] = t[0], v[e + 1] = t[1], v[e + 2] = t[2], v[e + 3] = t[3];
         }
-        if (EPI & kEpiPos) {
-          int mp = mp0 + row;
-          if (mp >= g.pos_period) mp -= g.pos_period;
-#pragma unroll
-          for (int e = 0; e < CPL; e += 4) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(g.pos + (long)mp * g.N + n + e);
-            v[e] += t[0], v[e + 1] += t[1], v[e + 2] += t[2], v[e + 3] += t[3];
-          }
-        }
-        if (PLANES_OUT) {
-          const long o = (long)mb * g.c_bs + (long)mt * g.ldc + n;
-          half8 hi, lo;
+        if (mbase + row < g.M) {
+          int mb = mb0, mt = mt0 + row;
+          if (mt >= g.c_rpb) mt -= g.c_rpb, mb += 1;
 #pragma unroll
           for (int e = 0; e < CPL; ++e) {
-            _Float16 h, l;
-            split_f16(v[e] * oscale, &h, &l);
-            hi[e] = h;
-            lo[e] = l;
+            v[e] += bias_v[e];
+            if (EPI & kEpiGelu) v[e] = gelu_erf(v[e]);
           }
-          *reinterpret_cast<half8*>(g.P + o) = hi;
-          *reinterpret_cast<half8*>(g.P + g.p_plane + o) = lo;
-        } else if (EPI & kEpiKvLayout) {
-          const long o = (((long)slab * g.kv_batch + mb) * g.kv_heads + head) * (long)g.c_rpb * 64 + (long)mt * 64 + dd;
-          *reinterpret_cast<f32x4*>(g.C + o) = f32x4{v[0], v[1], v[2], v[3]};
-        } else {
-          const long o = (long)mb * g.c_bs + (long)mt * g.ldc + n;
-          f32x4 out = {v[0], v[1], v[2], v[3]};
-          if (EPI & kEpiResidual) out += *reinterpret_cast<const f32x4*>(g.R + o);
-          *reinterpret_cast<f32x4*>(g.C + o) = out;
+          if (EPI & kEpiPos) {
+            int mp = mp0 + row;
+            if (mp >= g.pos_period) mp -= g.pos_period;
+#pragma unroll
+            for (int e = 0; e < CPL; e += 4) {
+              const f32x4 t = *reinterpret_cast<const f32x4*>(g.pos + (long)mp * g.N + n + e);
+              v[e] += t[0], v[e + 1] += t[1], v[e + 2] += t[2], v[e + 3] += t[3];
+            }
+          }
+          if (PLANES_OUT) {
+            const long o = (long)mb * g.c_bs + (long)mt * g.ldc + n;
+            half8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) {
+              _Float16 h, l;
+              split_f16(v[e] * oscale, &h, &l);
+              hi[e] = h;
+              lo[e] = l;
+            }
+            *reinterpret_cast<half8*>(g.P + o) = hi;
+            *reinterpret_cast<half8*>(g.P + g.p_plane + o) = lo;
+          } else if (EPI & kEpiKvLayout) {
+            const long o = (((long)slab * g.kv_batch + mb) * g.kv_heads + head) * (long)g.c_rpb * 64 + (long)mt * 64 + dd;
+            *reinterpret_cast<f32x4*>(g.C + o) = f32x4{v[0], v[1], v[2], v[3]};
+          } else {
+            const long o = (long)mb * g.c_bs + (long)mt * g.ldc + n;
+            f32x4 out = {v[0], v[1], v[2], v[3]};
+            if (EPI & kEpiResidual) out += *reinterpret_cast<const f32x4*>(g.R + o);
+            *reinterpret_cast<f32x4*>(g.C + o) = out;
+          }
         }
       }
     }
   }
 }
 
-template <int EPI, bool PLANES_OUT>
-void launch_planes(const PlaneGemmDev& g, hipStream_t s) {
+template <int EPI, bool PLANES_OUT, int WN, int NI>
+void launch_planes_shape(const PlaneGemmDev& g, hipStream_t s) {
+  constexpr int BN = WN * NI * 32;
   const int blocks = ((g.M + BM - 1) / BM) * (g.N / BN);
-  constexpr size_t smem = 2 * kStage;  // 80 KB: two blocks share a CU; the epilogue stage (4 x 32 x 68 x 4 B) fits inside
+  constexpr size_t smem = 2 * (2 * BM * BK * 2 + 2 * BN * BK * 2);  // two stages; the epilogue stages fit inside
   static const bool raised = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_planes_tile<EPI, PLANES_OUT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_planes_tile<EPI, PLANES_OUT, WN, NI>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return true;
   }();
   (void)raised;
-  hipLaunchKernelGGL((gemm_planes_tile<EPI, PLANES_OUT>), dim3(blocks), dim3(256), smem, s, g);
+  hipLaunchKernelGGL((gemm_planes_tile<EPI, PLANES_OUT, WN, NI>), dim3(blocks), dim3(128 * WN), smem, s, g);
+}
+
+template <int EPI, bool PLANES_OUT>
+void launch_planes(const PlaneGemmDev& g, hipStream_t s) {
+  static const int narrow = [] {
+    const char* v = getenv("WT_PLANE_TILE");  // measurement knob (tools/gemm_planes_bench.py): 128 = the 192 x 128 tile
+    return v ? atoi(v) == 128 : 0;
+  }();
+  if (g.N % 384 == 0 && !narrow) {
+    launch_planes_shape<EPI, PLANES_OUT, 4, 3>(g, s);
+  } else {
+    launch_planes_shape<EPI, PLANES_OUT, 2, 2>(g, s);
+  }
 }
 
 }  // namespace
@@ -286,7 +305,7 @@ void launch_gemm_planes(const PlaneGemmArgs& a, int epi, hipStream_t s) {
   const bool planes = a.P != nullptr;
   // shape contract of the kernel (16-byte chunks, whole k-tiles; the epilogue wraps clip / position rows at most once
   // per 32 rows; 8 output columns never straddle a scale segment)
-  if (a.N % BN != 0 || a.K % BK != 0 || a.M < 1 || a.c_rpb < 32 || a.pos_period < (epi & kEpiPos ? 32 : 1) || a.lda % 8 != 0 ||
+  if (a.N % 128 != 0 || a.K % BK != 0 || a.M < 1 || a.c_rpb < 32 || a.pos_period < (epi & kEpiPos ? 32 : 1) || a.lda % 8 != 0 ||
       a.a_bs % 8 != 0 || a.ldc % 8 != 0 || a.c_bs % 8 != 0 || (planes && (g.seg % 8 != 0 || (a.N + g.seg - 1) / g.seg > 3)) ||
       (!planes && !a.C) || !(a.a_scale > 0.0f) || !(a.w_scale > 0.0f)) {
     throw Error(kErrInvalidArg, "plane GEMM shape outside the kernel contract");

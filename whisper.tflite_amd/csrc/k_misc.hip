@@ -57,49 +57,60 @@ __global__ __launch_bounds__(256) void layernorm_rows(const float* __restrict__ 
 
 // LayerNorm rows written as two fp16 planes (hi, lo) of y * scale — the A operand format of the plane GEMM — and
 // optionally as fp32 too (the encoder's final LayerNorm feeds both the cross-KV GEMM and the debug tap).
+// 32 lanes per row (two rows per wavefront), PER float4 per lane: 16-byte loads, 8-byte plane stores.
 template <int PER>
 __global__ __launch_bounds__(256) void layernorm_rows_planes(const float* __restrict__ x, _Float16* __restrict__ yp,
                                                              long plane, float scale, float* __restrict__ y32,
                                                              const float* __restrict__ g, const float* __restrict__ b,
                                                              int M, int d, int* __restrict__ nonfinite) {
-  using half2v = __attribute__((ext_vector_type(2))) _Float16;
-  const int lane = threadIdx.x & 63;
-  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
-  // lane owns column pairs (2 lane + 128 i, + 1): 4-byte plane stores, 8-byte row loads
+  using f32x4 = __attribute__((ext_vector_type(4))) float;
+  using half4 = __attribute__((ext_vector_type(4))) _Float16;
+  const int l32 = threadIdx.x & 31;
+  const long row = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
+  if (row >= M) return;  // whole 32-lane halves leave together; the shuffles below stay inside a half
   const float* xr = x + row * d;
-  float v0[PER], v1[PER];
+  f32x4 v[PER], gg[PER], bb[PER];
   float s = 0.0f;
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
-    const int c = 2 * lane + 128 * i;
-    const float2 t = c < d ? *reinterpret_cast<const float2*>(xr + c) : float2{0.0f, 0.0f};
-    v0[i] = t.x, v1[i] = t.y;
-    s += t.x + t.y;
+    const int c = (l32 + 32 * i) * 4;
+    v[i] = *reinterpret_cast<const f32x4*>(xr + c);
+    gg[i] = *reinterpret_cast<const f32x4*>(g + c);  // gain / shift requested with the row, not after its statistics
+    bb[i] = *reinterpret_cast<const f32x4*>(b + c);
+    s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
   }
-  const float mean = wave_sum(s) / (float)d;
+#pragma unroll
+  for (int off = 16; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+  const float mean = s / (float)d;
   float q = 0.0f;
 #pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    const int c = 2 * lane + 128 * i;
-    const float t0 = c < d ? v0[i] - mean : 0.0f, t1 = c < d ? v1[i] - mean : 0.0f;
-    q += t0 * t0 + t1 * t1;
-  }
-  const float var = wave_sum(q) / (float)d;
-  if (nonfinite != nullptr && lane == 0 && !(fabsf(mean) <= 3.0e38f && var <= 3.0e38f)) atomicOr(nonfinite, 1);
+  for (int i = 0; i < PER; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float t = v[i][e] - mean;
+      q += t * t;
+    }
+#pragma unroll
+  for (int off = 16; off >= 1; off >>= 1) q += __shfl_xor(q, off, 64);
+  const float var = q / (float)d;
+  if (nonfinite != nullptr && l32 == 0 && !(fabsf(mean) <= 3.0e38f && var <= 3.0e38f)) atomicOr(nonfinite, 1);
   const float rstd = rsqrtf(var + 1e-5f);
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
-    const int c = 2 * lane + 128 * i;
-    if (c < d) {
-      const float y0 = (v0[i] - mean) * rstd * g[c] + b[c], y1 = (v1[i] - mean) * rstd * g[c + 1] + b[c + 1];
-      if (y32 != nullptr) *reinterpret_cast<float2*>(y32 + row * d + c) = float2{y0, y1};
-      _Float16 h0, l0, h1, l1;
-      split_f16(y0 * scale, &h0, &l0);
-      split_f16(y1 * scale, &h1, &l1);
-      *reinterpret_cast<half2v*>(yp + row * d + c) = half2v{h0, h1};
-      *reinterpret_cast<half2v*>(yp + plane + row * d + c) = half2v{l0, l1};
+    const int c = (l32 + 32 * i) * 4;
+    f32x4 y;
+    half4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      y[e] = (v[i][e] - mean) * rstd * gg[i][e] + bb[i][e];
+      _Float16 h, l;
+      split_f16(y[e] * scale, &h, &l);
+      hi[e] = h;
+      lo[e] = l;
     }
+    if (y32 != nullptr) *reinterpret_cast<f32x4*>(y32 + row * d + c) = y;
+    *reinterpret_cast<half4*>(yp + row * d + c) = hi;
+    *reinterpret_cast<half4*>(yp + plane + row * d + c) = lo;
   }
 }
 
@@ -278,17 +289,16 @@ void launch_layernorm(const float* x, float* y, const float* g, const float* b, 
 
 void launch_layernorm_planes(const float* x, unsigned short* yp, long plane, float scale, float* y32, const float* g,
                              const float* b, int M, int d, hipStream_t s, int* nonfinite) {
-  const int blocks = (M + 3) / 4;
+  const int blocks = (M + 7) / 8;
   _Float16* y = reinterpret_cast<_Float16*>(yp);
-  if (d % 2 != 0) throw Error(kErrFormat, "LayerNorm plane kernel needs an even row length");
-  if (d <= 128) {
+  if (d == 128) {
     hipLaunchKernelGGL(layernorm_rows_planes<1>, dim3(blocks), dim3(256), 0, s, x, y, plane, scale, y32, g, b, M, d, nonfinite);
-  } else if (d <= 384) {
+  } else if (d == 384) {
     hipLaunchKernelGGL(layernorm_rows_planes<3>, dim3(blocks), dim3(256), 0, s, x, y, plane, scale, y32, g, b, M, d, nonfinite);
-  } else if (d <= 512) {
+  } else if (d == 512) {
     hipLaunchKernelGGL(layernorm_rows_planes<4>, dim3(blocks), dim3(256), 0, s, x, y, plane, scale, y32, g, b, M, d, nonfinite);
   } else {
-    throw Error(kErrFormat, "LayerNorm kernel supports rows of at most 512 elements");
+    throw Error(kErrFormat, "LayerNorm plane kernel supports rows of 128, 384 or 512 elements");
   }
 }
 
