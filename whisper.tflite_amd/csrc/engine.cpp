@@ -540,6 +540,7 @@ void Engine::create_streams() {
   // within 2 % of each other. Synchronous calls keep the whole chip.
   int reserve = 4;
   if (const char* v = getenv("WT_ENC_CU_RESERVE")) reserve = std::min(std::max(atoi(v), 0), 16);
+  reserve_ = reserve;
   const int n_cu = n_cu_;
   if (reserve > 0 && n_cu >= 64 && n_cu % 8 == 0) {
     const int keep = n_cu - 8 * reserve;
@@ -991,6 +992,7 @@ void Engine::encode_enqueue_planes(const float* d_mel, int batch) {
   const wtw::Dims& c = dims_;
   const int T0 = mel_frames(), T = c.n_audio_ctx, d = c.n_audio_state, M = batch * T, nm = c.n_mels;
   const long Bw = ws_.batch;  // plane strides follow the workspace, not the call
+  const int cus = (stream_ == stream_masked_ && stream_masked_) ? n_cu_ - 8 * reserve_ : n_cu_;  // CUs of this stream
   Slot& slot = slots_[enc_slot_];
   if (slot.used) HIPCHK(hipStreamWaitEvent(stream_, slot.dec_done, 0));
   slot.kt_cls.clear();
@@ -1014,7 +1016,7 @@ void Engine::encode_enqueue_planes(const float* d_mel, int batch) {
   launch_mel_transpose_planes(d_mel, ws_.melTp, melT_plane, sc_conv1_.a, batch, nm, T0, nm, stream_);
   kt_end();
   {
-    PlaneGemmArgs g;  // conv1 + GELU: rows (clip, t) read melT rows t..t+2 (input t-1..t+1)
+    PlaneGemmArgs g; g.n_cu = cus;  // conv1 + GELU: rows (clip, t) read melT rows t..t+2 (input t-1..t+1)
     g.A = ws_.melTp; g.a_plane = melT_plane; g.a_rpb = T0; g.a_bs = long(T0 + 2) * nm; g.lda = nm;
     g.W = conv1_p_.w; g.w_plane = conv1_p_.plane; g.bias = conv1_b;
     g.P = ws_.h1pp + d; g.p_plane = h1p_plane;  // row t lands at padded row t + 1
@@ -1026,7 +1028,7 @@ void Engine::encode_enqueue_planes(const float* d_mel, int batch) {
     kt_end();
   }
   {
-    PlaneGemmArgs g;  // conv2 (stride 2) + GELU + positional embedding
+    PlaneGemmArgs g; g.n_cu = cus;  // conv2 (stride 2) + GELU + positional embedding
     g.A = ws_.h1pp; g.a_plane = h1p_plane; g.a_rpb = T; g.a_bs = long(T0 + 2) * d; g.lda = 2 * d;  // output t reads padded rows 2t..2t+2
     g.W = conv2_p_.w; g.w_plane = conv2_p_.plane; g.bias = conv2_b; g.pos = enc_pos; g.pos_period = T;
     g.C = ws_.x; g.ldc = d;
@@ -1044,7 +1046,7 @@ void Engine::encode_enqueue_planes(const float* d_mel, int batch) {
     kt_begin(kKcLayerNorm, 0, 2.0 * M * d * 4);
     launch_layernorm_planes(ws_.x, lnp, ln_plane, sc.qkv.a, nullptr, w.attn_ln_g, w.attn_ln_b, M, d, stream_);
     kt_end();
-    PlaneGemmArgs q;  // q | k | v, written as the attention kernel's operand planes
+    PlaneGemmArgs q; q.n_cu = cus;  // q | k | v, written as the attention kernel's operand planes
     q.A = lnp; q.a_plane = ln_plane; q.lda = d; q.W = wp.qkv.w; q.w_plane = wp.qkv.plane; q.bias = w.attn.bqkv;
     q.P = qkvp; q.p_plane = qkv_plane; q.ldc = 3 * d; q.M = M; q.N = 3 * d; q.K = d;
     q.a_scale = sc.qkv.a; q.w_scale = sc.qkv.w; q.seg = d;
@@ -1056,7 +1058,7 @@ void Engine::encode_enqueue_planes(const float* d_mel, int batch) {
     launch_encoder_attention_planes(qkvp, qkv_plane, attp, ln_plane, batch, T, c.n_audio_head, sc.q, sc.k, sc.v, sc.out.a,
                                     stream_);
     kt_end();
-    PlaneGemmArgs o;
+    PlaneGemmArgs o; o.n_cu = cus;
     o.A = attp; o.a_plane = ln_plane; o.lda = d; o.W = wp.out.w; o.w_plane = wp.out.plane; o.bias = w.attn.bo;
     o.C = ws_.x; o.R = ws_.x; o.ldc = d; o.M = M; o.N = d; o.K = d; o.a_scale = sc.out.a; o.w_scale = sc.out.w;
     kt_begin(kKcGemm, 2.0 * o.M * o.N * o.K, 0);
@@ -1065,14 +1067,14 @@ void Engine::encode_enqueue_planes(const float* d_mel, int batch) {
     kt_begin(kKcLayerNorm, 0, 2.0 * M * d * 4);
     launch_layernorm_planes(ws_.x, lnp, ln_plane, sc.fc1.a, nullptr, w.mlp_ln_g, w.mlp_ln_b, M, d, stream_);
     kt_end();
-    PlaneGemmArgs f1;
+    PlaneGemmArgs f1; f1.n_cu = cus;
     f1.A = lnp; f1.a_plane = ln_plane; f1.lda = d; f1.W = wp.fc1.w; f1.w_plane = wp.fc1.plane; f1.bias = w.b1;
     f1.P = hidp; f1.p_plane = hid_plane; f1.ldc = 4 * d; f1.M = M; f1.N = 4 * d; f1.K = d;
     f1.a_scale = sc.fc1.a; f1.w_scale = sc.fc1.w; f1.out_scale[0] = sc.fc2.a;
     kt_begin(kKcGemm, 2.0 * f1.M * f1.N * f1.K, 0);
     launch_gemm_planes(f1, kEpiBias | kEpiGelu, stream_);
     kt_end();
-    PlaneGemmArgs f2;
+    PlaneGemmArgs f2; f2.n_cu = cus;
     f2.A = hidp; f2.a_plane = hid_plane; f2.lda = 4 * d; f2.W = wp.fc2.w; f2.w_plane = wp.fc2.plane; f2.bias = w.b2;
     f2.C = ws_.x; f2.R = ws_.x; f2.ldc = d; f2.M = M; f2.N = d; f2.K = 4 * d; f2.a_scale = sc.fc2.a; f2.w_scale = sc.fc2.w;
     kt_begin(kKcGemm, 2.0 * f2.M * f2.N * f2.K, 0);
@@ -1087,7 +1089,7 @@ void Engine::encode_enqueue_planes(const float* d_mel, int batch) {
   HIPCHK(hipEventRecord(slot.enc_mid, stream_));
   {
     // cross-attention K/V of every decoder layer, projected once per clip into the persistent cache
-    PlaneGemmArgs g;
+    PlaneGemmArgs g; g.n_cu = cus;
     g.A = lnp; g.a_plane = ln_plane; g.lda = d; g.W = cross_kv_p_.w; g.w_plane = cross_kv_p_.plane; g.bias = cross_kv_b;
     g.C = slot.cross_kv; g.M = M; g.N = c.n_text_layer * 2 * d; g.K = d;
     g.c_rpb = T; g.kv_batch = batch; g.kv_heads = c.n_text_head; g.kv_dmodel = d;

@@ -274,12 +274,25 @@ void launch_planes_shape(const PlaneGemmDev& g, hipStream_t s) {
 }
 
 template <int EPI, bool PLANES_OUT>
-void launch_planes(const PlaneGemmDev& g, hipStream_t s) {
-  static const int narrow = [] {
-    const char* v = getenv("WT_PLANE_TILE");  // measurement knob (tools/gemm_planes_bench.py): 128 = the 192 x 128 tile
-    return v ? atoi(v) == 128 : 0;
+void launch_planes(const PlaneGemmDev& g, int n_cu, hipStream_t s) {
+  static const int forced = [] {
+    const char* v = getenv("WT_PLANE_TILE");  // measurement knob (tools/gemm_planes_bench.py): 128 / 384 = that tile only
+    return v ? atoi(v) : 0;
   }();
-  if (g.N % 384 == 0 && !narrow) {
+  // Tile choice by how the blocks fill the CUs this stream may use (the pipelined encoder stream leaves some CUs
+  // to the decoders).  In units of one 192 x 128 tile: the wide kernel runs one block (3 units) per CU per round,
+  // the narrow one two co-resident blocks per CU at ~10 % less per unit.  250 wide row tiles are one round on 256
+  // CUs but two on 224.
+  const long row_tiles = (g.M + BM - 1) / BM;
+  bool wide = g.N % 384 == 0;
+  if (wide && n_cu > 0) {
+    const long wide_rounds = (row_tiles * (g.N / 384) + n_cu - 1) / n_cu;
+    const long narrow_units = (row_tiles * (g.N / 128) + n_cu - 1) / n_cu;
+    wide = 3.0 * wide_rounds <= 1.1 * narrow_units;
+  }
+  if (forced == 128) wide = false;
+  if (forced == 384 && g.N % 384 == 0) wide = true;
+  if (wide) {
     launch_planes_shape<EPI, PLANES_OUT, 4, 3>(g, s);
   } else {
     launch_planes_shape<EPI, PLANES_OUT, 2, 2>(g, s);
@@ -311,12 +324,12 @@ void launch_gemm_planes(const PlaneGemmArgs& a, int epi, hipStream_t s) {
     throw Error(kErrInvalidArg, "plane GEMM shape outside the kernel contract");
   }
   switch (epi | (planes ? 256 : 0)) {
-    case kEpiBias: launch_planes<kEpiBias, false>(g, s); break;
-    case kEpiBias | kEpiResidual: launch_planes<kEpiBias | kEpiResidual, false>(g, s); break;
-    case kEpiBias | kEpiGelu | kEpiPos: launch_planes<kEpiBias | kEpiGelu | kEpiPos, false>(g, s); break;
-    case kEpiBias | kEpiKvLayout: launch_planes<kEpiBias | kEpiKvLayout, false>(g, s); break;
-    case kEpiBias | 256: launch_planes<kEpiBias, true>(g, s); break;
-    case kEpiBias | kEpiGelu | 256: launch_planes<kEpiBias | kEpiGelu, true>(g, s); break;
+    case kEpiBias: launch_planes<kEpiBias, false>(g, a.n_cu, s); break;
+    case kEpiBias | kEpiResidual: launch_planes<kEpiBias | kEpiResidual, false>(g, a.n_cu, s); break;
+    case kEpiBias | kEpiGelu | kEpiPos: launch_planes<kEpiBias | kEpiGelu | kEpiPos, false>(g, a.n_cu, s); break;
+    case kEpiBias | kEpiKvLayout: launch_planes<kEpiBias | kEpiKvLayout, false>(g, a.n_cu, s); break;
+    case kEpiBias | 256: launch_planes<kEpiBias, true>(g, a.n_cu, s); break;
+    case kEpiBias | kEpiGelu | 256: launch_planes<kEpiBias | kEpiGelu, true>(g, a.n_cu, s); break;
     default: throw Error(kErrInvalidArg, "unsupported plane GEMM epilogue combination");
   }
 }

@@ -89,6 +89,7 @@ struct PlaneGemmArgs {
   float a_scale = 1.0f, w_scale = 1.0f;  // the powers of two baked into the A and W planes
   float out_scale[3] = {1.0f, 1.0f, 1.0f};
   int seg = 0;  // columns per out_scale segment (0 = one segment)
+  int n_cu = 256;  // CUs the launching stream may use (tile choice, k_gemm_planes.hip)
 };
 void launch_gemm_planes(const PlaneGemmArgs& a, int epi, hipStream_t s);
 // W [N][K] fp32 -> hi plane [N][Kpad] followed by lo plane [N][Kpad] (Kpad >= K, zero filled), scaled by `scale`
