@@ -332,7 +332,8 @@ def main() -> None:
         fp32_leg = {"value": round(world * B * 10 * CLIP_SECONDS / dt, 1), "unit": "audio-sec/s", "steps": 10,
                     "ms_per_step": round(1e3 * dt / 10, 3),
                     "ids_match_split_path": bool(np.array_equal(ids32, ids) and np.array_equal(n32, n)),
-                    "what": "gemm_variant=0 (gemm_f32_tile), attn_variant=0 (encoder_attention_f32): v_mfma_f32_32x32x2_f32 only"}
+                    "what": "encoder on gemm_variant=0 (gemm_f32_tile), attn_variant=0 (encoder_attention_f32): "
+                            "v_mfma_f32_32x32x2_f32 only; the decoder keeps its fp16-plane GEMMs"}
         # and on the bf16 three-plane split kernels (full fp32 operand range)
         eng.set_option("gemm_variant", 16)
         eng.set_option("attn_variant", 1)
@@ -412,13 +413,14 @@ def main() -> None:
                     continue
                 mfma = v["flops"] > 0
                 ach = (v["flops"] / 1e12 if mfma else v["bytes"] / 1e9) / (v["ms"] * 1e-3)
-                split = mfma and "split" in name
-                # split kernels spend 3 (two fp16 planes per operand, the default) or 6 (three bf16
+                planes = "planes" in name  # the default kernels: operands stored as two fp16 planes
+                split = mfma and ("split" in name or planes)
+                # plane / split kernels spend 3 (two fp16 planes per operand, the default) or 6 (three bf16
                 # planes) 16-bit MFMA FLOPs per algorithmic fp32 FLOP: their MFMA ceiling in algorithmic
                 # FLOP/s is the dense f16/bf16 peak / products; fp32-MFMA kernels are priced against
                 # the fp32 MFMA peak
                 gv, av = eng.get_option("gemm_variant"), eng.get_option("attn_variant")
-                products = (3 if av == 4 else 6) if "attention" in name else (3 if gv in (-1, 17, 18) else 6)
+                products = 3 if planes else (3 if av == 4 else 6) if "attention" in name else (3 if gv in (-1, 17, 18) else 6)
                 peak = (round(PEAK_BF16_MFMA_TFLOPS / products, 1) if split else PEAK_F32_MFMA_TFLOPS) if mfma else PEAK_HBM_GBPS
                 det[name] = {"bound": "mfma" if mfma else "hbm", "achieved": round(ach, 2), "peak": peak,
                              "unit": "TFLOP/s" if mfma else "GB/s", "frac": round(ach / peak, 4),
@@ -441,10 +443,10 @@ def main() -> None:
             # passes (FETCH_SIZE, WRITE_SIZE) whose summary is committed under profiles/
             traffic, traffic_src = None, None
             try:
-                with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
                     t = json.load(f)
                 if t["kernel_class"].startswith(dom):
-                    traffic, traffic_src = int(t["traffic_bytes_per_launch"]), "profiles/r01_pmc_traffic.json"
+                    traffic, traffic_src = int(t["traffic_bytes_per_launch"]), "profiles/r02_pmc_traffic.json"
             except (OSError, KeyError, ValueError):
                 pass
             roof = {"kernel": dom, "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"],
@@ -471,7 +473,7 @@ def main() -> None:
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 (fp16x2-split MFMA, f32 accumulate)" if eng.get_option("gemm_variant") < 0 else "f32",
+            "dtype": "f32 (operands as two fp16 planes, f16 MFMA, f32 accumulate)" if eng.get_option("gemm_variant") < 0 else "f32",
             "data": "synthetic",
             "config": {"workload": f"whisper-{args.arch} batch={B}x30s synthetic mel U(-1,1.5), fp32, random-init "
                                    "weights (BASELINE.json configs[1]); mel resident in HBM -> token ids on host",
@@ -479,10 +481,10 @@ def main() -> None:
                        "argmax_steps": 27, "parallelism": f"clip-parallel dp{world}, one RCCL all_gather of id records per {GATHER_EVERY} batches",
                        "pipelined": pipelined, "batches_in_flight": args.depth if pipelined else 1,
                        "priming_batches": 1,
-                       "compute": "encoder GEMMs and attention: fp32 operands split into 2 fp16 planes (22 significand "
-                                  "bits), 3 fp16-MFMA products, fp32 accumulate (measured error below the fp32-MFMA "
-                                  "kernel's, tests/test_gpu_kernels.py; bf16 x3 split and fp32 MFMA selectable); "
-                                  "decoder: fp32 MFMA; no value leaves fp32 storage"},
+                       "compute": "every contraction (encoder GEMMs and attention, decoder GEMMs and logits): operands as 2 fp16 "
+                                  "planes (22 significand bits: hi + lo, 4 bytes per element like fp32), 3 f16-MFMA products, "
+                                  "fp32 accumulate (measured error at or below the fp32-MFMA kernel's, tests/test_gpu_kernels.py; "
+                                  "bf16 x3 split and fp32 MFMA forms selectable); residual streams, softmax, LayerNorm, KV caches fp32"},
             "roofline": ({**roof, "isolated": {k: iso_det[dom][k] for k in ("achieved", "frac", "avg_launch_us")},
                           "note": "achieved/avg_launch_us: HIP events inside the timed (pipelined) region, where decoder "
                                   "chains share the chip; isolated: the same launches in two synchronous passes after it — "

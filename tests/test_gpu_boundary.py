@@ -350,6 +350,36 @@ def test_fp16_split_falls_back_to_full_range_when_a_bound_is_far_above_typical(p
     assert err["default"] < 3.0 * err["fp32_mfma"] + 1e-6 * scale, (err, scale)
 
 
+# --------------------------------------------------------------- .tflite model files (f1) ---
+
+def test_engine_accepts_the_reference_tflite_pair(pkg, orc, tmp_path):
+    """`--model-prefix` as the reference's users have it: only <prefix>.encoder.tflite and <prefix>.decoder.tflite
+    exist (whisper.cpp:743-744).  wt_engine_create extracts the weights (int8 dynamic-range de-quantised) into
+    <prefix>.wtw and runs; ids and logits equal the oracle's on exactly those de-quantised weights.
+    PARITY UNPINNED against TFLite itself: the pair comes from tests/tflite_writer.py (no .tflite exists here)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_tflite_extract import make_pair
+    prefix, dims, expected = make_pair(pkg, tmp_path, "micro", named=False)
+    vocab = str(tmp_path / "v.bin")
+    pkg.write_synthetic_vocab(vocab, 1000)
+    assert not os.path.exists(prefix + ".wtw")
+    e = pkg.Engine(prefix, vocab, True)
+    assert os.path.exists(prefix + ".wtw")
+    e.set_option("stop_at_eot", 0)
+    e.set_prompt([3, 5, 7, 11])
+    mel = np.random.default_rng(2).uniform(-1.0, 1.5, size=(2,) + e.mel_shape).astype(np.float32)
+    ids, n, enc, logits = e.encdec_debug_batch(mel)
+    e.close()
+    m = orc.Model(prefix + ".wtw")
+    for b in range(2):
+        enc_ref = m.encode(mel[b])
+        assert np.abs(enc[b] - enc_ref).max() < ENC_TOL
+        ids_ref, lg = m.decode_greedy(enc_ref, [3, 5, 7, 11], 30, -1, False, True, 4, True)
+        assert np.abs(logits[b] - lg).max() < LOGIT_TOL
+        assert list(ids[b, :31]) == list(ids_ref)
+    m.close()
+
+
 # ------------------------------------------------------------------ front end as a free function ---
 
 def test_log_mel_spectrogram_free_function(pkg, orc):

@@ -2,6 +2,8 @@
 // absent (no network in this environment):
 //   wt-make-assets weights <out.wtw> <tiny|tiny.en|base|micro> [seed]
 //   wt-make-assets vocab   <out.bin> [n_tokens]
+// and converts the reference's model files into the engine's weight file:
+//   wt-make-assets convert <prefix> <out.wtw>     (<prefix>.encoder.tflite + <prefix>.decoder.tflite -> .wtw)
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -21,9 +23,15 @@ int main(int argc, char** argv) {
     if (rc != WT_OK) std::fprintf(stderr, "error: %s\n", wt_last_error(nullptr));
     return rc;
   }
+  if (argc >= 4 && std::string(argv[1]) == "convert") {
+    const int rc = wt_convert_tflite(argv[2], argv[3]);
+    if (rc != WT_OK) std::fprintf(stderr, "error: %s\n", wt_last_error(nullptr));
+    return rc;
+  }
   std::fprintf(stderr,
                "usage: %s weights <out.wtw> <tiny|tiny.en|base|micro> [seed]\n"
-               "       %s vocab <out.bin> [n_tokens]\n",
-               argv[0], argv[0]);
+               "       %s vocab <out.bin> [n_tokens]\n"
+               "       %s convert <prefix> <out.wtw>\n",
+               argv[0], argv[0], argv[0]);
   return 2;
 }
