@@ -72,20 +72,24 @@ __global__ __launch_bounds__(256, 2) void encoder_attention_planes(const _Float1
   // staging: a tile is 4 planes x 64 rows x 8 chunks of 16 B = 2048 chunks, 8 per thread: thread = (row tid >> 2,
   // chunk pair tid & 3) for each plane
   const int srow = tid >> 2, sc0 = (tid & 3) * 2;
+  // ds_write_b128 is served in groups of 8 consecutive lanes (= two rows of this mapping) over 32 banks = 128 B: the
+  // two rows of a group must write DIFFERENT chunks, so odd rows take their chunk pair in the opposite order (their
+  // swizzle terms are equal: both depend on row >> 1)
+  const int e0 = (srow & 1) * 8, e1 = 8 - e0;  // element offsets of the first / second chunk this thread moves
   const _Float16* kbase = base + d_model + sc0 * 8;
   const _Float16* vbase = base + 2 * d_model + sc0 * 8;
   u32x4 st[8];
   auto load_tile = [&](int kt) {
     const int key = kt * AK + srow;
     const long ro = (long)(key < T ? key : T - 1) * ld;  // rows past T re-read row T - 1; their scores are masked
-    st[0] = *reinterpret_cast<const u32x4*>(kbase + ro);
-    st[1] = *reinterpret_cast<const u32x4*>(kbase + ro + 8);
-    st[2] = *reinterpret_cast<const u32x4*>(kbase + plane + ro);
-    st[3] = *reinterpret_cast<const u32x4*>(kbase + plane + ro + 8);
-    st[4] = *reinterpret_cast<const u32x4*>(vbase + ro);
-    st[5] = *reinterpret_cast<const u32x4*>(vbase + ro + 8);
-    st[6] = *reinterpret_cast<const u32x4*>(vbase + plane + ro);
-    st[7] = *reinterpret_cast<const u32x4*>(vbase + plane + ro + 8);
+    st[0] = *reinterpret_cast<const u32x4*>(kbase + ro + e0);
+    st[1] = *reinterpret_cast<const u32x4*>(kbase + ro + e1);
+    st[2] = *reinterpret_cast<const u32x4*>(kbase + plane + ro + e0);
+    st[3] = *reinterpret_cast<const u32x4*>(kbase + plane + ro + e1);
+    st[4] = *reinterpret_cast<const u32x4*>(vbase + ro + e0);
+    st[5] = *reinterpret_cast<const u32x4*>(vbase + ro + e1);
+    st[6] = *reinterpret_cast<const u32x4*>(vbase + plane + ro + e0);
+    st[7] = *reinterpret_cast<const u32x4*>(vbase + plane + ro + e1);
   };
   const int kx = (srow >> 1) & 7, vx = ((srow >> 1) & 1) << 2;
   auto store_tile = [&]() {
@@ -94,8 +98,9 @@ __global__ __launch_bounds__(256, 2) void encoder_attention_planes(const _Float1
     for (int p = 0; p < 2; ++p) {
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        *reinterpret_cast<u32x4*>(row + p * kPlaneBytes + (((sc0 + e) ^ kx) << 4)) = st[2 * p + e];
-        *reinterpret_cast<u32x4*>(row + (2 + p) * kPlaneBytes + (((sc0 + e) ^ vx) << 4)) = st[4 + 2 * p + e];
+        const int ch = sc0 + (e ^ (srow & 1));
+        *reinterpret_cast<u32x4*>(row + p * kPlaneBytes + ((ch ^ kx) << 4)) = st[2 * p + e];
+        *reinterpret_cast<u32x4*>(row + (2 + p) * kPlaneBytes + ((ch ^ vx) << 4)) = st[4 + 2 * p + e];
       }
     }
   };
