@@ -83,6 +83,21 @@ __device__ __forceinline__ void split_f16(float a, _Float16* hi, _Float16* lo) {
   *lo = (_Float16)(a - (float)h);
 }
 
+// Two elements at once, three instructions: hi pair = v_cvt_pk_f16_f32(a, b) (round to nearest even), lo halves =
+// v_fma_mixlo/mixhi_f16(hi, -1, x): the fp16 hi read straight as an fma operand, x - hi exact in fp32 (hi keeps the
+// top 11 of x's 24 significand bits), rounded once to fp16.  Both lo's come from the SAME stored hi, so the pair
+// is consistent by construction; the generic form above costs 5 instructions per element (cvt, cvt back, sub, cvt,
+// pack), which made the softmax's probability split the longest VALU stretch of the encoder attention.
+// Returns packed dwords: element a in bits 0-15, b in bits 16-31 (the order MFMA fragments want).
+__device__ __forceinline__ void split_f16x2(float a, float b, unsigned* hi, unsigned* lo) {
+  unsigned h, l;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(a), "v"(b));
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=&v"(l) : "v"(h), "v"(a));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(b));
+  *hi = h;
+  *lo = l;
+}
+
 // erf for the GELU epilogues of the plane GEMM (one evaluation per output element: 73.7 M per fc1 launch).  The
 // library erff costs ~37 VALU instructions and a divergent branch per element there (measured in the ISA: the GELU
 // epilogue was as long as the K = 384 main loop).  Same two-interval minimax scheme, evaluated branch-free: both

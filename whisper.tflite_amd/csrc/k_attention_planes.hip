@@ -135,11 +135,6 @@ __global__ __launch_bounds__(256, 2) void encoder_attention_planes(const _Float1
       s1 = WT_MM16(k1l, qh[c], s1);
       s1 = WT_MM16(k1h, qh[c], s1);
     }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {  // the operand scales of the planes leave the scores
-      s0[r] *= s_inv;
-      s1[r] *= s_inv;
-    }
     if ((kt + 1) * AK > T) {  // last tile: keys past T do not exist
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -147,19 +142,23 @@ __global__ __launch_bounds__(256, 2) void encoder_attention_planes(const _Float1
         if (kt * AK + 32 + crow(r, lh) >= T) s1[r] = -1e30f;
       }
     }
-    // online softmax; the row (query) lives on lanes l and l ^ 32
+    // online softmax; the row (query) lives on lanes l and l ^ 32.  The scores still carry the operand scales of
+    // the planes (s_inv > 0 takes them out): the maximum is taken on the raw values, and s_inv, the running maximum
+    // and the 2^14 that puts the probabilities into fp16's normal range all go into ONE fma per score in front of
+    // the exp2.  l_run and O then both carry the 2^14, which cancels in O / l.
     float tmax = s0[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s0[r]);
 #pragma unroll
     for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s1[r]);
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * s_inv;
     const float m_new = fmaxf(m_run, tmax);
+    const float shift = 14.0f - m_new;
     float psum = 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      s0[r] = __builtin_amdgcn_exp2f(s0[r] - m_new);
-      s1[r] = __builtin_amdgcn_exp2f(s1[r] - m_new);
+      s0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], s_inv, shift));
+      s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], s_inv, shift));
       psum += s0[r] + s1[r];
     }
     psum += __shfl_xor(psum, 32, 64);
@@ -178,14 +177,15 @@ __global__ __launch_bounds__(256, 2) void encoder_attention_planes(const _Float1
     auto pv_half = [&](const f32x16& sp, const int hf) {
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        half8 ph, pl;
+        u32x4 phu, plu;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          _Float16 hh, ll;
-          split_f16(sp[8 * s2 + e] * 16384.0f, &hh, &ll);  // probabilities into fp16's normal range
-          ph[e] = hh;
-          pl[e] = ll;
+        for (int e = 0; e < 4; ++e) {
+          unsigned hh, ll;
+          split_f16x2(sp[8 * s2 + 2 * e], sp[8 * s2 + 2 * e + 1], &hh, &ll);
+          phu[e] = hh;
+          plu[e] = ll;
         }
+        const half8 ph = __builtin_bit_cast(half8, phu), pl = __builtin_bit_cast(half8, plu);
         // element j of lane half lh of that fragment is key 16 s2 + 8 (j >> 2) + 4 lh + (j & 3) (the C/D row map of
         // the S^T accumulator): the V^T fragment takes its keys in the same order
         const int key0 = hf * 32 + 16 * s2 + 4 * lh;
@@ -225,25 +225,21 @@ __global__ __launch_bounds__(256, 2) void encoder_attention_planes(const _Float1
   }
 
   if (q_row < T) {
-    const float inv = o_scale / l_run;  // o_scale = out_scale / (2^14 * v_scale)
+    const float inv = o_scale / l_run;  // o_scale = out_scale / v_scale (the 2^14 of the probabilities is in l_run too)
     _Float16* orow = out + ((long)b * T + q_row) * d_model + h * 64;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      half4 ah, al, ch, cl;
+      unsigned ah[2], al[2], ch[2], cl[2];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        _Float16 x, xl, y, yl;
-        split_f16(o0[4 * g + j] * inv, &x, &xl);
-        split_f16(o1[4 * g + j] * inv, &y, &yl);
-        ah[j] = x;
-        al[j] = xl;
-        ch[j] = y;
-        cl[j] = yl;
+      for (int j = 0; j < 2; ++j) {
+        split_f16x2(o0[4 * g + 2 * j] * inv, o0[4 * g + 2 * j + 1] * inv, &ah[j], &al[j]);
+        split_f16x2(o1[4 * g + 2 * j] * inv, o1[4 * g + 2 * j + 1] * inv, &ch[j], &cl[j]);
       }
-      *reinterpret_cast<half4*>(orow + 8 * g + 4 * lh) = ah;
-      *reinterpret_cast<half4*>(orow + out_plane + 8 * g + 4 * lh) = al;
-      *reinterpret_cast<half4*>(orow + 32 + 8 * g + 4 * lh) = ch;
-      *reinterpret_cast<half4*>(orow + out_plane + 32 + 8 * g + 4 * lh) = cl;
+      using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+      *reinterpret_cast<u32x2*>(orow + 8 * g + 4 * lh) = u32x2{ah[0], ah[1]};
+      *reinterpret_cast<u32x2*>(orow + out_plane + 8 * g + 4 * lh) = u32x2{al[0], al[1]};
+      *reinterpret_cast<u32x2*>(orow + 32 + 8 * g + 4 * lh) = u32x2{ch[0], ch[1]};
+      *reinterpret_cast<u32x2*>(orow + out_plane + 32 + 8 * g + 4 * lh) = u32x2{cl[0], cl[1]};
     }
   }
 }
@@ -258,7 +254,7 @@ void launch_encoder_attention_planes(const unsigned short* qkv, long plane, unsi
   const int q_blocks = (T + 127) / 128;
   hipLaunchKernelGGL(encoder_attention_planes, dim3(batch * heads * q_blocks), dim3(256), 0, stream,
                      reinterpret_cast<const _Float16*>(qkv), plane, reinterpret_cast<_Float16*>(out), out_plane, T, heads,
-                     1.0f / (q_scale * k_scale), out_scale / (16384.0f * v_scale));
+                     1.0f / (q_scale * k_scale), out_scale / v_scale);
 }
 
 }  // namespace wt

@@ -238,16 +238,16 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 2) void gemm_planes_tile(Pl
           }
           if (PLANES_OUT) {
             const long o = (long)mb * g.c_bs + (long)mt * g.ldc + n;
-            half8 hi, lo;
+            u32x4 hi, lo;
 #pragma unroll
-            for (int e = 0; e < CPL; ++e) {
-              _Float16 h, l;
-              split_f16(v[e] * oscale, &h, &l);
-              hi[e] = h;
-              lo[e] = l;
+            for (int e = 0; e < CPL; e += 2) {
+              unsigned h, l;
+              split_f16x2(v[e] * oscale, v[e + 1] * oscale, &h, &l);
+              hi[e / 2] = h;
+              lo[e / 2] = l;
             }
-            *reinterpret_cast<half8*>(g.P + o) = hi;
-            *reinterpret_cast<half8*>(g.P + g.p_plane + o) = lo;
+            *reinterpret_cast<u32x4*>(g.P + o) = hi;
+            *reinterpret_cast<u32x4*>(g.P + g.p_plane + o) = lo;
           } else if (EPI & kEpiKvLayout) {
             const long o = (((long)slab * g.kv_batch + mb) * g.kv_heads + head) * (long)g.c_rpb * 64 + (long)mt * 64 + dd;
             *reinterpret_cast<f32x4*>(g.C + o) = f32x4{v[0], v[1], v[2], v[3]};
