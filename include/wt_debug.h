@@ -58,6 +58,13 @@ int wt_dbg_cross_attention(wt_engine* h, int batch, int heads, int T, int chunks
 /* qkv [npos*B][3d] (row = p * B + b); caches [B][cap][d] updated in place at rows pos .. pos+npos-1; out [npos*B][d] */
 int wt_dbg_self_attention(wt_engine* h, int batch, int heads, int cap, int pos, int npos, const float* qkv,
                           float* kcache, float* vcache, float* out);
+/* bf16 storage mode kernels (option "bf16"): operands are rounded to bf16 on the host, contracted by
+ * gemm_bf16_planes / encoder_attention_planes<true>; bf16_out = 1 returns the kernel's bf16 output widened to fp32 */
+int wt_dbg_gemm_bf16(wt_engine* h, int M, int N, int K, const float* A, const float* W, const float* bias,
+                     const float* R, const float* pos, int pos_period, int epi, int bf16_out, int iters, float* C,
+                     float* avg_ms);
+int wt_dbg_encoder_attention_bf16(wt_engine* h, int batch, int T, int heads, const float* qkv, int iters, float* out,
+                                  float* avg_ms);
 #ifdef __cplusplus
 }
 #endif

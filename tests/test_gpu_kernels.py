@@ -435,3 +435,78 @@ def test_self_attention_several_positions_in_one_pass(eng, pos0, npos):
                 ref = attn_ref(qkv[p * B + b, sl].astype(np.float64)[None], kc[b, :n, sl].astype(np.float64),
                                vc[b, :n, sl].astype(np.float64))[0]
                 assert np.abs(out[p * B + b, sl] - ref).max() < 1e-5, (p, b, h)
+
+
+# ---------------------------------------------------------------- bf16 storage mode (BASELINE configs[3]) ---
+
+def bf16_round(x):
+    """round-to-nearest-even to bf16, returned as float32 (what the bf16 storage mode keeps in HBM)"""
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32)
+
+
+@pytest.mark.parametrize("M,N,K", [(192, 128, 64), (300, 256, 128), (1, 128, 64), (257, 384, 448), (1500, 512, 1536), (3000, 1536, 512)])
+def test_bf16_gemm_matches_bf16_rounded_operands(eng, M, N, K):
+    """gemm_bf16_planes contracts bf16 operands EXACTLY (bf16 x bf16 products are exact in fp32) with fp32
+    accumulation: against fp64 on the rounded operands the error is the fp32 accumulation error, not a bf16 one.
+    The bf16 OUTPUT is that result rounded once more (half an ulp of bf16 = 2^-9 relative)."""
+    rng = np.random.default_rng(M + 3 * N + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    ref = bf16_round(A).astype(np.float64) @ bf16_round(W).astype(np.float64).T + bias
+    assert rel_err(eng.dbg_gemm_bf16(A, W, bias, epi=1), ref) < 2e-6
+    out16 = eng.dbg_gemm_bf16(A, W, bias, epi=3, bf16_out=True)
+    g = gelu(ref)
+    assert np.array_equal(out16, bf16_round(out16))  # values on the bf16 grid
+    assert (np.abs(out16 - g) <= np.abs(g) * 2.0 ** -8 + 1e-6).all()
+
+
+@pytest.mark.parametrize("epi", [1, 5, 11])
+def test_bf16_gemm_epilogues(eng, epi):
+    rng = np.random.default_rng(100 + epi)
+    M, N, K, P = 400, 256, 64, 100
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / 8).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    R = rng.standard_normal((M, N)).astype(np.float32)
+    pos = rng.standard_normal((P, N)).astype(np.float32)
+    C = eng.dbg_gemm_bf16(A, W, bias=bias, R=R if epi & 4 else None, pos=pos if epi & 8 else None, epi=epi)
+    ref = bf16_round(A).astype(np.float64) @ bf16_round(W).astype(np.float64).T + bias
+    if epi & 2:
+        ref = gelu(ref)
+    if epi & 8:
+        ref = ref + pos[np.arange(M) % P]
+    if epi & 4:
+        ref = ref + R
+    assert rel_err(C, ref) < 3e-6
+
+
+def test_bf16_gemm_is_exact_on_integers(eng):
+    """Small integers are exact in bf16: an asymmetric integer W against an identity-plus-pattern A catches a swapped
+    fragment map or a wrong LDS swizzle of the 128-byte-row image."""
+    K, N = 128, 256
+    W = ((np.arange(N)[:, None] * 3 + np.arange(K)[None, :] * 7) % 127).astype(np.float32)
+    A = np.zeros((K + 70, K), np.float32)
+    A[np.arange(K), np.arange(K)] = 1.0
+    A[K:, :] = (np.arange(70)[:, None] % 5 - 2 + (np.arange(K)[None, :] % 3)).astype(np.float32)
+    C = eng.dbg_gemm_bf16(A, W, epi=1)
+    assert np.array_equal(C, (A.astype(np.float64) @ W.astype(np.float64).T).astype(np.float32))
+
+
+@pytest.mark.parametrize("B,T,H", [(1, 64, 1), (2, 100, 2), (1, 1500, 8), (3, 333, 2)])
+def test_encoder_attention_bf16_storage(eng, B, T, H):
+    """encoder_attention_planes<true>: q, k, v read as bf16, probabilities rounded to bf16 for the PV product, fp32
+    accumulation and softmax statistics.  Against fp64 attention on the bf16-rounded inputs what is left is the
+    rounding of the probabilities (2^-9 relative each, averaging down over the keys) and of the bf16 output."""
+    rng = np.random.default_rng(B * 1000 + T + H)
+    d = 64 * H
+    qkv = rng.standard_normal((B * T, 3 * d)).astype(np.float32)
+    out = eng.dbg_encoder_attention_bf16(qkv, B, T, H)
+    q = bf16_round(qkv).astype(np.float64).reshape(B, T, 3 * d)
+    for b in range(B):
+        for h in range(H):
+            ref = attn_ref(q[b, :, h * 64:(h + 1) * 64], q[b, :, d + h * 64:d + (h + 1) * 64], q[b, :, 2 * d + h * 64:2 * d + (h + 1) * 64])
+            err = np.abs(out.reshape(B, T, d)[b, :, h * 64:(h + 1) * 64] - ref)
+            assert err.max() < 2.0 ** -8 * np.abs(ref).max() + 4e-3, (b, h, err.max())

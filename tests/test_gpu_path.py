@@ -460,3 +460,75 @@ def test_graph_replay_and_kernel_variants_keep_ids(tiny):
         e.set_option("gemm_variant", 19)
     with pytest.raises(Exception):
         e.set_option("attn_variant", 5)
+
+
+# ------------------------------------------------ bf16 storage mode (BASELINE configs[3], option "bf16") ---
+# Error bar, stated: bf16 keeps 8 significant bits (2^-9 relative rounding per stored value).  Across the encoder's
+# contractions (K = 128 .. 2048, fp32 accumulation) the independent roundings average down, and the residual stream
+# stays fp32, so encoder outputs (O(1) after ln_post) differ from the fp32 oracle by ~1e-2 rms; the bars below are
+# 8e-2 absolute / 1.5e-2 rms on encoder output and 1.5e-1 absolute on logits (O(1..10)), with token ids required to
+# agree wherever the fp32 top-2 margin exceeds twice the measured logit error (greedy decoding is discontinuous:
+# inside that margin either token is a correct bf16 answer).
+
+def _bf16_vs_fp32(e, mel, enc_ref=None):
+    e.set_option("bf16", 0)
+    ids32, n32, enc32, lg32 = e.encdec_debug_batch(mel)
+    e.set_option("bf16", 1)
+    assert e.get_option("bf16") == 1
+    ids16, n16, enc16, lg16 = e.encdec_debug_batch(mel)
+    ref = enc32 if enc_ref is None else enc_ref
+    err = enc16 - ref
+    assert np.abs(err).max() < 8e-2 and np.sqrt((err ** 2).mean()) < 1.5e-2, (np.abs(err).max(), np.sqrt((err ** 2).mean()))
+    assert np.abs(err).max() > 1e-4  # and it is not the fp32 path
+    # first argmax step: both runs see the same prefix
+    dl = np.abs(lg16[:, 0] - lg32[:, 0]).max()
+    assert dl < 1.5e-1, dl
+    top2 = np.sort(lg32[:, 0], axis=1)[:, -2:]
+    for b in range(mel.shape[0]):
+        if top2[b, 1] - top2[b, 0] > 2 * dl:
+            assert ids16[b, 4] == ids32[b, 4]
+    return ids16, n16, ids32, n32
+
+
+def test_bf16_storage_mode_micro_and_tiny(micro, tiny, orc):
+    """The bf16 storage mode on the two small architectures (d_model 128 and 384) against the fp32 engine (itself
+    pinned to the oracle above) and, for micro, directly against the oracle's encoder."""
+    e, prefix = micro
+    e.set_prompt([3, 5, 7, 11])
+    rng = np.random.default_rng(77)
+    mel = rng.uniform(-1.0, 1.5, size=(5,) + e.mel_shape).astype(np.float32)
+    m = orc.Model(prefix + ".wtw")
+    enc_ref = np.stack([m.encode(mel[b], 4) for b in range(5)])
+    m.close()
+    ids16, n16, ids32, n32 = _bf16_vs_fp32(e, mel, enc_ref)
+    # deterministic, and the pipelined path runs the same kernels
+    ids_p, n_p = e.encdec_tokens_batch(mel)
+    assert np.array_equal(ids_p, ids16) and np.array_equal(n_p, n16)
+    # switching back restores the fp32 results bit for bit (the two modes lay their padded buffers out differently)
+    e.set_option("bf16", 0)
+    ids_b, n_b = e.encdec_tokens_batch(mel)
+    assert np.array_equal(ids_b, ids32) and np.array_equal(n_b, n32)
+    e2, _ = tiny
+    mel2 = np.random.default_rng(78).uniform(-1.0, 1.5, size=(3, 80, 3000)).astype(np.float32)
+    try:
+        _bf16_vs_fp32(e2, mel2)
+    finally:
+        e2.set_option("bf16", 0)
+
+
+def test_config4_base_batch64_bf16_storage(pkg, assets, orc):
+    """BASELINE configs[3] as stated: whisper-base, batch 64 x 30 s, bf16 weights / activations / KV caches with fp32
+    accumulation.  Two clips are compared in detail against the fp32 ORACLE's encoder and the fp32 engine's logits;
+    the 64-clip batch then runs pipelined and must reproduce those clips' ids."""
+    prefix, vocab = assets("base", 0)
+    e = pkg.Engine(prefix, vocab, True)
+    e.set_option("stop_at_eot", 0)
+    rng = np.random.default_rng(43)
+    mel = rng.uniform(-1.0, 1.5, size=(64, 80, 3000)).astype(np.float32)
+    m = orc.Model(prefix + ".wtw")
+    enc_ref = np.stack([m.encode(mel[b], 16) for b in range(2)])
+    m.close()
+    ids16, n16, _, _ = _bf16_vs_fp32(e, mel[:2], enc_ref)
+    ids64, n64 = e.encdec_tokens_batch(mel)
+    assert np.array_equal(ids64[:2], ids16) and (n64 == 31).all()
+    e.close()

@@ -48,7 +48,7 @@ CAPI_SYMBOLS = [
 DEBUG_SYMBOLS = [
     "wt_dbg_gemm", "wt_dbg_gemm_bench", "wt_dbg_dec_gemm_bench", "wt_dbg_dec_gemm", "wt_dbg_dec_ln_gemm", "wt_dbg_layernorm", "wt_dbg_encoder_attention",
     "wt_dbg_cross_attention", "wt_dbg_self_attention", "wt_dbg_interference", "wt_dbg_concurrency",
-    "wt_dbg_gemm_planes", "wt_dbg_encoder_attention_planes",
+    "wt_dbg_gemm_planes", "wt_dbg_encoder_attention_planes", "wt_dbg_gemm_bf16", "wt_dbg_encoder_attention_bf16",
 ]
 
 
@@ -139,6 +139,9 @@ def lib() -> ctypes.CDLL:
         L.wt_dbg_gemm_planes.argtypes = [c_void_p, c_int, c_int, c_int, fp, fp, fp, fp, fp, c_int, c_int, c_int, c_int, fp,
                                          POINTER(c_float)]
         L.wt_dbg_encoder_attention_planes.argtypes = [c_void_p, c_int, c_int, c_int, fp, c_int, fp, POINTER(c_float)]
+        L.wt_dbg_gemm_bf16.argtypes = [c_void_p, c_int, c_int, c_int, fp, fp, fp, fp, fp, c_int, c_int, c_int, c_int, fp,
+                                       POINTER(c_float)]
+        L.wt_dbg_encoder_attention_bf16.argtypes = [c_void_p, c_int, c_int, c_int, fp, c_int, fp, POINTER(c_float)]
         L.wt_dbg_gemm_bench.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_float)]
         L.wt_dbg_dec_gemm_bench.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_float)]
         L.wt_dbg_dec_gemm.argtypes = [c_void_p, c_int, c_int, c_int, c_int, fp, fp, fp, fp, fp, ip64]
@@ -477,6 +480,28 @@ class Engine:
         out = np.zeros((batch * T, heads * 64), np.float32)
         ms = c_float(0)
         self._check(lib().wt_dbg_encoder_attention_planes(self._h, batch, T, heads, _fp(qkv), iters, _fp(out), byref(ms)))
+        return (out, ms.value) if iters > 0 else out
+
+    def dbg_gemm_bf16(self, A, W, bias=None, R=None, pos=None, epi=1, bf16_out=False, iters=0):
+        """The encoder GEMM of the bf16 storage mode (operands rounded to bf16 on the host side of the tap)."""
+        A, W = _f32(A), _f32(W)
+        M, K = A.shape
+        N = W.shape[0]
+        C = np.zeros((M, N), np.float32)
+        bias = _f32(bias) if bias is not None else np.zeros(N, np.float32)
+        R = _f32(R) if R is not None else None
+        pos = _f32(pos) if pos is not None else None
+        ms = c_float(0)
+        self._check(lib().wt_dbg_gemm_bf16(self._h, M, N, K, _fp(A), _fp(W), _fp(bias), _fp(R), _fp(pos),
+                                           pos.shape[0] if pos is not None else 0, epi, int(bf16_out), iters, _fp(C),
+                                           byref(ms)))
+        return (C, ms.value) if iters > 0 else C
+
+    def dbg_encoder_attention_bf16(self, qkv, batch, T, heads, iters=0):
+        qkv = _f32(qkv)
+        out = np.zeros((batch * T, heads * 64), np.float32)
+        ms = c_float(0)
+        self._check(lib().wt_dbg_encoder_attention_bf16(self._h, batch, T, heads, _fp(qkv), iters, _fp(out), byref(ms)))
         return (out, ms.value) if iters > 0 else out
 
     def dbg_gemm_bench(self, M, N, K, epi=1, variant=0, iters=10) -> float:

@@ -98,6 +98,15 @@ __device__ __forceinline__ void split_f16x2(float a, float b, unsigned* hi, unsi
   *lo = l;
 }
 
+// bf16 storage mode: two fp32 values -> one packed dword of bf16 (a in bits 0-15), round to nearest even in hardware
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float bf16_lo(unsigned packed) { return __uint_as_float(packed << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned packed) { return __uint_as_float(packed & 0xFFFF0000u); }
+
 // erf for the GELU epilogues of the plane GEMM (one evaluation per output element: 73.7 M per fc1 launch).  The
 // library erff costs ~37 VALU instructions and a divergent branch per element there (measured in the ISA: the GELU
 // epilogue was as long as the K = 384 main loop).  Same two-interval minimax scheme, evaluated branch-free: both

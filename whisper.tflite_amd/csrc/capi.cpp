@@ -3,6 +3,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <functional>
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -139,6 +141,16 @@ int wt_engine_set_option(wt_engine* h, const char* key, long value) {
       return fail(h, WT_ERR_INVALID_ARG, "gemm_variant must be -1 (default), 0, 11, 13, 16, 17 or 18");
     }
     e.gemm_variant = value;
+  } else if (k == "bf16") {
+    // bf16 storage mode (BASELINE configs[3]); the first switch reads the weight file again for the bf16 copies
+    try {
+      e.bind_device();
+      e.set_bf16(value != 0);
+    } catch (const wt::Error& err) {
+      return fail(h, err.code, err.what());
+    } catch (const std::exception& err) {
+      return fail(h, WT_ERR_DEVICE, err.what());
+    }
   } else {
     return fail(h, WT_ERR_INVALID_ARG, "unknown option: " + k);
   }
@@ -162,6 +174,7 @@ int wt_engine_get_option(const wt_engine* h, const char* key, long* value) {
   else if (k == "cross_chunks") *value = e.cross_chunks;
   else if (k == "gemm_variant") *value = e.gemm_variant;
   else if (k == "use_graphs") *value = e.use_graphs;
+  else if (k == "bf16") *value = e.bf16;
   else if (k == "fc2_ksplit") *value = e.fc2_ksplit;
   else if (k == "attn_variant") *value = e.attn_variant;
   else if (k == "f16_fallbacks") *value = e.f16_fallbacks();  // read-only
@@ -759,6 +772,91 @@ int wt_dbg_encoder_attention_planes(wt_engine* h, int batch, int T, int heads, c
       *avg_ms = ms / iters;
       (void)hipEventDestroy(e0);
       (void)hipEventDestroy(e1);
+    }
+  });
+}
+
+namespace {
+// fp32 [n] -> device bf16 [n + pad] (round to nearest even) and back
+struct DevBf16 {
+  void* p = nullptr;
+  size_t n = 0;
+  static unsigned short rne(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return static_cast<unsigned short>((u >> 16) | 0x40u);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return static_cast<unsigned short>(u >> 16);
+  }
+  DevBf16(const float* x, size_t n_, size_t pad = 256) : n(n_) {
+    std::vector<unsigned short> host(n + pad, 0);
+    for (size_t i = 0; x && i < n; ++i) host[i] = rne(x[i]);
+    hipchk(hipMalloc(&p, host.size() * 2), "hipMalloc");
+    hipchk(hipMemcpy(p, host.data(), host.size() * 2, hipMemcpyHostToDevice), "H2D");
+  }
+  ~DevBf16() { (void)hipFree(p); }
+  unsigned short* ptr() const { return static_cast<unsigned short*>(p); }
+  void to_host(float* out, size_t count) const {
+    std::vector<unsigned short> host(count);
+    hipchk(hipMemcpy(host.data(), p, count * 2, hipMemcpyDeviceToHost), "D2H");
+    for (size_t i = 0; i < count; ++i) {
+      const uint32_t u = uint32_t(host[i]) << 16;
+      std::memcpy(&out[i], &u, 4);
+    }
+  }
+};
+float time_launches(hipStream_t st, int iters, const std::function<void()>& f) {
+  hipEvent_t e0, e1;
+  hipchk(hipEventCreate(&e0), "event");
+  hipchk(hipEventCreate(&e1), "event");
+  for (int i = 0; i < 3; ++i) f();
+  hipchk(hipEventRecord(e0, st), "record");
+  for (int i = 0; i < iters; ++i) f();
+  hipchk(hipEventRecord(e1, st), "record");
+  hipchk(hipEventSynchronize(e1), "sync");
+  float ms = 0;
+  hipchk(hipEventElapsedTime(&ms, e0, e1), "elapsed");
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return ms / iters;
+}
+}  // namespace
+
+int wt_dbg_gemm_bf16(wt_engine* h, int M, int N, int K, const float* A, const float* W, const float* bias,
+                     const float* R, const float* pos, int pos_period, int epi, int bf16_out, int iters, float* C,
+                     float* avg_ms) {
+  if (!h || !A || !W || !C || N % 128 || K % 64 || M < 1) return WT_ERR_INVALID_ARG;
+  return guarded(h, [&] {
+    const DevBf16 dA(A, size_t(M) * K), dW(W, size_t(N) * K);
+    DevBuf dB(bias, N), dC(R ? R : nullptr, size_t(M) * N), dP(pos, pos ? size_t(pos_period) * N : 0);
+    const DevBf16 dO(nullptr, size_t(M) * N);
+    wt::PlaneGemmArgs g;
+    g.A = dA.ptr(); g.lda = K; g.W = dW.ptr(); g.bias = dB.p;
+    g.C = dC.p; g.R = dC.p; g.ldc = N; g.pos = dP.p; g.pos_period = pos_period > 0 ? pos_period : 1;
+    g.M = M; g.N = N; g.K = K;
+    if (bf16_out) g.P = dO.ptr();
+    hipStream_t st = h->impl->stream();
+    wt::launch_gemm_bf16_planes(g, epi, st);
+    h->impl->sync();
+    if (bf16_out) dO.to_host(C, size_t(M) * N); else dC.to_host(C, size_t(M) * N);
+    if (avg_ms && iters > 0 && !(epi & wt::kEpiResidual)) {
+      *avg_ms = time_launches(st, iters, [&] { wt::launch_gemm_bf16_planes(g, epi, st); });
+    }
+  });
+}
+
+int wt_dbg_encoder_attention_bf16(wt_engine* h, int batch, int T, int heads, const float* qkv, int iters, float* out,
+                                  float* avg_ms) {
+  if (!h || !qkv || !out) return WT_ERR_INVALID_ARG;
+  return guarded(h, [&] {
+    const size_t d = size_t(heads) * 64, rows = size_t(batch) * T;
+    const DevBf16 dQ(qkv, rows * 3 * d), dO(nullptr, rows * d);
+    hipStream_t st = h->impl->stream();
+    wt::launch_encoder_attention_bf16(dQ.ptr(), dO.ptr(), batch, T, heads, st);
+    h->impl->sync();
+    dO.to_host(out, rows * d);
+    if (avg_ms && iters > 0) {
+      *avg_ms = time_launches(st, iters, [&] { wt::launch_encoder_attention_bf16(dQ.ptr(), dO.ptr(), batch, T, heads, st); });
     }
   });
 }

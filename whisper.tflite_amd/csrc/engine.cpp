@@ -59,6 +59,40 @@ std::vector<unsigned short> tile_weights_f16(const float* W, int N, int K, float
   return out;
 }
 
+namespace {
+inline unsigned short bf16_rne(float f) {
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  if ((u & 0x7FFFFFFFu) > 0x7F800000u) return static_cast<unsigned short>((u >> 16) | 0x40u);  // NaN stays NaN
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return static_cast<unsigned short>(u >> 16);
+}
+}  // namespace
+
+// bf16 storage mode: one bf16 plane in the decoder GEMM's fragment order [ceil(N/32)][K/16][64 lanes][8]
+std::vector<unsigned short> tile_weights_bf16(const float* W, int N, int K) {
+  const int n_tiles = (N + 31) / 32, steps = K / 16;
+  std::vector<unsigned short> out(size_t(n_tiles) * steps * 512, 0);
+  for (int t = 0; t < n_tiles; ++t)
+    for (int s = 0; s < steps; ++s)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int n = t * 32 + (lane & 31);
+        if (n >= N) continue;
+        const float* src = W + size_t(n) * K + 16 * s + 8 * (lane >> 5);
+        unsigned short* dst = out.data() + (size_t(t) * steps + s) * 512 + lane * 8;
+        for (int e = 0; e < 8; ++e) dst[e] = bf16_rne(src[e]);
+      }
+  return out;
+}
+
+// bf16 storage mode: W [N][K] fp32 -> bf16 [N][Kpad], zero filled
+std::vector<unsigned short> round_weights_bf16(const float* W, int N, int K, int Kpad) {
+  std::vector<unsigned short> out(size_t(N) * Kpad, 0);
+  for (int n = 0; n < N; ++n)
+    for (int k = 0; k < K; ++k) out[size_t(n) * Kpad + k] = bf16_rne(W[size_t(n) * K + k]);
+  return out;
+}
+
 // Wq [d][d] (row = output) -> [head][d / 4][64 outputs of the head][4 k]: thread (output j, k-quarter) of
 // cross_attention_step reads 16 contiguous bytes per step and a wavefront 1 KiB
 std::vector<float> cross_q_layout(const float* Wq, int d) {
@@ -128,32 +162,70 @@ const float* Engine::dev(const std::string& name) const {
   return it->second;
 }
 
+namespace {
+// A .wtw file mapped read-only: header checked, tensor table parsed into name -> (fp32 payload, element count).
+struct WtwFile {
+  void* map = MAP_FAILED;
+  size_t bytes = 0;
+  wtw::WtwHeader hdr{};
+  std::map<std::string, std::pair<const float*, size_t>> host;
+
+  explicit WtwFile(const std::string& path) {
+    const int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) throw Error(2, "Failed to open file: " + path);
+    struct stat st;
+    if (fstat(fd, &st) != 0 || size_t(st.st_size) < sizeof(wtw::WtwHeader)) {
+      ::close(fd);
+      throw Error(3, "weight file too small: " + path);
+    }
+    bytes = size_t(st.st_size);
+    map = mmap(nullptr, bytes, PROT_READ, MAP_PRIVATE, fd, 0);
+    ::close(fd);
+    if (map == MAP_FAILED) throw Error(2, "Failed to mmap file: " + path);
+    try {
+      const char* base = static_cast<const char*>(map);
+      std::memcpy(&hdr, base, sizeof(hdr));
+      if (hdr.magic != wtw::kMagic || hdr.version != wtw::kVersion || hdr.n_tensors > (1u << 20) ||
+          size_t(hdr.table_offset) + size_t(hdr.n_tensors) * sizeof(wtw::WtwTensor) > bytes) {
+        throw Error(3, "not a .wtw weight file: " + path);
+      }
+      const uint64_t file_bytes = uint64_t(bytes);
+      for (uint32_t i = 0; i < hdr.n_tensors; ++i) {
+        wtw::WtwTensor t;
+        std::memcpy(&t, base + hdr.table_offset + size_t(i) * sizeof(t), sizeof(t));
+        // overflow-safe range check; fp32 payloads are read in place, so they must be 4-byte aligned
+        if (t.dtype != 0 || t.offset > file_bytes || t.nbytes > file_bytes - t.offset || t.offset % 4 != 0 || t.nbytes % 4 != 0) {
+          throw Error(kErrFormat, "corrupt tensor table in " + path);
+        }
+        t.name[sizeof(t.name) - 1] = 0;
+        host[t.name] = {reinterpret_cast<const float*>(base + t.offset), t.nbytes / sizeof(float)};
+      }
+    } catch (...) {
+      munmap(map, bytes);
+      throw;
+    }
+  }
+  ~WtwFile() {
+    if (map != MAP_FAILED) munmap(map, bytes);
+  }
+  WtwFile(const WtwFile&) = delete;
+  WtwFile& operator=(const WtwFile&) = delete;
+  const float* get(const std::string& n, size_t expect) const {
+    auto it = host.find(n);
+    if (it == host.end()) throw Error(3, "weight file: missing tensor " + n);
+    if (it->second.second != expect) throw Error(3, "weight file: bad shape for " + n);
+    return it->second.first;
+  }
+};
+}  // namespace
+
 void Engine::upload_weights(const std::string& path) {
   // Replaces Atom::Atom (whisper.cpp:261-271): instead of mmapping a .tflite FlatBuffer and
   // building an interpreter, the flat .wtw payload is mapped, re-laid-out for the kernels
   // and copied to HBM once.
-  const int fd = ::open(path.c_str(), O_RDONLY);
-  if (fd < 0) throw Error(2, "Failed to open file: " + path);
-  struct stat st;
-  if (fstat(fd, &st) != 0 || size_t(st.st_size) < sizeof(wtw::WtwHeader)) {
-    ::close(fd);
-    throw Error(3, "weight file too small: " + path);
-  }
-  void* map = mmap(nullptr, st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
-  ::close(fd);
-  if (map == MAP_FAILED) throw Error(2, "Failed to mmap file: " + path);
-  struct Unmap {
-    void* p;
-    size_t n;
-    ~Unmap() { munmap(p, n); }
-  } unmap{map, size_t(st.st_size)};
-  const char* base = static_cast<const char*>(map);
-  wtw::WtwHeader hdr;
-  std::memcpy(&hdr, base, sizeof(hdr));
-  if (hdr.magic != wtw::kMagic || hdr.version != wtw::kVersion || hdr.n_tensors > (1u << 20) ||
-      size_t(hdr.table_offset) + size_t(hdr.n_tensors) * sizeof(wtw::WtwTensor) > size_t(st.st_size)) {
-    throw Error(3, "not a .wtw weight file: " + path);
-  }
+  const WtwFile file(path);
+  weights_path_ = path;
+  const wtw::WtwHeader& hdr = file.hdr;
   dims_ = hdr.dims;
   const wtw::Dims& c = dims_;
   // Everything the kernels index with comes from this header: reject what they do not support here, as a
@@ -170,24 +242,7 @@ void Engine::upload_weights(const std::string& path) {
       !in(c.n_audio_layer, 1, 64) || !in(c.n_text_layer, 1, 64) || !in(c.n_vocab, 1, 1 << 20)) {
     throw Error(kErrFormat, "unsupported model dims: n_mels 1..128, n_audio_ctx / n_text_ctx 32..4096, layers 1..64, n_vocab 1..2^20");
   }
-  std::map<std::string, std::pair<const float*, size_t>> host;
-  const uint64_t file_bytes = uint64_t(st.st_size);
-  for (uint32_t i = 0; i < hdr.n_tensors; ++i) {
-    wtw::WtwTensor t;
-    std::memcpy(&t, base + hdr.table_offset + size_t(i) * sizeof(t), sizeof(t));
-    // overflow-safe range check; fp32 payloads are read in place, so they must be 4-byte aligned
-    if (t.dtype != 0 || t.offset > file_bytes || t.nbytes > file_bytes - t.offset || t.offset % 4 != 0 || t.nbytes % 4 != 0) {
-      throw Error(kErrFormat, "corrupt tensor table in " + path);
-    }
-    t.name[sizeof(t.name) - 1] = 0;
-    host[t.name] = {reinterpret_cast<const float*>(base + t.offset), t.nbytes / sizeof(float)};
-  }
-  auto H = [&](const std::string& n, size_t expect) -> const float* {
-    auto it = host.find(n);
-    if (it == host.end()) throw Error(3, "weight file: missing tensor " + n);
-    if (it->second.second != expect) throw Error(3, "weight file: bad shape for " + n);
-    return it->second.first;
-  };
+  auto H = [&](const std::string& n, size_t expect) -> const float* { return file.get(n, expect); };
   auto up = [&](const std::string& n, size_t expect) -> const float* {
     const float* p = H(n, expect);
     const float* d = upload(std::vector<float>(p, p + expect));
@@ -423,6 +478,73 @@ void Engine::upload_weights(const std::string& path) {
     cross_kv_p_ = upload_planes(ckv_w.data(), c.n_text_layer * 2 * d, d, d, sc_cross_kv_.w);
   }
 
+}
+
+// bf16 storage mode (option "bf16", BASELINE configs[3]): bf16 copies of every matrix a kernel contracts with, made
+// from the weight file the first time the mode is switched on.  Biases, LayerNorm gains / shifts, positional tables
+// and the embedding rows the decoder looks up stay fp32 (epilogue / prologue operands, never MFMA operands), and so
+// does the cross-attention query projection, which runs as an fp32 matrix-vector product inside cross_attention_step.
+void Engine::ensure_bf16_weights() {
+  if (bf16_ready_) return;
+  if (dims_.n_audio_state == 0) throw Error(kErrUnsupported, "front-end-only engine: no model weights loaded");
+  const WtwFile file(weights_path_);
+  const wtw::Dims& c = dims_;
+  const int d = c.n_audio_state, nm = c.n_mels;
+  auto H = [&](const std::string& n, size_t expect) -> const float* { return file.get(n, expect); };
+  auto up16 = [&](const std::vector<unsigned short>& v) -> const unsigned short* {
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, std::max<size_t>(v.size(), 1) * sizeof(unsigned short) + 256));
+    allocations_.push_back(p);
+    HIPCHK(hipMemcpy(p, v.data(), v.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+    return static_cast<const unsigned short*>(p);
+  };
+  const size_t dd = size_t(d) * d;
+  {
+    bf_.conv1_kpad = int(round_up(size_t(3) * nm, 64));
+    std::vector<float> r(size_t(d) * 3 * nm);
+    const float* w = H("encoder.conv1.weight", size_t(d) * nm * 3);
+    for (int co = 0; co < d; ++co)
+      for (int ci = 0; ci < nm; ++ci)
+        for (int kk = 0; kk < 3; ++kk) r[size_t(co) * 3 * nm + kk * nm + ci] = w[(size_t(co) * nm + ci) * 3 + kk];
+    bf_.conv1 = up16(round_weights_bf16(r.data(), d, 3 * nm, bf_.conv1_kpad));
+    std::vector<float> r2(size_t(d) * 3 * d);
+    const float* w2 = H("encoder.conv2.weight", size_t(d) * d * 3);
+    for (int co = 0; co < d; ++co)
+      for (int ci = 0; ci < d; ++ci)
+        for (int kk = 0; kk < 3; ++kk) r2[size_t(co) * 3 * d + kk * d + ci] = w2[(size_t(co) * d + ci) * 3 + kk];
+    bf_.conv2 = up16(round_weights_bf16(r2.data(), d, 3 * d, 3 * d));
+  }
+  auto fused_qkv = [&](const std::string& p) {
+    std::vector<float> w(3 * dd);
+    std::memcpy(w.data(), H(p + ".query.weight", dd), dd * 4);
+    std::memcpy(w.data() + dd, H(p + ".key.weight", dd), dd * 4);
+    std::memcpy(w.data() + 2 * dd, H(p + ".value.weight", dd), dd * 4);
+    return w;
+  };
+  bf_.layers.resize(c.n_audio_layer);
+  for (int l = 0; l < c.n_audio_layer; ++l) {
+    const std::string blk = "encoder.blocks." + std::to_string(l);
+    bf_.layers[l].qkv = up16(round_weights_bf16(fused_qkv(blk + ".attn").data(), 3 * d, d, d));
+    bf_.layers[l].out = up16(round_weights_bf16(H(blk + ".attn.out.weight", dd), d, d, d));
+    bf_.layers[l].fc1 = up16(round_weights_bf16(H(blk + ".mlp.0.weight", 4 * dd), 4 * d, d, d));
+    bf_.layers[l].fc2 = up16(round_weights_bf16(H(blk + ".mlp.2.weight", 4 * dd), d, 4 * d, 4 * d));
+  }
+  std::vector<float> ckv_w(size_t(c.n_text_layer) * 2 * dd);
+  dec_blocks_bf_ = dec_blocks_;  // fp32 vectors shared; the tiled matrices are replaced below
+  for (int l = 0; l < c.n_text_layer; ++l) {
+    const std::string blk = "decoder.blocks." + std::to_string(l);
+    std::memcpy(ckv_w.data() + (size_t(l) * 2 + 0) * dd, H(blk + ".cross_attn.key.weight", dd), dd * 4);
+    std::memcpy(ckv_w.data() + (size_t(l) * 2 + 1) * dd, H(blk + ".cross_attn.value.weight", dd), dd * 4);
+    DecBlockWeights& bw = dec_blocks_bf_[l];
+    bw.wqkv = TiledW{up16(tile_weights_bf16(fused_qkv(blk + ".attn").data(), 3 * d, d)), 1.0f};
+    bw.wo = TiledW{up16(tile_weights_bf16(H(blk + ".attn.out.weight", dd), d, d)), 1.0f};
+    bw.cross_wo = TiledW{up16(tile_weights_bf16(H(blk + ".cross_attn.out.weight", dd), d, d)), 1.0f};
+    bw.w1 = TiledW{up16(tile_weights_bf16(H(blk + ".mlp.0.weight", 4 * dd), 4 * d, d)), 1.0f};
+    bw.w2 = TiledW{up16(tile_weights_bf16(H(blk + ".mlp.2.weight", 4 * dd), d, 4 * d)), 1.0f};
+  }
+  bf_.cross_kv = up16(round_weights_bf16(ckv_w.data(), c.n_text_layer * 2 * d, d, d));
+  tok_emb_tiled_bf_ = TiledW{up16(tile_weights_bf16(H("decoder.token_embedding.weight", size_t(c.n_vocab) * d), c.n_vocab, d)), 1.0f};
+  bf16_ready_ = true;
 }
 
 namespace {
@@ -864,6 +986,10 @@ void Engine::encode(const float* d_mel, int batch) {
 void Engine::encode_enqueue(const float* d_mel, int batch) {
   if (dims_.n_audio_state == 0) throw Error(kErrUnsupported, "front-end-only engine: no model weights loaded");
   ensure_batch(batch);
+  if (bf16) {
+    encode_enqueue_bf16(d_mel, batch);
+    return;
+  }
   if (use_planes()) {
     encode_enqueue_planes(d_mel, batch);
     return;
@@ -1104,6 +1230,122 @@ void Engine::encode_enqueue_planes(const float* d_mel, int batch) {
   enc_slot_ = (enc_slot_ + 1) % kSlots;
 }
 
+// bf16 storage mode (option "bf16"): the same graph with every contraction operand stored as ONE bf16 matrix
+// (k_gemm_bf16.hip, encoder_attention_planes<true>); the residual stream x and the API's enc_out stay fp32, the
+// cross-KV cache of the slot is written as bf16 (half the bytes of the default mode, same layout).
+void Engine::encode_enqueue_bf16(const float* d_mel, int batch) {
+  const wtw::Dims& c = dims_;
+  const int T0 = mel_frames(), T = c.n_audio_ctx, d = c.n_audio_state, M = batch * T, nm = c.n_mels;
+  Slot& slot = slots_[enc_slot_];
+  if (slot.used) HIPCHK(hipStreamWaitEvent(stream_, slot.dec_done, 0));
+  slot.kt_cls.clear();
+  slot.kt_flops.clear();
+  slot.kt_bytes.clear();
+  slot.batch = batch;
+  HIPCHK(hipMemsetAsync(slot.d_flag, 0, sizeof(int), stream_));
+  HIPCHK(hipEventRecord(slot.enc_begin, stream_));
+  unsigned short* const lnp = reinterpret_cast<unsigned short*>(ws_.ln);
+  unsigned short* const qkvp = reinterpret_cast<unsigned short*>(ws_.qkv);
+  unsigned short* const attp = reinterpret_cast<unsigned short*>(ws_.att);
+  unsigned short* const hidp = reinterpret_cast<unsigned short*>(ws_.hid);
+
+  kt_begin(kKcTranspose, 0, 1.5 * batch * nm * T0 * 4);
+  launch_mel_transpose_planes(d_mel, ws_.melTp, 0, 1.0f, batch, nm, T0, nm, stream_, true);
+  kt_end();
+  {
+    PlaneGemmArgs g;  // conv1 + GELU: rows (clip, t) read melT rows t..t+2 (input t-1..t+1)
+    g.A = ws_.melTp; g.a_rpb = T0; g.a_bs = long(T0 + 2) * nm; g.lda = nm;
+    g.W = bf_.conv1; g.bias = conv1_b;
+    g.P = ws_.h1pp + d;  // row t lands at padded row t + 1
+    g.c_rpb = T0; g.c_bs = long(T0 + 2) * d; g.ldc = d;
+    g.M = batch * T0; g.N = d; g.K = bf_.conv1_kpad;
+    kt_begin(kKcGemm, 2.0 * g.M * g.N * (3.0 * nm), 0);
+    launch_gemm_bf16_planes(g, kEpiBias | kEpiGelu, stream_);
+    kt_end();
+  }
+  {
+    PlaneGemmArgs g;  // conv2 (stride 2) + GELU + positional embedding
+    g.A = ws_.h1pp; g.a_rpb = T; g.a_bs = long(T0 + 2) * d; g.lda = 2 * d;
+    g.W = bf_.conv2; g.bias = conv2_b; g.pos = enc_pos; g.pos_period = T;
+    g.C = ws_.x; g.ldc = d;
+    g.M = M; g.N = d; g.K = 3 * d;
+    kt_begin(kKcGemm, 2.0 * g.M * g.N * g.K, 0);
+    launch_gemm_bf16_planes(g, kEpiBias | kEpiGelu | kEpiPos, stream_);
+    kt_end();
+  }
+  for (int l = 0; l < c.n_audio_layer; ++l) {
+    const BlockWeights& w = enc_blocks_[l];
+    const Bf16Encoder::Layer& wb = bf_.layers[l];
+    kt_begin(kKcLayerNorm, 0, 1.5 * M * d * 4);
+    launch_layernorm_planes(ws_.x, lnp, 0, 1.0f, nullptr, w.attn_ln_g, w.attn_ln_b, M, d, stream_, nullptr, true);
+    kt_end();
+    PlaneGemmArgs q;
+    q.A = lnp; q.lda = d; q.W = wb.qkv; q.bias = w.attn.bqkv;
+    q.P = qkvp; q.ldc = 3 * d; q.M = M; q.N = 3 * d; q.K = d;
+    kt_begin(kKcGemm, 2.0 * q.M * q.N * q.K, 0);
+    launch_gemm_bf16_planes(q, kEpiBias, stream_);
+    kt_end();
+    kt_begin(kKcEncAttn, 4.0 * batch * c.n_audio_head * double(T) * T * 64, 0);
+    launch_encoder_attention_bf16(qkvp, attp, batch, T, c.n_audio_head, stream_);
+    kt_end();
+    PlaneGemmArgs o;
+    o.A = attp; o.lda = d; o.W = wb.out; o.bias = w.attn.bo;
+    o.C = ws_.x; o.R = ws_.x; o.ldc = d; o.M = M; o.N = d; o.K = d;
+    kt_begin(kKcGemm, 2.0 * o.M * o.N * o.K, 0);
+    launch_gemm_bf16_planes(o, kEpiBias | kEpiResidual, stream_);
+    kt_end();
+    kt_begin(kKcLayerNorm, 0, 1.5 * M * d * 4);
+    launch_layernorm_planes(ws_.x, lnp, 0, 1.0f, nullptr, w.mlp_ln_g, w.mlp_ln_b, M, d, stream_, nullptr, true);
+    kt_end();
+    PlaneGemmArgs f1;
+    f1.A = lnp; f1.lda = d; f1.W = wb.fc1; f1.bias = w.b1;
+    f1.P = hidp; f1.ldc = 4 * d; f1.M = M; f1.N = 4 * d; f1.K = d;
+    kt_begin(kKcGemm, 2.0 * f1.M * f1.N * f1.K, 0);
+    launch_gemm_bf16_planes(f1, kEpiBias | kEpiGelu, stream_);
+    kt_end();
+    PlaneGemmArgs f2;
+    f2.A = hidp; f2.lda = 4 * d; f2.W = wb.fc2; f2.bias = w.b2;
+    f2.C = ws_.x; f2.R = ws_.x; f2.ldc = d; f2.M = M; f2.N = d; f2.K = 4 * d;
+    kt_begin(kKcGemm, 2.0 * f2.M * f2.N * f2.K, 0);
+    launch_gemm_bf16_planes(f2, kEpiBias | kEpiResidual, stream_);
+    kt_end();
+  }
+  kt_begin(kKcLayerNorm, 0, 2.5 * M * d * 4);
+  launch_layernorm_planes(ws_.x, lnp, 0, 1.0f, ws_.enc_out, enc_ln_post_g, enc_ln_post_b, M, d, stream_, slot.d_flag, true);
+  HIPCHK(hipMemcpyAsync(slot.h_flag, slot.d_flag, sizeof(int), hipMemcpyDeviceToHost, stream_));
+  kt_end();
+  HIPCHK(hipEventRecord(slot.enc_mid, stream_));
+  {
+    PlaneGemmArgs g;  // cross-attention K/V of every decoder layer into the slot's cache, as bf16
+    g.A = lnp; g.lda = d; g.W = bf_.cross_kv; g.bias = cross_kv_b;
+    g.P = reinterpret_cast<unsigned short*>(slot.cross_kv); g.M = M; g.N = c.n_text_layer * 2 * d; g.K = d;
+    g.c_rpb = T; g.kv_batch = batch; g.kv_heads = c.n_text_head; g.kv_dmodel = d;
+    kt_begin(kKcGemm, 2.0 * g.M * g.N * g.K, 0);
+    launch_gemm_bf16_planes(g, kEpiBias | kEpiKvLayout, stream_);
+    kt_end();
+  }
+  HIPCHK(hipEventRecord(slot.enc_done, stream_));
+  slot.used = true;
+  last_enc_slot_ = enc_slot_;
+  enc_slot_ = (enc_slot_ + 1) % kSlots;
+}
+
+void Engine::set_bf16(bool on) {
+  require_idle();
+  if (on) ensure_bf16_weights();
+  if ((bf16 != 0) != on && ws_.batch > 0 && dims_.n_audio_state != 0) {
+    // the zero pad rows of the two convolution inputs sit at different offsets in the two layouts
+    const size_t B = ws_.batch, T0 = mel_frames();
+    sync();
+    HIPCHK(hipMemset(ws_.melTp, 0, (B * (T0 + 2) * dims_.n_mels + 256) * sizeof(float)));
+    HIPCHK(hipMemset(ws_.h1pp, 0, (B * (T0 + 2) * dims_.n_audio_state + 256) * sizeof(float)));
+    for (DecWorkspace& dw : dws_) {
+      if (dw.self_kv) HIPCHK(hipMemset(dw.self_kv, 0, size_t(dims_.n_text_layer) * 2 * B * self_cap_ * dims_.n_text_state * sizeof(float)));
+    }
+  }
+  bf16 = on ? 1 : 0;
+}
+
 // ------------------------------------------------------------ decoder ---
 
 void Engine::decode(int batch, int64_t* ids, int32_t* n_ids, float* logits_host,
@@ -1213,8 +1455,12 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
     HIPCHK(hipMemcpyAsync(dw.n_ids, h_n_, size_t(batch) * sizeof(int), hipMemcpyHostToDevice, stream_));
     HIPCHK(hipMemsetAsync(dw.finished, 0, size_t(batch) * sizeof(int), stream_));
 
+    const bool bf = bf16 != 0;  // bf16 storage mode: bf16 weights and caches (element size 2 in the cache offsets)
     const size_t kv_slab = size_t(batch) * T * d;  // one (layer, k|v) slab of the cross cache
     const size_t self_slab = size_t(batch) * self_cap_ * d;
+    auto cache_at = [&](float* base, size_t elems) -> void* {
+      return bf ? static_cast<void*>(reinterpret_cast<unsigned short*>(base) + elems) : static_cast<void*>(base + elems);
+    };
     float* const x = dw.xd;  // residual stream [rows][d], updated in place by the residual GEMMs
     // fc2 (K = 4 d) runs over twice the blocks when its K splits evenly over 2 x 8 waves x 16
     const bool split = fc2_ksplit == 2 && (4 * d) % 256 == 0;
@@ -1226,8 +1472,9 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
     for (int pos0 = 0, np = first; pos0 < max_pos; pos0 += np, np = 1) {
       const int M = np * batch, last = pos0 + np - 1;
       for (int l = 0; l < c.n_text_layer; ++l) {
-        const DecBlockWeights& w = dec_blocks_[l];
+        const DecBlockWeights& w = bf ? dec_blocks_bf_[l] : dec_blocks_[l];
         DecGemmArgs q;  // LN + fused q|k|v projection (+ token/positional embedding at layer 0)
+        q.bf16 = bf;
         q.Wt = w.wqkv.w; q.w_scale = w.wqkv.scale; q.N = 3 * d; q.K = d; q.B = batch; q.M = M;
         q.xin = x; q.ln_g = w.attn_ln_g; q.ln_b = w.attn_ln_b;
         if (l > 0 && split) {  // the previous layer's fc2 left x in two halves: sum them, block 0 completes x
@@ -1239,31 +1486,36 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
         }
         q.bias = w.bqkv; q.Y = dw.qkvd; q.ldy = 3 * d;
         DT(0, launch_dec_gemm(q, kProLn, kDecBias, stream_));
-        DT(1, launch_self_attention(dw.qkvd, dw.self_kv + (size_t(l) * 2 + 0) * self_slab,
-                                    dw.self_kv + (size_t(l) * 2 + 1) * self_slab, self_cap_, pos0, np, dw.attd,
-                                    batch, H, stream_));
+        DT(1, launch_self_attention(dw.qkvd, cache_at(dw.self_kv, (size_t(l) * 2 + 0) * self_slab),
+                                    cache_at(dw.self_kv, (size_t(l) * 2 + 1) * self_slab), self_cap_, pos0, np, dw.attd,
+                                    batch, H, stream_, bf));
         DecGemmArgs o;  // x += attn . Wo^T + bo
+        o.bf16 = bf;
         o.Wt = w.wo.w; o.w_scale = w.wo.scale; o.N = d; o.K = d; o.B = batch; o.M = M; o.X = dw.attd; o.ldx = d;
         o.bias = w.bo; o.R = x; o.Y = x; o.ldy = d;
         DT(2, launch_dec_gemm(o, kProNone, kDecResid, stream_));
 
         CrossAttnArgs ca;  // LN + query projection + attention over the cached encoder keys, per key chunk
         ca.x = x; ca.ln_g = w.cross_ln_g; ca.ln_b = w.cross_ln_b; ca.wq_t = w.cross_wq_t; ca.bq = w.cross_bq;
-        ca.kc = slot.cross_kv + (size_t(l) * 2 + 0) * kv_slab; ca.vc = slot.cross_kv + (size_t(l) * 2 + 1) * kv_slab;
+        ca.kc = cache_at(slot.cross_kv, (size_t(l) * 2 + 0) * kv_slab); ca.vc = cache_at(slot.cross_kv, (size_t(l) * 2 + 1) * kv_slab);
+        ca.bf16 = bf;
         ca.ws = dw.cross_ws; ca.batch = batch; ca.heads = H; ca.T = T; ca.chunks = chunks; ca.nq = np;
         DT(4, launch_cross_attention(ca, stream_));
         DecGemmArgs co;  // x += combine(chunks) . Wco^T + bco
+        co.bf16 = bf;
         co.Wt = w.cross_wo.w; co.w_scale = w.cross_wo.scale; co.N = d; co.K = d; co.B = batch; co.M = M;
         co.cross_ws = dw.cross_ws; co.heads = H; co.chunks = chunks;
         co.bias = w.cross_bo; co.R = x; co.Y = x; co.ldy = d;
         DT(5, launch_dec_gemm(co, kProCombine, kDecResid, stream_));
 
         DecGemmArgs f1;  // LN + fc1 + GELU
+        f1.bf16 = bf;
         f1.Wt = w.w1.w; f1.w_scale = w.w1.scale; f1.N = 4 * d; f1.K = d; f1.B = batch; f1.M = M;
         f1.xin = x; f1.ln_g = w.mlp_ln_g; f1.ln_b = w.mlp_ln_b;
         f1.bias = w.b1; f1.Y = dw.hd; f1.ldy = 4 * d;
         DT(6, launch_dec_gemm(f1, kProLn, kDecBiasGelu, stream_));
         DecGemmArgs f2;  // x += h . W2^T + b2
+        f2.bf16 = bf;
         f2.Wt = w.w2.w; f2.w_scale = w.w2.scale; f2.N = d; f2.K = 4 * d; f2.B = batch; f2.M = M; f2.X = dw.hd; f2.ldx = 4 * d;
         f2.bias = w.b2; f2.R = x; f2.Y = x; f2.ldy = d;
         if (split) {
@@ -1278,7 +1530,8 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
         DT(8, launch_dec_finalize_ln((split ? dw.xb : x) + off, dec_ln_g, dec_ln_b, dw.lnd, batch, d, stream_,
                                      split ? dw.xpart + off : nullptr));
         DecGemmArgs lg;
-        lg.Wt = tok_emb_tiled.w; lg.w_scale = tok_emb_tiled.scale; lg.N = V; lg.K = d; lg.B = batch; lg.X = dw.lnd; lg.ldx = d;
+        lg.bf16 = bf;
+        lg.Wt = (bf ? tok_emb_tiled_bf_ : tok_emb_tiled).w; lg.w_scale = (bf ? tok_emb_tiled_bf_ : tok_emb_tiled).scale; lg.N = V; lg.K = d; lg.B = batch; lg.X = dw.lnd; lg.ldx = d;
         lg.Y = logits_host ? dw.logits : nullptr; lg.ldy = V; lg.best = dw.best;
         DT(9, launch_dec_gemm(lg, kProNone, kDecLogits, stream_));
         if (logits_host && steps < logits_steps_cap) {
@@ -1300,7 +1553,7 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
   // kernels' one-time attribute set-up) and then captures one hipGraph per slot; later calls
   // replay the slot's graph: one host call instead of ~1100. The logits tap stays eager.
   auto key_of = [&](int si) {
-    return std::vector<long long>{si, batch, max_pos, n_prompt, chunks, long(stop_at_eot), fc2_ksplit};
+    return std::vector<long long>{si, batch, max_pos, n_prompt, chunks, long(stop_at_eot), fc2_ksplit, bf16};
   };
   hipGraphExec_t exec = nullptr;
   if (use_graphs && !logits_host) {

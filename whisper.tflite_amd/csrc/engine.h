@@ -84,6 +84,11 @@ class Engine {
   long fc2_ksplit = 2;  // decoder fc2 (K = 4 d_model) over twice the blocks, halves summed by the consumer
   long use_graphs = 1;  // replay the decoder's launch sequence from a captured hipGraph
   long gemm_variant = -1;  // encoder GEMM tile variant (k_gemm.hip); -1 = per-shape choice
+  // 1 = bf16 STORAGE mode (BASELINE configs[3]): bf16 weights, activations and both KV caches, fp32 accumulation,
+  // fp32 residual stream; k_gemm_bf16.hip and the BF variants of the attention / decoder kernels.  Set through
+  // set_bf16(): the first switch uploads the bf16 weight copies.
+  long bf16 = 0;
+  void set_bf16(bool on);
   // non-empty: replaces the reference's hard-coded prompt (test-sized vocabularies)
   std::vector<long long> prompt_override;
   // ids the decoder starts from (prompt_override, or the reference's rule for the engine type)
@@ -139,6 +144,18 @@ class Engine {
   void create_streams();  // streams, events, pinned id buffers of the pipeline slots
   void release() noexcept;  // frees every device / host resource; idempotent (destructor and failed constructor)
   void upload_weights(const std::string& path);
+  void ensure_bf16_weights();
+  std::string weights_path_;
+  bool bf16_ready_ = false;
+  struct Bf16Encoder {  // bf16 [N][Kpad] matrices of the encoder (k_gemm_bf16.hip)
+    const unsigned short *conv1 = nullptr, *conv2 = nullptr, *cross_kv = nullptr;
+    int conv1_kpad = 0;
+    struct Layer {
+      const unsigned short *qkv = nullptr, *out = nullptr, *fc1 = nullptr, *fc2 = nullptr;
+    };
+    std::vector<Layer> layers;
+  } bf_;
+  void encode_enqueue_bf16(const float* d_mel, int batch);
   const float* dev(const std::string& name) const;
   float* upload(const std::vector<float>& host);
   TiledW upload_tiled(const float* W, int N, int K);
@@ -217,6 +234,8 @@ class Engine {
   const float* enc_pos = nullptr;
   std::vector<BlockWeights> enc_blocks_;
   std::vector<DecBlockWeights> dec_blocks_;
+  std::vector<DecBlockWeights> dec_blocks_bf_;  // bf16 storage mode: TiledW members are single bf16 planes
+  TiledW tok_emb_tiled_bf_;
   // Operand scales of the two-plane fp16 encoder kernels (powers of two, f16_scale_for): derived at load
   // time from weight-only upper bounds of every contraction operand (LayerNorm output <= |g| sqrt(d-1) + |b|,
   // Linear output <= sum |W| * input bound + |bias|, GELU(x) <= max(x, 0.17), attention output <= V bound),

@@ -6,6 +6,8 @@
 // :375; graph per export/generate_onnx.py:85-120).
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "bf16_split.h"
 #include "kernels.h"
 
@@ -458,16 +460,21 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void encoder_attention_sp
 // One block = one wavefront per (clip, head).  Appends the k, v of `npos` new positions (pos0 .. pos0 + npos - 1;
 // npos = 1 for a generated position, the whole prompt in the first pass) to the cache, then for each new position
 // lane j scores cached position j and lane d accumulates output d.  qkv / out rows: row(p) = p * B + b.
-__global__ void self_attention_step(const float* __restrict__ qkv, float* __restrict__ kcache,
-                                    float* __restrict__ vcache, int cap, int pos0, int npos, int B,
+// BF: the cache rows are bf16 (bf16 storage mode); the new position's k and v are rounded before they are used, so a
+// row contributes the same values whether it was just computed or read back.
+template <bool BF>
+__global__ void self_attention_step(const float* __restrict__ qkv, void* __restrict__ kcache_v,
+                                    void* __restrict__ vcache_v, int cap, int pos0, int npos, int B,
                                     float* __restrict__ out, int heads) {
   // Everything this (clip, head) needs is requested in one batch of independent loads — the new q/k/v rows and the
-  // cached K and V rows of positions < pos0 (16 lanes x 16 B per row) — and staged in LDS; scores, softmax and the
-  // weighted sum then run out of LDS.  One round trip to memory.
+  // cached K and V rows of positions < pos0 (16 lanes x 16 B per row; 8 B in the bf16 mode) — and staged in LDS;
+  // scores, softmax and the weighted sum then run out of LDS.  One round trip to memory.
+  using CT = typename std::conditional<BF, unsigned short, float>::type;
+  using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
   const int b = blockIdx.x / heads, h = blockIdx.x % heads, lane = threadIdx.x;
   const int d = heads * 64;
-  float* kc = kcache + ((long)b * cap) * d + h * 64;
-  float* vc = vcache + ((long)b * cap) * d + h * 64;
+  CT* kc = static_cast<CT*>(kcache_v) + ((long)b * cap) * d + h * 64;
+  CT* vc = static_cast<CT*>(vcache_v) + ((long)b * cap) * d + h * 64;
   __shared__ __attribute__((aligned(16))) float Ks[32][68];
   __shared__ __attribute__((aligned(16))) float Vs[32][64];
   __shared__ float qs[64];
@@ -478,15 +485,30 @@ __global__ void self_attention_step(const float* __restrict__ qkv, float* __rest
   for (int i = 0; i < 8; ++i) {  // rows 4i + r16 < pos0 (pos0 <= 31); rows past pos0 re-read row 0
     const int j = 4 * i + r16;
     const int jj = j < pos0 ? j : 0;
-    kr[i] = *reinterpret_cast<const f32x4*>(kc + (long)jj * d + c4);
-    vr[i] = *reinterpret_cast<const f32x4*>(vc + (long)jj * d + c4);
+    if (BF) {
+      const u32x2 k2 = *reinterpret_cast<const u32x2*>(kc + (long)jj * d + c4);
+      const u32x2 v2 = *reinterpret_cast<const u32x2*>(vc + (long)jj * d + c4);
+      kr[i] = f32x4{bf16_lo(k2[0]), bf16_hi(k2[0]), bf16_lo(k2[1]), bf16_hi(k2[1])};
+      vr[i] = f32x4{bf16_lo(v2[0]), bf16_hi(v2[0]), bf16_lo(v2[1]), bf16_hi(v2[1])};
+    } else {
+      kr[i] = *reinterpret_cast<const f32x4*>(kc + (long)jj * d + c4);
+      vr[i] = *reinterpret_cast<const f32x4*>(vc + (long)jj * d + c4);
+    }
   }
   for (int p = 0; p < npos; ++p) {
     const float* row = qkv + ((long)p * B + b) * 3 * d;
-    const float knew = row[d + h * 64 + lane];
-    const float vnew = row[2 * d + h * 64 + lane];
-    kc[(long)(pos0 + p) * d + lane] = knew;
-    vc[(long)(pos0 + p) * d + lane] = vnew;
+    float knew = row[d + h * 64 + lane];
+    float vnew = row[2 * d + h * 64 + lane];
+    if (BF) {
+      const unsigned pk = pack_bf16x2(knew, vnew);
+      kc[(long)(pos0 + p) * d + lane] = (CT)(pk & 0xFFFFu);
+      vc[(long)(pos0 + p) * d + lane] = (CT)(pk >> 16);
+      knew = bf16_lo(pk);
+      vnew = bf16_hi(pk);
+    } else {
+      kc[(long)(pos0 + p) * d + lane] = knew;
+      vc[(long)(pos0 + p) * d + lane] = vnew;
+    }
     Ks[pos0 + p][lane] = knew;
     Vs[pos0 + p][lane] = vnew;
   }
@@ -536,39 +558,45 @@ __global__ void self_attention_step(const float* __restrict__ qkv, float* __rest
 // loads of 16 B per lane in flight), and the 16 group partials are merged through LDS at the end.
 // Output per (row, head, chunk): o[64] (unnormalised), m (running max, natural-log units), l (sum).
 // Wq_t: the query projection re-laid-out for this product: [head][DM / 4][64 outputs][4 k] (cross_q_layout()).
-template <int NQ, int DM>
+// BF (bf16 storage mode): the cache rows are 64 bf16 = 128 B, 8 lanes own a key row (16-byte loads of 8 elements) and
+// a block sweeps 32 keys per step instead of 16: half the bytes AND half the per-key shuffle / exp2 work per lane.
+template <int NQ, int DM, bool BF>
 __global__ __launch_bounds__(256) void cross_attention_step(const float* __restrict__ x, const float* __restrict__ ln_g,
                                                             const float* __restrict__ ln_b,
                                                             const float* __restrict__ Wq_t, const float* __restrict__ bq,
-                                                            const float* __restrict__ kc, const float* __restrict__ vc,
+                                                            const void* __restrict__ kc_v, const void* __restrict__ vc_v,
                                                             float* __restrict__ ws, int B, int heads, int T,
                                                             int chunks) {
+  using CT = typename std::conditional<BF, unsigned short, float>::type;
+  constexpr int LPK = BF ? 8 : 16;   // lanes per key row
+  constexpr int EPL = 64 / LPK;      // elements per lane: one 16-byte load either way
+  constexpr int NG = 256 / LPK;      // key rows in flight per load round
   __shared__ __attribute__((aligned(16))) float lnx[NQ][DM];
   __shared__ __attribute__((aligned(16))) float qpart[4][NQ][64];
   __shared__ __attribute__((aligned(16))) float qs[NQ][64];
-  __shared__ __attribute__((aligned(16))) float go[NQ][16 * 64];
-  __shared__ float gm[NQ][16], gl[NQ][16];
+  __shared__ __attribute__((aligned(16))) float go[NQ][NG * 64];
+  __shared__ float gm[NQ][NG], gl[NQ][NG];
   __shared__ float red[4][NQ];
   const int chunk = blockIdx.x % chunks, bh = blockIdx.x / chunks;
   const int b = bh / heads, h = bh % heads;
   const int per = (T + chunks - 1) / chunks;
   const int k_begin = chunk * per, k_end = min(T, k_begin + per), nk = k_end - k_begin;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, grp = tid >> 4, gl16 = tid & 15;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, grp = tid / LPK, gl16 = tid % LPK;
   constexpr float kLog2e = 1.44269504088896340736f;
   constexpr int U = 4;
   constexpr int C4 = DM / 4;    // float4 per row
   constexpr int CW = DM / 16;   // float4 of the k-quarter one wavefront contracts
 
   // (0) the first K/V rows: nothing below touches them before the queries exist
-  const float* kb = kc + ((long)bh * T + k_begin) * 64 + gl16 * 4;
-  const float* vb = vc + ((long)bh * T + k_begin) * 64 + gl16 * 4;
-  f32x4 kv[U], vv[U];
+  const CT* kb = static_cast<const CT*>(kc_v) + ((long)bh * T + k_begin) * 64 + gl16 * EPL;
+  const CT* vb = static_cast<const CT*>(vc_v) + ((long)bh * T + k_begin) * 64 + gl16 * EPL;
+  u32x4_t kv[U], vv[U];  // 16 bytes: four floats, or eight bf16
 #pragma unroll
   for (int u = 0; u < U; ++u) {  // unguarded loads: keys past the chunk re-read its last row
-    const int k = grp + 16 * u;
+    const int k = grp + NG * u;
     const int kk = k < nk ? k : nk - 1;
-    kv[u] = *reinterpret_cast<const f32x4*>(kb + (long)kk * 64);
-    vv[u] = *reinterpret_cast<const f32x4*>(vb + (long)kk * 64);
+    kv[u] = *reinterpret_cast<const u32x4_t*>(kb + (long)kk * 64);
+    vv[u] = *reinterpret_cast<const u32x4_t*>(vb + (long)kk * 64);
   }
   // (1) query-projection weights of this head, k-quarter `wid`, output `lane`: CW independent 16-byte loads
   f32x4 wq[CW];
@@ -641,36 +669,54 @@ __global__ __launch_bounds__(256) void cross_attention_step(const float* __restr
     qs[p][lane] = (((qpart[0][p][lane] + qpart[1][p][lane]) + (qpart[2][p][lane] + qpart[3][p][lane])) + bq[h * 64 + lane]) * kScale;
   }
   __syncthreads();
-  f32x4 qv[NQ];
+  float qv[NQ][EPL];
 #pragma unroll
-  for (int p = 0; p < NQ; ++p) qv[p] = *reinterpret_cast<const f32x4*>(&qs[p][gl16 * 4]);
+  for (int p = 0; p < NQ; ++p)
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) qv[p][e] = qs[p][gl16 * EPL + e];
 
   // (4) one sweep of the chunk's keys
   float m[NQ], l[NQ];
-  f32x4 o[NQ];
+  float o[NQ][EPL];
 #pragma unroll
   for (int p = 0; p < NQ; ++p) {
     m[p] = -1e30f;
     l[p] = 0.0f;
-    o[p] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) o[p][e] = 0.0f;
   }
-  for (int k0 = grp; k0 < nk; k0 += 16 * U) {
+  for (int k0 = grp; k0 < nk; k0 += NG * U) {
     if (k0 != grp) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int k = k0 + 16 * u;
+        const int k = k0 + NG * u;
         const int kk = k < nk ? k : nk - 1;
-        kv[u] = *reinterpret_cast<const f32x4*>(kb + (long)kk * 64);
-        vv[u] = *reinterpret_cast<const f32x4*>(vb + (long)kk * 64);
+        kv[u] = *reinterpret_cast<const u32x4_t*>(kb + (long)kk * 64);
+        vv[u] = *reinterpret_cast<const u32x4_t*>(vb + (long)kk * 64);
       }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const bool past = k0 + 16 * u >= nk;
+      const bool past = k0 + NG * u >= nk;
+      float kf[EPL], vf[EPL];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if constexpr (BF) {
+          kf[2 * e] = bf16_lo(kv[u][e]);
+          kf[2 * e + 1] = bf16_hi(kv[u][e]);
+          vf[2 * e] = bf16_lo(vv[u][e]);
+          vf[2 * e + 1] = bf16_hi(vv[u][e]);
+        } else {
+          kf[e % EPL] = __uint_as_float(kv[u][e]);
+          vf[e % EPL] = __uint_as_float(vv[u][e]);
+        }
+      }
 #pragma unroll
       for (int p = 0; p < NQ; ++p) {
-        float s = kv[u][0] * qv[p][0] + kv[u][1] * qv[p][1] + kv[u][2] * qv[p][2] + kv[u][3] * qv[p][3];
-        s += __shfl_xor(s, 8, 64);
+        float s = 0.0f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) s += kf[e] * qv[p][e];
+        if (!BF) s += __shfl_xor(s, 8, 64);
         s += __shfl_xor(s, 4, 64);
         s += __shfl_xor(s, 2, 64);
         s += __shfl_xor(s, 1, 64);
@@ -679,14 +725,15 @@ __global__ __launch_bounds__(256) void cross_attention_step(const float* __restr
         const float a = exp2f(m[p] - mn), pr = exp2f(s - mn);
         l[p] = l[p] * a + pr;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[p][j] = o[p][j] * a + pr * vv[u][j];
+        for (int j = 0; j < EPL; ++j) o[p][j] = o[p][j] * a + pr * vf[j];
         m[p] = mn;
       }
     }
   }
 #pragma unroll
   for (int p = 0; p < NQ; ++p) {
-    *reinterpret_cast<f32x4*>(&go[p][grp * 64 + gl16 * 4]) = o[p];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) go[p][grp * 64 + gl16 * EPL + e] = o[p][e];
     if (gl16 == 0) {
       gm[p][grp] = m[p];
       gl[p][grp] = l[p];
@@ -697,10 +744,10 @@ __global__ __launch_bounds__(256) void cross_attention_step(const float* __restr
     const int p = tid >> 6;
     float mx = gm[p][0];
 #pragma unroll
-    for (int gI = 1; gI < 16; ++gI) mx = fmaxf(mx, gm[p][gI]);
+    for (int gI = 1; gI < NG; ++gI) mx = fmaxf(mx, gm[p][gI]);
     float acc = 0.0f, lsum = 0.0f;
 #pragma unroll
-    for (int gI = 0; gI < 16; ++gI) {
+    for (int gI = 0; gI < NG; ++gI) {
       const float w = exp2f(gm[p][gI] - mx);
       acc += w * go[p][gI * 64 + lane];
       lsum += w * gl[p][gI];
@@ -736,35 +783,49 @@ void launch_encoder_attention(const float* qkv, float* out, int batch, int T, in
   }
 }
 
-void launch_self_attention(const float* qkv, float* kcache, float* vcache, int cap, int pos0, int npos, float* out,
-                           int batch, int heads, hipStream_t s) {
+void launch_self_attention(const float* qkv, void* kcache, void* vcache, int cap, int pos0, int npos, float* out,
+                           int batch, int heads, hipStream_t s, bool bf16) {
   // the kernel stages at most 32 cached rows in LDS
   if (pos0 < 0 || npos < 1 || pos0 + npos > 32 || pos0 + npos > cap) {
     throw Error(kErrInvalidArg, "decoder self-attention: positions outside [0, 31]");
   }
-  hipLaunchKernelGGL(self_attention_step, dim3(batch * heads), dim3(64), 0, s, qkv, kcache, vcache, cap, pos0, npos,
-                     batch, out, heads);
+  if (bf16) {
+    hipLaunchKernelGGL(self_attention_step<true>, dim3(batch * heads), dim3(64), 0, s, qkv, kcache, vcache, cap, pos0,
+                       npos, batch, out, heads);
+  } else {
+    hipLaunchKernelGGL(self_attention_step<false>, dim3(batch * heads), dim3(64), 0, s, qkv, kcache, vcache, cap, pos0,
+                       npos, batch, out, heads);
+  }
 }
 
-template <int NQ>
+template <int NQ, bool BF>
 static void launch_cross_nq(const CrossAttnArgs& a, hipStream_t s) {
   const dim3 grid(a.batch * a.heads * a.chunks);
   switch (a.heads * 64) {
-    case 128: hipLaunchKernelGGL((cross_attention_step<NQ, 128>), grid, dim3(256), 0, s, a.x, a.ln_g, a.ln_b, a.wq_t, a.bq, a.kc, a.vc, a.ws, a.batch, a.heads, a.T, a.chunks); break;
-    case 384: hipLaunchKernelGGL((cross_attention_step<NQ, 384>), grid, dim3(256), 0, s, a.x, a.ln_g, a.ln_b, a.wq_t, a.bq, a.kc, a.vc, a.ws, a.batch, a.heads, a.T, a.chunks); break;
-    case 512: hipLaunchKernelGGL((cross_attention_step<NQ, 512>), grid, dim3(256), 0, s, a.x, a.ln_g, a.ln_b, a.wq_t, a.bq, a.kc, a.vc, a.ws, a.batch, a.heads, a.T, a.chunks); break;
+    case 128: hipLaunchKernelGGL((cross_attention_step<NQ, 128, BF>), grid, dim3(256), 0, s, a.x, a.ln_g, a.ln_b, a.wq_t, a.bq, a.kc, a.vc, a.ws, a.batch, a.heads, a.T, a.chunks); break;
+    case 384: hipLaunchKernelGGL((cross_attention_step<NQ, 384, BF>), grid, dim3(256), 0, s, a.x, a.ln_g, a.ln_b, a.wq_t, a.bq, a.kc, a.vc, a.ws, a.batch, a.heads, a.T, a.chunks); break;
+    case 512: hipLaunchKernelGGL((cross_attention_step<NQ, 512, BF>), grid, dim3(256), 0, s, a.x, a.ln_g, a.ln_b, a.wq_t, a.bq, a.kc, a.vc, a.ws, a.batch, a.heads, a.T, a.chunks); break;
     default: throw Error(kErrFormat, "decoder kernels support d_model 128, 384 or 512");
+  }
+}
+
+template <bool BF>
+static void launch_cross_bf(const CrossAttnArgs& a, hipStream_t s) {
+  switch (a.nq) {
+    case 1: launch_cross_nq<1, BF>(a, s); break;
+    case 2: launch_cross_nq<2, BF>(a, s); break;
+    case 3: launch_cross_nq<3, BF>(a, s); break;
+    case 4: launch_cross_nq<4, BF>(a, s); break;
+    default: throw Error(kErrInvalidArg, "cross attention: 1..4 query rows per clip");
   }
 }
 
 void launch_cross_attention(const CrossAttnArgs& a, hipStream_t s) {
   if (a.batch < 1 || a.T < 1 || a.chunks < 1 || a.chunks > a.T) throw Error(kErrInvalidArg, "cross attention: bad shape");
-  switch (a.nq) {
-    case 1: launch_cross_nq<1>(a, s); break;
-    case 2: launch_cross_nq<2>(a, s); break;
-    case 3: launch_cross_nq<3>(a, s); break;
-    case 4: launch_cross_nq<4>(a, s); break;
-    default: throw Error(kErrInvalidArg, "cross attention: 1..4 query rows per clip");
+  if (a.bf16) {
+    launch_cross_bf<true>(a, s);
+  } else {
+    launch_cross_bf<false>(a, s);
   }
 }
 

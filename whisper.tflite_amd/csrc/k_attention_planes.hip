@@ -34,11 +34,16 @@ __device__ __forceinline__ int crow(int r, int h) { return (r & 3) + 8 * (r >> 2
 
 #define WT_MM16(A, B, ACC) __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, ACC, 0, 0, 0)
 
+// BF: bf16 storage mode — q, k, v and the output are ONE bf16 plane each (plane offsets unused), one
+// v_mfma_f32_32x32x16_bf16 per product, probabilities rounded to bf16; s_inv then carries the softmax scale itself
+// (d_head^-1/2 * log2 e: the qkv GEMM does not pre-scale q in that mode) and o_scale is 1.
+template <bool BF>
 __global__ __launch_bounds__(256, 2) void encoder_attention_planes(const _Float16* __restrict__ qkv, long plane,
                                                                    _Float16* __restrict__ out, long out_plane, int T,
                                                                    int heads, float s_inv, float o_scale) {
-  // [K hi][K lo][V hi][V lo], 8 KB each
+  // [K hi][K lo][V hi][V lo], 8 KB each; bf16 mode: [K][unused][V][unused]
   __shared__ __attribute__((aligned(16))) unsigned char lds[4 * kPlaneBytes];
+  using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
   const int d_model = heads * 64, ld = 3 * d_model;
   const int q_blocks = (T + 127) / 128;
@@ -61,7 +66,7 @@ __global__ __launch_bounds__(256, 2) void encoder_attention_planes(const _Float1
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     qh[c] = *reinterpret_cast<const half8*>(base + (long)q_ld * ld + 16 * c + 8 * lh);
-    ql[c] = *reinterpret_cast<const half8*>(base + plane + (long)q_ld * ld + 16 * c + 8 * lh);
+    if (!BF) ql[c] = *reinterpret_cast<const half8*>(base + plane + (long)q_ld * ld + 16 * c + 8 * lh);
   }
 
   f32x16 o0, o1;  // O^T tiles: d in [0,32) and [32,64)
@@ -84,18 +89,22 @@ __global__ __launch_bounds__(256, 2) void encoder_attention_planes(const _Float1
     const long ro = (long)(key < T ? key : T - 1) * ld;  // rows past T re-read row T - 1; their scores are masked
     st[0] = *reinterpret_cast<const u32x4*>(kbase + ro + e0);
     st[1] = *reinterpret_cast<const u32x4*>(kbase + ro + e1);
-    st[2] = *reinterpret_cast<const u32x4*>(kbase + plane + ro + e0);
-    st[3] = *reinterpret_cast<const u32x4*>(kbase + plane + ro + e1);
+    if (!BF) {
+      st[2] = *reinterpret_cast<const u32x4*>(kbase + plane + ro + e0);
+      st[3] = *reinterpret_cast<const u32x4*>(kbase + plane + ro + e1);
+    }
     st[4] = *reinterpret_cast<const u32x4*>(vbase + ro + e0);
     st[5] = *reinterpret_cast<const u32x4*>(vbase + ro + e1);
-    st[6] = *reinterpret_cast<const u32x4*>(vbase + plane + ro + e0);
-    st[7] = *reinterpret_cast<const u32x4*>(vbase + plane + ro + e1);
+    if (!BF) {
+      st[6] = *reinterpret_cast<const u32x4*>(vbase + plane + ro + e0);
+      st[7] = *reinterpret_cast<const u32x4*>(vbase + plane + ro + e1);
+    }
   };
   const int kx = (srow >> 1) & 7, vx = ((srow >> 1) & 1) << 2;
   auto store_tile = [&]() {
     unsigned char* row = lds + srow * 128;
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < (BF ? 1 : 2); ++p) {
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const int ch = sc0 + (e ^ (srow & 1));
@@ -125,8 +134,13 @@ __global__ __launch_bounds__(256, 2) void encoder_attention_planes(const _Float1
     for (int c = 0; c < 4; ++c) {
       const int slot = ((2 * c + lh) ^ kfx) << 4;
       const half8 k0h = *reinterpret_cast<const half8*>(lds + l31 * 128 + slot);
-      const half8 k0l = *reinterpret_cast<const half8*>(lds + kPlaneBytes + l31 * 128 + slot);
       const half8 k1h = *reinterpret_cast<const half8*>(lds + (32 + l31) * 128 + slot);
+      if constexpr (BF) {
+        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, k0h), __builtin_bit_cast(bf16x8, qh[c]), s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, k1h), __builtin_bit_cast(bf16x8, qh[c]), s1, 0, 0, 0);
+        continue;
+      }
+      const half8 k0l = *reinterpret_cast<const half8*>(lds + kPlaneBytes + l31 * 128 + slot);
       const half8 k1l = *reinterpret_cast<const half8*>(lds + kPlaneBytes + (32 + l31) * 128 + slot);
       s0 = WT_MM16(k0h, ql[c], s0);
       s0 = WT_MM16(k0l, qh[c], s0);
@@ -153,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void encoder_attention_planes(const _Float1
     for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s1[r]);
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * s_inv;
     const float m_new = fmaxf(m_run, tmax);
-    const float shift = 14.0f - m_new;
+    const float shift = (BF ? 0.0f : 14.0f) - m_new;
     float psum = 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -180,8 +194,12 @@ __global__ __launch_bounds__(256, 2) void encoder_attention_planes(const _Float1
         u32x4 phu, plu;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          unsigned hh, ll;
-          split_f16x2(sp[8 * s2 + 2 * e], sp[8 * s2 + 2 * e + 1], &hh, &ll);
+          unsigned hh, ll = 0;
+          if constexpr (BF) {
+            hh = pack_bf16x2(sp[8 * s2 + 2 * e], sp[8 * s2 + 2 * e + 1]);
+          } else {
+            split_f16x2(sp[8 * s2 + 2 * e], sp[8 * s2 + 2 * e + 1], &hh, &ll);
+          }
           phu[e] = hh;
           plu[e] = ll;
         }
@@ -198,25 +216,35 @@ __global__ __launch_bounds__(256, 2) void encoder_attention_planes(const _Float1
           const unsigned char* r0 = lds + 2 * kPlaneBytes + key * 128 + ((vp & 1) << 3);
           const int c0 = ((2 * vg + (vp >> 1)) ^ vsw) << 4, c1 = ((4 + 2 * vg + (vp >> 1)) ^ vsw) << 4;
           const i16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(r0 + c0));
-          const i16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(r0 + kPlaneBytes + c0));
           const i16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(r0 + c1));
-          const i16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(r0 + kPlaneBytes + c1));
-          const half4 a0h = __builtin_bit_cast(half4, a0), a1h = __builtin_bit_cast(half4, a1);
-          const half4 b0h = __builtin_bit_cast(half4, b0), b1h = __builtin_bit_cast(half4, b1);
+          const half4 a0h = __builtin_bit_cast(half4, a0), b0h = __builtin_bit_cast(half4, b0);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             v0h[4 * ri + e] = a0h[e];
-            v0l[4 * ri + e] = a1h[e];
             v1h[4 * ri + e] = b0h[e];
-            v1l[4 * ri + e] = b1h[e];
+          }
+          if constexpr (!BF) {
+            const i16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(r0 + kPlaneBytes + c0));
+            const i16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(r0 + kPlaneBytes + c1));
+            const half4 a1h = __builtin_bit_cast(half4, a1), b1h = __builtin_bit_cast(half4, b1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v0l[4 * ri + e] = a1h[e];
+              v1l[4 * ri + e] = b1h[e];
+            }
           }
         }
-        o0 = WT_MM16(v0h, pl, o0);
-        o0 = WT_MM16(v0l, ph, o0);
-        o0 = WT_MM16(v0h, ph, o0);
-        o1 = WT_MM16(v1h, pl, o1);
-        o1 = WT_MM16(v1l, ph, o1);
-        o1 = WT_MM16(v1h, ph, o1);
+        if constexpr (BF) {
+          o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v0h), __builtin_bit_cast(bf16x8, ph), o0, 0, 0, 0);
+          o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v1h), __builtin_bit_cast(bf16x8, ph), o1, 0, 0, 0);
+        } else {
+          o0 = WT_MM16(v0h, pl, o0);
+          o0 = WT_MM16(v0l, ph, o0);
+          o0 = WT_MM16(v0h, ph, o0);
+          o1 = WT_MM16(v1h, pl, o1);
+          o1 = WT_MM16(v1l, ph, o1);
+          o1 = WT_MM16(v1h, ph, o1);
+        }
       }
     };
     pv_half(s0, 0);
@@ -230,16 +258,23 @@ __global__ __launch_bounds__(256, 2) void encoder_attention_planes(const _Float1
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       unsigned ah[2], al[2], ch[2], cl[2];
+      using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        split_f16x2(o0[4 * g + 2 * j] * inv, o0[4 * g + 2 * j + 1] * inv, &ah[j], &al[j]);
-        split_f16x2(o1[4 * g + 2 * j] * inv, o1[4 * g + 2 * j + 1] * inv, &ch[j], &cl[j]);
+        if constexpr (BF) {
+          ah[j] = pack_bf16x2(o0[4 * g + 2 * j] * inv, o0[4 * g + 2 * j + 1] * inv);
+          ch[j] = pack_bf16x2(o1[4 * g + 2 * j] * inv, o1[4 * g + 2 * j + 1] * inv);
+        } else {
+          split_f16x2(o0[4 * g + 2 * j] * inv, o0[4 * g + 2 * j + 1] * inv, &ah[j], &al[j]);
+          split_f16x2(o1[4 * g + 2 * j] * inv, o1[4 * g + 2 * j + 1] * inv, &ch[j], &cl[j]);
+        }
       }
-      using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
       *reinterpret_cast<u32x2*>(orow + 8 * g + 4 * lh) = u32x2{ah[0], ah[1]};
-      *reinterpret_cast<u32x2*>(orow + out_plane + 8 * g + 4 * lh) = u32x2{al[0], al[1]};
       *reinterpret_cast<u32x2*>(orow + 32 + 8 * g + 4 * lh) = u32x2{ch[0], ch[1]};
-      *reinterpret_cast<u32x2*>(orow + out_plane + 32 + 8 * g + 4 * lh) = u32x2{cl[0], cl[1]};
+      if constexpr (!BF) {
+        *reinterpret_cast<u32x2*>(orow + out_plane + 8 * g + 4 * lh) = u32x2{al[0], al[1]};
+        *reinterpret_cast<u32x2*>(orow + out_plane + 32 + 8 * g + 4 * lh) = u32x2{cl[0], cl[1]};
+      }
     }
   }
 }
@@ -252,9 +287,18 @@ void launch_encoder_attention_planes(const unsigned short* qkv, long plane, unsi
                                      float out_scale, hipStream_t stream) {
   if (batch < 1 || T < 1 || heads < 1 || (3 * heads * 64) % 8 != 0) throw Error(kErrInvalidArg, "encoder attention: bad shape");
   const int q_blocks = (T + 127) / 128;
-  hipLaunchKernelGGL(encoder_attention_planes, dim3(batch * heads * q_blocks), dim3(256), 0, stream,
+  hipLaunchKernelGGL(encoder_attention_planes<false>, dim3(batch * heads * q_blocks), dim3(256), 0, stream,
                      reinterpret_cast<const _Float16*>(qkv), plane, reinterpret_cast<_Float16*>(out), out_plane, T, heads,
                      1.0f / (q_scale * k_scale), out_scale / v_scale);
+}
+
+void launch_encoder_attention_bf16(const unsigned short* qkv, unsigned short* out, int batch, int T, int heads,
+                                   hipStream_t stream) {
+  if (batch < 1 || T < 1 || heads < 1) throw Error(kErrInvalidArg, "encoder attention: bad shape");
+  const int q_blocks = (T + 127) / 128;
+  hipLaunchKernelGGL(encoder_attention_planes<true>, dim3(batch * heads * q_blocks), dim3(256), 0, stream,
+                     reinterpret_cast<const _Float16*>(qkv), 0L, reinterpret_cast<_Float16*>(out), 0L, T, heads,
+                     0.125f * 1.44269504088896340736f, 1.0f);
 }
 
 }  // namespace wt

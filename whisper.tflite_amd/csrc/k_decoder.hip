@@ -142,7 +142,10 @@ __device__ __forceinline__ void row_stats(const f32x4 (&v)[NF4], int K, float* m
 // tiles: parallelism has to come from K); CH = compile-time key-chunk count of the combine prologue; SMAX =
 // 16-deep k-steps a wavefront keeps in flight (>= its k-slice / 16; weights: 2 planes x 16 B per lane per step).
 // Rows are processed in groups of GT 32-row tiles: the LayerNorm rows of one group live in LDS at a time.
-template <int PRO, int EPI, int NF4, int LNMODE, int WAVES, int CH, int GT, int SMAX>
+// BF: the bf16 storage mode (BASELINE configs[3]): weights are ONE bf16 plane in the same fragment order
+// ([tile][k/16][lane][8]), activations are rounded to bf16 in registers, one v_mfma_f32_32x32x16_bf16 per k-step —
+// no scales anywhere (bf16 has fp32's exponent range).
+template <int PRO, int EPI, int NF4, int LNMODE, int WAVES, int CH, int GT, int SMAX, bool BF>
 __global__ __launch_bounds__(WAVES * 64) void dec_gemm(DecGemmDev g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // [GT*32][K + 4] LayerNorm rows (kProLn) and, once they are dead, [WAVES][GT][16][64] split-K partials; behind
@@ -166,13 +169,14 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm(DecGemmDev g) {
   // prologue, so it goes in flight now and its HBM/L2 latency overlaps the LayerNorm / combine work below.
   // Steps past nsteps re-read the last valid step (no branch around a load) and are never used.  (With more than
   // SMAX steps or several row groups the registers are refilled per round, below.)
-  const unsigned short* wp = g.Wt + ((long)tile * (K >> 4) + (k0 >> 4)) * 1024 + lane * 8;
-  u32x4_t wh[SMAX], wl[SMAX];
+  constexpr int WSTEP = BF ? 512 : 1024;  // 16-bit elements per (tile, k-step): one or two planes of 64 lanes x 8
+  const unsigned short* wp = g.Wt + ((long)tile * (K >> 4) + (k0 >> 4)) * WSTEP + lane * 8;
+  u32x4_t wh[SMAX], wl[BF ? 1 : SMAX];
 #pragma unroll
   for (int s = 0; s < SMAX; ++s) {
     const int ss = s < nsteps ? s : nsteps - 1;
-    wh[s] = *reinterpret_cast<const u32x4_t*>(wp + (long)ss * 1024);
-    wl[s] = *reinterpret_cast<const u32x4_t*>(wp + (long)ss * 1024 + 512);
+    wh[s] = *reinterpret_cast<const u32x4_t*>(wp + (long)ss * WSTEP);
+    if (!BF) wl[s] = *reinterpret_cast<const u32x4_t*>(wp + (long)ss * WSTEP + 512);
   }
   // LayerNorm gain / shift are row-independent: requested now (one 16-byte load per thread), parked in LDS while
   // the rows are in flight, read back after the row statistics — not a second dependent trip to memory
@@ -256,8 +260,8 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm(DecGemmDev g) {
 #pragma unroll
           for (int s = 0; s < SMAX; ++s) {
             const int ss = c0 + s < nsteps ? c0 + s : nsteps - 1;
-            wh[s] = *reinterpret_cast<const u32x4_t*>(wp + (long)ss * 1024);
-            wl[s] = *reinterpret_cast<const u32x4_t*>(wp + (long)ss * 1024 + 512);
+            wh[s] = *reinterpret_cast<const u32x4_t*>(wp + (long)ss * WSTEP);
+            if (!BF) wl[s] = *reinterpret_cast<const u32x4_t*>(wp + (long)ss * WSTEP + 512);
           }
         }
       }
@@ -320,6 +324,20 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm(DecGemmDev g) {
             }
           }
         }
+        if (BF) {
+          using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+#pragma unroll
+          for (int s = 0; s < SMAX; ++s) {
+            if (c0 + s < nsteps) {
+              u32x4_t pa;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) pa[e] = pack_bf16x2(xa[s][2 * e], xa[s][2 * e + 1]);
+              acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa), __builtin_bit_cast(bf16x8, wh[s]),
+                                                               acc[t], 0, 0, 0);
+            }
+          }
+          continue;
+        }
         // dynamic scale of this (row, k-round): the largest element goes to [2^14, 2^15), inside fp16's range
         float mx = 0.0f;
 #pragma unroll
@@ -339,7 +357,7 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm(DecGemmDev g) {
             u32x4_t pl[3];
             split8_f16x2(xa[s], sc, pl);
             const half8 ah = __builtin_bit_cast(half8, pl[0]), al = __builtin_bit_cast(half8, pl[1]);
-            const half8 bh = __builtin_bit_cast(half8, wh[s]), bl = __builtin_bit_cast(half8, wl[s]);
+            const half8 bh = __builtin_bit_cast(half8, wh[s]), bl = __builtin_bit_cast(half8, wl[BF ? 0 : s]);
             part = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, part, 0, 0, 0);
             part = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, part, 0, 0, 0);
             part = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, part, 0, 0, 0);
@@ -430,19 +448,19 @@ __global__ __launch_bounds__(256) void dec_finalize_ln(RowSrc src, const float* 
   }
 }
 
-template <int PRO, int EPI, int NF4, int LNMODE, int WAVES, int CH, int GT, int SMAX>
+template <int PRO, int EPI, int NF4, int LNMODE, int WAVES, int CH, int GT, int SMAX, bool BF>
 void launch_one(const DecGemmDev& g, size_t smem, dim3 grid, hipStream_t s) {
   // dynamic LDS beyond the 64 KiB default needs an opt-in, once per kernel
   static const bool raised = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_gemm<PRO, EPI, NF4, LNMODE, WAVES, CH, GT, SMAX>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_gemm<PRO, EPI, NF4, LNMODE, WAVES, CH, GT, SMAX, BF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return true;
   }();
   (void)raised;
-  hipLaunchKernelGGL((dec_gemm<PRO, EPI, NF4, LNMODE, WAVES, CH, GT, SMAX>), grid, dim3(WAVES * 64), smem, s, g);
+  hipLaunchKernelGGL((dec_gemm<PRO, EPI, NF4, LNMODE, WAVES, CH, GT, SMAX, BF>), grid, dim3(WAVES * 64), smem, s, g);
 }
 
-template <int PRO, int EPI, int NF4, int LNMODE, int WAVES, int CH, int GT>
+template <int PRO, int EPI, int NF4, int LNMODE, int WAVES, int CH, int GT, bool BF>
 void launch_steps(DecGemmDev g, hipStream_t s) {
   const int n_tiles = (g.N + 31) / 32;
   const dim3 grid(n_tiles * (PRO == kProNone && EPI == kDecResid ? g.ksplit : 1));
@@ -452,36 +470,68 @@ void launch_steps(DecGemmDev g, hipStream_t s) {
   g.lnp_off = (int)(body / sizeof(float));
   const size_t smem = body + (PRO == kProLn ? (size_t)2 * g.K * sizeof(float) : 0);
   const int nsteps = (g.K / g.ksplit) / WAVES / 16;  // k-steps per wavefront; deeper slices run in rounds of 8
-  if (nsteps <= 2) launch_one<PRO, EPI, NF4, LNMODE, WAVES, CH, GT, 2>(g, smem, grid, s);
-  else if (nsteps == 3) launch_one<PRO, EPI, NF4, LNMODE, WAVES, CH, GT, 3>(g, smem, grid, s);
-  else if (nsteps == 4) launch_one<PRO, EPI, NF4, LNMODE, WAVES, CH, GT, 4>(g, smem, grid, s);
-  else if (nsteps <= 6) launch_one<PRO, EPI, NF4, LNMODE, WAVES, CH, GT, 6>(g, smem, grid, s);
-  else launch_one<PRO, EPI, NF4, LNMODE, WAVES, CH, GT, 8>(g, smem, grid, s);
+  if (nsteps <= 2) launch_one<PRO, EPI, NF4, LNMODE, WAVES, CH, GT, 2, BF>(g, smem, grid, s);
+  else if (nsteps == 3) launch_one<PRO, EPI, NF4, LNMODE, WAVES, CH, GT, 3, BF>(g, smem, grid, s);
+  else if (nsteps == 4) launch_one<PRO, EPI, NF4, LNMODE, WAVES, CH, GT, 4, BF>(g, smem, grid, s);
+  else if (nsteps <= 6) launch_one<PRO, EPI, NF4, LNMODE, WAVES, CH, GT, 6, BF>(g, smem, grid, s);
+  else launch_one<PRO, EPI, NF4, LNMODE, WAVES, CH, GT, 8, BF>(g, smem, grid, s);
 }
 
-template <int PRO, int EPI, int NF4, int LNMODE, int WAVES, int CH>
+template <int PRO, int EPI, int NF4, int LNMODE, int WAVES, int CH, bool BF>
 void launch_gt(const DecGemmDev& g, hipStream_t s) {
   // row groups of two 32-row tiles when there is more than one tile, while the LayerNorm rows of a group fit in LDS
   // (K <= 384: 64 x 388 x 4 B = 99 KB); one tile per group otherwise
   const bool two = g.M > 32 && !(PRO == kProLn && g.K > 384);
   if (two) {
-    launch_steps<PRO, EPI, NF4, LNMODE, WAVES, CH, 2>(g, s);
+    launch_steps<PRO, EPI, NF4, LNMODE, WAVES, CH, 2, BF>(g, s);
   } else {
-    launch_steps<PRO, EPI, NF4, LNMODE, WAVES, CH, 1>(g, s);
+    launch_steps<PRO, EPI, NF4, LNMODE, WAVES, CH, 1, BF>(g, s);
   }
 }
 
-template <int LNMODE>
+template <int LNMODE, bool BF>
 void launch_ln(const DecGemmDev& g, hipStream_t s) {
   switch (g.K) {
-    case 128: launch_gt<kProLn, kDecBias, 4, LNMODE, 4, 1>(g, s); break;
-    case 384: launch_gt<kProLn, kDecBias, 12, LNMODE, 4, 1>(g, s); break;
-    case 512: launch_gt<kProLn, kDecBias, 16, LNMODE, 4, 1>(g, s); break;
+    case 128: launch_gt<kProLn, kDecBias, 4, LNMODE, 4, 1, BF>(g, s); break;
+    case 384: launch_gt<kProLn, kDecBias, 12, LNMODE, 4, 1, BF>(g, s); break;
+    case 512: launch_gt<kProLn, kDecBias, 16, LNMODE, 4, 1, BF>(g, s); break;
     default: throw Error(kErrFormat, "decoder kernels support d_model 128, 384 or 512");
   }
 }
 
 }  // namespace
+
+template <bool BF>
+static void dispatch_dec_gemm(const DecGemmArgs& a, const DecGemmDev& g, int pro, int epi, hipStream_t s) {
+  if (pro == kProLn) {
+    if (epi != kDecBias) throw Error(kErrInvalidArg, "decoder GEMM: the LayerNorm prologue pairs with the bias epilogue");
+    if (a.ids) {
+      if (a.xpart) throw Error(kErrInvalidArg, "decoder GEMM: embedding rows have no pending partial");
+      launch_ln<2, BF>(g, s);
+    } else if (a.xpart) {
+      launch_ln<3, BF>(g, s);
+    } else {
+      launch_ln<0, BF>(g, s);
+    }
+    return;
+  }
+  const int key = pro * 8 + epi;
+  switch (key) {
+    case kProNone * 8 + kDecResid: launch_gt<kProNone, kDecResid, 0, 0, 8, 1, BF>(g, s); break;
+    case kProNone * 8 + kDecBias: launch_gt<kProNone, kDecBias, 0, 0, 4, 1, BF>(g, s); break;
+    case kProNone * 8 + kDecLogits: launch_gt<kProNone, kDecLogits, 0, 0, 4, 1, BF>(g, s); break;
+    case kProCombine * 8 + kDecResid:
+      switch (a.chunks) {  // compile-time chunk count keeps the partial loads independent
+        case 1: launch_gt<kProCombine, kDecResid, 0, 0, 8, 1, BF>(g, s); break;
+        case 2: launch_gt<kProCombine, kDecResid, 0, 0, 8, 2, BF>(g, s); break;
+        case 4: launch_gt<kProCombine, kDecResid, 0, 0, 8, 4, BF>(g, s); break;
+        case 8: launch_gt<kProCombine, kDecResid, 0, 0, 8, 8, BF>(g, s); break;
+        default: throw Error(kErrInvalidArg, "cross_chunks must be 1, 2, 4 or 8");
+      }
+      break;
+    default: throw Error(kErrInvalidArg, "unsupported decoder GEMM prologue / epilogue pair");
+  }
+}
 
 void launch_dec_gemm(const DecGemmArgs& a, int pro, int epi, hipStream_t s) {
   const int gelu = epi == kDecBiasGelu ? 1 : 0;
@@ -505,33 +555,10 @@ void launch_dec_gemm(const DecGemmArgs& a, int pro, int epi, hipStream_t s) {
     // split K: residual GEMM only, with a partial buffer, out of place (the consumer completes the rows into R)
     throw Error(kErrInvalidArg, "decoder GEMM: K split needs the out-of-place residual form");
   }
-  if (pro == kProLn) {
-    if (epi != kDecBias) throw Error(kErrInvalidArg, "decoder GEMM: the LayerNorm prologue pairs with the bias epilogue");
-    if (a.ids) {
-      if (a.xpart) throw Error(kErrInvalidArg, "decoder GEMM: embedding rows have no pending partial");
-      launch_ln<2>(g, s);
-    } else if (a.xpart) {
-      launch_ln<3>(g, s);
-    } else {
-      launch_ln<0>(g, s);
-    }
-    return;
-  }
-  const int key = pro * 8 + epi;
-  switch (key) {
-    case kProNone * 8 + kDecResid: launch_gt<kProNone, kDecResid, 0, 0, 8, 1>(g, s); break;
-    case kProNone * 8 + kDecBias: launch_gt<kProNone, kDecBias, 0, 0, 4, 1>(g, s); break;
-    case kProNone * 8 + kDecLogits: launch_gt<kProNone, kDecLogits, 0, 0, 4, 1>(g, s); break;
-    case kProCombine * 8 + kDecResid:
-      switch (a.chunks) {  // compile-time chunk count keeps the partial loads independent
-        case 1: launch_gt<kProCombine, kDecResid, 0, 0, 8, 1>(g, s); break;
-        case 2: launch_gt<kProCombine, kDecResid, 0, 0, 8, 2>(g, s); break;
-        case 4: launch_gt<kProCombine, kDecResid, 0, 0, 8, 4>(g, s); break;
-        case 8: launch_gt<kProCombine, kDecResid, 0, 0, 8, 8>(g, s); break;
-        default: throw Error(kErrInvalidArg, "cross_chunks must be 1, 2, 4 or 8");
-      }
-      break;
-    default: throw Error(kErrInvalidArg, "unsupported decoder GEMM prologue / epilogue pair");
+  if (a.bf16) {
+    dispatch_dec_gemm<true>(a, g, pro, epi, s);
+  } else {
+    dispatch_dec_gemm<false>(a, g, pro, epi, s);
   }
 }
 

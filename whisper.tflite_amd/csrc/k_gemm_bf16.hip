@@ -1,0 +1,270 @@
+// Encoder GEMM of the bf16 STORAGE mode (BASELINE configs[3]: whisper-base, bf16 weights / activations / KV with
+// fp32 accumulation; option "bf16").  C = epilogue(A . W^T): A [M][K] and W [N][K] are bf16 in HBM — weights rounded
+// once at load time, activations written as bf16 by the kernel that produces them (LayerNorm, this kernel's GELU /
+// plain epilogues, encoder attention) — one v_mfma_f32_32x32x16_bf16 product per k-step, fp32 accumulators, fp32
+// bias / GELU / positional add / residual in the epilogue.  The residual stream itself stays fp32 (it is only ever an
+// epilogue operand); everything a matrix unit reads is bf16.
+//
+// Same skeleton as k_gemm_planes.hip (LDS-DMA straight into swizzled LDS stages, no VALU work in the loop, per-wave
+// transposing epilogue), re-balanced for a third of the MFMA work per byte: k-tiles of 64 (128-byte LDS rows, the
+// eight 16-byte chunks XOR-swizzled by (row >> 1) & 7 on the SOURCE address of the LDS-DMA) so that a stage holds
+// twice the k-depth in the same bytes and a barrier covers 4 k-steps.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
+#include "bf16_split.h"
+#include "kernels.h"
+
+namespace wt {
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+
+constexpr int BM = 192, BK = 64;
+constexpr int MI = 3;
+
+__device__ __forceinline__ float gelu_erf(float x) {
+  return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f));
+}
+
+struct Bf16GemmDev {
+  const unsigned short* A;
+  const unsigned short* W;
+  float* C;            // fp32 output
+  unsigned short* P;   // bf16 output (row-major like C, or the cross-KV cache layout)
+  const float* bias;
+  const float* R;
+  const float* pos;
+  int M, N, K;
+  int a_rpb;
+  long a_bs;
+  int lda;
+  int c_rpb;
+  long c_bs;
+  int ldc;
+  int pos_period;
+  int kv_batch, kv_heads, kv_dmodel;
+};
+
+// Block tile 192 x BN, BN = WN * NI * 32, 2 x WN wavefronts of 3 x NI MFMA tiles:
+//   (2, 2) 192 x 128, 4 wavefronts, 40 KB per stage, two blocks per CU;  (4, 2) 192 x 256 and (4, 3) 192 x 384,
+//   8 wavefronts, 56 / 72 KB per stage, one block per CU.
+template <int EPI, bool BF_OUT, int WN, int NI>
+__global__ __launch_bounds__(128 * WN, 2) void gemm_bf16_planes(Bf16GemmDev g) {
+  constexpr int BN = WN * NI * 32, NW = 2 * WN;
+  constexpr int kABytes = BM * BK * 2, kWBytes = BN * BK * 2;
+  constexpr int kStage = kABytes + kWBytes;
+  constexpr int QA = BM / 8, QW = BN / 8;  // LDS-DMA instructions per operand tile (8 rows of 128 B each)
+  constexpr int QT = QA + QW, QPW = QT / NW;
+  static_assert(QT % NW == 0, "whole instructions per wavefront");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int nb = gridDim.x, bid = blockIdx.x;
+  const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int n_tiles = g.N / BN;
+  const int m0 = (logical / n_tiles) * BM;
+  const int n0 = (logical % n_tiles) * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WN, wn = wid % WN;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  // LDS-DMA: instruction q copies rows 8 q .. 8 q + 7 of the A tile (q < QA) or of the W tile; lane i fills slot
+  // (row i >> 3, chunk i & 7) with the global chunk (i & 7) ^ ((row >> 1) & 7) of that row
+  const int srow = lane >> 3;
+  const unsigned short* src[QPW];
+#pragma unroll
+  for (int j = 0; j < QPW; ++j) {
+    const int q = wid + NW * j;
+    const bool is_a = q < QA;
+    const int row = 8 * (is_a ? q : q - QA) + srow;
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    if (is_a) {
+      int m = m0 + row;
+      m = m < g.M ? m : g.M - 1;
+      src[j] = g.A + (long)(m / g.a_rpb) * g.a_bs + (long)(m % g.a_rpb) * g.lda + chunk * 8;
+    } else {
+      src[j] = g.W + (long)(n0 + row) * g.K + chunk * 8;
+    }
+  }
+  auto issue_stage = [&](int kt, int buf) {
+    unsigned char* base = smem + buf * kStage;
+    const int ko = kt * BK;
+#pragma unroll
+    for (int j = 0; j < QPW; ++j) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + ko),
+                                       (__attribute__((address_space(3))) void*)(base + (wid + NW * j) * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const int swz = (l31 >> 1) & 7;  // tile bases are multiples of 32 rows: the swizzle term depends on the lane only
+  const int a_off = (wm * 96 + l31) * 128, b_off = kABytes + (wn * NI * 32 + l31) * 128;
+  auto compute = [&](int buf) {
+    const unsigned char* base = smem + buf * kStage;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      const int slot = ((ks * 2 + lh) ^ swz) * 16;
+      bf16x8 af[MI], bf[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(base + a_off + i * 32 * 128 + slot);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(base + b_off + j * 32 * 128 + slot);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  const int nkt = g.K / BK;
+  issue_stage(0, 0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 1 < nkt) issue_stage(kt + 1, (kt + 1) & 1);
+    compute(kt & 1);
+  }
+  __syncthreads();
+
+  // epilogue: per-wave 32 x 32 transposing stage, conflict-free image of k_gemm_planes.hip
+  constexpr int SLD = 32;
+  float* const stage = reinterpret_cast<float*>(smem) + wid * (32 * SLD);
+  constexpr int CPL = BF_OUT ? 8 : 4;
+  constexpr int LPR = 32 / CPL;
+  constexpr int RPS = 64 / LPR;
+  const int prow = lane / LPR, c0 = (lane % LPR) * CPL;
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int n = n0 + (wn * NI + ni) * 32 + c0;
+    float bias_v[CPL];
+#pragma unroll
+    for (int e = 0; e < CPL; ++e) bias_v[e] = (EPI & kEpiBias) ? g.bias[n + e] : 0.0f;
+    const int slab = (EPI & kEpiKvLayout) ? n / g.kv_dmodel : 0, rem = (EPI & kEpiKvLayout) ? n % g.kv_dmodel : 0;
+    const int head = rem >> 6, dd = rem & 63;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * lh) * SLD + (l31 ^ (lh << 2))] = acc[mi][ni][r];
+      const int mbase = m0 + wm * 96 + mi * 32;
+      const int mb0 = mbase / g.c_rpb, mt0 = mbase % g.c_rpb;
+      const int mp0 = (EPI & kEpiPos) ? mbase % g.pos_period : 0;
+#pragma unroll
+      for (int p = 0; p < 32 / RPS; ++p) {
+        const int row = p * RPS + prow;
+        float v[CPL];
+#pragma unroll
+        for (int e = 0; e < CPL; e += 4) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(&stage[row * SLD + ((c0 + e) ^ (((row >> 2) & 1) << 2))]);
+          v[e] = t[0], v[e + 1] = t[1], v[e + 2] = t[2], v[e + 3] = t[3];
+        }
+        if (mbase + row < g.M) {
+          int mb = mb0, mt = mt0 + row;
+          if (mt >= g.c_rpb) mt -= g.c_rpb, mb += 1;
+#pragma unroll
+          for (int e = 0; e < CPL; ++e) {
+            v[e] += bias_v[e];
+            if (EPI & kEpiGelu) v[e] = gelu_erf(v[e]);
+          }
+          if (EPI & kEpiPos) {
+            int mp = mp0 + row;
+            if (mp >= g.pos_period) mp -= g.pos_period;
+#pragma unroll
+            for (int e = 0; e < CPL; e += 4) {
+              const f32x4 t = *reinterpret_cast<const f32x4*>(g.pos + (long)mp * g.N + n + e);
+              v[e] += t[0], v[e + 1] += t[1], v[e + 2] += t[2], v[e + 3] += t[3];
+            }
+          }
+          if (BF_OUT) {
+            const long o = (EPI & kEpiKvLayout)
+                               ? (((long)slab * g.kv_batch + mb) * g.kv_heads + head) * (long)g.c_rpb * 64 + (long)mt * 64 + dd
+                               : (long)mb * g.c_bs + (long)mt * g.ldc + n;
+            u32x4 pk;
+#pragma unroll
+            for (int e = 0; e < CPL; e += 2) pk[e / 2] = pack_bf16x2(v[e], v[e + 1]);
+            *reinterpret_cast<u32x4*>(g.P + o) = pk;
+          } else {
+            const long o = (long)mb * g.c_bs + (long)mt * g.ldc + n;
+            f32x4 out = {v[0], v[1], v[2], v[3]};
+            if (EPI & kEpiResidual) out += *reinterpret_cast<const f32x4*>(g.R + o);
+            *reinterpret_cast<f32x4*>(g.C + o) = out;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int EPI, bool BF_OUT, int WN, int NI>
+void launch_shape(const Bf16GemmDev& g, hipStream_t s) {
+  constexpr int BN = WN * NI * 32;
+  const int blocks = ((g.M + BM - 1) / BM) * (g.N / BN);
+  constexpr size_t smem = 2 * (BM * BK * 2 + BN * BK * 2);
+  static const bool raised = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_planes<EPI, BF_OUT, WN, NI>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return true;
+  }();
+  (void)raised;
+  hipLaunchKernelGGL((gemm_bf16_planes<EPI, BF_OUT, WN, NI>), dim3(blocks), dim3(128 * WN), smem, s, g);
+}
+
+template <int EPI, bool BF_OUT>
+void launch_bf16_planes(const Bf16GemmDev& g, hipStream_t s) {
+  static const int forced = [] {
+    const char* v = getenv("WT_BF16_TILE");  // measurement knob: 128 / 256 / 384 = that tile where N allows it
+    return v ? atoi(v) : 0;
+  }();
+  int bn = g.N % 384 == 0 ? 384 : g.N % 256 == 0 ? 256 : 128;
+  if (forced && g.N % forced == 0) bn = forced;
+  if (bn == 384) {
+    launch_shape<EPI, BF_OUT, 4, 3>(g, s);
+  } else if (bn == 256) {
+    launch_shape<EPI, BF_OUT, 4, 2>(g, s);
+  } else {
+    launch_shape<EPI, BF_OUT, 2, 2>(g, s);
+  }
+}
+
+}  // namespace
+
+void launch_gemm_bf16_planes(const PlaneGemmArgs& a, int epi, hipStream_t s) {
+  Bf16GemmDev g{};
+  g.A = a.A; g.W = a.W; g.C = a.C; g.P = a.P;
+  g.bias = a.bias; g.R = a.R; g.pos = a.pos;
+  g.M = a.M; g.N = a.N; g.K = a.K;
+  g.a_rpb = a.a_rpb; g.a_bs = a.a_bs; g.lda = a.lda;
+  g.c_rpb = a.c_rpb; g.c_bs = a.c_bs; g.ldc = a.ldc;
+  g.pos_period = a.pos_period;
+  g.kv_batch = a.kv_batch; g.kv_heads = a.kv_heads; g.kv_dmodel = a.kv_dmodel;
+  const bool bf_out = a.P != nullptr;
+  if (a.N % 128 != 0 || a.K % BK != 0 || a.M < 1 || a.c_rpb < 32 || a.pos_period < (epi & kEpiPos ? 32 : 1) || a.lda % 8 != 0 ||
+      a.a_bs % 8 != 0 || a.ldc % 8 != 0 || a.c_bs % 8 != 0 || (!bf_out && !a.C) ||
+      ((epi & kEpiKvLayout) && (!bf_out || a.kv_dmodel % 64 != 0))) {
+    throw Error(kErrInvalidArg, "bf16 GEMM shape outside the kernel contract");
+  }
+  switch (epi | (bf_out ? 256 : 0)) {
+    case kEpiBias: launch_bf16_planes<kEpiBias, false>(g, s); break;
+    case kEpiBias | kEpiResidual: launch_bf16_planes<kEpiBias | kEpiResidual, false>(g, s); break;
+    case kEpiBias | kEpiGelu | kEpiPos: launch_bf16_planes<kEpiBias | kEpiGelu | kEpiPos, false>(g, s); break;
+    case kEpiBias | 256: launch_bf16_planes<kEpiBias, true>(g, s); break;
+    case kEpiBias | kEpiGelu | 256: launch_bf16_planes<kEpiBias | kEpiGelu, true>(g, s); break;
+    case kEpiBias | kEpiKvLayout | 256: launch_bf16_planes<kEpiBias | kEpiKvLayout, true>(g, s); break;
+    default: throw Error(kErrInvalidArg, "unsupported bf16 GEMM epilogue combination");
+  }
+}
+
+}  // namespace wt

@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256) void layernorm_rows(const float* __restrict__ 
 // LayerNorm rows written as two fp16 planes (hi, lo) of y * scale — the A operand format of the plane GEMM — and
 // optionally as fp32 too (the encoder's final LayerNorm feeds both the cross-KV GEMM and the debug tap).
 // 32 lanes per row (two rows per wavefront), PER float4 per lane: 16-byte loads, 8-byte plane stores.
-template <int PER>
+// BF: one bf16 plane instead (bf16 storage mode; scale and the plane offset unused).
+template <int PER, bool BF>
 __global__ __launch_bounds__(256) void layernorm_rows_planes(const float* __restrict__ x, _Float16* __restrict__ yp,
                                                              long plane, float scale, float* __restrict__ y32,
                                                              const float* __restrict__ g, const float* __restrict__ b,
@@ -103,18 +104,26 @@ __global__ __launch_bounds__(256) void layernorm_rows_planes(const float* __rest
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       y[e] = (v[i][e] - mean) * rstd * gg[i][e] + bb[i][e];
-      _Float16 h, l;
-      split_f16(y[e] * scale, &h, &l);
-      hi[e] = h;
-      lo[e] = l;
+      if (!BF) {
+        _Float16 h, l;
+        split_f16(y[e] * scale, &h, &l);
+        hi[e] = h;
+        lo[e] = l;
+      }
     }
     if (y32 != nullptr) *reinterpret_cast<f32x4*>(y32 + row * d + c) = y;
-    *reinterpret_cast<half4*>(yp + row * d + c) = hi;
-    *reinterpret_cast<half4*>(yp + plane + row * d + c) = lo;
+    if (BF) {
+      using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+      *reinterpret_cast<u32x2*>(yp + row * d + c) = u32x2{pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
+    } else {
+      *reinterpret_cast<half4*>(yp + row * d + c) = hi;
+      *reinterpret_cast<half4*>(yp + plane + row * d + c) = lo;
+    }
   }
 }
 
 // mel [B][C][T] -> fp16 planes of melT * scale, [B][T + 2][ld] (rows 1..T, columns < C).  32x32 LDS tile transpose.
+template <bool BF>
 __global__ __launch_bounds__(256) void mel_transpose_planes(const float* __restrict__ mel, _Float16* __restrict__ out,
                                                             long plane, float scale, int C, int T, int ld) {
   __shared__ float tile[32][33];
@@ -132,10 +141,15 @@ __global__ __launch_bounds__(256) void mel_transpose_planes(const float* __restr
   for (int i = 0; i < 4; ++i) {
     const int t = t0 + ty + 8 * i, c = c0 + tx;
     if (c < C && t < T) {
-      _Float16 h, l;
-      split_f16(tile[tx][ty + 8 * i] * scale, &h, &l);
-      dst[(long)(t + 1) * ld + c] = h;
-      dst[plane + (long)(t + 1) * ld + c] = l;
+      if (BF) {
+        const unsigned pk = pack_bf16x2(tile[tx][ty + 8 * i], 0.0f);
+        reinterpret_cast<unsigned short*>(dst)[(long)(t + 1) * ld + c] = (unsigned short)(pk & 0xFFFFu);
+      } else {
+        _Float16 h, l;
+        split_f16(tile[tx][ty + 8 * i] * scale, &h, &l);
+        dst[(long)(t + 1) * ld + c] = h;
+        dst[plane + (long)(t + 1) * ld + c] = l;
+      }
     }
   }
 }
@@ -287,25 +301,41 @@ void launch_layernorm(const float* x, float* y, const float* g, const float* b, 
   }
 }
 
-void launch_layernorm_planes(const float* x, unsigned short* yp, long plane, float scale, float* y32, const float* g,
-                             const float* b, int M, int d, hipStream_t s, int* nonfinite) {
+template <bool BF>
+static void launch_ln_planes(const float* x, _Float16* y, long plane, float scale, float* y32, const float* g, const float* b,
+                             int M, int d, hipStream_t s, int* nonfinite) {
   const int blocks = (M + 7) / 8;
-  _Float16* y = reinterpret_cast<_Float16*>(yp);
   if (d == 128) {
-    hipLaunchKernelGGL(layernorm_rows_planes<1>, dim3(blocks), dim3(256), 0, s, x, y, plane, scale, y32, g, b, M, d, nonfinite);
+    hipLaunchKernelGGL((layernorm_rows_planes<1, BF>), dim3(blocks), dim3(256), 0, s, x, y, plane, scale, y32, g, b, M, d, nonfinite);
   } else if (d == 384) {
-    hipLaunchKernelGGL(layernorm_rows_planes<3>, dim3(blocks), dim3(256), 0, s, x, y, plane, scale, y32, g, b, M, d, nonfinite);
+    hipLaunchKernelGGL((layernorm_rows_planes<3, BF>), dim3(blocks), dim3(256), 0, s, x, y, plane, scale, y32, g, b, M, d, nonfinite);
   } else if (d == 512) {
-    hipLaunchKernelGGL(layernorm_rows_planes<4>, dim3(blocks), dim3(256), 0, s, x, y, plane, scale, y32, g, b, M, d, nonfinite);
+    hipLaunchKernelGGL((layernorm_rows_planes<4, BF>), dim3(blocks), dim3(256), 0, s, x, y, plane, scale, y32, g, b, M, d, nonfinite);
   } else {
     throw Error(kErrFormat, "LayerNorm plane kernel supports rows of 128, 384 or 512 elements");
   }
 }
 
+void launch_layernorm_planes(const float* x, unsigned short* yp, long plane, float scale, float* y32, const float* g,
+                             const float* b, int M, int d, hipStream_t s, int* nonfinite, bool bf16) {
+  _Float16* y = reinterpret_cast<_Float16*>(yp);
+  if (bf16) {
+    launch_ln_planes<true>(x, y, plane, scale, y32, g, b, M, d, s, nonfinite);
+  } else {
+    launch_ln_planes<false>(x, y, plane, scale, y32, g, b, M, d, s, nonfinite);
+  }
+}
+
 void launch_mel_transpose_planes(const float* mel, unsigned short* out, long plane, float scale, int batch, int n_mels,
-                                 int T, int ld, hipStream_t s) {
-  hipLaunchKernelGGL(mel_transpose_planes, dim3((T + 31) / 32, (n_mels + 31) / 32, batch), dim3(256), 0, s, mel,
-                     reinterpret_cast<_Float16*>(out), plane, scale, n_mels, T, ld);
+                                 int T, int ld, hipStream_t s, bool bf16) {
+  const dim3 grid((T + 31) / 32, (n_mels + 31) / 32, batch);
+  if (bf16) {
+    hipLaunchKernelGGL(mel_transpose_planes<true>, grid, dim3(256), 0, s, mel, reinterpret_cast<_Float16*>(out), plane, scale,
+                       n_mels, T, ld);
+  } else {
+    hipLaunchKernelGGL(mel_transpose_planes<false>, grid, dim3(256), 0, s, mel, reinterpret_cast<_Float16*>(out), plane, scale,
+                       n_mels, T, ld);
+  }
 }
 
 __global__ void chain_probe(float* p) {

@@ -92,6 +92,12 @@ struct PlaneGemmArgs {
   int n_cu = 256;  // CUs the launching stream may use (tile choice, k_gemm_planes.hip)
 };
 void launch_gemm_planes(const PlaneGemmArgs& a, int epi, hipStream_t s);
+// bf16 storage mode (k_gemm_bf16.hip): A, W single bf16 matrices (the plane offsets and scales of the struct are
+// unused), K a multiple of 64; P set = bf16 output (row-major, or the cross-KV cache layout with kEpiKvLayout),
+// else fp32 output C
+void launch_gemm_bf16_planes(const PlaneGemmArgs& a, int epi, hipStream_t s);
+// W [N][K] fp32 -> bf16 [N][Kpad] (round to nearest even, zero filled)
+std::vector<unsigned short> round_weights_bf16(const float* W, int N, int K, int Kpad);
 // W [N][K] fp32 -> hi plane [N][Kpad] followed by lo plane [N][Kpad] (Kpad >= K, zero filled), scaled by `scale`
 std::vector<unsigned short> split_weight_planes(const float* W, int N, int K, int Kpad, float scale);
 
@@ -142,6 +148,8 @@ struct DecGemmArgs {
   // kProLn: rows = xin + xpart (the pending second half of the previous residual GEMM); block 0 stores the
   // completed rows to xout
   const float* xpart = nullptr;
+  // bf16 storage mode: Wt is ONE bf16 plane in fragment order (tile_weights_bf16), w_scale unused
+  bool bf16 = false;
 };
 void launch_dec_gemm(const DecGemmArgs& a, int pro, int epi, hipStream_t s);
 // y = LayerNorm(x) * g + b : input rows of the logits GEMM
@@ -155,7 +163,7 @@ void launch_layernorm(const float* x, float* y, const float* g, const float* b, 
 // Same rows, written as two fp16 planes of y * scale (hi at yp, lo at yp + plane) for the plane GEMM, and
 // optionally (y32 != nullptr) also as fp32.
 void launch_layernorm_planes(const float* x, unsigned short* yp, long plane, float scale, float* y32, const float* g,
-                             const float* b, int M, int d, hipStream_t s, int* nonfinite = nullptr);
+                             const float* b, int M, int d, hipStream_t s, int* nonfinite = nullptr, bool bf16 = false);
 
 // ------------------------------------------------------ encoder attention ---
 // qkv [B*T][3*d] (q | k | v, heads of 64 inside each third) -> out [B*T][d].
@@ -170,6 +178,9 @@ void launch_encoder_attention(const float* qkv, float* out, int batch, int T, in
 void launch_encoder_attention_planes(const unsigned short* qkv, long plane, unsigned short* out, long out_plane,
                                      int batch, int T, int heads, float q_scale, float k_scale, float v_scale,
                                      float out_scale, hipStream_t stream);
+// bf16 storage mode: qkv and out are single bf16 matrices; q arrives unscaled
+void launch_encoder_attention_bf16(const unsigned short* qkv, unsigned short* out, int batch, int T, int heads,
+                                   hipStream_t stream);
 
 // ------------------------------------------------------------- front end ---
 // mel [B][n_mels][T] -> melT [B][T + 2][n_mels] rows 1..T (rows 0 and T+1 stay zero).
@@ -180,7 +191,7 @@ void launch_mel_transpose(const float* mel, float* melT, int batch, int n_mels, 
 // mel [B][n_mels][T] -> fp16 planes of melT * scale, [B][T + 2][ld] rows 1..T, columns [0, n_mels) (the rest and
 // rows 0, T + 1 stay zero): hi at out, lo at out + plane
 void launch_mel_transpose_planes(const float* mel, unsigned short* out, long plane, float scale, int batch, int n_mels,
-                                 int T, int ld, hipStream_t s);
+                                 int T, int ld, hipStream_t s, bool bf16 = false);
 // spec [M][ld] holding re parts of all n_fft bins at columns [0,n_fft) and im parts at
 // [im_off, im_off+n_fft) -> pw [M][ldp]: |X[k]|^2 (+ |X[n_fft-k]|^2 for 0 < k < n_fft/2, the
 // reference's mirror fold) for k <= n_fft/2; columns above zeroed up to ldp.
@@ -198,8 +209,9 @@ void launch_mel_normalize(float* logmel, const unsigned* clip_max, int batch, in
 // --------------------------------------------------------------- decoder ---
 // Appends k, v of positions pos0 .. pos0 + npos - 1 (from qkv rows p * B + b, [.][3d]) to the self-attention
 // cache [2][B][cap][d] and attends each new position's q causally over positions 0 .. pos0 + p.  out rows likewise.
-void launch_self_attention(const float* qkv, float* kcache, float* vcache, int cap, int pos0, int npos, float* out,
-                           int batch, int heads, hipStream_t s);
+// bf16: the cache holds bf16 elements (bf16 storage mode).
+void launch_self_attention(const float* qkv, void* kcache, void* vcache, int cap, int pos0, int npos, float* out,
+                           int batch, int heads, hipStream_t s, bool bf16 = false);
 // Cross attention of nq (1..4) query rows per clip over T cached keys, the query projection included:
 // q = LayerNorm(x[row]) . Wq^T + bq with x the residual stream [nq * B][d], rows p * B + b.  wq_t = Wq in the
 // layout of cross_q_layout(); kc, vc [B][heads][T][64]; partial results per key chunk in ws
@@ -207,9 +219,10 @@ void launch_self_attention(const float* qkv, float* kcache, float* vcache, int c
 struct CrossAttnArgs {
   const float* x = nullptr;
   const float *ln_g = nullptr, *ln_b = nullptr, *wq_t = nullptr, *bq = nullptr;
-  const float *kc = nullptr, *vc = nullptr;
+  const void *kc = nullptr, *vc = nullptr;  // [clip][head][T][64] fp32, or bf16 when `bf16`
   float* ws = nullptr;
   int batch = 0, heads = 0, T = 0, chunks = 1, nq = 1;
+  bool bf16 = false;
 };
 void launch_cross_attention(const CrossAttnArgs& a, hipStream_t s);
 // Greedy selection after the logits GEMM: reduces the per-tile (value, column) records
@@ -219,6 +232,9 @@ void launch_select_token(const unsigned long long* best, int n_tiles, long long*
                          hipStream_t s);
 
 // ---- load-time re-layouts of decoder weights (host) ----
+// bf16 storage mode: W [N][K] fp32 -> ONE bf16 plane (round to nearest even) in the same fragment order,
+// [ceil(N/32)][K/16][64 lanes][8]
+std::vector<unsigned short> tile_weights_bf16(const float* W, int N, int K);
 // W [N][K] fp32 -> two fp16 planes in MFMA-fragment order [ceil(N/32)][K/16][plane][64 lanes][8] (rows past N zero):
 // lane (l & 31, l >> 5) of tile t, step s holds W[32t + (l & 31)][16s + 8(l >> 5) .. +7] * scale as hi = fp16(v),
 // lo = fp16(v - hi).  *scale = f16_scale_for(max |W|).  K % 16 == 0.
