@@ -167,6 +167,9 @@ def main() -> None:
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--dry-run-gloo", action="store_true")
+    ap.add_argument("--bf16", action="store_true",
+                    help="bf16 storage mode (BASELINE.json configs[3]: bf16 weights / activations / KV caches, fp32 "
+                         "accumulate); quote it with --arch base --batch 64")
     ap.add_argument("--emit-ids", action="store_true", help="add a CRC of every step's ids and the gathered record count to the line")
     ap.add_argument("--rehearse-nccl", action="store_true",
                     help="single rank: create the RCCL communicator and run the N > 1 collectives anyway")
@@ -212,6 +215,8 @@ def main() -> None:
         eng.set_option("use_graphs", 0)
     if args.gemm_variant is not None:
         eng.set_option("gemm_variant", args.gemm_variant)
+    if args.bf16:
+        eng.set_option("bf16", 1)
     eng.set_option("stop_at_eot", 0)  # full-length decode: 30 positions, 27 argmax steps
     B = args.batch
     lo, hi = shard_range(rank, world, world * B)
@@ -320,7 +325,7 @@ def main() -> None:
     # the same pipeline with every encoder contraction on the fp32 MFMA instruction (reported beside
     # the headline, outside the timed region, so the effect of the bf16-split kernels is visible)
     fp32_leg = None
-    if pipelined and args.gemm_variant is None and args.attn_variant is None and not args.no_fp32_leg:
+    if pipelined and args.gemm_variant is None and args.attn_variant is None and not args.no_fp32_leg and not args.bf16:
         eng.set_option("gemm_variant", 0)
         eng.set_option("attn_variant", 0)
         run_steps(3)
@@ -353,7 +358,7 @@ def main() -> None:
     # second number of SURVEY 8(d): the same pipeline fed with device-resident PCM, i.e. with the log-mel
     # front end (whisper.cpp:109-216) inside every step; PCM ~ N(0, 0.1^2) clipped to [-1, 1]
     with_frontend = None
-    if pipelined and not args.no_fp32_leg:
+    if pipelined and not args.no_fp32_leg and not args.bf16:
         pcm_host = np.clip(np.random.default_rng([MEL_SEED, 7]).normal(0.0, 0.1, size=(B, eng.pcm_len)), -1, 1).astype(np.float32)
         d_pcm = torch.from_numpy(pcm_host).cuda()
         torch.cuda.synchronize()
@@ -413,14 +418,15 @@ def main() -> None:
                     continue
                 mfma = v["flops"] > 0
                 ach = (v["flops"] / 1e12 if mfma else v["bytes"] / 1e9) / (v["ms"] * 1e-3)
-                planes = "planes" in name  # the default kernels: operands stored as two fp16 planes
-                split = mfma and ("split" in name or planes)
+                bf = "bf16_planes" in name or name == "encoder_attention_bf16"  # bf16 storage mode: one product
+                planes = "planes" in name and not bf  # the default kernels: operands stored as two fp16 planes
+                split = mfma and ("split" in name or planes or bf)
                 # plane / split kernels spend 3 (two fp16 planes per operand, the default) or 6 (three bf16
                 # planes) 16-bit MFMA FLOPs per algorithmic fp32 FLOP: their MFMA ceiling in algorithmic
                 # FLOP/s is the dense f16/bf16 peak / products; fp32-MFMA kernels are priced against
                 # the fp32 MFMA peak
                 gv, av = eng.get_option("gemm_variant"), eng.get_option("attn_variant")
-                products = 3 if planes else (3 if av == 4 else 6) if "attention" in name else (3 if gv in (-1, 17, 18) else 6)
+                products = 1 if bf else 3 if planes else (3 if av == 4 else 6) if "attention" in name else (3 if gv in (-1, 17, 18) else 6)
                 peak = (round(PEAK_BF16_MFMA_TFLOPS / products, 1) if split else PEAK_F32_MFMA_TFLOPS) if mfma else PEAK_HBM_GBPS
                 det[name] = {"bound": "mfma" if mfma else "hbm", "achieved": round(ach, 2), "peak": peak,
                              "unit": "TFLOP/s" if mfma else "GB/s", "frac": round(ach / peak, 4),
@@ -458,9 +464,13 @@ def main() -> None:
         # decoder phase against HBM: algorithmic bytes per step of this batch
         dm = eng.dims
         dstate, L, T, V = dm.n_text_state, dm.n_text_layer, dm.n_audio_ctx, dm.n_vocab
-        kv_bytes = L * 2 * T * dstate * 4 * B                        # cross KV read once per position
-        w_bytes = (L * 12 * dstate * dstate + V * dstate) * 4          # layer weights + tied embedding
-        dec_bytes = 30 * kv_bytes + 30 * (w_bytes - V * dstate * 4) + 27 * V * dstate * 4
+        esz = 2 if args.bf16 else 4                                    # bytes per stored element
+        kv_bytes = L * 2 * T * dstate * esz * B                      # cross KV read once per position
+        wq_bytes = L * dstate * dstate * 4                             # cross-attention query projection: fp32 in both modes
+        w_bytes = L * 11 * dstate * dstate * esz + wq_bytes            # layer weights
+        emb_bytes = V * dstate * esz                                   # tied embedding (logits GEMM)
+        # the prompt's positions share one pass: 27 passes over the weights and the cache, 27 logits GEMMs
+        dec_bytes = 27 * kv_bytes + 27 * w_bytes + 27 * emb_bytes
         dec_ach = dec_bytes / (stage["decoder_ms"] * 1e-3) / 1e9 if stage["decoder_ms"] > 0 else 0.0
         out = {
             "metric": "audio-sec/s (RTF) whisper-tiny 30s clips batch=32 at 1/2/4/8 MI355X",
@@ -473,15 +483,21 @@ def main() -> None:
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 (operands as two fp16 planes, f16 MFMA, f32 accumulate)" if eng.get_option("gemm_variant") < 0 else "f32",
+            "dtype": "bf16 (weights, activations, KV caches; f32 accumulate and residual stream)" if args.bf16 else
+                     "f32 (operands as two fp16 planes, f16 MFMA, f32 accumulate)" if eng.get_option("gemm_variant") < 0 else "f32",
             "data": "synthetic",
-            "config": {"workload": f"whisper-{args.arch} batch={B}x30s synthetic mel U(-1,1.5), fp32, random-init "
-                                   "weights (BASELINE.json configs[1]); mel resident in HBM -> token ids on host",
+            "config": {"workload": (f"whisper-{args.arch} multilingual batch={B}x30s synthetic mel U(-1,1.5), bf16 MFMA, random-init "
+                                    "weights (BASELINE.json configs[3]); mel resident in HBM -> token ids on host") if args.bf16 else
+                                   (f"whisper-{args.arch} batch={B}x30s synthetic mel U(-1,1.5), fp32, random-init "
+                                    "weights (BASELINE.json configs[1]); mel resident in HBM -> token ids on host"),
                        "clips_per_gpu": B, "global_batch": world * B, "decoder_positions": 30,
                        "argmax_steps": 27, "parallelism": f"clip-parallel dp{world}, one RCCL all_gather of id records per {GATHER_EVERY} batches",
                        "pipelined": pipelined, "batches_in_flight": args.depth if pipelined else 1,
                        "priming_batches": 1,
-                       "compute": "every contraction (encoder GEMMs and attention, decoder GEMMs and logits): operands as 2 fp16 "
+                       "compute": "bf16 storage mode: weights, activations, cross- and self-attention KV caches stored as bf16; every "
+                                  "contraction one bf16 MFMA product with fp32 accumulation; residual streams, softmax statistics, "
+                                  "LayerNorm, biases and the cross-attention query projection fp32" if args.bf16 else
+                                  "every contraction (encoder GEMMs and attention, decoder GEMMs and logits): operands as 2 fp16 "
                                   "planes (22 significand bits: hi + lo, 4 bytes per element like fp32), 3 f16-MFMA products, "
                                   "fp32 accumulate (measured error at or below the fp32-MFMA kernel's, tests/test_gpu_kernels.py; "
                                   "bf16 x3 split and fp32 MFMA forms selectable); residual streams, softmax, LayerNorm, KV caches fp32"},

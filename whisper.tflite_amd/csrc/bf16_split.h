@@ -134,6 +134,38 @@ __device__ __forceinline__ float erf_fast(float a) {
   return t > 0.927734375f ? big : small;
 }
 
+// GELU(x) = x/2 (1 + erf(x / sqrt 2)) on TWO values at once: the same polynomials as erf_fast written on 2-vectors so
+// that hipcc emits packed fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32: two lanes' worth of fma per issue slot).
+// The GEMM epilogues that apply it run with no MFMA beside them (all wavefronts of a block reach the epilogue
+// together), which is where packed fp32 pays (MI355X_MICROARCH.md: an anti-lever only NEXT to MFMAs).
+using f32x2_t = __attribute__((ext_vector_type(2))) float;
+__device__ __forceinline__ f32x2_t gelu_erf2(f32x2_t x) {
+  const f32x2_t a = x * 0.70710678118654752440f;
+  const f32x2_t t = __builtin_elementwise_abs(a), s = a * a;
+  f32x2_t r = __builtin_elementwise_fma(f32x2_t{-1.72853470e-5f, -1.72853470e-5f}, t, f32x2_t{3.83197126e-4f, 3.83197126e-4f});
+  const f32x2_t u = __builtin_elementwise_fma(f32x2_t{-3.88396438e-3f, -3.88396438e-3f}, t, f32x2_t{2.42546219e-2f, 2.42546219e-2f});
+  r = __builtin_elementwise_fma(r, s, u);
+  r = __builtin_elementwise_fma(r, t, f32x2_t{-1.06777877e-1f, -1.06777877e-1f});
+  r = __builtin_elementwise_fma(r, t, f32x2_t{-6.34846687e-1f, -6.34846687e-1f});
+  r = __builtin_elementwise_fma(r, t, f32x2_t{-1.28717512e-1f, -1.28717512e-1f});
+  r = __builtin_elementwise_fma(r, t, -t);
+  r = r * 1.44269504088896340736f;
+  f32x2_t q = __builtin_elementwise_fma(f32x2_t{-5.96761703e-4f, -5.96761703e-4f}, s, f32x2_t{4.99119423e-3f, 4.99119423e-3f});
+  q = __builtin_elementwise_fma(q, s, f32x2_t{-2.67681349e-2f, -2.67681349e-2f});
+  q = __builtin_elementwise_fma(q, s, f32x2_t{1.12819925e-1f, 1.12819925e-1f});
+  q = __builtin_elementwise_fma(q, s, f32x2_t{-3.76125336e-1f, -3.76125336e-1f});
+  q = __builtin_elementwise_fma(q, s, f32x2_t{1.28379166e-1f, 1.28379166e-1f});
+  const f32x2_t small = __builtin_elementwise_fma(q, a, a);
+  f32x2_t erf;
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const float big = copysignf(1.0f - __builtin_amdgcn_exp2f(r[e]), a[e]);
+    erf[e] = t[e] > 0.927734375f ? big : small[e];
+  }
+  const f32x2_t hx = x * 0.5f;
+  return __builtin_elementwise_fma(hx, erf, hx);
+}
+
 // bf16 compute mode (BASELINE configs[3]): 8 values rounded to nearest-even bf16, one fragment
 __device__ __forceinline__ u32x4_t round8_bf16(const float (&x)[8]) {
   u32x4_t o;

@@ -214,7 +214,7 @@ int wt_encdec_tokens_batch_dev(wt_engine* h, const float* d_mel, int batch, int6
   return guarded(h, [&] {
     wt::Engine& e = *h->impl;
     e.require_idle();
-    if (batch <= 32) {
+    if (batch <= 64) {  // one encoder pass + one decode (the decoder kernels take up to 64 clips per pass)
       e.encode(d_mel, batch);
       e.decode(batch, ids, n_ids, nullptr, 0);
       return;

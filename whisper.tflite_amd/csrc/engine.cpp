@@ -955,8 +955,8 @@ void Engine::resolve_kernel_stats(int slot) {
   Slot& sl = slots_[slot];
   // class names = the kernels the current options select (what rocprofv3 lists)
   const long gv = gemm_variant;
-  kstats_[kKcGemm].name = use_planes() ? "gemm_planes_tile" : gv < 0 || (gv >= 13 && gv <= 18) ? "gemm_split16_tile" : gv == 11 ? "gemm_bf16_tile" : "gemm_f32_tile";
-  kstats_[kKcEncAttn].name = use_planes() ? "encoder_attention_planes" : attn_variant ? "encoder_attention_split" : "encoder_attention_f32";
+  kstats_[kKcGemm].name = bf16 ? "gemm_bf16_planes" : use_planes() ? "gemm_planes_tile" : gv < 0 || (gv >= 13 && gv <= 18) ? "gemm_split16_tile" : gv == 11 ? "gemm_bf16_tile" : "gemm_f32_tile";
+  kstats_[kKcEncAttn].name = bf16 ? "encoder_attention_bf16" : use_planes() ? "encoder_attention_planes" : attn_variant ? "encoder_attention_split" : "encoder_attention_f32";
   for (auto& k : kstats_) k.launches = 0, k.ms = 0, k.flops = 0, k.bytes = 0;
   for (size_t i = 0; i < sl.kt_cls.size(); ++i) {
     float ms = 0;

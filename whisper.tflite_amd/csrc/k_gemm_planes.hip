@@ -33,10 +33,6 @@ using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 constexpr int BM = 192, BK = 32;
 constexpr int MI = 3;  // 32-row MFMA tiles per wavefront: two wavefront rows of 96
 
-__device__ __forceinline__ float gelu_erf(float x) {
-  return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f));
-}
-
 struct PlaneGemmDev {
   const _Float16* A;   // hi plane; lo plane at A + a_plane
   long a_plane;
@@ -223,9 +219,14 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 2) void gemm_planes_tile(Pl
           int mb = mb0, mt = mt0 + row;
           if (mt >= g.c_rpb) mt -= g.c_rpb, mb += 1;
 #pragma unroll
-          for (int e = 0; e < CPL; ++e) {
+          for (int e = 0; e < CPL; e += 2) {
             v[e] += bias_v[e];
-            if (EPI & kEpiGelu) v[e] = gelu_erf(v[e]);
+            v[e + 1] += bias_v[e + 1];
+            if (EPI & kEpiGelu) {
+              const f32x2_t gl = gelu_erf2(f32x2_t{v[e], v[e + 1]});
+              v[e] = gl[0];
+              v[e + 1] = gl[1];
+            }
           }
           if (EPI & kEpiPos) {
             int mp = mp0 + row;
