@@ -170,6 +170,8 @@ def main() -> None:
     ap.add_argument("--bf16", action="store_true",
                     help="bf16 storage mode (BASELINE.json configs[3]: bf16 weights / activations / KV caches, fp32 "
                          "accumulate); quote it with --arch base --batch 64")
+    ap.add_argument("--kernel-timers", type=int, default=None,
+                    help="event pairs around every encoder launch on every N-th pass (0 = off; engine default 1)")
     ap.add_argument("--emit-ids", action="store_true", help="add a CRC of every step's ids and the gathered record count to the line")
     ap.add_argument("--rehearse-nccl", action="store_true",
                     help="single rank: create the RCCL communicator and run the N > 1 collectives anyway")
@@ -217,6 +219,9 @@ def main() -> None:
         eng.set_option("gemm_variant", args.gemm_variant)
     if args.bf16:
         eng.set_option("bf16", 1)
+    # per-launch HIP event pairs on every 4th encoder pass of the timed region (an event pair per launch on every
+    # pass costs ~1 % of the pipeline period)
+    eng.set_option("kernel_timers", 4 if args.kernel_timers is None else args.kernel_timers)
     eng.set_option("stop_at_eot", 0)  # full-length decode: 30 positions, 27 argmax steps
     B = args.batch
     lo, hi = shard_range(rank, world, world * B)
@@ -301,11 +306,15 @@ def main() -> None:
 
     stage = {"encoder_ms": 0.0, "cross_kv_ms": 0.0, "decoder_ms": 0.0}
     kstats = {}
+    sampled = {"steps": 0}  # steps whose encoder pass carried per-launch event pairs (option kernel_timers)
     def accumulate():
         t = eng.timings()
         for k in stage:
             stage[k] += getattr(t, k)
-        for name, v in eng.kernel_stats().items():
+        ks = eng.kernel_stats()
+        if any(v["launches"] for v in ks.values()):
+            sampled["steps"] += 1
+        for name, v in ks.items():
             acc = kstats.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
             for k in acc:
                 acc[k] += v[k]
@@ -398,6 +407,7 @@ def main() -> None:
         # outside the timed region: two synchronous passes, so the per-kernel figures are also
         # reported without the encoder and the decoders sharing the chip
         iso_stats = {}
+        eng.set_option("kernel_timers", 1)
         for _ in range(2):
             step()
             for name, v in eng.kernel_stats().items():
@@ -440,7 +450,7 @@ def main() -> None:
             return det
 
         # dominant kernel = the class with the most device time inside the timed region
-        detail = rooflines(kstats, args.steps)
+        detail = rooflines(kstats, max(1, sampled["steps"]))
         dom = max(detail, key=lambda k: detail[k]["ms_per_step"]) if detail else None
         roof = None
         if dom:
@@ -449,10 +459,11 @@ def main() -> None:
             # passes (FETCH_SIZE, WRITE_SIZE) whose summary is committed under profiles/
             traffic, traffic_src = None, None
             try:
-                with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+                tf = "r02_c4_pmc_traffic.json" if args.bf16 else "r02_pmc_traffic.json"
+                with open(os.path.join(ROOT, "profiles", tf)) as f:
                     t = json.load(f)
                 if t["kernel_class"].startswith(dom):
-                    traffic, traffic_src = int(t["traffic_bytes_per_launch"]), "profiles/r02_pmc_traffic.json"
+                    traffic, traffic_src = int(t["traffic_bytes_per_launch"]), "profiles/" + tf
             except (OSError, KeyError, ValueError):
                 pass
             roof = {"kernel": dom, "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"],
@@ -473,7 +484,7 @@ def main() -> None:
         dec_bytes = 27 * kv_bytes + 27 * w_bytes + 27 * emb_bytes
         dec_ach = dec_bytes / (stage["decoder_ms"] * 1e-3) / 1e9 if stage["decoder_ms"] > 0 else 0.0
         out = {
-            "metric": "audio-sec/s (RTF) whisper-tiny 30s clips batch=32 at 1/2/4/8 MI355X",
+            "metric": f"audio-sec/s (RTF) whisper-{args.arch} 30s clips batch={B} at 1/2/4/8 MI355X",
             "value": round(value, 1),
             "unit": "audio-sec/s",
             "n_gpus": world,

@@ -1,0 +1,14 @@
+# the round's bench lines (GPU box): default workload with all legs, configs[3], and the N=1 RCCL rehearsal
+set -o pipefail
+python bench.py > gpurun_out/r02_bench.json 2> gpurun_out/r02_bench.err || { tail -5 gpurun_out/r02_bench.err; exit 1; }
+echo "default done"
+python bench.py --arch base --batch 64 --bf16 --steps 100 > gpurun_out/r02_c4_bench.json 2> gpurun_out/r02_c4_bench.err || { tail -5 gpurun_out/r02_c4_bench.err; exit 1; }
+echo "c4 done"
+python bench.py --arch base --batch 64 --steps 50 --no-cpu-baseline --no-fp32-leg > gpurun_out/r02_c4_f32accurate_bench.json 2>/dev/null || exit 1
+python - <<'PY'
+import json
+for f in ("r02_bench","r02_c4_bench","r02_c4_f32accurate_bench"):
+    d=json.load(open(f"gpurun_out/{f}.json"))
+    print(f, d["value"], d["ms_per_step"], d["stage_ms_per_step"], d["roofline"]["kernel"], d["roofline"]["achieved"], d["roofline"]["frac"], d["roofline"].get("isolated"), d["roofline"]["traffic"], "dec", d["decoder_roofline"]["frac"], d.get("cpu_baseline",{}).get("value"), d.get("cpu_baseline",{}).get("ids_match_gpu"))
+    print("   fp32 leg", d.get("fp32_mfma_only") and (d["fp32_mfma_only"]["value"], d["fp32_mfma_only"]["bf16x3_split"]["value"]), "frontend", d.get("with_frontend") and d["with_frontend"]["value"])
+PY

@@ -141,6 +141,9 @@ int wt_engine_set_option(wt_engine* h, const char* key, long value) {
       return fail(h, WT_ERR_INVALID_ARG, "gemm_variant must be -1 (default), 0, 11, 13, 16, 17 or 18");
     }
     e.gemm_variant = value;
+  } else if (k == "kernel_timers") {
+    if (value < 0 || value > 1024) return fail(h, WT_ERR_INVALID_ARG, "kernel_timers must be in [0, 1024]");
+    e.kernel_timers = value;
   } else if (k == "bf16") {
     // bf16 storage mode (BASELINE configs[3]); the first switch reads the weight file again for the bf16 copies
     try {
@@ -175,6 +178,7 @@ int wt_engine_get_option(const wt_engine* h, const char* key, long* value) {
   else if (k == "gemm_variant") *value = e.gemm_variant;
   else if (k == "use_graphs") *value = e.use_graphs;
   else if (k == "bf16") *value = e.bf16;
+  else if (k == "kernel_timers") *value = e.kernel_timers;
   else if (k == "fc2_ksplit") *value = e.fc2_ksplit;
   else if (k == "attn_variant") *value = e.attn_variant;
   else if (k == "f16_fallbacks") *value = e.f16_fallbacks();  // read-only

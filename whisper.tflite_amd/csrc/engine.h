@@ -89,6 +89,9 @@ class Engine {
   // set_bf16(): the first switch uploads the bf16 weight copies.
   long bf16 = 0;
   void set_bf16(bool on);
+  // encoder kernel-class timers (wt_last_kernel_stats): 0 = off, N = event pairs around every launch of every N-th
+  // encoder pass; passes without them report zero launches
+  long kernel_timers = 1;
   // non-empty: replaces the reference's hard-coded prompt (test-sized vocabularies)
   std::vector<long long> prompt_override;
   // ids the decoder starts from (prompt_override, or the reference's rule for the engine type)
@@ -290,6 +293,8 @@ class Engine {
     std::vector<void*> owned;
   } ws_;
   // kernel-class timer (events live in the pipeline slot being encoded)
+  bool kt_on_ = true;
+  long enc_count_ = 0;
   void kt_begin(int cls, double flops, double bytes);
   void kt_end();
   void resolve_kernel_stats(int slot);
