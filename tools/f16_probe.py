@@ -1,6 +1,6 @@
 import os, sys, tempfile
 import numpy as np
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge
 pkg = ge.load_package()
 prefix, vocab = ge._assets(tempfile.mkdtemp(), "micro", 0)

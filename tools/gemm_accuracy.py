@@ -20,7 +20,7 @@ for M, N, K in [(512, 384, 384), (512, 384, 1536), (384, 1152, 384)]:
     ref32 = A @ W.T  # numpy/BLAS fp32
     print(f"M={M} N={N} K={K}  |ref| rms {np.sqrt((ref ** 2).mean()):.3f}")
     print(f"  numpy fp32      : max abs err {np.abs(ref32 - ref).max():.3e}  rms {np.sqrt(((ref32 - ref) ** 2).mean()):.3e}")
-    for v, name in [(0, "fp32 MFMA      "), (10, "bf16 x6 split  "), (13, "split k16      "), (14, "split k16 sched"), (15, "k16 stage-first"), (17, "fp16 x2 split   "), (11, "bf16 rounded   ")]:
+    for v, name in [(0, "fp32 MFMA      "), (13, "bf16 x3 split  "), (16, "bf16 x3 2blk/CU"), (17, "fp16 x2 split  "), (18, "fp16 x2 2blk/CU"), (11, "bf16 rounded   ")]:
         eng.set_option("gemm_variant", v)
         C = eng.dbg_gemm(A, W).astype(np.float64)
         print(f"  {name} : max abs err {np.abs(C - ref).max():.3e}  rms {np.sqrt(((C - ref) ** 2).mean()):.3e}  "

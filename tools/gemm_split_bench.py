@@ -1,4 +1,5 @@
-"""Split-GEMM variants on the encoder shapes (GPU box): python tools/gemm_split_bench.py [variants...]"""
+"""The selectable fp32-storage GEMM variants (k_gemm.hip) on the encoder shapes (GPU box):
+python tools/gemm_split_bench.py [variants...]; the default plane GEMM: tools/gemm_planes_bench.py"""
 import os
 import sys
 import tempfile
@@ -9,7 +10,7 @@ import __graft_entry__ as ge
 pkg = ge.load_package()
 prefix, vocab = ge._assets(tempfile.mkdtemp(), "micro", 0)
 eng = pkg.Engine(prefix, vocab, True)
-names = {0: "fp32 128x128", 10: "split-3", 11: "bf16", 12: "split-3 Wpre", 13: "split k16", 14: "split k16 sch", 15: "k16 stage1st", 16: "k16 2blk/CU", 17: "fp16x2", 18: "fp16x2 2blk", 21: "no gload", 22: "no split", 23: "no gl+split", 24: "1 product", 27: "skeleton"}
+names = {0: "fp32 128x128", 11: "bf16 operands", 13: "bf16x3 k16", 16: "bf16x3 2blk/CU", 17: "fp16x2", 18: "fp16x2 2blk"}  # the variants the library keeps (k_gemm.hip)
 shapes = [(48000, 384, 384, 5, "out-proj"), (48000, 1152, 384, 1, "qkv"), (48000, 1536, 384, 3, "fc1"),
           (48000, 384, 1536, 5, "fc2"), (48000, 384, 1152, 3, "conv2"), (96000, 384, 256, 3, "conv1"),
           (48000, 3072, 384, 1, "cross-kv")]
