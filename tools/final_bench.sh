@@ -1,4 +1,4 @@
-# the round's bench lines (GPU box): default workload with all legs, configs[3], and the N=1 RCCL rehearsal
+# the bench lines of a round (GPU box): default workload with all legs, configs[3] in bf16 and in the default mode
 set -o pipefail
 python bench.py > gpurun_out/r02_bench.json 2> gpurun_out/r02_bench.err || { tail -5 gpurun_out/r02_bench.err; exit 1; }
 echo "default done"

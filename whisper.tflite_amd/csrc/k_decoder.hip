@@ -479,9 +479,10 @@ void launch_steps(DecGemmDev g, hipStream_t s) {
 
 template <int PRO, int EPI, int NF4, int LNMODE, int WAVES, int CH, bool BF>
 void launch_gt(const DecGemmDev& g, hipStream_t s) {
-  // row groups of two 32-row tiles when there is more than one tile, while the LayerNorm rows of a group fit in LDS
-  // (K <= 384: 64 x 388 x 4 B = 99 KB); one tile per group otherwise
-  const bool two = g.M > 32 && !(PRO == kProLn && g.K > 384);
+  // row groups of two 32-row tiles when there is more than one tile: the weights of a (tile, k-slice) are then loaded
+  // once per 64 rows.  The LayerNorm rows of a group live in LDS: 64 x (K + 4) x 4 B = 99 KB at K = 384, 132 KB at
+  // K = 512 (+ 4 KB of gain / shift: inside the 160 KB a block may use)
+  const bool two = g.M > 32 && !(PRO == kProLn && g.K > 512);
   if (two) {
     launch_steps<PRO, EPI, NF4, LNMODE, WAVES, CH, 2, BF>(g, s);
   } else {
