@@ -420,6 +420,164 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm(DecGemmDev g) {
   }
 }
 
+// Logits GEMM, one 32-row tile per blockIdx.y (a generated position of a <= 32-clip batch is one tile): logits[m][n] = x[m] . E[n] against the
+// tied embedding, N = n_vocab (51865: 1621 column tiles), plus the per-tile argmax records.  dec_gemm gives every
+// column tile its own short-lived block (load 49 KB, 18 MFMAs, reduce, leave): 1621 blocks x ~11 us on 2 blocks per
+// CU = 37 us per launch for 80 MB of weights.  Here 512 PERSISTENT blocks walk the column tiles: the activation
+// planes (and their per-row scales) are made once per block instead of once per tile, and the weights of the next
+// tile are requested before the MFMAs of the current one, so the stream never waits for a block to start.  Same
+// arithmetic in the same order as dec_gemm<kProNone, kDecLogits> (per-wavefront k-slice partials, scaled back per row,
+// summed over wavefronts 0..3), hence bit-identical logits and records.
+template <int KS, bool BF>  // KS = 16-deep k-steps per wavefront = K / 64
+__global__ __launch_bounds__(256, 2) void dec_logits_persistent(DecGemmDev g) {
+  __shared__ __attribute__((aligned(16))) float red[2][4][16][64];  // [tile parity][wavefront][register][lane]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int n_tiles = (g.N + 31) / 32, K = g.K, M = g.M;
+  const int k0 = wid * (K >> 2);
+  constexpr int WSTEP = BF ? 512 : 1024;
+  const unsigned short* const wbase = g.Wt + (long)(k0 >> 4) * WSTEP + lane * 8;
+  const long tile_stride = (long)(K >> 4) * WSTEP;
+  int tile = blockIdx.x;
+  u32x4_t wh[KS], wl[BF ? 1 : KS];
+  {
+    const unsigned short* wp = wbase + (long)(tile < n_tiles ? tile : n_tiles - 1) * tile_stride;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      wh[s] = *reinterpret_cast<const u32x4_t*>(wp + (long)s * WSTEP);
+      if (!BF) wl[s] = *reinterpret_cast<const u32x4_t*>(wp + (long)s * WSTEP + 512);
+    }
+  }
+  // activation planes of this wavefront's k-slice: lane (row l31, half lh) holds x[row][k0 + 16 s + 8 lh .. + 7]
+  u32x4_t ah[KS], al[BF ? 1 : KS];
+  float inv = 1.0f;
+  const int m0 = blockIdx.y * 32;  // row tile: each one streams the weights (blockIdx.y > 0 only for more than 32 rows)
+  {
+    int row = m0 + l31;
+    row = row < M ? row : M - 1;
+    const float* xp = g.X + (long)row * g.ldx + k0 + 8 * lh;
+    float xa[KS][8];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(xp + 16 * s);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(xp + 16 * s + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        xa[s][e] = a[e];
+        xa[s][4 + e] = b[e];
+      }
+    }
+    if (BF) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ah[s][e] = pack_bf16x2(xa[s][2 * e], xa[s][2 * e + 1]);
+    } else {
+      float mx = 0.0f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mx = fmaxf(mx, fabsf(xa[s][e]));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const unsigned ex = (__float_as_uint(mx) >> 23) & 0xFFu;
+      const float sc = ex < 32u ? 1.0f : __uint_as_float((268u - ex) << 23);
+      inv = ex < 32u ? 1.0f : __uint_as_float((ex - 14u) << 23);
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        u32x4_t pl[3];
+        split8_f16x2(xa[s], sc, pl);
+        ah[s] = pl[0];
+        al[s] = pl[1];
+      }
+    }
+  }
+  float rscale[16];  // accumulator register r belongs to row crow(r, lh), whose scale lane crow(r, lh) holds
+#pragma unroll
+  for (int r = 0; r < 16; ++r) rscale[r] = BF ? 1.0f : __shfl(inv, crow(r, lh), 64) * g.w_descale;
+
+  for (int par = 0; tile < n_tiles; tile += gridDim.x, par ^= 1) {
+    // the next tile's weights first (a tile past the end re-reads this one: no branch around a load)
+    const int nt = tile + (int)gridDim.x < n_tiles ? tile + (int)gridDim.x : tile;
+    const unsigned short* np = wbase + (long)nt * tile_stride;
+    u32x4_t nwh[KS], nwl[BF ? 1 : KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      nwh[s] = *reinterpret_cast<const u32x4_t*>(np + (long)s * WSTEP);
+      if (!BF) nwl[s] = *reinterpret_cast<const u32x4_t*>(np + (long)s * WSTEP + 512);
+    }
+    f32x16 part;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[r] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      if (BF) {
+        using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+        part = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[s]), __builtin_bit_cast(bf16x8, wh[s]), part, 0, 0, 0);
+      } else {
+        const half8 a_h = __builtin_bit_cast(half8, ah[s]), a_l = __builtin_bit_cast(half8, al[BF ? 0 : s]);
+        const half8 b_h = __builtin_bit_cast(half8, wh[s]), b_l = __builtin_bit_cast(half8, wl[BF ? 0 : s]);
+        part = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h, b_l, part, 0, 0, 0);
+        part = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_l, b_h, part, 0, 0, 0);
+        part = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h, b_h, part, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[par][wid][r][lane] = BF ? part[r] : 0.0f + part[r] * rscale[r];
+    __syncthreads();  // one barrier per tile: the other parity's buffer is only rewritten after the NEXT barrier
+    {
+      // every wavefront finishes four of the sixteen accumulator registers (= eight rows)
+      const int n_epi = tile * 32 + l31;
+      const bool n_ok = n_epi < g.N;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int r = wid * 4 + rr;
+        float v = red[par][0][r][lane];
+        v += red[par][1][r][lane];
+        v += red[par][2][r][lane];
+        v += red[par][3][r][lane];
+        v += 0.0f;
+        const int m = m0 + crow(r, lh);
+        const bool ok = n_ok && m < M;
+        if (ok && g.Y) g.Y[(long)m * g.ldy + n_epi] = v;
+        // (value, column) record of this row over the tile's 32 columns: the largest ordered key, then the LARGEST
+        // column among equals (the reference's `>=` scan, whisper.cpp:353) = the highest lane of the ballot
+        const unsigned key = ok ? ordered_bits(v) : 0u;
+        unsigned kmax = key;
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) {
+          const unsigned o2 = __shfl_xor(kmax, off, 64);
+          kmax = o2 > kmax ? o2 : kmax;
+        }
+        const unsigned long long hit = __ballot(ok && key == kmax);
+        const unsigned half_hits = (unsigned)(hit >> (32 * lh));
+        if (l31 == 0 && m < M) {
+          const unsigned col = half_hits ? (unsigned)(tile * 32 + 31 - __clz(half_hits)) : 0u;
+          g.best[(long)m * g.best_stride + tile] = half_hits ? (((unsigned long long)kmax << 32) | col) : 0ull;
+        }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      wh[s] = nwh[s];
+      if (!BF) wl[s] = nwl[s];
+    }
+  }
+}
+
+template <bool BF>
+bool launch_logits_persistent(const DecGemmDev& g, hipStream_t s) {
+  if (g.K % 64 != 0 || g.ksplit != 1) return false;
+  const int n_tiles = (g.N + 31) / 32, m_tiles = (g.M + 31) / 32;
+  const int per = 512 / m_tiles;  // 512 resident blocks in all
+  const dim3 grid(n_tiles < per ? n_tiles : per, m_tiles);
+  switch (g.K / 64) {
+    case 2: hipLaunchKernelGGL((dec_logits_persistent<2, BF>), grid, dim3(256), 0, s, g); return true;
+    case 6: hipLaunchKernelGGL((dec_logits_persistent<6, BF>), grid, dim3(256), 0, s, g); return true;
+    case 8: hipLaunchKernelGGL((dec_logits_persistent<8, BF>), grid, dim3(256), 0, s, g); return true;
+    default: return false;
+  }
+}
+
 // y = LayerNorm(x)   (input rows of the logits GEMM).
 template <int NF4, int LNMODE>
 __global__ __launch_bounds__(256) void dec_finalize_ln(RowSrc src, const float* __restrict__ g,
@@ -520,7 +678,9 @@ static void dispatch_dec_gemm(const DecGemmArgs& a, const DecGemmDev& g, int pro
   switch (key) {
     case kProNone * 8 + kDecResid: launch_gt<kProNone, kDecResid, 0, 0, 8, 1, BF>(g, s); break;
     case kProNone * 8 + kDecBias: launch_gt<kProNone, kDecBias, 0, 0, 4, 1, BF>(g, s); break;
-    case kProNone * 8 + kDecLogits: launch_gt<kProNone, kDecLogits, 0, 0, 4, 1, BF>(g, s); break;
+    case kProNone * 8 + kDecLogits:
+      if (!launch_logits_persistent<BF>(g, s)) launch_gt<kProNone, kDecLogits, 0, 0, 4, 1, BF>(g, s);
+      break;
     case kProCombine * 8 + kDecResid:
       switch (a.chunks) {  // compile-time chunk count keeps the partial loads independent
         case 1: launch_gt<kProCombine, kDecResid, 0, 0, 8, 1, BF>(g, s); break;
