@@ -239,12 +239,17 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm(DecGemmDev g) {
 
     // the residual rows of the tile this wave will finish do not depend on the product: requested before the
     // contraction instead of after the split-K combine (one dependent round trip less per launch)
-    float r_pre[EPI == kDecResid ? 16 : 1];
-    if (EPI == kDecResid && khalf == 0 && wid < GT && g0 + wid < m_tiles) {
+    // The GT x 16 accumulator registers of the group are finished by ALL wavefronts, PER of them each (item i = tile
+    // i >> 4, register i & 15; wavefront w takes items w PER .. w PER + PER - 1) — one wavefront finishing a whole tile
+    // while the others idle was the serial tail of every launch.
+    constexpr int PER = GT * 16 / WAVES;
+    float r_pre[EPI == kDecResid ? PER : 1];
+    if (EPI == kDecResid && khalf == 0) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = (g0 + wid) * 32 + crow(r, lh);
-        r_pre[r] = g.R[(long)(m < M ? m : M - 1) * g.ldy + (n_ok ? n_epi : 0)];
+      for (int j = 0; j < PER; ++j) {
+        const int i = wid * PER + j, t = i >> 4, r = i & 15;
+        const int m = (g0 + t) * 32 + crow(r, lh);
+        r_pre[j] = g.R[(long)(m < M ? m : M - 1) * g.ldy + (n_ok ? n_epi : 0)];
       }
     }
     f32x16 acc[GT];
@@ -370,7 +375,7 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm(DecGemmDev g) {
       }
     }
 
-    // split-K combine through LDS, fixed order; tile t of the group is finished by wave t
+    // split-K combine through LDS, fixed order
     if (PRO == kProLn) {
       __syncthreads();  // every wave is done reading the LayerNorm rows the partials alias
     } else if (g0 > 0) {
@@ -381,40 +386,35 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm(DecGemmDev g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) red[((wid * GT + t) * 16 + r) * 64 + lane] = acc[t][r];
     __syncthreads();
-    if (wid < GT && g0 + wid < m_tiles) {
-      const int t = wid;
-      f32x16 sum;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sum[r] = red[(t * 16 + r) * 64 + lane];
-#pragma unroll 1
-      for (int wv = 1; wv < WAVES; ++wv)  // fixed order: wave 0, 1, 2, ...
+    for (int j = 0; j < PER; ++j) {
+      const int i = wid * PER + j, t = i >> 4, r = i & 15;
+      if (g0 + t >= m_tiles) continue;  // wave-uniform
+      float sum = red[(t * 16 + r) * 64 + lane];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sum[r] += red[((wv * GT + t) * 16 + r) * 64 + lane];
+      for (int wv = 1; wv < WAVES; ++wv) sum += red[((wv * GT + t) * 16 + r) * 64 + lane];  // fixed order: wave 0, 1, 2, ...
+      const int m = (g0 + t) * 32 + crow(r, lh);
+      float v = sum + bias;
+      if (EPI == kDecBias && g.gelu) v = gelu_erf(v);
+      const bool ok = n_ok && m < M;
+      if (EPI == kDecResid && khalf == 1) {  // second K-half: the raw partial, summed by the consumer
+        if (ok) g.part[(long)m * g.ldy + n_epi] = sum;
+        continue;
+      }
+      // R may alias Y: each element is read and written by the same thread
+      if (EPI == kDecResid && ok) v += r_pre[EPI == kDecResid ? j : 0];
+      if (ok && g.Y) g.Y[(long)m * g.ldy + n_epi] = v;
+      if (EPI == kDecLogits) {
+        // fold (value, column): larger value wins, then the larger column — the reference's
+        // `>=` scan keeps the LAST maximal index (whisper.cpp:353)
+        unsigned long long p = ok ? (((unsigned long long)ordered_bits(v) << 32) | (unsigned)n_epi) : 0ull;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = (g0 + t) * 32 + crow(r, lh);
-        float v = sum[r] + bias;
-        if (EPI == kDecBias && g.gelu) v = gelu_erf(v);
-        const bool ok = n_ok && m < M;
-        if (EPI == kDecResid && khalf == 1) {  // second K-half: the raw partial, summed by the consumer
-          if (ok) g.part[(long)m * g.ldy + n_epi] = sum[r];
-          continue;
+        for (int off = 16; off >= 1; off >>= 1) {
+          const unsigned long long o2 = __shfl_xor(p, off, 64);
+          p = o2 > p ? o2 : p;
         }
-        // R may alias Y: each element is read and written by the same thread
-        if (EPI == kDecResid && ok) v += r_pre[EPI == kDecResid ? r : 0];
-        if (ok && g.Y) g.Y[(long)m * g.ldy + n_epi] = v;
-        if (EPI == kDecLogits) {
-          // fold (value, column): larger value wins, then the larger column — the reference's
-          // `>=` scan keeps the LAST maximal index (whisper.cpp:353)
-          unsigned long long p = ok ? (((unsigned long long)ordered_bits(v) << 32) | (unsigned)n_epi) : 0ull;
-#pragma unroll
-          for (int off = 16; off >= 1; off >>= 1) {
-            const unsigned long long o2 = __shfl_xor(p, off, 64);
-            p = o2 > p ? o2 : p;
-          }
-          // one record per (row, tile); select_token reduces them (no same-address atomics)
-          if (l31 == 0 && m < M) g.best[(long)m * g.best_stride + tile] = p;
-        }
+        // one record per (row, tile); select_token reduces them (no same-address atomics)
+        if (l31 == 0 && m < M) g.best[(long)m * g.best_stride + tile] = p;
       }
     }
   }
