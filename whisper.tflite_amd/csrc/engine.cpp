@@ -1532,13 +1532,12 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
         // logits against the tied embedding + greedy argmax (whisper.cpp:379-399); only the
         // last position's rows exist here, the reference computes and drops the others
         const size_t off = size_t(np - 1) * batch * d;
-        DT(8, launch_dec_finalize_ln((split ? dw.xb : x) + off, dec_ln_g, dec_ln_b, dw.lnd, batch, d, stream_,
-                                     split ? dw.xpart + off : nullptr));
-        DecGemmArgs lg;
+        DecGemmArgs lg;  // final LayerNorm (of x, or of the two halves a K-split fc2 left) + logits + argmax records
         lg.bf16 = bf;
-        lg.Wt = (bf ? tok_emb_tiled_bf_ : tok_emb_tiled).w; lg.w_scale = (bf ? tok_emb_tiled_bf_ : tok_emb_tiled).scale; lg.N = V; lg.K = d; lg.B = batch; lg.X = dw.lnd; lg.ldx = d;
+        lg.Wt = (bf ? tok_emb_tiled_bf_ : tok_emb_tiled).w; lg.w_scale = (bf ? tok_emb_tiled_bf_ : tok_emb_tiled).scale; lg.N = V; lg.K = d; lg.B = batch;
+        lg.xin = (split ? dw.xb : x) + off; lg.xpart = split ? dw.xpart + off : nullptr; lg.ln_g = dec_ln_g; lg.ln_b = dec_ln_b;
         lg.Y = logits_host ? dw.logits : nullptr; lg.ldy = V; lg.best = dw.best;
-        DT(9, launch_dec_gemm(lg, kProNone, kDecLogits, stream_));
+        DT(9, launch_dec_gemm(lg, kProLn, kDecLogits, stream_));
         if (logits_host && steps < logits_steps_cap) {
           HIPCHK(hipMemcpy2DAsync(logits_host + size_t(steps) * V, size_t(logits_steps_cap) * V * sizeof(float),
                                   dw.logits, size_t(V) * sizeof(float), size_t(V) * sizeof(float), batch,

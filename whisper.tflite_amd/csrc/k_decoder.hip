@@ -428,9 +428,17 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm(DecGemmDev g) {
 // tile are requested before the MFMAs of the current one, so the stream never waits for a block to start.  Same
 // arithmetic in the same order as dec_gemm<kProNone, kDecLogits> (per-wavefront k-slice partials, scaled back per row,
 // summed over wavefronts 0..3), hence bit-identical logits and records.
-template <int KS, bool BF>  // KS = 16-deep k-steps per wavefront = K / 64
+// LNMODE >= 0: the rows are LayerNorm(xin [+ xpart]) (the decoder's final LayerNorm, load_row's modes 0 / 3), made
+// by the block itself once — what used to be a separate dec_finalize_ln launch in front of every logits GEMM;
+// LNMODE < 0: the rows are g.X as they are.
+template <int KS, bool BF, int LNMODE>  // KS = 16-deep k-steps per wavefront = K / 64
 __global__ __launch_bounds__(256, 2) void dec_logits_persistent(DecGemmDev g) {
-  __shared__ __attribute__((aligned(16))) float red[2][4][16][64];  // [tile parity][wavefront][register][lane]
+  constexpr int KC = KS * 64, XLD = KC + 4;
+  constexpr int kRed = 2 * 4 * 16 * 64, kXs = LNMODE >= 0 ? 32 * XLD : 0;
+  // [tile parity][wavefront][register][lane] split-K partials; before the first tile the same memory holds the 32
+  // normalised rows (LNMODE >= 0)
+  __shared__ __attribute__((aligned(16))) float smem_l[kRed > kXs ? kRed : kXs];
+  float (*red)[4][16][64] = reinterpret_cast<float (*)[4][16][64]>(smem_l);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
   const int n_tiles = (g.N + 31) / 32, K = g.K, M = g.M;
@@ -452,10 +460,34 @@ __global__ __launch_bounds__(256, 2) void dec_logits_persistent(DecGemmDev g) {
   u32x4_t ah[KS], al[BF ? 1 : KS];
   float inv = 1.0f;
   const int m0 = blockIdx.y * 32;  // row tile: each one streams the weights (blockIdx.y > 0 only for more than 32 rows)
+  if (LNMODE >= 0) {
+    // 8 lanes per row, a wavefront normalises 8 rows: the 32 rows of the tile in one pass (as dec_finalize_ln did)
+    constexpr int NF4 = 2 * KS;
+    const int r8 = lane >> 3, sub = lane & 7, lrow = wid * 8 + r8, row = m0 + lrow;
+    const RowSrc src{g.xin, g.xpart, nullptr, 0, 0, g.B, nullptr, nullptr, 0};
+    f32x4 v[NF4], gg[NF4], bb[NF4];
+#pragma unroll
+    for (int j = 0; j < NF4; ++j) {
+      gg[j] = *reinterpret_cast<const f32x4*>(g.ln_g + (sub + 8 * j) * 4);
+      bb[j] = *reinterpret_cast<const f32x4*>(g.ln_b + (sub + 8 * j) * 4);
+    }
+    load_row<NF4, LNMODE < 0 ? 0 : LNMODE>(v, src, row < M ? row : M - 1, sub, K);
+    float mean, rstd;
+    row_stats<NF4>(v, K, &mean, &rstd);
+#pragma unroll
+    for (int j = 0; j < NF4; ++j) {
+      const int c = (sub + 8 * j) * 4;
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[j][e] - mean) * rstd * gg[j][e] + bb[j][e];
+      *reinterpret_cast<f32x4*>(&smem_l[lrow * XLD + c]) = o;
+    }
+    __syncthreads();
+  }
   {
     int row = m0 + l31;
     row = row < M ? row : M - 1;
-    const float* xp = g.X + (long)row * g.ldx + k0 + 8 * lh;
+    const float* xp = (LNMODE >= 0 ? smem_l + l31 * XLD : g.X + (long)row * g.ldx) + k0 + 8 * lh;
     float xa[KS][8];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -491,6 +523,7 @@ __global__ __launch_bounds__(256, 2) void dec_logits_persistent(DecGemmDev g) {
       }
     }
   }
+  if (LNMODE >= 0) __syncthreads();  // every wavefront has its fragments: the rows' memory becomes the partials'
   float rscale[16];  // accumulator register r belongs to row crow(r, lh), whose scale lane crow(r, lh) holds
 #pragma unroll
   for (int r = 0; r < 16; ++r) rscale[r] = BF ? 1.0f : __shfl(inv, crow(r, lh), 64) * g.w_descale;
@@ -564,16 +597,16 @@ __global__ __launch_bounds__(256, 2) void dec_logits_persistent(DecGemmDev g) {
   }
 }
 
-template <bool BF>
+template <bool BF, int LNMODE>
 bool launch_logits_persistent(const DecGemmDev& g, hipStream_t s) {
   if (g.K % 64 != 0 || g.ksplit != 1) return false;
   const int n_tiles = (g.N + 31) / 32, m_tiles = (g.M + 31) / 32;
   const int per = 512 / m_tiles;  // 512 resident blocks in all
   const dim3 grid(n_tiles < per ? n_tiles : per, m_tiles);
   switch (g.K / 64) {
-    case 2: hipLaunchKernelGGL((dec_logits_persistent<2, BF>), grid, dim3(256), 0, s, g); return true;
-    case 6: hipLaunchKernelGGL((dec_logits_persistent<6, BF>), grid, dim3(256), 0, s, g); return true;
-    case 8: hipLaunchKernelGGL((dec_logits_persistent<8, BF>), grid, dim3(256), 0, s, g); return true;
+    case 2: hipLaunchKernelGGL((dec_logits_persistent<2, BF, LNMODE>), grid, dim3(256), 0, s, g); return true;
+    case 6: hipLaunchKernelGGL((dec_logits_persistent<6, BF, LNMODE>), grid, dim3(256), 0, s, g); return true;
+    case 8: hipLaunchKernelGGL((dec_logits_persistent<8, BF, LNMODE>), grid, dim3(256), 0, s, g); return true;
     default: return false;
   }
 }
@@ -662,6 +695,12 @@ void launch_ln(const DecGemmDev& g, hipStream_t s) {
 
 template <bool BF>
 static void dispatch_dec_gemm(const DecGemmArgs& a, const DecGemmDev& g, int pro, int epi, hipStream_t s) {
+  if (pro == kProLn && epi == kDecLogits) {  // final LayerNorm inside the persistent logits kernel
+    if (a.ids || !a.xin || !a.ln_g || !a.ln_b) throw Error(kErrInvalidArg, "logits GEMM: LayerNorm rows come from xin (+ xpart)");
+    const bool ok = a.xpart ? launch_logits_persistent<BF, 3>(g, s) : launch_logits_persistent<BF, 0>(g, s);
+    if (!ok) throw Error(kErrInvalidArg, "logits GEMM with the LayerNorm prologue: K must be a multiple of 64");
+    return;
+  }
   if (pro == kProLn) {
     if (epi != kDecBias) throw Error(kErrInvalidArg, "decoder GEMM: the LayerNorm prologue pairs with the bias epilogue");
     if (a.ids) {
@@ -679,7 +718,7 @@ static void dispatch_dec_gemm(const DecGemmArgs& a, const DecGemmDev& g, int pro
     case kProNone * 8 + kDecResid: launch_gt<kProNone, kDecResid, 0, 0, 8, 1, BF>(g, s); break;
     case kProNone * 8 + kDecBias: launch_gt<kProNone, kDecBias, 0, 0, 4, 1, BF>(g, s); break;
     case kProNone * 8 + kDecLogits:
-      if (!launch_logits_persistent<BF>(g, s)) launch_gt<kProNone, kDecLogits, 0, 0, 4, 1, BF>(g, s);
+      if (!launch_logits_persistent<BF, -1>(g, s)) launch_gt<kProNone, kDecLogits, 0, 0, 4, 1, BF>(g, s);
       break;
     case kProCombine * 8 + kDecResid:
       switch (a.chunks) {  // compile-time chunk count keeps the partial loads independent
