@@ -665,7 +665,9 @@ void Engine::create_streams() {
   reserve_ = reserve;
   const int n_cu = n_cu_;
   if (reserve > 0 && n_cu >= 64 && n_cu % 8 == 0) {
-    const int keep = n_cu - 8 * reserve;
+    int keep = n_cu - 8 * reserve;
+    if (const char* v = getenv("WT_ENC_CU_KEEP")) keep = std::min(std::max(atoi(v), 64), n_cu);  // CUs of the masked stream
+    enc_cus_masked_ = keep;
     std::vector<uint32_t> mask((n_cu + 31) / 32, 0u);
     for (int i = 0; i < keep; ++i) mask[i / 32] |= 1u << (i % 32);
     HIPCHK(hipExtStreamCreateWithCUMask(&stream_masked_, uint32_t(mask.size()), mask.data()));
@@ -1123,7 +1125,7 @@ void Engine::encode_enqueue_planes(const float* d_mel, int batch) {
   const wtw::Dims& c = dims_;
   const int T0 = mel_frames(), T = c.n_audio_ctx, d = c.n_audio_state, M = batch * T, nm = c.n_mels;
   const long Bw = ws_.batch;  // plane strides follow the workspace, not the call
-  const int cus = (stream_ == stream_masked_ && stream_masked_) ? n_cu_ - 8 * reserve_ : n_cu_;  // CUs of this stream
+  const int cus = (stream_ == stream_masked_ && stream_masked_) ? enc_cus_masked_ : n_cu_;  // CUs of this stream
   Slot& slot = slots_[enc_slot_];
   if (slot.used) HIPCHK(hipStreamWaitEvent(stream_, slot.dec_done, 0));
   slot.kt_cls.clear();
