@@ -30,8 +30,7 @@ using half8 = __attribute__((ext_vector_type(8))) _Float16;
 using half4 = __attribute__((ext_vector_type(4))) _Float16;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
-constexpr int BM = 192, BK = 32;
-constexpr int MI = 3;  // 32-row MFMA tiles per wavefront: two wavefront rows of 96
+constexpr int BK = 32;
 
 struct PlaneGemmDev {
   const _Float16* A;   // hi plane; lo plane at A + a_plane
@@ -65,9 +64,12 @@ struct PlaneGemmDev {
 //   the wide tile contracts 197 FLOP per staged byte instead of 118 and needs 24 ds_read_b128 per 54 MFMAs instead of
 //   20 per 36.  Every N of the encoder (384, 1152, 1536, 3072) is a multiple of 384, and 250 row tiles x {1, 3, 4, 8}
 //   column tiles fill 0.98 / 2.93 / 3.9 / 7.8 rounds of the 256 CUs.
-template <int EPI, bool PLANES_OUT, int WN, int NI>
+//   MI = 32-row MFMA tiles per wavefront (two wavefront rows): 3 -> 192 block rows; 4 -> 256 rows x 384 columns, the
+//   whole register file (255 VGPRs) and all 160 KB of LDS, 230 FLOP per staged byte — used where 188 row tiles fill the
+//   available CUs in fewer rounds than 250 (the CU-masked stream of the pipeline on the N = d_model shapes).
+template <int EPI, bool PLANES_OUT, int WN, int NI, int MI>
 __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 2) void gemm_planes_tile(PlaneGemmDev g) {
-  constexpr int BN = WN * NI * 32, NW = 2 * WN;
+  constexpr int BN = WN * NI * 32, NW = 2 * WN, BM = 64 * MI;
   constexpr int kAPlane = BM * BK * 2, kWPlane = BN * BK * 2;  // bytes of one plane of a stage
   constexpr int kStage = 2 * kAPlane + 2 * kWPlane;
   constexpr int QA = BM / 16, QW = BN / 16;                   // LDS-DMA instructions per A / W plane (16 rows each)
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 2) void gemm_planes_tile(Pl
 
   // fragment addresses: row = tile base (a multiple of 32) + l31, so the swizzle term depends on the lane only
   const int swz = (l31 >> 2) & 3;
-  const int a_off = (wm * 96 + l31) * 64, b_off = 2 * kAPlane + (wn * NI * 32 + l31) * 64;
+  const int a_off = (wm * (32 * MI) + l31) * 64, b_off = 2 * kAPlane + (wn * NI * 32 + l31) * 64;
   auto compute = [&](int buf) {
     const unsigned char* base = smem + buf * kStage;
 #pragma unroll
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 2) void gemm_planes_tile(Pl
       for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * lh) * SLD + (l31 ^ (lh << 2))] = acc[mi][ni][r] * g.descale;
       // the stage is private to this wavefront and LDS executes a wave's operations in order.
       // One division per 32-row slab: rows advance by at most 31 < c_rpb, pos_period (host-checked).
-      const int mbase = m0 + wm * 96 + mi * 32;
+      const int mbase = m0 + wm * (32 * MI) + mi * 32;
       const int mb0 = mbase / g.c_rpb, mt0 = mbase % g.c_rpb;
       const int mp0 = (EPI & kEpiPos) ? mbase % g.pos_period : 0;
 #pragma unroll
@@ -264,18 +266,18 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 2) void gemm_planes_tile(Pl
   }
 }
 
-template <int EPI, bool PLANES_OUT, int WN, int NI>
+template <int EPI, bool PLANES_OUT, int WN, int NI, int MI = 3>
 void launch_planes_shape(const PlaneGemmDev& g, hipStream_t s) {
-  constexpr int BN = WN * NI * 32;
+  constexpr int BN = WN * NI * 32, BM = 64 * MI;
   const int blocks = ((g.M + BM - 1) / BM) * (g.N / BN);
   constexpr size_t smem = 2 * (2 * BM * BK * 2 + 2 * BN * BK * 2);  // two stages; the epilogue stages fit inside
   static const bool raised = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_planes_tile<EPI, PLANES_OUT, WN, NI>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_planes_tile<EPI, PLANES_OUT, WN, NI, MI>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return true;
   }();
   (void)raised;
-  hipLaunchKernelGGL((gemm_planes_tile<EPI, PLANES_OUT, WN, NI>), dim3(blocks), dim3(128 * WN), smem, s, g);
+  hipLaunchKernelGGL((gemm_planes_tile<EPI, PLANES_OUT, WN, NI, MI>), dim3(blocks), dim3(128 * WN), smem, s, g);
 }
 
 template <int EPI, bool PLANES_OUT>
@@ -285,22 +287,27 @@ void launch_planes(const PlaneGemmDev& g, int n_cu, hipStream_t s) {
     return v ? atoi(v) : 0;
   }();
   // Tile choice by how the blocks fill the CUs this stream may use (the pipelined encoder stream leaves some CUs
-  // to the decoders).  In units of one 192 x 128 tile: the wide kernel runs one block (3 units) per CU per round,
-  // the narrow one two co-resident blocks per CU at ~10 % less per unit.  250 wide row tiles are one round on 256
-  // CUs but two on 224.
-  const long row_tiles = (g.M + BM - 1) / BM;
-  bool wide = g.N % 384 == 0;
-  if (wide && n_cu > 0) {
-    const long wide_rounds = (row_tiles * (g.N / 384) + n_cu - 1) / n_cu;
-    const long narrow_units = (row_tiles * (g.N / 128) + n_cu - 1) / n_cu;
-    wide = 3.0 * wide_rounds <= 1.1 * narrow_units;
-  }
-  if (forced == 128) wide = false;
-  if (forced == 384 && g.N % 384 == 0) wide = true;
-  if (wide) {
-    launch_planes_shape<EPI, PLANES_OUT, 4, 3>(g, s);
+  // to the decoders): 250 wide row tiles are one round on 256 CUs but two on 224, 188 tall ones one round on either.
+  // Cost of a candidate = rows x 128-column units x rounds of the CUs; the narrow kernel (two co-resident blocks per
+  // CU, which share the CU's throughput) costs ~10 % more per unit, the 256-row tile ~5 % less (fewer staged bytes
+  // per FLOP).
+  const int cu = n_cu > 0 ? n_cu : 256;
+  auto rounds = [&](long tiles) { return (tiles + cu - 1) / cu; };
+  const long rt192 = (g.M + 191) / 192, rt256 = (g.M + 255) / 256;
+  const bool can_wide = g.N % 384 == 0;
+  const double c_wide = can_wide ? 192.0 * 3 * rounds(rt192 * (g.N / 384)) : 1e30;
+  const double c_tall = can_wide ? 256.0 * 3 * 0.95 * rounds(rt256 * (g.N / 384)) : 1e30;
+  const double c_narrow = 192.0 * 1.1 * rounds(rt192 * (g.N / 128));
+  int pick = c_wide <= c_narrow ? (c_tall < c_wide ? 2 : 1) : (c_tall < c_narrow ? 2 : 0);
+  if (forced == 128) pick = 0;
+  if (forced == 384 && can_wide) pick = 1;
+  if (forced == 256 && can_wide) pick = 2;
+  if (pick == 2) {
+    launch_planes_shape<EPI, PLANES_OUT, 4, 3, 4>(g, s);
+  } else if (pick == 1) {
+    launch_planes_shape<EPI, PLANES_OUT, 4, 3, 3>(g, s);
   } else {
-    launch_planes_shape<EPI, PLANES_OUT, 2, 2>(g, s);
+    launch_planes_shape<EPI, PLANES_OUT, 2, 2, 3>(g, s);
   }
 }
 
