@@ -587,7 +587,8 @@ __global__ __launch_bounds__(256) void cross_attention_step(const float* __restr
   constexpr int C4 = DM / 4;    // float4 per row
   constexpr int CW = DM / 16;   // float4 of the k-quarter one wavefront contracts
 
-  // (0) the first K/V rows: nothing below touches them before the queries exist
+  // (0) the first K/V rows: nothing below touches them before the queries exist.  The cache is read once per launch
+  // and is far larger than L2 + Infinity Cache: streaming (non-temporal) loads keep those for the decoder's weights.
   const CT* kb = static_cast<const CT*>(kc_v) + ((long)bh * T + k_begin) * 64 + gl16 * EPL;
   const CT* vb = static_cast<const CT*>(vc_v) + ((long)bh * T + k_begin) * 64 + gl16 * EPL;
   u32x4_t kv[U], vv[U];  // 16 bytes: four floats, or eight bf16
@@ -595,8 +596,8 @@ __global__ __launch_bounds__(256) void cross_attention_step(const float* __restr
   for (int u = 0; u < U; ++u) {  // unguarded loads: keys past the chunk re-read its last row
     const int k = grp + NG * u;
     const int kk = k < nk ? k : nk - 1;
-    kv[u] = *reinterpret_cast<const u32x4_t*>(kb + (long)kk * 64);
-    vv[u] = *reinterpret_cast<const u32x4_t*>(vb + (long)kk * 64);
+    kv[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(kb + (long)kk * 64));
+    vv[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(vb + (long)kk * 64));
   }
   // (1) query-projection weights of this head, k-quarter `wid`, output `lane`: CW independent 16-byte loads
   f32x4 wq[CW];
@@ -691,8 +692,8 @@ __global__ __launch_bounds__(256) void cross_attention_step(const float* __restr
       for (int u = 0; u < U; ++u) {
         const int k = k0 + NG * u;
         const int kk = k < nk ? k : nk - 1;
-        kv[u] = *reinterpret_cast<const u32x4_t*>(kb + (long)kk * 64);
-        vv[u] = *reinterpret_cast<const u32x4_t*>(vb + (long)kk * 64);
+        kv[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(kb + (long)kk * 64));
+        vv[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(vb + (long)kk * 64));
       }
     }
 #pragma unroll
