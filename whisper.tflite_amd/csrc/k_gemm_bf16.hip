@@ -196,7 +196,11 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_bf16_planes(Bf16GemmDev g) {
             u32x4 pk;
 #pragma unroll
             for (int e = 0; e < CPL; e += 2) pk[e / 2] = pack_bf16x2(v[e], v[e + 1]);
-            *reinterpret_cast<u32x4*>(g.P + o) = pk;
+            if (EPI & kEpiKvLayout) {  // read next by the decoder, after the caches have turned over: streaming store
+              __builtin_nontemporal_store(pk, reinterpret_cast<u32x4*>(g.P + o));
+            } else {
+              *reinterpret_cast<u32x4*>(g.P + o) = pk;
+            }
           } else {
             const long o = (long)mb * g.c_bs + (long)mt * g.ldc + n;
             f32x4 out = {v[0], v[1], v[2], v[3]};

@@ -253,7 +253,8 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 2) void gemm_planes_tile(Pl
             *reinterpret_cast<u32x4*>(g.P + g.p_plane + o) = lo;
           } else if (EPI & kEpiKvLayout) {
             const long o = (((long)slab * g.kv_batch + mb) * g.kv_heads + head) * (long)g.c_rpb * 64 + (long)mt * 64 + dd;
-            *reinterpret_cast<f32x4*>(g.C + o) = f32x4{v[0], v[1], v[2], v[3]};
+            // the cache is next read by the decoder, long after L2 / Infinity Cache have turned over: streaming store
+            __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4*>(g.C + o));
           } else {
             const long o = (long)mb * g.c_bs + (long)mt * g.ldc + n;
             f32x4 out = {v[0], v[1], v[2], v[3]};

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void layernorm_rows_planes(const float* __rest
         lo[e] = l;
       }
     }
-    if (y32 != nullptr) *reinterpret_cast<f32x4*>(y32 + row * d + c) = y;
+    if (y32 != nullptr) __builtin_nontemporal_store(y, reinterpret_cast<f32x4*>(y32 + row * d + c));  // API copy of enc_out: not read on the device
     if (BF) {
       using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
       *reinterpret_cast<u32x2*>(yp + row * d + c) = u32x2{pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
