@@ -77,7 +77,7 @@ int wt_engine_dims(const wt_engine* h, wt_dims* out);
 /* Options (reference hard-codes them): "language" (prompt language id, whisper.cpp:327,
  * default language_id("de") = 2), "max_tokens" (max decoder positions, whisper.cpp:364,
  * default 30), "stop_at_eot" (whisper.cpp:397-399, default 1), "verbose" (default 0),
- * "cross_chunks" (key chunks per (clip, head) in the decoder cross attention: 1, 2, 4 or 8).
+ * "cross_chunks" (key chunks per (clip, head) in the decoder cross attention: 1, 2, 4, 8, or 0 = by batch size, the default).
  * Kernel selection (results stay within the fp32 error budget for every value except
  * gemm_variant 11 / attn_variant 3, the bf16 compute mode of BASELINE configs[3]): "gemm_variant"
  * (-1 = default: encoder GEMMs on the f16 matrix cores, fp32 operands split into two fp16 planes

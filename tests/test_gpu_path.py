@@ -450,7 +450,7 @@ def test_graph_replay_and_kernel_variants_keep_ids(tiny):
     ids_w, n_w = want[(30, 2)]
     assert not np.array_equal(want[(30, 0)][0], ids_w)  # the language id is part of the prompt
     for key, values, restore in (("gemm_variant", (0, 13, 16, 17, 18), -1), ("attn_variant", (0, 1, 2), 4),
-                                 ("cross_chunks", (1, 4, 8), 2), ("fc2_ksplit", (1,), 2)):
+                                 ("cross_chunks", (1, 2, 4, 8), 0), ("fc2_ksplit", (1,), 2)):
         for v in values:
             e.set_option(key, v)
             ids, n = e.encdec_tokens_batch(mel)

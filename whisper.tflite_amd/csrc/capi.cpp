@@ -126,7 +126,7 @@ int wt_engine_set_option(wt_engine* h, const char* key, long value) {
   } else if (k == "verbose") {
     e.verbose = value;
   } else if (k == "cross_chunks") {
-    if (value != 1 && value != 2 && value != 4 && value != 8) return fail(h, WT_ERR_INVALID_ARG, "cross_chunks must be 1, 2, 4 or 8");
+    if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return fail(h, WT_ERR_INVALID_ARG, "cross_chunks must be 0 (by batch size), 1, 2, 4 or 8");
     e.cross_chunks = value;
   } else if (k == "attn_variant") {
     if (value < 0 || value > 4) return fail(h, WT_ERR_INVALID_ARG, "attn_variant must be 0 (fp32 MFMA), 1 or 2 (bf16 x3 split, 128 / 256 queries per block), 3 (bf16 operands) or 4 (fp16 x2 split)");

@@ -1424,7 +1424,11 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
     for (int i = 0; i < stride; ++i) h_ids_[size_t(b) * stride + i] = i < n_prompt ? prompt[i] : 0;
     h_n_[b] = n_prompt;
   }
-  const int chunks = int(cross_chunks);  // 1, 2, 4 or 8 (wt_engine_set_option)
+  int chunks = int(cross_chunks);  // 1, 2, 4 or 8 (wt_engine_set_option), 0 = by batch size
+  if (chunks == 0) {
+    chunks = 1;
+    while (chunks < 8 && batch * H * chunks < 192) chunks *= 2;
+  }
   int steps = 0;
   // WT_DEC_KERNEL_TIMERS=1 (diagnostics, eager launches only): event pairs around every decoder launch
   static const bool dec_timers = getenv("WT_DEC_KERNEL_TIMERS") != nullptr;

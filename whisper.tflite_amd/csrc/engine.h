@@ -79,7 +79,11 @@ class Engine {
   long max_tokens = 30;
   long stop_at_eot = 1;
   long verbose = 0;
-  long cross_chunks = 2;  // key chunks per (clip, head) of the decoder cross-attention (measured: 2 beats 4 by 6 % alone)
+  // key chunks per (clip, head) of the decoder cross-attention: 1, 2, 4, 8, or 0 = as many as make clips x heads x
+  // chunks reach 192 blocks (32 clips x 6 heads: one chunk — in the pipeline fewer, longer blocks with one query
+  // prologue per (clip, head) measured 121.2 k audio-sec/s against 119.0 k with two chunks and 113.8 k with four; a
+  // single clip needs the chunks to spread its 6 heads over the chip)
+  long cross_chunks = 0;
   long attn_variant = 4;  // encoder attention: 0 = fp32 MFMA, 1/2 = bf16 x3 split, 3 = bf16 operands, 4 = fp16 x2 split
   long fc2_ksplit = 2;  // decoder fc2 (K = 4 d_model) over twice the blocks, halves summed by the consumer
   long use_graphs = 1;  // replay the decoder's launch sequence from a captured hipGraph
