@@ -15,7 +15,7 @@ int wt_dbg_gemm(wt_engine* h, int M, int N, int K, const float* A, const float* 
  * planes_out != 0 returns the plane output reconstructed as (hi + lo) / scale; iters > 0 also times the launch */
 int wt_dbg_gemm_planes(wt_engine* h, int M, int N, int K, const float* A, const float* W, const float* bias,
                        const float* R, const float* pos, int pos_period, int epi, int planes_out, int iters, float* C,
-                       float* avg_ms);
+                       float* avg_ms, int n_cu /* CUs the tile choice assumes; 0 = all */);
 /* encoder attention on planes (k_attention_planes.hip): qkv fp32 [B*T][3*heads*64] is split on the host the way the
  * qkv GEMM's epilogue writes it; out [B*T][heads*64] reconstructed from the output planes */
 int wt_dbg_encoder_attention_planes(wt_engine* h, int batch, int T, int heads, const float* qkv, int iters, float* out,

@@ -510,3 +510,24 @@ def test_encoder_attention_bf16_storage(eng, B, T, H):
             ref = attn_ref(q[b, :, h * 64:(h + 1) * 64], q[b, :, d + h * 64:d + (h + 1) * 64], q[b, :, 2 * d + h * 64:2 * d + (h + 1) * 64])
             err = np.abs(out.reshape(B, T, d)[b, :, h * 64:(h + 1) * 64] - ref)
             assert err.max() < 2.0 ** -8 * np.abs(ref).max() + 4e-3, (b, h, err.max())
+
+
+@pytest.mark.parametrize("n_cu,expect", [(8, "256-row"), (11, "192-row"), (3, "256-row, three rounds")])
+def test_plane_gemm_every_tile_shape_gives_the_same_result(eng, n_cu, expect):
+    """The plane GEMM picks its tile (192 x 128, 192 x 384, 256 x 384) from how the blocks fill the CUs the stream may
+    use.  With M = 2000, N = 384: 11 row tiles of 192 or 8 of 256 — on 8 CUs the 256-row tile wins (one round instead of
+    two), on 11 CUs the 192-row one.  Whatever is picked, the result is the fp32-accurate product, and the tiles
+    agree with each other to accumulation-order rounding (same k order: bit-identical)."""
+    rng = np.random.default_rng(2000)
+    M, N, K = 2000, 384, 384
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    R = rng.standard_normal((M, N)).astype(np.float32)
+    ref = A.astype(np.float64) @ W.astype(np.float64).T + bias
+    base = eng.dbg_gemm_planes(A, W, bias, epi=1)
+    got = eng.dbg_gemm_planes(A, W, bias, epi=1, n_cu=n_cu)
+    assert rel_err(got, ref) < 2e-6, expect
+    assert np.array_equal(got, base), expect
+    assert rel_err(eng.dbg_gemm_planes(A, W, bias, R=R, epi=5, n_cu=n_cu), ref + R) < 3e-6
+    assert rel_err(eng.dbg_gemm_planes(A, W, bias, epi=3, planes_out=True, n_cu=n_cu), gelu(ref)) < 4e-6

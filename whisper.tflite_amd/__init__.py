@@ -137,7 +137,7 @@ def lib() -> ctypes.CDLL:
         L.wt_convert_tflite.argtypes = [c_char_p, c_char_p]
         L.wt_dbg_gemm.argtypes = [c_void_p, c_int, c_int, c_int, fp, fp, fp, fp, fp, c_int, c_int, fp]
         L.wt_dbg_gemm_planes.argtypes = [c_void_p, c_int, c_int, c_int, fp, fp, fp, fp, fp, c_int, c_int, c_int, c_int, fp,
-                                         POINTER(c_float)]
+                                         POINTER(c_float), c_int]
         L.wt_dbg_encoder_attention_planes.argtypes = [c_void_p, c_int, c_int, c_int, fp, c_int, fp, POINTER(c_float)]
         L.wt_dbg_gemm_bf16.argtypes = [c_void_p, c_int, c_int, c_int, fp, fp, fp, fp, fp, c_int, c_int, c_int, c_int, fp,
                                        POINTER(c_float)]
@@ -460,7 +460,7 @@ class Engine:
                                       pos.shape[0] if pos is not None else 0, epi, _fp(C)))
         return C
 
-    def dbg_gemm_planes(self, A, W, bias=None, R=None, pos=None, epi=1, planes_out=False, iters=0):
+    def dbg_gemm_planes(self, A, W, bias=None, R=None, pos=None, epi=1, planes_out=False, iters=0, n_cu=0):
         """The default encoder GEMM (fp16 planes).  Returns C, or (C, ms per launch) when iters > 0."""
         A, W = _f32(A), _f32(W)
         M, K = A.shape
@@ -472,7 +472,7 @@ class Engine:
         ms = c_float(0)
         self._check(lib().wt_dbg_gemm_planes(self._h, M, N, K, _fp(A), _fp(W), _fp(bias), _fp(R), _fp(pos),
                                              pos.shape[0] if pos is not None else 0, epi, int(planes_out), iters, _fp(C),
-                                             byref(ms)))
+                                             byref(ms), int(n_cu)))
         return (C, ms.value) if iters > 0 else C
 
     def dbg_encoder_attention_planes(self, qkv, batch, T, heads, iters=0):

@@ -697,8 +697,8 @@ float max_abs(const float* x, size_t n) {
 
 int wt_dbg_gemm_planes(wt_engine* h, int M, int N, int K, const float* A, const float* W, const float* bias,
                        const float* R, const float* pos, int pos_period, int epi, int planes_out, int iters, float* C,
-                       float* avg_ms) {
-  if (!h || !A || !W || !C || N % 128 || K % 32 || M < 1) return WT_ERR_INVALID_ARG;
+                       float* avg_ms, int n_cu) {
+  if (!h || !A || !W || !C || N % 128 || K % 32 || M < 1 || n_cu < 0) return WT_ERR_INVALID_ARG;
   return guarded(h, [&] {
     const float sa = wt::f16_scale_for(max_abs(A, size_t(M) * K)), sw = wt::f16_scale_for(max_abs(W, size_t(N) * K));
     const DevPlanes dA(A, size_t(M) * K, sa), dW(W, size_t(N) * K, sw);
@@ -711,7 +711,7 @@ int wt_dbg_gemm_planes(wt_engine* h, int M, int N, int K, const float* A, const 
     wt::PlaneGemmArgs g;
     g.A = dA.ptr(); g.a_plane = dA.plane; g.lda = K; g.W = dW.ptr(); g.w_plane = dW.plane; g.bias = dB.p;
     g.C = dC.p; g.R = dC.p; g.ldc = N; g.pos = dP.p; g.pos_period = pos_period > 0 ? pos_period : 1;
-    g.M = M; g.N = N; g.K = K; g.a_scale = sa; g.w_scale = sw;
+    g.M = M; g.N = N; g.K = K; g.a_scale = sa; g.w_scale = sw; g.n_cu = n_cu;
     if (planes_out) { g.P = dO.ptr(); g.p_plane = dO.plane; g.out_scale[0] = so; }
     hipStream_t st = h->impl->stream();
     wt::launch_gemm_planes(g, epi, st);
