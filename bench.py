@@ -144,6 +144,100 @@ def cpu_baseline(prefix: str, mel: np.ndarray, prompt, eot: int) -> dict:
     }
 
 
+
+# ----------------------------------------------------------------------- rooflines ---
+
+def rooflines(ks, steps):
+    """per kernel class: achieved = algorithmic FLOPs (bytes) / summed launch durations (HIP event pairs on the
+    stream the kernels run on).  Plane / split kernels spend 3 (two fp16 planes per operand, the default) or 6 (three
+    bf16 planes: the fp32-storage fall-back form) 16-bit MFMA FLOPs per algorithmic fp32 FLOP: their MFMA ceiling in
+    algorithmic FLOP/s is the dense f16/bf16 peak / products; fp32-MFMA kernels are priced against the fp32 MFMA peak."""
+    det = {}
+    for name, v in ks.items():
+        if v["launches"] == 0 or v["ms"] <= 0:
+            continue
+        mfma = v["flops"] > 0
+        ach = (v["flops"] / 1e12 if mfma else v["bytes"] / 1e9) / (v["ms"] * 1e-3)
+        bf = "bf16_planes" in name or name == "encoder_attention_bf16"  # bf16 storage mode: one product
+        planes = "planes" in name and not bf  # the default kernels: operands stored as two fp16 planes
+        split = mfma and ("split" in name or planes or bf)
+        products = 1 if bf else 3 if planes else 6
+        peak = (round(PEAK_BF16_MFMA_TFLOPS / products, 1) if split else PEAK_F32_MFMA_TFLOPS) if mfma else PEAK_HBM_GBPS
+        det[name] = {"bound": "mfma" if mfma else "hbm", "achieved": round(ach, 2), "peak": peak,
+                     "unit": "TFLOP/s" if mfma else "GB/s", "frac": round(ach / peak, 4),
+                     "avg_launch_us": round(1e3 * v["ms"] / v["launches"], 2),
+                     "launches_per_step": v["launches"] // steps,
+                     "ms_per_step": round(v["ms"] / steps, 4)}
+        if split:
+            det[name].update({"peak_is": f"dense f16/bf16 MFMA peak 2500 TFLOP/s / {products} plane products",
+                              "executed_16bit_tflops": round(products * ach, 1),
+                              "vs_fp32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4)})
+    return det
+
+
+def add_stats(acc, ks):
+    for name, v in ks.items():
+        a = acc.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+        for k in a:
+            a[k] += v[k]
+
+
+def pipeline_run(eng, ptr, batch, k, depth, on_collect=None):
+    """k pipelined passes of the hot path over the device-resident batch at `ptr`; returns the last (ids, n)"""
+    in_flight, out = 0, None
+    for _ in range(k):
+        eng.pipeline_submit_dev(ptr, batch)
+        in_flight += 1
+        if in_flight == depth:
+            out = eng.pipeline_collect()
+            in_flight -= 1
+            if on_collect:
+                on_collect()
+    while in_flight:
+        out = eng.pipeline_collect()
+        in_flight -= 1
+        if on_collect:
+            on_collect()
+    return out
+
+
+def timed_leg(eng, ptr, batch, steps, warm, depth, sync):
+    """steps timed pipelined passes after `warm` untimed ones; per-launch kernel stats of the sampled passes"""
+    pipeline_run(eng, ptr, batch, warm, depth)
+    sync()
+    ks, sampled = {}, [0]
+
+    def acc():
+        st = eng.kernel_stats()
+        if any(v["launches"] for v in st.values()):
+            sampled[0] += 1
+        add_stats(ks, st)
+
+    t0 = time.perf_counter()
+    ids, n = pipeline_run(eng, ptr, batch, steps, depth, acc)
+    sync()
+    dt = time.perf_counter() - t0
+    return dt, ids, n, rooflines(ks, max(1, sampled[0]))
+
+
+def traffic_from_profile(dom, bf16, known_names):
+    """HBM-side bytes per launch of kernel class `dom` from the committed rocprofv3 --pmc summary (separate
+    FETCH_SIZE / WRITE_SIZE passes, tools/pmc_traffic.py).  A summary that was recorded for kernels this library no
+    longer launches is refused (traffic null) instead of being quoted stale."""
+    for tf in (("r03_c4_pmc_traffic.json", "r02_c4_pmc_traffic.json") if bf16 else ("r03_pmc_traffic.json", "r02_pmc_traffic.json")):
+        try:
+            with open(os.path.join(ROOT, "profiles", tf)) as f:
+                t = json.load(f)
+            recorded = t["kernel_class"].split()[0]
+            per = [k.split("<")[0] for k in t.get("per_kernel", {}) if k.startswith(recorded)]
+            if recorded != dom or recorded not in known_names or not per:
+                continue
+            return int(t["traffic_bytes_per_launch"]), "profiles/" + tf
+        except (OSError, KeyError, ValueError, IndexError):
+            continue
+    return None, "no committed --pmc summary names kernel class " + str(dom)
+
+
 # ---------------------------------------------------------------------------- main ---
 
 def main() -> None:
@@ -331,8 +425,8 @@ def main() -> None:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # the same pipeline with every encoder contraction on the fp32 MFMA instruction (reported beside
-    # the headline, outside the timed region, so the effect of the bf16-split kernels is visible)
+    # the same pipeline with every ENCODER contraction on the fp32 MFMA instruction (reported beside
+    # the headline, outside the timed region, so the effect of the plane kernels is visible)
     fp32_leg = None
     if pipelined and args.gemm_variant is None and args.attn_variant is None and not args.no_fp32_leg and not args.bf16:
         eng.set_option("gemm_variant", 0)
@@ -346,8 +440,9 @@ def main() -> None:
         fp32_leg = {"value": round(world * B * 10 * CLIP_SECONDS / dt, 1), "unit": "audio-sec/s", "steps": 10,
                     "ms_per_step": round(1e3 * dt / 10, 3),
                     "ids_match_split_path": bool(np.array_equal(ids32, ids) and np.array_equal(n32, n)),
-                    "what": "encoder on gemm_variant=0 (gemm_f32_tile), attn_variant=0 (encoder_attention_f32): "
-                            "v_mfma_f32_32x32x2_f32 only; the decoder keeps its fp16-plane GEMMs"}
+                    "what": "ENCODER on gemm_variant=0 (gemm_f32_tile), attn_variant=0 (encoder_attention_f32): "
+                            "v_mfma_f32_32x32x2_f32 only; the decoder keeps its fp16-plane GEMMs (not an end-to-end "
+                            "IEEE-fp32 line: the leg prices the encoder's contraction form)"}
         # and on the bf16 three-plane split kernels (full fp32 operand range)
         eng.set_option("gemm_variant", 16)
         eng.set_option("attn_variant", 1)
@@ -402,6 +497,57 @@ def main() -> None:
                          "input": "PCM [32][480000] resident in HBM, N(0, 0.1^2) clipped"}
         del d_pcm
 
+    legs_ok = pipelined and world == 1 and not args.no_fp32_leg and not args.bf16 and args.arch == "tiny" \
+        and args.gemm_variant is None and args.attn_variant is None
+
+    # What trained-like weight statistics cost: the same workload on weights whose layer-0 value projection has one
+    # channel 10^4 x larger (and the out-projection column that much smaller).  The load-time slack check gives THAT
+    # attention and out-projection the full-range three-plane kernels; every other contraction keeps the plane kernels.
+    outlier_leg = None
+    if legs_ok:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from wtw import adversarial_weights
+        adv = os.path.join(tmp, "tiny-outlier")
+        adversarial_weights(prefix + ".wtw", adv + ".wtw", ln_gain=1.0, heavy=False, v_row_scale=1.0e4)
+        e2 = pkg.Engine(adv, vocab, True, device_id=local_rank)
+        e2.set_option("stop_at_eot", 0)
+        e2.set_option("kernel_timers", 4)
+        dt, _, n2, det2 = timed_leg(e2, d_mel.data_ptr(), B, 20, 4, args.depth, fence)
+        outlier_leg = {"value": round(B * 20 * CLIP_SECONDS / dt, 1), "unit": "audio-sec/s", "steps": 20,
+                       "ms_per_step": round(1e3 * dt / 20, 3), "f16_fallbacks": int(e2.get_option("f16_fallbacks")),
+                       "launches_per_step": {k: v["launches_per_step"] for k, v in det2.items()},
+                       "all_clips_decoded": bool((n2 == 31).all()),
+                       "weights": "tools/wtw.py adversarial_weights(v_row_scale=1e4): layer 0 attention + out-projection "
+                                  "fall back to three bf16 planes (gemm_split16_tile / encoder_attention_split), the "
+                                  "other contractions stay on the plane kernels"}
+        e2.close()
+
+    # BASELINE.json configs[3] in the driver's line: whisper-base, batch 64, bf16 storage + bf16 MFMA
+    c3_leg = None
+    if legs_ok:
+        prefix3, vocab3 = ge._assets(tmp, "base", 0)
+        e3 = pkg.Engine(prefix3, vocab3, True, device_id=local_rank)
+        e3.set_option("bf16", 1)
+        e3.set_option("stop_at_eot", 0)
+        e3.set_option("kernel_timers", 4)
+        B3 = 64
+        d_mel3 = torch.from_numpy(synthetic_mel(0, B3, e3.mel_shape)).cuda()
+        torch.cuda.synchronize()
+        dt, _, n3, det3 = timed_leg(e3, d_mel3.data_ptr(), B3, 20, 4, args.depth, fence)
+        dom3 = max(det3, key=lambda k: det3[k]["ms_per_step"]) if det3 else None
+        tr3, tr3_src = traffic_from_profile(dom3, True, set(e3.kernel_stats())) if dom3 else (None, None)
+        c3_leg = {"value": round(B3 * 20 * CLIP_SECONDS / dt, 1), "unit": "audio-sec/s", "steps": 20,
+                  "ms_per_step": round(1e3 * dt / 20, 3), "dtype": "bf16 (weights, activations, KV caches; f32 accumulate)",
+                  "config": {"workload": "whisper-base multilingual batch=64x30s synthetic mel U(-1,1.5), bf16 MFMA, random-init "
+                                         "weights (BASELINE.json configs[3]); mel resident in HBM -> token ids on host"},
+                  "all_clips_decoded": bool((n3 == 31).all()),
+                  "roofline": ({"kernel": dom3, **{k: det3[dom3][k] for k in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_us")},
+                                "traffic": tr3, "traffic_source": tr3_src,
+                                "note": "HIP events inside the pipelined region of this leg"} if dom3 else None),
+                  "roofline_detail": det3}
+        e3.close()
+        del d_mel3
+
     iso = None
     if pipelined:
         # outside the timed region: two synchronous passes, so the per-kernel figures are also
@@ -420,35 +566,6 @@ def main() -> None:
         value = total_clips * CLIP_SECONDS / elapsed
         for k in stage:
             stage[k] = round(stage[k] / args.steps, 4)
-        def rooflines(ks, steps):
-            """per kernel class: achieved = algorithmic FLOPs (bytes) / summed launch durations"""
-            det = {}
-            for name, v in ks.items():
-                if v["launches"] == 0 or v["ms"] <= 0:
-                    continue
-                mfma = v["flops"] > 0
-                ach = (v["flops"] / 1e12 if mfma else v["bytes"] / 1e9) / (v["ms"] * 1e-3)
-                bf = "bf16_planes" in name or name == "encoder_attention_bf16"  # bf16 storage mode: one product
-                planes = "planes" in name and not bf  # the default kernels: operands stored as two fp16 planes
-                split = mfma and ("split" in name or planes or bf)
-                # plane / split kernels spend 3 (two fp16 planes per operand, the default) or 6 (three bf16
-                # planes) 16-bit MFMA FLOPs per algorithmic fp32 FLOP: their MFMA ceiling in algorithmic
-                # FLOP/s is the dense f16/bf16 peak / products; fp32-MFMA kernels are priced against
-                # the fp32 MFMA peak
-                gv, av = eng.get_option("gemm_variant"), eng.get_option("attn_variant")
-                products = 1 if bf else 3 if planes else (3 if av == 4 else 6) if "attention" in name else (3 if gv in (-1, 17, 18) else 6)
-                peak = (round(PEAK_BF16_MFMA_TFLOPS / products, 1) if split else PEAK_F32_MFMA_TFLOPS) if mfma else PEAK_HBM_GBPS
-                det[name] = {"bound": "mfma" if mfma else "hbm", "achieved": round(ach, 2), "peak": peak,
-                             "unit": "TFLOP/s" if mfma else "GB/s", "frac": round(ach / peak, 4),
-                             "avg_launch_us": round(1e3 * v["ms"] / v["launches"], 2),
-                             "launches_per_step": v["launches"] // steps,
-                             "ms_per_step": round(v["ms"] / steps, 4)}
-                if split:
-                    det[name].update({"peak_is": f"dense f16/bf16 MFMA peak 2500 TFLOP/s / {products} plane products",
-                                      "executed_16bit_tflops": round(products * ach, 1),
-                                      "vs_fp32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4)})
-            return det
-
         # dominant kernel = the class with the most device time inside the timed region
         detail = rooflines(kstats, max(1, sampled["steps"]))
         dom = max(detail, key=lambda k: detail[k]["ms_per_step"]) if detail else None
@@ -457,15 +574,7 @@ def main() -> None:
             d = detail[dom]
             # HBM-side bytes per launch of this kernel class come from separate rocprofv3 --pmc
             # passes (FETCH_SIZE, WRITE_SIZE) whose summary is committed under profiles/
-            traffic, traffic_src = None, None
-            try:
-                tf = "r02_c4_pmc_traffic.json" if args.bf16 else "r02_pmc_traffic.json"
-                with open(os.path.join(ROOT, "profiles", tf)) as f:
-                    t = json.load(f)
-                if t["kernel_class"].startswith(dom):
-                    traffic, traffic_src = int(t["traffic_bytes_per_launch"]), "profiles/" + tf
-            except (OSError, KeyError, ValueError):
-                pass
+            traffic, traffic_src = traffic_from_profile(dom, args.bf16, set(eng.kernel_stats()))
             roof = {"kernel": dom, "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"],
                     "unit": d["unit"], "frac": d["frac"], "traffic": traffic, "traffic_source": traffic_src,
                     **{k: d[k] for k in ("peak_is", "executed_16bit_tflops", "vs_fp32_mfma_peak") if k in d},
@@ -522,7 +631,9 @@ def main() -> None:
             "decoder_roofline": {"bound": "hbm", "achieved": round(dec_ach, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                                  "frac": round(dec_ach / PEAK_HBM_GBPS, 4),
                                  "algorithmic_bytes_per_step": int(dec_bytes)},
-            "fp32_mfma_only": fp32_leg,
+            "encoder_fp32_mfma": fp32_leg,
+            "outlier_weights": outlier_leg,
+            "configs3_bf16_base": c3_leg,
             "with_frontend": with_frontend,
             "stage_ms_per_step": stage,
             "host_enqueue_ms_per_step": round(1e3 * host["submit_s"] / max(1, host["submits"]), 3) if pipelined else None,

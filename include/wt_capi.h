@@ -78,18 +78,17 @@ int wt_engine_dims(const wt_engine* h, wt_dims* out);
  * default language_id("de") = 2), "max_tokens" (max decoder positions, whisper.cpp:364,
  * default 30), "stop_at_eot" (whisper.cpp:397-399, default 1), "verbose" (default 0),
  * "cross_chunks" (key chunks per (clip, head) in the decoder cross attention: 1, 2, 4, 8, or 0 = by batch size, the default).
- * Kernel selection (results stay within the fp32 error budget for every value except
- * gemm_variant 11 / attn_variant 3, the bf16 compute mode of BASELINE configs[3]): "gemm_variant"
- * (-1 = default: encoder GEMMs on the f16 matrix cores, fp32 operands split into two fp16 planes
- * with power-of-two scales from weight-derived bounds, csrc/bf16_split.h; 17, 18 = the same at 3 / 2
- * blocks per CU; 10, 13..16 = three bf16 planes, full fp32 operand range; 0..9 = fp32-MFMA tile
- * shapes; 11 = operands rounded to bf16), "attn_variant" (4 = default, two fp16 planes; 1, 2 = three
- * bf16 planes with 128 / 256 queries per block; 0 = fp32 MFMA; 3 = operands rounded to bf16),
+ * Kernel selection (results stay within the fp32 error budget for every value): "gemm_variant"
+ * (-1 = default: every encoder GEMM on the plane kernel, operands as two fp16 planes with power-of-two scales
+ * from weight-derived bounds, csrc/bf16_split.h — except the contractions the load-time slack check flagged,
+ * which run the full-range form by themselves; 13, 16 = all of them on three bf16 planes split in the loop, full
+ * fp32 operand range, at 3 / 2 blocks per CU; 0 = fp32 MFMA), "attn_variant" (4 = default, two fp16 planes;
+ * 1 = three bf16 planes; 0 = fp32 MFMA),
  * "fc2_ksplit" (2 = default: the decoder's fc2 GEMM over twice the blocks, halves added by the
  * consumer; 1 = one block per column tile), "use_graphs" (1 = default: the decoder's launch sequence is replayed from a hipGraph).
  * Read-only (wt_engine_get_option): "f16_fallbacks" = contractions that were given the full-range bf16
  * three-plane kernels at load time because an operand's weight-derived bound lies more than 2^12 above its
- * typical magnitude (csrc/engine.cpp, upload_weights); "in_flight" = submitted, uncollected batches.
+ * typical magnitude (csrc/engine.cpp, upload_weights) — only those leave the plane kernels, the others keep them; "in_flight" = submitted, uncollected batches.
  * Environment, read at wt_engine_create: WT_ENC_CU_RESERVE (CUs per XCD the pipelined encoder
  * stream leaves to the decoders, default 4, 0 = none), WT_DEC_STREAMS (decoder streams, default 3),
  * WT_TRACE_PIPELINE (per-batch device timeline on stderr). */
@@ -206,7 +205,10 @@ int wt_vocab_decode(const wt_vocab* v, const int64_t* ids, int n, int omit_speci
  * Filters table but no engine: the same gfx950 kernels the engine uses, on `device_id`, through a
  * process-wide front-end context created at the first call.  Only the reference's fixed geometry is
  * provided (16 kHz, fft 400, hop 160, 80 x 201 filters, n_samples <= 480000), anything else is
- * WT_ERR_UNSUPPORTED.  mel_out [n_mel][n_len] with n_len = n_samples / 160, the layout of Mel::data. */
+ * WT_ERR_UNSUPPORTED.  mel_out [n_mel][n_len] with n_len = n_samples / 160, the layout of Mel::data.
+ * At most four contexts (device x filter table) are kept, least recently used evicted; wt_shutdown() releases
+ * them (call it before unloading the library / at exit, ahead of the HIP runtime's own teardown). */
+void wt_shutdown(void);
 int wt_log_mel_spectrogram(const float* samples, int n_samples, const float* filters, int n_mel,
                            int n_fft_bins, int device_id, float* mel_out, size_t cap, int* n_len);
 

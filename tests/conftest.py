@@ -75,3 +75,8 @@ class DevBuf:
 
     def data_ptr(self):
         return self.p.value
+
+    def free(self):
+        if self.p:
+            DevBuf._hip.hipFree(self.p)
+            self.p = None

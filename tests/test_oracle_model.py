@@ -83,3 +83,25 @@ def test_tiny_vs_hf(orc, assets):
     assert np.abs(logits[:, ::997] - g["logits_cols"][0]).max() < LOGIT_TOL
     assert list(ids) == list(g["ids"][0])
     m.close()
+
+
+def test_oracle_encoder_against_the_graph_in_float64(pkg, orc, assets, tmp_path):
+    """The encoder graph evaluated in numpy float64 (tests/fp64_encoder.py) pins the ORACLE's own rounding error: 1e-6
+    of the output scale on N(0, 1/fan_in) weights.  On weights with LayerNorm-gain outliers and heavy-tailed rows the
+    same oracle is 1e-5 .. 1e-3 of the scale away from fp64 — the network is ill-conditioned there, which is why the
+    GPU tests on such weights (tests/test_gpu_boundary.py) judge every fp32 form against the float64 graph."""
+    from fp64_encoder import encoder_fp64
+    from wtw import adversarial_weights, read_wtw
+    prefix, _ = assets("micro")
+    mel = np.random.default_rng(3).uniform(-1.0, 1.5, size=(80, 200)).astype(np.float32)
+    adv = str(tmp_path / "micro-outliers")
+    adversarial_weights(prefix + ".wtw", adv + ".wtw", ln_gain=30.0, heavy=True)
+    rel = {}
+    for name, p in (("plain", prefix), ("outliers", adv)):
+        dims, t = read_wtw(p + ".wtw")
+        ref = encoder_fp64(dims, t, mel)
+        m = orc.Model(p + ".wtw")
+        rel[name] = float(np.abs(m.encode(mel, 4) - ref).max() / np.abs(ref).max())
+        m.close()
+    assert rel["plain"] < 2e-6, rel
+    assert rel["outliers"] < 1e-3, rel

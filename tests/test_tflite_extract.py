@@ -17,9 +17,12 @@ import tflite_writer as tw  # noqa: E402
 from wtw import read_wtw  # noqa: E402
 
 
-def make_pair(pkg, tmp_path, arch="micro", named=True, seed=5):
+def make_pair(pkg, tmp_path, arch="micro", named=True, seed=5, fuse_bias=False, fuse_ln=False, shuffle_qkv=False, tag=""):
     """Writes <prefix>.encoder.tflite / .decoder.tflite from synthetic weights the way the reference's converter
-    stores them, and returns (prefix, dims, expected) with `expected` the de-quantised tensors in torch layout."""
+    stores them, and returns (prefix, dims, expected) with `expected` the de-quantised tensors in torch layout.
+    fuse_bias: a Linear's weight and bias are inputs 1 and 2 of ONE FULLY_CONNECTED operator; fuse_ln: a LayerNorm's
+    gain and shift are read by one operator; shuffle_qkv: the value projection comes first in the file, then key,
+    then query (a converter is free to order them so)."""
     src = str(tmp_path / f"src-{arch}.wtw")
     pkg.write_synthetic_weights(src, arch, seed)
     dims, t = read_wtw(src)
@@ -68,7 +71,30 @@ def make_pair(pkg, tmp_path, arch="micro", named=True, seed=5):
             add(graph, name, arr, "matmul" if (".key." in name or ".mlp.0." in name or ".out." in name) else "fc")
         else:
             add(graph, name, arr, "f32")
-    prefix = str(tmp_path / f"model-{arch}-{'named' if named else 'anon'}")
+    if fuse_bias or fuse_ln or shuffle_qkv:
+        for gname, consts in graphs.items():
+            names = [n for n in t if n.split(".", 1)[0] == gname]
+            idx = {n: i for i, n in enumerate(names)}
+            if shuffle_qkv:
+                for n in names:
+                    if n.endswith(".query.weight") and n.replace(".query.", ".value.") in idx:
+                        i, j = idx[n], idx[n.replace(".query.", ".value.")]
+                        consts[i], consts[j] = consts[j], consts[i]
+                        names[i], names[j] = names[j], names[i]
+                        idx = {m: k for k, m in enumerate(names)}
+            out, skip = [], set()
+            for i, n in enumerate(names):
+                if i in skip:
+                    continue
+                partner = n[:-len("weight")] + "bias" if n.endswith(".weight") else None
+                is_ln = n.endswith("_ln.weight") or n.endswith("ln_post.weight") or n.endswith("decoder.ln.weight")
+                if partner in idx and ((fuse_ln and is_ln) or (fuse_bias and consts[i]["opcode"] == tw.OP_FULLY_CONNECTED)):
+                    out.append([consts[i], consts[idx[partner]]])
+                    skip.add(idx[partner])
+                else:
+                    out.append(consts[i])
+            graphs[gname] = out
+    prefix = str(tmp_path / f"model-{arch}-{'named' if named else 'anon'}{tag}")
     tw.write_tflite(prefix + ".encoder.tflite", graphs["encoder"])
     tw.write_tflite(prefix + ".decoder.tflite", graphs["decoder"])
     return prefix, dims, expected
@@ -125,3 +151,69 @@ def test_extractor_errors_are_status_codes(pkg, tmp_path):
     with pytest.raises(pkg.WtError) as e:
         pkg.convert_tflite(p, out)
     assert e.value.code == 3
+
+
+def _same(got, expected):
+    return all(got[k].shape == v.shape and np.array_equal(got[k].view(np.uint32), v.view(np.uint32)) for k, v in expected.items())
+
+
+def test_extractor_operator_shapes_a_converter_may_emit(pkg, tmp_path):
+    """(a) anonymous constants, a Linear's weight and bias carried by ONE FULLY_CONNECTED operator (inputs 1 and 2):
+    rule 2 orders by operator, then by input position, and still maps every tensor;
+    (b) named constants with q / k / v in another order: rule 1 does not depend on the order;
+    (c) anonymous constants where one operator reads a LayerNorm's gain AND shift (equal size, no order to tell them
+    apart): refused with WT_ERR_FORMAT naming the parameter and the operator, instead of guessed."""
+    prefix, dims, expected = make_pair(pkg, tmp_path, "micro", named=False, fuse_bias=True, tag="-fb")
+    out = str(tmp_path / "fb.wtw")
+    pkg.convert_tflite(prefix, out)
+    assert _same(read_wtw(out)[1], expected)
+    prefix, dims, expected = make_pair(pkg, tmp_path, "micro", named=True, shuffle_qkv=True, fuse_bias=True, tag="-sh")
+    out = str(tmp_path / "sh.wtw")
+    pkg.convert_tflite(prefix, out)
+    assert _same(read_wtw(out)[1], expected)
+    prefix, dims, expected = make_pair(pkg, tmp_path, "micro", named=False, fuse_ln=True, tag="-ln")
+    with pytest.raises(pkg.WtError) as e:
+        pkg.convert_tflite(prefix, str(tmp_path / "ln.wtw"))
+    assert e.value.code == 3 and "cannot tell which constant" in str(e.value) and "attn_ln" in str(e.value)
+    assert not os.path.exists(str(tmp_path / "ln.wtw"))  # nothing half-written is left behind
+    # the same file WITH names converts
+    prefix, dims, expected = make_pair(pkg, tmp_path, "micro", named=True, fuse_ln=True, tag="-lnn")
+    out = str(tmp_path / "lnn.wtw")
+    pkg.convert_tflite(prefix, out)
+    assert _same(read_wtw(out)[1], expected)
+
+
+def test_converted_file_appears_atomically_and_a_broken_one_is_rebuilt(pkg, tmp_path):
+    """wt_engine_create on a prefix that only has the reference's .tflite pair converts it into <prefix>.wtw through a
+    temporary file renamed into place (ranks that start together never see a short file); a .wtw that is there but
+    truncated is rebuilt from the pair rather than reported as 'not a .wtw' for ever.  No GPU here: creation itself
+    ends with WT_ERR_DEVICE, AFTER the host-side conversion / validation has run."""
+    prefix, dims, expected = make_pair(pkg, tmp_path, "micro", named=True, tag="-atomic")
+    vocab = str(tmp_path / "v.bin")
+    pkg.write_synthetic_vocab(vocab, 1000)
+
+    def create():
+        try:
+            pkg.Engine(prefix, vocab, True).close()
+            return 0
+        except pkg.WtError as e:
+            return e.code
+
+    have_gpu = create() == 0
+    assert os.path.exists(prefix + ".wtw") and _same(read_wtw(prefix + ".wtw")[1], expected)
+    assert not [f for f in os.listdir(tmp_path) if ".tmp." in f]
+    good = open(prefix + ".wtw", "rb").read()
+    for blob in (good[: len(good) // 2], good[:100], b"garbage" * 100):
+        open(prefix + ".wtw", "wb").write(blob)
+        rc = create()
+        assert rc == (0 if have_gpu else 5)
+        assert open(prefix + ".wtw", "rb").read() == good
+    # without the pair a truncated .wtw is an error that says so (WT_ERR_FORMAT), and the file is left alone
+    lone = str(tmp_path / "lone")
+    open(lone + ".wtw", "wb").write(good[: len(good) // 2])
+    try:
+        pkg.Engine(lone, vocab, True).close()
+        raise AssertionError("a truncated weight file was accepted")
+    except pkg.WtError as e:
+        assert e.code in (3, 5)
+    assert len(open(lone + ".wtw", "rb").read()) == len(good) // 2

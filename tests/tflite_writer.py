@@ -126,29 +126,34 @@ def quantize_int8(w, per_axis=None):
 
 
 def write_tflite(path, constants):
-    """constants: list of dicts in FORWARD (first-use) order:
+    """constants: list in FORWARD (first-use) order; an entry is a dict
          name, data (np array: float32 / float16 / int8), opcode (builtin operator that consumes it),
          scale (float32 array, int8 only), qdim (int8 per-axis only)
-    Every constant becomes one tensor + one buffer and is read by its own operator (inputs: the running
-    activation and the constant), so the operator order is the order of the list."""
-    opcodes = sorted({c["opcode"] for c in constants})
+    or a LIST of such dicts that ONE operator reads together (a FULLY_CONNECTED with its weight at input 1 and its bias
+    at input 2; a folded LayerNorm with gain and shift): the operator takes the opcode of the first.
+    Every constant becomes one tensor + one buffer; an operator's inputs are the running activation and its
+    constants, so the operator order is the order of the list."""
+    groups = [c if isinstance(c, list) else [c] for c in constants]
+    opcodes = sorted({g[0]["opcode"] for g in groups})
     op_tables = [Table(f0=("i8", min(o, 127)), f2=("i32", 1), f3=("i32", o)) for o in opcodes]
     buffers = [Table()]  # buffer 0: the empty sentinel
     tensors = [Table(f0=("vec", ("i", [1, 8])), f1=("u8", FLOAT32), f2=("u32", 0), f3=("string", "activation"))]
     operators = []
-    for c in constants:
-        a = np.ascontiguousarray(c["data"])
-        ttype = {np.dtype(np.float32): FLOAT32, np.dtype(np.float16): FLOAT16, np.dtype(np.int8): INT8}[a.dtype]
-        buffers.append(Table(f0=("bytes", a.tobytes())))
-        fields = dict(f0=("vec", ("i", list(a.shape))), f1=("u8", ttype), f2=("u32", len(buffers) - 1),
-                      f3=("string", c["name"]))
-        if ttype == INT8:
-            sc = np.asarray(c["scale"], np.float32).reshape(-1)
-            fields["f4"] = ("table", Table(f2=("vec", ("f", [float(x) for x in sc])), f3=("vec", ("q", [0] * len(sc))),
-                                           f6=("i32", int(c.get("qdim", 0)))))
-        tensors.append(Table(**fields))
-        operators.append(Table(f0=("u32", opcodes.index(c["opcode"])), f1=("vec", ("i", [0, len(tensors) - 1])),
-                               f2=("vec", ("i", [0]))))
+    for g in groups:
+        ins = [0]
+        for c in g:
+            a = np.ascontiguousarray(c["data"])
+            ttype = {np.dtype(np.float32): FLOAT32, np.dtype(np.float16): FLOAT16, np.dtype(np.int8): INT8}[a.dtype]
+            buffers.append(Table(f0=("bytes", a.tobytes())))
+            fields = dict(f0=("vec", ("i", list(a.shape))), f1=("u8", ttype), f2=("u32", len(buffers) - 1),
+                          f3=("string", c["name"]))
+            if ttype == INT8:
+                sc = np.asarray(c["scale"], np.float32).reshape(-1)
+                fields["f4"] = ("table", Table(f2=("vec", ("f", [float(x) for x in sc])), f3=("vec", ("q", [0] * len(sc))),
+                                               f6=("i32", int(c.get("qdim", 0)))))
+            tensors.append(Table(**fields))
+            ins.append(len(tensors) - 1)
+        operators.append(Table(f0=("u32", opcodes.index(g[0]["opcode"])), f1=("vec", ("i", ins)), f2=("vec", ("i", [0]))))
     sub = Table(f0=("vec_table", tensors), f1=("vec", ("i", [0])), f2=("vec", ("i", [0])), f3=("vec_table", operators),
                 f4=("string", "main"))
     model = Table(f0=("u32", 3), f1=("vec_table", op_tables), f2=("vec_table", [sub]), f3=("string", "wt test fixture"),

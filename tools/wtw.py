@@ -53,3 +53,29 @@ def write_wtw(path, dims, tensors, seed=0):
         buf[offs[i]:offs[i] + a.nbytes] = a.tobytes()
     with open(path, "wb") as f:
         f.write(buf)
+
+
+def adversarial_weights(src_wtw, dst_wtw, ln_gain=30.0, heavy=True, v_row_scale=1.0, seed=1234):
+    """Random-init weights with the statistics a trained checkpoint can have and N(0, 1/fan_in) does not: LayerNorm
+    gains `ln_gain` x larger on six channels of every encoder LayerNorm, LayerNorm shifts on others, heavy-tailed rows
+    (2 % of the entries of every encoder Linear 8..40 x larger), and optionally one output channel of layer 0's value
+    projection `v_row_scale` x larger with the matching out-projection column that much smaller (the rescaling
+    symmetry a trained network is free to use).  Used by tests/test_gpu_boundary.py and bench.py's outlier_weights leg."""
+    dims, t = read_wtw(src_wtw)
+    rng = np.random.default_rng(seed)
+    out = {}
+    for k, v in t.items():
+        a = np.array(v, dtype=np.float32)
+        if (k.startswith("encoder.") and k.endswith("_ln.weight")) or k == "encoder.ln_post.weight":
+            a[rng.choice(a.size, 6, replace=False)] *= ln_gain
+        elif k.startswith("encoder.") and (k.endswith("_ln.bias") or k == "encoder.ln_post.bias"):
+            a[rng.choice(a.size, 6, replace=False)] += rng.uniform(-3, 3, 6).astype(np.float32)
+        elif heavy and k.startswith("encoder.blocks.") and k.endswith(".weight") and a.ndim == 2:
+            mask = rng.random(a.shape) < 0.02
+            a[mask] *= rng.uniform(8, 40, int(mask.sum())).astype(np.float32)
+        out[k] = a
+    if v_row_scale != 1.0:
+        out["encoder.blocks.0.attn.value.weight"][77] *= v_row_scale
+        out["encoder.blocks.0.attn.value.bias"][77] *= v_row_scale
+        out["encoder.blocks.0.attn.out.weight"][:, 77] /= v_row_scale
+    write_wtw(dst_wtw, dims, out)

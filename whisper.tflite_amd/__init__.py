@@ -43,7 +43,7 @@ CAPI_SYMBOLS = [
     "wt_last_timings", "wt_last_kernel_stats", "wt_decode_text", "wt_language_id", "wt_lang_code", "wt_wav_read_legacy",
     "wt_vocab_info", "wt_filters", "wt_write_synthetic_weights", "wt_write_synthetic_vocab",
     "wt_vocab_open", "wt_vocab_close", "wt_vocab_get_info", "wt_vocab_get_filters", "wt_vocab_size", "wt_vocab_token",
-    "wt_vocab_decode", "wt_log_mel_spectrogram", "wt_convert_tflite",
+    "wt_vocab_decode", "wt_log_mel_spectrogram", "wt_convert_tflite", "wt_shutdown",
 ]
 DEBUG_SYMBOLS = [
     "wt_dbg_gemm", "wt_dbg_gemm_bench", "wt_dbg_dec_gemm_bench", "wt_dbg_dec_gemm", "wt_dbg_dec_ln_gemm", "wt_dbg_layernorm", "wt_dbg_encoder_attention",

@@ -86,12 +86,43 @@ int wt_engine_create(int engine_type, const char* model_prefix, const char* voca
   const int rc = guarded(nullptr, [&] {
     const std::string prefix(model_prefix);
     // the reference's users hold <prefix>.encoder.tflite / .decoder.tflite (whisper.cpp:743-744): extract
-    // their weights once when no .wtw sits next to them
-    if (!wt::file_exists(prefix + ".wtw") && wt::file_exists(prefix + ".encoder.tflite") &&
-        wt::file_exists(prefix + ".decoder.tflite")) {
-      wt::convert_tflite(prefix, prefix + ".wtw");
+    // their weights once when no .wtw sits next to them.  The converted file is renamed into place atomically
+    // (wtw::write_tensors), so ranks that start together on one prefix never read a half-written file; a model
+    // directory that cannot be written falls back to a file under $TMPDIR; and a .wtw that is there but broken (a
+    // conversion killed before the atomic writer existed, a truncated copy) is rebuilt from the pair once.
+    const bool have_pair = wt::file_exists(prefix + ".encoder.tflite") && wt::file_exists(prefix + ".decoder.tflite");
+    std::string wpath = prefix + ".wtw";
+    bool converted = false;
+    auto convert = [&] {
+      try {
+        wt::convert_tflite(prefix, wpath);
+      } catch (const wt::Error& e) {
+        if (e.code != wt::kErrIo) throw;
+        const char* t = getenv("TMPDIR");
+        wpath = std::string(t && *t ? t : "/tmp") + "/wt-" + std::to_string(std::hash<std::string>{}(prefix)) + ".wtw";
+        wt::convert_tflite(prefix, wpath);
+      }
+      converted = true;
+    };
+    if (!wt::file_exists(wpath) && have_pair) convert();
+    if (have_pair && !converted) {
+      try {
+        wt::check_wtw_file(wpath);  // host-only: header, tensor table, length
+      } catch (const wt::Error& e) {
+        if (e.code != wt::kErrFormat) throw;
+        convert();
+      }
     }
-    h->impl.reset(new wt::Engine(prefix, vocab_path, multilingual != 0, device_id, engine_type == WT_ENGINE_MONOLITH));
+    auto make = [&] {
+      h->impl.reset(new wt::Engine(prefix, vocab_path, multilingual != 0, device_id, engine_type == WT_ENGINE_MONOLITH, wpath));
+    };
+    try {
+      make();
+    } catch (const wt::Error& e) {
+      if (e.code != wt::kErrFormat || !have_pair || converted) throw;
+      convert();
+      make();
+    }
   });
   if (rc != WT_OK) return rc;
   *out = h.release();
@@ -129,7 +160,7 @@ int wt_engine_set_option(wt_engine* h, const char* key, long value) {
     if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return fail(h, WT_ERR_INVALID_ARG, "cross_chunks must be 0 (by batch size), 1, 2, 4 or 8");
     e.cross_chunks = value;
   } else if (k == "attn_variant") {
-    if (value < 0 || value > 4) return fail(h, WT_ERR_INVALID_ARG, "attn_variant must be 0 (fp32 MFMA), 1 or 2 (bf16 x3 split, 128 / 256 queries per block), 3 (bf16 operands) or 4 (fp16 x2 split)");
+    if (value != 0 && value != 1 && value != 4) return fail(h, WT_ERR_INVALID_ARG, "attn_variant must be 4 (default: two fp16 planes), 1 (three bf16 planes, full range) or 0 (fp32 MFMA)");
     e.attn_variant = value;
   } else if (k == "fc2_ksplit") {
     if (value != 1 && value != 2) return fail(h, WT_ERR_INVALID_ARG, "fc2_ksplit must be 1 or 2");
@@ -138,9 +169,16 @@ int wt_engine_set_option(wt_engine* h, const char* key, long value) {
     e.use_graphs = value != 0;
   } else if (k == "gemm_variant") {
     if (value != -1 && !wt::gemm_variant_supported(int(value))) {
-      return fail(h, WT_ERR_INVALID_ARG, "gemm_variant must be -1 (default), 0, 11, 13, 16, 17 or 18");
+      return fail(h, WT_ERR_INVALID_ARG, "gemm_variant must be -1 (default: plane GEMM), 0 (fp32 MFMA), 13 or 16 (three bf16 planes)");
     }
     e.gemm_variant = value;
+  } else if (k == "force_fallback") {
+    // test hook: bit i flags contraction i (launch order) as if the load-time slack check had (engine.h)
+    try {
+      e.set_force_fallback(value);
+    } catch (const wt::Error& err) {
+      return fail(h, err.code, err.what());
+    }
   } else if (k == "kernel_timers") {
     if (value < 0 || value > 1024) return fail(h, WT_ERR_INVALID_ARG, "kernel_timers must be in [0, 1024]");
     e.kernel_timers = value;
@@ -181,6 +219,7 @@ int wt_engine_get_option(const wt_engine* h, const char* key, long* value) {
   else if (k == "kernel_timers") *value = e.kernel_timers;
   else if (k == "fc2_ksplit") *value = e.fc2_ksplit;
   else if (k == "attn_variant") *value = e.attn_variant;
+  else if (k == "force_fallback") *value = e.force_fallback();
   else if (k == "f16_fallbacks") *value = e.f16_fallbacks();  // read-only
   else if (k == "in_flight") *value = e.in_flight();          // read-only
   else return WT_ERR_INVALID_ARG;
@@ -527,6 +566,23 @@ int wt_vocab_decode(const wt_vocab* v, const int64_t* ids, int n, int omit_speci
 
 // ------------------------------------------- log-mel as a free function ---
 
+namespace {
+struct LogmelCtx {
+  int device = 0;
+  std::vector<float> filters;
+  std::unique_ptr<wt::Engine> eng;
+  std::mutex mu;
+  unsigned long stamp = 0;
+};
+std::mutex g_logmel_mu;
+std::vector<std::shared_ptr<LogmelCtx>> g_logmel_ctxs;
+}  // namespace
+
+void wt_shutdown(void) {
+  std::lock_guard<std::mutex> lock(g_logmel_mu);
+  g_logmel_ctxs.clear();
+}
+
 int wt_log_mel_spectrogram(const float* samples, int n_samples, const float* filters, int n_mel,
                            int n_fft_bins, int device_id, float* mel_out, size_t cap, int* n_len) {
   if ((!samples && n_samples) || !filters || !mel_out || n_samples < 0) return fail(nullptr, WT_ERR_INVALID_ARG, "NULL argument");
@@ -535,32 +591,40 @@ int wt_log_mel_spectrogram(const float* samples, int n_samples, const float* fil
                 "log_mel_spectrogram: only the reference's fixed geometry (80 x 201 filters, <= 480000 samples at "
                 "16 kHz, fft 400, hop 160) runs on the gfx950 front end");
   }
-  // one front-end context per (device, filter table): the DFT basis and the mel matrix are uploaded once
-  struct Ctx {
-    int device;
-    std::vector<float> filters;
-    std::unique_ptr<wt::Engine> eng;
-  };
-  static std::mutex mu;
-  static std::vector<std::unique_ptr<Ctx>> ctxs;
-  std::lock_guard<std::mutex> lock(mu);
+  // Front-end contexts (DFT basis + mel matrix in HBM, streams, staging buffers), one per (device, filter table), at
+  // most kMaxCtx of them: the least recently used one is destroyed when a new table arrives, so a caller that varies
+  // its filters cannot grow the cache without bound.  The table lock is held only to find / create the context; the
+  // GPU round trip runs under the context's own lock, so callers on different devices do not serialise.
+  // wt_shutdown() releases the contexts before the HIP runtime is torn down.
+  constexpr size_t kMaxCtx = 4;
   return guarded(nullptr, [&] {
     const size_t nf = size_t(n_mel) * n_fft_bins;
-    Ctx* c = nullptr;
-    for (auto& x : ctxs)
-      if (x->device == device_id && std::memcmp(x->filters.data(), filters, nf * sizeof(float)) == 0) c = x.get();
-    if (!c) {
-      std::unique_ptr<Ctx> n(new Ctx);
-      n->device = device_id;
-      n->filters.assign(filters, filters + nf);
-      wt::FilterBank fb;
-      fb.n_mel = n_mel;
-      fb.n_fft = n_fft_bins;
-      fb.data = n->filters;
-      n->eng.reset(new wt::Engine(fb, device_id));
-      ctxs.push_back(std::move(n));
-      c = ctxs.back().get();
+    std::shared_ptr<LogmelCtx> c;
+    {
+      std::lock_guard<std::mutex> lock(g_logmel_mu);
+      static unsigned long clock = 0;
+      for (auto& x : g_logmel_ctxs)
+        if (x->device == device_id && std::memcmp(x->filters.data(), filters, nf * sizeof(float)) == 0) c = x;
+      if (!c) {
+        if (g_logmel_ctxs.size() >= kMaxCtx) {  // evict the least recently used context nobody is inside
+          size_t victim = g_logmel_ctxs.size();
+          for (size_t i = 0; i < g_logmel_ctxs.size(); ++i)
+            if (g_logmel_ctxs[i].use_count() == 1 && (victim == g_logmel_ctxs.size() || g_logmel_ctxs[i]->stamp < g_logmel_ctxs[victim]->stamp)) victim = i;
+          if (victim < g_logmel_ctxs.size()) g_logmel_ctxs.erase(g_logmel_ctxs.begin() + long(victim));
+        }
+        c = std::make_shared<LogmelCtx>();
+        c->device = device_id;
+        c->filters.assign(filters, filters + nf);
+        wt::FilterBank fb;
+        fb.n_mel = n_mel;
+        fb.n_fft = n_fft_bins;
+        fb.data = c->filters;
+        c->eng.reset(new wt::Engine(fb, device_id));
+        g_logmel_ctxs.push_back(c);
+      }
+      c->stamp = ++clock;
     }
+    std::lock_guard<std::mutex> ctx_lock(c->mu);
     wt::Engine& e = *c->eng;
     e.bind_device();
     const int frames = n_samples / WT_HOP;  // Mel::n_len (whisper.cpp:123)
@@ -645,13 +709,6 @@ int wt_dbg_gemm(wt_engine* h, int M, int N, int K, const float* A, const float* 
     g.A = dA.p; g.lda = K; g.W = dW.p; g.bias = dB.p; g.C = dC.p; g.R = dC.p; g.ldc = N;
     g.pos = dP.p; g.pos_period = pos_period > 0 ? pos_period : 1;
     g.M = M; g.N = N; g.K = K; g.variant = int(h->impl->gemm_variant);
-    {  // operand scales of the two-plane fp16 variants: from the data, as the engine derives them from bounds
-      float ma = 0.0f, mw = 0.0f;
-      for (size_t i = 0; i < size_t(M) * K; ++i) ma = std::max(ma, std::fabs(A[i]));
-      for (size_t i = 0; i < size_t(N) * K; ++i) mw = std::max(mw, std::fabs(W[i]));
-      g.a_scale = wt::f16_scale_for(ma);
-      g.w_scale = wt::f16_scale_for(mw);
-    }
     wt::launch_gemm(g, epi, h->impl->stream());
     h->impl->sync();
     dC.to_host(C, size_t(M) * N);
@@ -1065,9 +1122,10 @@ int wt_dbg_encoder_attention(wt_engine* h, int batch, int T, int heads, const fl
         mv = std::max(mv, std::fabs(row[2 * d + c]));
       }
     }
-    wt::launch_encoder_attention(dq.p, dout.p, batch, T, heads, int(h->impl->attn_variant), h->impl->stream(),
-                                 wt::f16_scale_for(mq * 0.125f * 1.44269504f), wt::f16_scale_for(mk),
-                                 wt::f16_scale_for(mv));
+    (void)mq; (void)mk; (void)mv;
+    // fp32-storage forms only (0, 1); the default plane kernel has its own tap (wt_dbg_encoder_attention_planes)
+    wt::launch_encoder_attention(dq.p, dout.p, batch, T, heads, h->impl->attn_variant == 4 ? 1 : int(h->impl->attn_variant),
+                                 h->impl->stream());
     h->impl->sync();
     dout.to_host(out, size_t(batch) * T * d);
   });

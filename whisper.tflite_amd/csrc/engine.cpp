@@ -219,6 +219,14 @@ struct WtwFile {
 };
 }  // namespace
 
+void check_wtw_file(const std::string& path) {
+  const WtwFile file(path);  // throws kErrIo / kErrFormat
+  if (file.hdr.file_bytes != 0 && file.hdr.file_bytes != file.bytes) {
+    throw Error(kErrFormat, "truncated or padded .wtw weight file (header says " + std::to_string(file.hdr.file_bytes) +
+                                " bytes, file has " + std::to_string(file.bytes) + "): " + path);
+  }
+}
+
 void Engine::upload_weights(const std::string& path) {
   // Replaces Atom::Atom (whisper.cpp:261-271): instead of mmapping a .tflite FlatBuffer and
   // building an interpreter, the flat .wtw payload is mapped, re-laid-out for the kernels
@@ -448,6 +456,8 @@ void Engine::upload_weights(const std::string& path) {
     const Op lnp = ln_op("encoder.ln_post.weight", "encoder.ln_post.bias");
     sc_cross_kv_ = GemmScale{f16_scale_for(vmax(lnp.bound)), f16_scale_for(maxabs(ckv_w.data(), ckv_w.size())), slack_ok(lnp)};
     if (!sc_cross_kv_.f16_ok) ++n_f16_fallbacks_;
+    load_ok_.clear();
+    for (bool* f : ok_flags()) load_ok_.push_back(*f);
   }
   // ---- encoder weights as fp16 planes (k_gemm_planes.hip): split once, here ----
   {
@@ -478,6 +488,27 @@ void Engine::upload_weights(const std::string& path) {
     cross_kv_p_ = upload_planes(ckv_w.data(), c.n_text_layer * 2 * d, d, d, sc_cross_kv_.w);
   }
 
+}
+
+std::vector<bool*> Engine::ok_flags() {
+  std::vector<bool*> f{&sc_conv1_.f16_ok, &sc_conv2_.f16_ok};
+  for (EncLayerScales& sl : sc_layers_) {
+    for (bool* p : {&sl.qkv.f16_ok, &sl.attn_f16_ok, &sl.out.f16_ok, &sl.fc1.f16_ok, &sl.fc2.f16_ok}) f.push_back(p);
+  }
+  f.push_back(&sc_cross_kv_.f16_ok);
+  return f;
+}
+
+void Engine::set_force_fallback(long mask) {
+  require_idle();
+  const std::vector<bool*> f = ok_flags();
+  if (mask < 0 || (f.size() < 63 && (mask >> f.size()) != 0)) throw Error(kErrInvalidArg, "force_fallback: bit beyond the last contraction");
+  n_f16_fallbacks_ = 0;
+  for (size_t i = 0; i < f.size(); ++i) {
+    *f[i] = load_ok_[i] && !((mask >> i) & 1);
+    if (!*f[i]) ++n_f16_fallbacks_;
+  }
+  force_fallback_ = mask;
 }
 
 // bf16 storage mode (option "bf16", BASELINE configs[3]): bf16 copies of every matrix a kernel contracts with, made
@@ -690,7 +721,7 @@ void Engine::create_streams() {
 }
 
 Engine::Engine(const std::string& model_prefix, const std::string& vocab_path, bool multilingual,
-               int device_id, bool monolith)
+               int device_id, bool monolith, const std::string& weights_path)
     : device_(device_id), monolith_(monolith), multilingual_(multilingual) {
   // vocab first: a missing vocab file throws exactly like the reference's MmapFile
   read_vocab_file(vocab_path, multilingual, &filters_, &vocab_);
@@ -701,7 +732,7 @@ Engine::Engine(const std::string& model_prefix, const std::string& vocab_path, b
   // wt_engine_create (missing or malformed .wtw) leaks nothing.
   try {
     create_streams();
-    upload_weights(model_prefix + ".wtw");
+    upload_weights(weights_path.empty() ? model_prefix + ".wtw" : weights_path);
     if (vocab_.n_vocab != dims_.n_vocab && verbose) {
       std::fprintf(stderr, "[wt] note: vocab file n_vocab %d != model n_vocab %d\n", vocab_.n_vocab,
                    dims_.n_vocab);
@@ -831,6 +862,7 @@ void Engine::ensure_batch(int batch) {
   ws_.att = alloc(B * T * d, false);
   ws_.hid = alloc(B * T * 4 * d, false);
   ws_.enc_out = alloc(B * T * d, false);
+  ws_.cvt = reinterpret_cast<unsigned short*>(alloc(B * T * 4 * d, false));
   for (Slot& sl : slots_) {
     sl.cross_kv = alloc(size_t(c.n_text_layer) * 2 * B * T * d, false);
     sl.used = false;
@@ -841,7 +873,6 @@ void Engine::ensure_batch(int batch) {
     dw.xd = alloc(R * d, false);
     dw.xb = alloc(R * d, false);
     dw.xpart = alloc(R * d, false);
-    dw.lnd = alloc(B * d, false);
     dw.qkvd = alloc(R * 3 * d, false);
     dw.attd = alloc(R * d, false);
     dw.hd = alloc(R * 4 * d, false);
@@ -959,8 +990,10 @@ void Engine::resolve_kernel_stats(int slot) {
   Slot& sl = slots_[slot];
   // class names = the kernels the current options select (what rocprofv3 lists)
   const long gv = gemm_variant;
-  kstats_[kKcGemm].name = bf16 ? "gemm_bf16_planes" : use_planes() ? "gemm_planes_tile" : gv < 0 || (gv >= 13 && gv <= 18) ? "gemm_split16_tile" : gv == 11 ? "gemm_bf16_tile" : "gemm_f32_tile";
-  kstats_[kKcEncAttn].name = bf16 ? "encoder_attention_bf16" : use_planes() ? "encoder_attention_planes" : attn_variant ? "encoder_attention_split" : "encoder_attention_f32";
+  kstats_[kKcGemm].name = bf16 ? "gemm_bf16_planes" : "gemm_planes_tile";
+  kstats_[kKcEncAttn].name = bf16 ? "encoder_attention_bf16" : "encoder_attention_planes";
+  kstats_[kKcGemmAlt].name = gv == 0 ? "gemm_f32_tile" : "gemm_split16_tile";
+  kstats_[kKcEncAttnAlt].name = attn_variant == 0 ? "encoder_attention_f32" : "encoder_attention_split";
   for (auto& k : kstats_) k.launches = 0, k.ms = 0, k.flops = 0, k.bytes = 0;
   for (size_t i = 0; i < sl.kt_cls.size(); ++i) {
     float ms = 0;
@@ -997,136 +1030,20 @@ void Engine::encode_enqueue(const float* d_mel, int batch) {
     encode_enqueue_bf16(d_mel, batch);
     return;
   }
-  if (use_planes()) {
-    encode_enqueue_planes(d_mel, batch);
-    return;
-  }
-  const wtw::Dims& c = dims_;
-  const int T0 = mel_frames(), T = c.n_audio_ctx, d = c.n_audio_state, M = batch * T;
-  Slot& slot = slots_[enc_slot_];
-  // the slot's cross-KV cache may still be read by the decoder of the batch before last
-  if (slot.used) HIPCHK(hipStreamWaitEvent(stream_, slot.dec_done, 0));
-  slot.kt_cls.clear();
-  slot.kt_flops.clear();
-  slot.kt_bytes.clear();
-  slot.batch = batch;
-  if (!trace_base_ && getenv("WT_TRACE_PIPELINE")) {
-    HIPCHK(hipEventCreate(&trace_base_));
-    HIPCHK(hipEventRecord(trace_base_, stream_));
-  }
-  HIPCHK(hipMemsetAsync(slot.d_flag, 0, sizeof(int), stream_));
-  HIPCHK(hipEventRecord(slot.enc_begin, stream_));
-  kt_begin(kKcTranspose, 0, 2.0 * batch * c.n_mels * T0 * 4);
-  launch_mel_transpose(d_mel, ws_.melT, batch, c.n_mels, T0, stream_);
-  kt_end();
-  {
-    GemmArgs g; g.variant = enc_gemm_variant(sc_conv1_); g.a_scale = sc_conv1_.a; g.w_scale = sc_conv1_.w;  // conv1 + GELU: rows (clip, t) read melT rows t..t+2 (input t-1..t+1)
-    g.A = ws_.melT;
-    g.a_rpb = T0;
-    g.a_bs = long(T0 + 2) * c.n_mels;
-    g.lda = c.n_mels;
-    g.W = conv1_w;
-    g.bias = conv1_b;
-    g.C = ws_.h1p + d;  // row t lands at padded row t + 1
-    g.c_rpb = T0;
-    g.c_bs = long(T0 + 2) * d;
-    g.ldc = d;
-    g.M = batch * T0;
-    g.N = d;
-    g.K = conv1_kpad;
-    kt_begin(kKcGemm, 2.0 * g.M * g.N * (3.0 * c.n_mels), 0);
-    launch_gemm(g, kEpiBias | kEpiGelu, stream_);
-    kt_end();
-  }
-  {
-    GemmArgs g; g.variant = enc_gemm_variant(sc_conv2_); g.a_scale = sc_conv2_.a; g.w_scale = sc_conv2_.w;  // conv2 (stride 2) + GELU + positional embedding
-    g.A = ws_.h1p;
-    g.a_rpb = T;
-    g.a_bs = long(T0 + 2) * d;
-    g.lda = 2 * d;  // output t reads padded rows 2t..2t+2
-    g.W = conv2_w;
-    g.bias = conv2_b;
-    g.pos = enc_pos;
-    g.pos_period = T;
-    g.C = ws_.x;
-    g.ldc = d;
-    g.M = M;
-    g.N = d;
-    g.K = 3 * d;
-    kt_begin(kKcGemm, 2.0 * g.M * g.N * g.K, 0);
-    launch_gemm(g, kEpiBias | kEpiGelu | kEpiPos, stream_);
-    kt_end();
-  }
-  for (int l = 0; l < c.n_audio_layer; ++l) {
-    const BlockWeights& w = enc_blocks_[l];
-    kt_begin(kKcLayerNorm, 0, 2.0 * M * d * 4);
-    launch_layernorm(ws_.x, ws_.ln, w.attn_ln_g, w.attn_ln_b, M, d, stream_);
-    kt_end();
-    const EncLayerScales& sc = sc_layers_[l];
-    GemmArgs q; q.variant = enc_gemm_variant(sc.qkv); q.a_scale = sc.qkv.a; q.w_scale = sc.qkv.w;
-    q.A = ws_.ln; q.lda = d; q.W = w.attn.wqkv; q.bias = w.attn.bqkv; q.C = ws_.qkv; q.ldc = 3 * d;
-    q.M = M; q.N = 3 * d; q.K = d;
-    kt_begin(kKcGemm, 2.0 * q.M * q.N * q.K, 0);
-    launch_gemm(q, kEpiBias, stream_);
-    kt_end();
-    kt_begin(kKcEncAttn, 4.0 * batch * c.n_audio_head * double(T) * T * 64, 0);
-    launch_encoder_attention(ws_.qkv, ws_.att, batch, T, c.n_audio_head,
-                             attn_variant == 4 && !sc.attn_f16_ok ? 1 : int(attn_variant), stream_, sc.q, sc.k, sc.v);
-    kt_end();
-    GemmArgs o; o.variant = enc_gemm_variant(sc.out); o.a_scale = sc.out.a; o.w_scale = sc.out.w;
-    o.A = ws_.att; o.lda = d; o.W = w.attn.wo; o.bias = w.attn.bo; o.C = ws_.x; o.R = ws_.x; o.ldc = d;
-    o.M = M; o.N = d; o.K = d;
-    kt_begin(kKcGemm, 2.0 * o.M * o.N * o.K, 0);
-    launch_gemm(o, kEpiBias | kEpiResidual, stream_);
-    kt_end();
-    kt_begin(kKcLayerNorm, 0, 2.0 * M * d * 4);
-    launch_layernorm(ws_.x, ws_.ln, w.mlp_ln_g, w.mlp_ln_b, M, d, stream_);
-    kt_end();
-    GemmArgs f1; f1.variant = enc_gemm_variant(sc.fc1); f1.a_scale = sc.fc1.a; f1.w_scale = sc.fc1.w;
-    f1.A = ws_.ln; f1.lda = d; f1.W = w.w1; f1.bias = w.b1; f1.C = ws_.hid; f1.ldc = 4 * d;
-    f1.M = M; f1.N = 4 * d; f1.K = d;
-    kt_begin(kKcGemm, 2.0 * f1.M * f1.N * f1.K, 0);
-    launch_gemm(f1, kEpiBias | kEpiGelu, stream_);
-    kt_end();
-    GemmArgs f2; f2.variant = enc_gemm_variant(sc.fc2); f2.a_scale = sc.fc2.a; f2.w_scale = sc.fc2.w;
-    f2.A = ws_.hid; f2.lda = 4 * d; f2.W = w.w2; f2.bias = w.b2; f2.C = ws_.x; f2.R = ws_.x; f2.ldc = d;
-    f2.M = M; f2.N = d; f2.K = 4 * d;
-    kt_begin(kKcGemm, 2.0 * f2.M * f2.N * f2.K, 0);
-    launch_gemm(f2, kEpiBias | kEpiResidual, stream_);
-    kt_end();
-  }
-  kt_begin(kKcLayerNorm, 0, 2.0 * M * d * 4);
-  launch_layernorm(ws_.x, ws_.enc_out, enc_ln_post_g, enc_ln_post_b, M, d, stream_, slot.d_flag);
-  HIPCHK(hipMemcpyAsync(slot.h_flag, slot.d_flag, sizeof(int), hipMemcpyDeviceToHost, stream_));
-  kt_end();
-  HIPCHK(hipEventRecord(slot.enc_mid, stream_));
-  {
-    // cross-attention K/V of every decoder layer, projected once per clip into the
-    // persistent cache [layer][k|v][clip][head][t][64] (the reference recomputes them
-    // inside every decoder Invoke(), whisper.cpp:375)
-    GemmArgs g; g.variant = enc_gemm_variant(sc_cross_kv_); g.a_scale = sc_cross_kv_.a; g.w_scale = sc_cross_kv_.w;
-    g.A = ws_.enc_out; g.lda = d; g.W = cross_kv_w; g.bias = cross_kv_b; g.C = slot.cross_kv;
-    g.M = M; g.N = c.n_text_layer * 2 * d; g.K = d;
-    g.c_rpb = T; g.kv_batch = batch; g.kv_heads = c.n_text_head; g.kv_dmodel = d;
-    kt_begin(kKcGemm, 2.0 * g.M * g.N * g.K, 0);
-    launch_gemm(g, kEpiBias | kEpiKvLayout, stream_);
-    kt_end();
-  }
-  HIPCHK(hipEventRecord(slot.enc_done, stream_));
-  slot.used = true;
-  last_enc_slot_ = enc_slot_;
-  enc_slot_ = (enc_slot_ + 1) % kSlots;
-}
-
-// The default encoder: every contraction operand travels as two fp16 planes (k_gemm_planes.hip,
-// k_attention_planes.hip); the residual stream x stays fp32.  Same graph, same scales, same event / timer protocol as
-// encode_enqueue above.
-void Engine::encode_enqueue_planes(const float* d_mel, int batch) {
+  // The encoder graph.  Every contraction chooses its kernel BY ITSELF: the plane kernels
+  // (k_gemm_planes.hip, k_attention_planes.hip: operands as two fp16 planes, made by the kernel that produces them)
+  // unless the load-time slack check flagged that contraction's operand (GemmScale::f16_ok, upload_weights) or an
+  // explicit gemm_variant / attn_variant asks for the fp32-storage kernels (k_gemm.hip, k_attention.hip: full fp32
+  // operand range).  A tensor has exactly one consumer, so its format follows the consumer: a plane kernel that feeds a
+  // flagged contraction writes fp32 (C instead of P), LayerNorm has both forms, and where a fall-back kernel feeds a
+  // plane kernel its fp32 output is split by launch_f32_to_planes into the scratch planes ws_.cvt.  The residual
+  // stream x stays fp32 throughout.
   const wtw::Dims& c = dims_;
   const int T0 = mel_frames(), T = c.n_audio_ctx, d = c.n_audio_state, M = batch * T, nm = c.n_mels;
   const long Bw = ws_.batch;  // plane strides follow the workspace, not the call
   const int cus = (stream_ == stream_masked_ && stream_masked_) ? enc_cus_masked_ : n_cu_;  // CUs of this stream
   Slot& slot = slots_[enc_slot_];
+  // the slot's cross-KV cache may still be read by the decoder of the batch before last
   if (slot.used) HIPCHK(hipStreamWaitEvent(stream_, slot.dec_done, 0));
   slot.kt_cls.clear();
   slot.kt_flops.clear();
@@ -1143,93 +1060,203 @@ void Engine::encode_enqueue_planes(const float* d_mel, int batch) {
   unsigned short* const attp = reinterpret_cast<unsigned short*>(ws_.att);
   unsigned short* const hidp = reinterpret_cast<unsigned short*>(ws_.hid);
   const long melT_plane = Bw * (T0 + 2) * nm + 128, h1p_plane = Bw * (T0 + 2) * d + 128;
-  const long ln_plane = Bw * T * d, qkv_plane = Bw * T * 3 * d, hid_plane = Bw * T * 4 * d;
+  const long ln_plane = Bw * T * d, qkv_plane = Bw * T * 3 * d, hid_plane = Bw * T * 4 * d, cvt_plane = Bw * T * 4 * d;
+  const int alt = alt_gemm_variant();
 
+  auto plane_gemm = [&](PlaneGemmArgs& g, const GemmScale& sc, int epi, double flops) {
+    g.n_cu = cus; g.a_scale = sc.a; g.w_scale = sc.w;
+    kt_begin(kKcGemm, flops, 0);
+    launch_gemm_planes(g, epi, stream_);
+    kt_end();
+  };
+  auto alt_gemm = [&](GemmArgs& g, const GemmScale& sc, int epi, double flops) {
+    g.variant = alt; g.a_scale = sc.a; g.w_scale = sc.w;
+    kt_begin(kKcGemmAlt, flops, 0);
+    launch_gemm(g, epi, stream_);
+    kt_end();
+  };
+  auto to_planes = [&](const float* src, unsigned short* dst, long plane, long rows, int ld, const float* scales, int seg) {
+    kt_begin(kKcConvert, 0, 2.0 * rows * ld * 4);
+    launch_f32_to_planes(src, dst, plane, rows, ld, scales, seg, stream_);
+    kt_end();
+  };
+
+  const bool c1p = gemm_on_planes(sc_conv1_), c2p = gemm_on_planes(sc_conv2_);
   kt_begin(kKcTranspose, 0, 2.0 * batch * nm * T0 * 4);
-  launch_mel_transpose_planes(d_mel, ws_.melTp, melT_plane, sc_conv1_.a, batch, nm, T0, nm, stream_);
+  if (c1p) {
+    launch_mel_transpose_planes(d_mel, ws_.melTp, melT_plane, sc_conv1_.a, batch, nm, T0, nm, stream_);
+  } else {
+    launch_mel_transpose(d_mel, ws_.melT, batch, nm, T0, stream_);
+  }
   kt_end();
-  {
-    PlaneGemmArgs g; g.n_cu = cus;  // conv1 + GELU: rows (clip, t) read melT rows t..t+2 (input t-1..t+1)
+  // conv1 + GELU: rows (clip, t) read melT rows t..t+2 (input t-1..t+1); row t lands at padded row t + 1 of h1
+  if (c1p) {
+    PlaneGemmArgs g;
     g.A = ws_.melTp; g.a_plane = melT_plane; g.a_rpb = T0; g.a_bs = long(T0 + 2) * nm; g.lda = nm;
     g.W = conv1_p_.w; g.w_plane = conv1_p_.plane; g.bias = conv1_b;
-    g.P = ws_.h1pp + d; g.p_plane = h1p_plane;  // row t lands at padded row t + 1
+    if (c2p) {
+      g.P = ws_.h1pp + d; g.p_plane = h1p_plane; g.out_scale[0] = sc_conv2_.a;
+    } else {
+      g.C = ws_.h1p + d;
+    }
     g.c_rpb = T0; g.c_bs = long(T0 + 2) * d; g.ldc = d;
     g.M = batch * T0; g.N = d; g.K = conv1_kpad_p_;
-    g.a_scale = sc_conv1_.a; g.w_scale = sc_conv1_.w; g.out_scale[0] = sc_conv2_.a;
-    kt_begin(kKcGemm, 2.0 * g.M * g.N * (3.0 * nm), 0);
-    launch_gemm_planes(g, kEpiBias | kEpiGelu, stream_);
-    kt_end();
+    plane_gemm(g, sc_conv1_, kEpiBias | kEpiGelu, 2.0 * g.M * g.N * (3.0 * nm));
+  } else {
+    GemmArgs g;
+    g.A = ws_.melT; g.a_rpb = T0; g.a_bs = long(T0 + 2) * nm; g.lda = nm;
+    g.W = conv1_w; g.bias = conv1_b;
+    g.C = ws_.h1p + d; g.c_rpb = T0; g.c_bs = long(T0 + 2) * d; g.ldc = d;
+    g.M = batch * T0; g.N = d; g.K = conv1_kpad;
+    alt_gemm(g, sc_conv1_, kEpiBias | kEpiGelu, 2.0 * g.M * g.N * (3.0 * nm));
+    // the pad rows of h1p are zero and stay zero as planes
+    if (c2p) to_planes(ws_.h1p, ws_.h1pp, h1p_plane, long(batch) * (T0 + 2), d, &sc_conv2_.a, 0);
   }
-  {
-    PlaneGemmArgs g; g.n_cu = cus;  // conv2 (stride 2) + GELU + positional embedding
-    g.A = ws_.h1pp; g.a_plane = h1p_plane; g.a_rpb = T; g.a_bs = long(T0 + 2) * d; g.lda = 2 * d;  // output t reads padded rows 2t..2t+2
+  // conv2 (stride 2) + GELU + positional embedding: output t reads padded rows 2t..2t+2
+  if (c2p) {
+    PlaneGemmArgs g;
+    g.A = ws_.h1pp; g.a_plane = h1p_plane; g.a_rpb = T; g.a_bs = long(T0 + 2) * d; g.lda = 2 * d;
     g.W = conv2_p_.w; g.w_plane = conv2_p_.plane; g.bias = conv2_b; g.pos = enc_pos; g.pos_period = T;
-    g.C = ws_.x; g.ldc = d;
-    g.M = M; g.N = d; g.K = 3 * d;
-    g.a_scale = sc_conv2_.a; g.w_scale = sc_conv2_.w;
-    kt_begin(kKcGemm, 2.0 * g.M * g.N * g.K, 0);
-    launch_gemm_planes(g, kEpiBias | kEpiGelu | kEpiPos, stream_);
-    kt_end();
+    g.C = ws_.x; g.ldc = d; g.M = M; g.N = d; g.K = 3 * d;
+    plane_gemm(g, sc_conv2_, kEpiBias | kEpiGelu | kEpiPos, 2.0 * g.M * g.N * g.K);
+  } else {
+    GemmArgs g;
+    g.A = ws_.h1p; g.a_rpb = T; g.a_bs = long(T0 + 2) * d; g.lda = 2 * d;
+    g.W = conv2_w; g.bias = conv2_b; g.pos = enc_pos; g.pos_period = T;
+    g.C = ws_.x; g.ldc = d; g.M = M; g.N = d; g.K = 3 * d;
+    alt_gemm(g, sc_conv2_, kEpiBias | kEpiGelu | kEpiPos, 2.0 * g.M * g.N * g.K);
   }
   constexpr float kQScale = 0.125f * 1.44269504088896340736f;  // d_head^-1/2 * log2(e): softmax as exp2
+  auto layernorm_for = [&](bool planes, float scale, const float* g, const float* b) {
+    kt_begin(kKcLayerNorm, 0, 2.0 * M * d * 4);
+    if (planes) {
+      launch_layernorm_planes(ws_.x, lnp, ln_plane, scale, nullptr, g, b, M, d, stream_);
+    } else {
+      launch_layernorm(ws_.x, ws_.ln, g, b, M, d, stream_);
+    }
+    kt_end();
+  };
   for (int l = 0; l < c.n_audio_layer; ++l) {
     const BlockWeights& w = enc_blocks_[l];
     const EncLayerPlanes& wp = enc_planes_[l];
     const EncLayerScales& sc = sc_layers_[l];
-    kt_begin(kKcLayerNorm, 0, 2.0 * M * d * 4);
-    launch_layernorm_planes(ws_.x, lnp, ln_plane, sc.qkv.a, nullptr, w.attn_ln_g, w.attn_ln_b, M, d, stream_);
-    kt_end();
-    PlaneGemmArgs q; q.n_cu = cus;  // q | k | v, written as the attention kernel's operand planes
-    q.A = lnp; q.a_plane = ln_plane; q.lda = d; q.W = wp.qkv.w; q.w_plane = wp.qkv.plane; q.bias = w.attn.bqkv;
-    q.P = qkvp; q.p_plane = qkv_plane; q.ldc = 3 * d; q.M = M; q.N = 3 * d; q.K = d;
-    q.a_scale = sc.qkv.a; q.w_scale = sc.qkv.w; q.seg = d;
-    q.out_scale[0] = kQScale * sc.q; q.out_scale[1] = sc.k; q.out_scale[2] = sc.v;
-    kt_begin(kKcGemm, 2.0 * q.M * q.N * q.K, 0);
-    launch_gemm_planes(q, kEpiBias, stream_);
-    kt_end();
-    kt_begin(kKcEncAttn, 4.0 * batch * c.n_audio_head * double(T) * T * 64, 0);
-    launch_encoder_attention_planes(qkvp, qkv_plane, attp, ln_plane, batch, T, c.n_audio_head, sc.q, sc.k, sc.v, sc.out.a,
-                                    stream_);
-    kt_end();
-    PlaneGemmArgs o; o.n_cu = cus;
-    o.A = attp; o.a_plane = ln_plane; o.lda = d; o.W = wp.out.w; o.w_plane = wp.out.plane; o.bias = w.attn.bo;
-    o.C = ws_.x; o.R = ws_.x; o.ldc = d; o.M = M; o.N = d; o.K = d; o.a_scale = sc.out.a; o.w_scale = sc.out.w;
-    kt_begin(kKcGemm, 2.0 * o.M * o.N * o.K, 0);
-    launch_gemm_planes(o, kEpiBias | kEpiResidual, stream_);
-    kt_end();
-    kt_begin(kKcLayerNorm, 0, 2.0 * M * d * 4);
-    launch_layernorm_planes(ws_.x, lnp, ln_plane, sc.fc1.a, nullptr, w.mlp_ln_g, w.mlp_ln_b, M, d, stream_);
-    kt_end();
-    PlaneGemmArgs f1; f1.n_cu = cus;
-    f1.A = lnp; f1.a_plane = ln_plane; f1.lda = d; f1.W = wp.fc1.w; f1.w_plane = wp.fc1.plane; f1.bias = w.b1;
-    f1.P = hidp; f1.p_plane = hid_plane; f1.ldc = 4 * d; f1.M = M; f1.N = 4 * d; f1.K = d;
-    f1.a_scale = sc.fc1.a; f1.w_scale = sc.fc1.w; f1.out_scale[0] = sc.fc2.a;
-    kt_begin(kKcGemm, 2.0 * f1.M * f1.N * f1.K, 0);
-    launch_gemm_planes(f1, kEpiBias | kEpiGelu, stream_);
-    kt_end();
-    PlaneGemmArgs f2; f2.n_cu = cus;
-    f2.A = hidp; f2.a_plane = hid_plane; f2.lda = 4 * d; f2.W = wp.fc2.w; f2.w_plane = wp.fc2.plane; f2.bias = w.b2;
-    f2.C = ws_.x; f2.R = ws_.x; f2.ldc = d; f2.M = M; f2.N = d; f2.K = 4 * d; f2.a_scale = sc.fc2.a; f2.w_scale = sc.fc2.w;
-    kt_begin(kKcGemm, 2.0 * f2.M * f2.N * f2.K, 0);
-    launch_gemm_planes(f2, kEpiBias | kEpiResidual, stream_);
-    kt_end();
+    const bool qp = gemm_on_planes(sc.qkv), op = gemm_on_planes(sc.out), f1p = gemm_on_planes(sc.fc1), f2p = gemm_on_planes(sc.fc2);
+    // the plane attention writes planes, so its consumer (the out-projection) must take them
+    const bool ap = gemm_variant < 0 && attn_variant == 4 && sc.attn_f16_ok && op;
+    const int attn_alt = attn_variant == 4 ? 1 : int(attn_variant);  // fall-back form: three bf16 planes
+
+    layernorm_for(qp, sc.qkv.a, w.attn_ln_g, w.attn_ln_b);
+    const float qkv_scales[3] = {kQScale * sc.q, sc.k, sc.v};
+    const unsigned short* qkv_src = qkvp;  // the plane attention's operand
+    long qkv_src_plane = qkv_plane;
+    if (qp) {
+      PlaneGemmArgs q;  // q | k | v: the attention kernel's operand planes, or fp32 for the fall-back attention
+      q.A = lnp; q.a_plane = ln_plane; q.lda = d; q.W = wp.qkv.w; q.w_plane = wp.qkv.plane; q.bias = w.attn.bqkv;
+      if (ap) {
+        q.P = qkvp; q.p_plane = qkv_plane; q.seg = d;
+        q.out_scale[0] = qkv_scales[0]; q.out_scale[1] = qkv_scales[1]; q.out_scale[2] = qkv_scales[2];
+      } else {
+        q.C = ws_.qkv;
+      }
+      q.ldc = 3 * d; q.M = M; q.N = 3 * d; q.K = d;
+      plane_gemm(q, sc.qkv, kEpiBias, 2.0 * q.M * q.N * q.K);
+    } else {
+      GemmArgs q;
+      q.A = ws_.ln; q.lda = d; q.W = w.attn.wqkv; q.bias = w.attn.bqkv; q.C = ws_.qkv; q.ldc = 3 * d;
+      q.M = M; q.N = 3 * d; q.K = d;
+      alt_gemm(q, sc.qkv, kEpiBias, 2.0 * q.M * q.N * q.K);
+      if (ap) {
+        to_planes(ws_.qkv, ws_.cvt, cvt_plane, M, 3 * d, qkv_scales, d);
+        qkv_src = ws_.cvt; qkv_src_plane = cvt_plane;
+      }
+    }
+    const unsigned short* att_src = attp;  // the plane out-projection's operand
+    long att_src_plane = ln_plane;
+    if (ap) {
+      kt_begin(kKcEncAttn, 4.0 * batch * c.n_audio_head * double(T) * T * 64, 0);
+      launch_encoder_attention_planes(qkv_src, qkv_src_plane, attp, ln_plane, batch, T, c.n_audio_head, sc.q, sc.k, sc.v,
+                                      sc.out.a, stream_);
+      kt_end();
+    } else {
+      kt_begin(kKcEncAttnAlt, 4.0 * batch * c.n_audio_head * double(T) * T * 64, 0);
+      launch_encoder_attention(ws_.qkv, ws_.att, batch, T, c.n_audio_head, attn_alt, stream_);
+      kt_end();
+      if (op) {
+        to_planes(ws_.att, ws_.cvt, cvt_plane, M, d, &sc.out.a, 0);
+        att_src = ws_.cvt; att_src_plane = cvt_plane;
+      }
+    }
+    if (op) {
+      PlaneGemmArgs o;
+      o.A = att_src; o.a_plane = att_src_plane; o.lda = d; o.W = wp.out.w; o.w_plane = wp.out.plane; o.bias = w.attn.bo;
+      o.C = ws_.x; o.R = ws_.x; o.ldc = d; o.M = M; o.N = d; o.K = d;
+      plane_gemm(o, sc.out, kEpiBias | kEpiResidual, 2.0 * o.M * o.N * o.K);
+    } else {
+      GemmArgs o;
+      o.A = ws_.att; o.lda = d; o.W = w.attn.wo; o.bias = w.attn.bo; o.C = ws_.x; o.R = ws_.x; o.ldc = d;
+      o.M = M; o.N = d; o.K = d;
+      alt_gemm(o, sc.out, kEpiBias | kEpiResidual, 2.0 * o.M * o.N * o.K);
+    }
+    layernorm_for(f1p, sc.fc1.a, w.mlp_ln_g, w.mlp_ln_b);
+    const unsigned short* hid_src = hidp;  // the plane fc2's operand
+    long hid_src_plane = hid_plane;
+    if (f1p) {
+      PlaneGemmArgs f1;
+      f1.A = lnp; f1.a_plane = ln_plane; f1.lda = d; f1.W = wp.fc1.w; f1.w_plane = wp.fc1.plane; f1.bias = w.b1;
+      if (f2p) {
+        f1.P = hidp; f1.p_plane = hid_plane; f1.out_scale[0] = sc.fc2.a;
+      } else {
+        f1.C = ws_.hid;
+      }
+      f1.ldc = 4 * d; f1.M = M; f1.N = 4 * d; f1.K = d;
+      plane_gemm(f1, sc.fc1, kEpiBias | kEpiGelu, 2.0 * f1.M * f1.N * f1.K);
+    } else {
+      GemmArgs f1;
+      f1.A = ws_.ln; f1.lda = d; f1.W = w.w1; f1.bias = w.b1; f1.C = ws_.hid; f1.ldc = 4 * d;
+      f1.M = M; f1.N = 4 * d; f1.K = d;
+      alt_gemm(f1, sc.fc1, kEpiBias | kEpiGelu, 2.0 * f1.M * f1.N * f1.K);
+      if (f2p) {
+        to_planes(ws_.hid, ws_.cvt, cvt_plane, M, 4 * d, &sc.fc2.a, 0);
+        hid_src = ws_.cvt; hid_src_plane = cvt_plane;
+      }
+    }
+    if (f2p) {
+      PlaneGemmArgs f2;
+      f2.A = hid_src; f2.a_plane = hid_src_plane; f2.lda = 4 * d; f2.W = wp.fc2.w; f2.w_plane = wp.fc2.plane; f2.bias = w.b2;
+      f2.C = ws_.x; f2.R = ws_.x; f2.ldc = d; f2.M = M; f2.N = d; f2.K = 4 * d;
+      plane_gemm(f2, sc.fc2, kEpiBias | kEpiResidual, 2.0 * f2.M * f2.N * f2.K);
+    } else {
+      GemmArgs f2;
+      f2.A = ws_.hid; f2.lda = 4 * d; f2.W = w.w2; f2.bias = w.b2; f2.C = ws_.x; f2.R = ws_.x; f2.ldc = d;
+      f2.M = M; f2.N = d; f2.K = 4 * d;
+      alt_gemm(f2, sc.fc2, kEpiBias | kEpiResidual, 2.0 * f2.M * f2.N * f2.K);
+    }
   }
+  const bool kp = gemm_on_planes(sc_cross_kv_);
   kt_begin(kKcLayerNorm, 0, 2.0 * M * d * 4);
-  launch_layernorm_planes(ws_.x, lnp, ln_plane, sc_cross_kv_.a, ws_.enc_out, enc_ln_post_g, enc_ln_post_b, M, d, stream_,
-                          slot.d_flag);
+  if (kp) {
+    launch_layernorm_planes(ws_.x, lnp, ln_plane, sc_cross_kv_.a, ws_.enc_out, enc_ln_post_g, enc_ln_post_b, M, d, stream_,
+                            slot.d_flag);
+  } else {
+    launch_layernorm(ws_.x, ws_.enc_out, enc_ln_post_g, enc_ln_post_b, M, d, stream_, slot.d_flag);
+  }
   HIPCHK(hipMemcpyAsync(slot.h_flag, slot.d_flag, sizeof(int), hipMemcpyDeviceToHost, stream_));
   kt_end();
   HIPCHK(hipEventRecord(slot.enc_mid, stream_));
-  {
-    // cross-attention K/V of every decoder layer, projected once per clip into the persistent cache
-    PlaneGemmArgs g; g.n_cu = cus;
+  // cross-attention K/V of every decoder layer, projected once per clip into the persistent cache
+  // [layer][k|v][clip][head][t][64] (the reference recomputes them inside every decoder Invoke(), whisper.cpp:375)
+  if (kp) {
+    PlaneGemmArgs g;
     g.A = lnp; g.a_plane = ln_plane; g.lda = d; g.W = cross_kv_p_.w; g.w_plane = cross_kv_p_.plane; g.bias = cross_kv_b;
     g.C = slot.cross_kv; g.M = M; g.N = c.n_text_layer * 2 * d; g.K = d;
     g.c_rpb = T; g.kv_batch = batch; g.kv_heads = c.n_text_head; g.kv_dmodel = d;
-    g.a_scale = sc_cross_kv_.a; g.w_scale = sc_cross_kv_.w;
-    kt_begin(kKcGemm, 2.0 * g.M * g.N * g.K, 0);
-    launch_gemm_planes(g, kEpiBias | kEpiKvLayout, stream_);
-    kt_end();
+    plane_gemm(g, sc_cross_kv_, kEpiBias | kEpiKvLayout, 2.0 * g.M * g.N * g.K);
+  } else {
+    GemmArgs g;
+    g.A = ws_.enc_out; g.lda = d; g.W = cross_kv_w; g.bias = cross_kv_b; g.C = slot.cross_kv;
+    g.M = M; g.N = c.n_text_layer * 2 * d; g.K = d;
+    g.c_rpb = T; g.kv_batch = batch; g.kv_heads = c.n_text_head; g.kv_dmodel = d;
+    alt_gemm(g, sc_cross_kv_, kEpiBias | kEpiKvLayout, 2.0 * g.M * g.N * g.K);
   }
   HIPCHK(hipEventRecord(slot.enc_done, stream_));
   slot.used = true;
@@ -1402,6 +1429,7 @@ std::vector<long long> Engine::prompt() const {
 }
 
 void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int logits_steps_cap) {
+  if (batch > 64) throw Error(1, "decoder batches are limited to 64 clips per call");  // before any stream operation
   ensure_batch(batch);
   Slot& slot = slots_[slot_idx];
   slot.dec = slot_idx % n_dec_streams_;  // fixed pairing keeps the number of captured graphs small
@@ -1411,7 +1439,6 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
   HIPCHK(hipEventRecord(slot.dec_begin, stream_));
   long long* const h_ids_ = slot.h_ids;
   int* const h_n_ = slot.h_n;
-  if (batch > 64) throw Error(1, "decoder batches are limited to 64 clips per call");
   const wtw::Dims& c = dims_;
   const int d = c.n_text_state, T = c.n_audio_ctx, H = c.n_text_head, V = c.n_vocab;
   const std::vector<long long> prompt = this->prompt();
@@ -1581,26 +1608,43 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
     enqueue_all(slot_idx);
     dt_on = false;
     const int eager_steps = steps;
+    // the eager work of THIS batch is queued: its completion event and step count are set before anything that can
+    // fail, so that submit() / collect() stay consistent whatever happens to the captures below
+    HIPCHK(hipEventRecord(slot.dec_done, stream_));
+    slot.steps = eager_steps;
     if (use_graphs && !logits_host) {
-      for (int si = 0; si < kSlots; ++si) {
-        hipStream_t cs = dstream_[si % n_dec_streams_];
-        hipGraph_t graph = nullptr;
-        hipGraphExec_t ge = nullptr;
-        HIPCHK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
-        try {
-          enqueue_all(si);
-        } catch (...) {
-          (void)hipStreamEndCapture(cs, &graph);
-          if (graph) (void)hipGraphDestroy(graph);
-          throw;
+      // A capture or instantiation failure is not fatal: the decoder keeps launching eagerly (same kernels, same
+      // results, more host time per batch) and the engine stops trying.
+      std::map<std::vector<long long>, GraphEntry> fresh;
+      try {
+        for (int si = 0; si < kSlots; ++si) {
+          hipStream_t cs = dstream_[si % n_dec_streams_];
+          hipGraph_t graph = nullptr;
+          hipGraphExec_t ge = nullptr;
+          HIPCHK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+          try {
+            enqueue_all(si);
+          } catch (...) {
+            (void)hipStreamEndCapture(cs, &graph);
+            if (graph) (void)hipGraphDestroy(graph);
+            throw;
+          }
+          HIPCHK(hipStreamEndCapture(cs, &graph));
+          const hipError_t ie = hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0);
+          (void)hipGraphDestroy(graph);
+          if (ie != hipSuccess) throw Error(kErrDevice, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie));
+          fresh[key_of(si)] = GraphEntry{ge, steps};
         }
-        HIPCHK(hipStreamEndCapture(cs, &graph));
-        HIPCHK(hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0));
-        (void)hipGraphDestroy(graph);
-        graphs_[key_of(si)] = GraphEntry{ge, steps};
+        for (auto& g : fresh) graphs_[g.first] = g.second;  // all six slots or none
+      } catch (const std::exception& e) {
+        for (auto& g : fresh) (void)hipGraphExecDestroy(g.second.exec);
+        (void)hipGetLastError();
+        use_graphs = 0;
+        std::fprintf(stderr, "[wt] decoder hipGraph capture failed (%s): continuing with eager launches\n", e.what());
       }
     }
     steps = eager_steps;
+    return;
   }
   HIPCHK(hipEventRecord(slot.dec_done, stream_));
   slot.steps = steps;

@@ -29,7 +29,10 @@ struct KernelStat {
   double flops;  // algorithmic FLOPs of those launches
   double bytes;  // algorithmic bytes (bandwidth-bound kernels)
 };
-enum KernelClass { kKcGemm = 0, kKcEncAttn, kKcLayerNorm, kKcTranspose, kKcCount };
+// kKcGemm / kKcEncAttn: the default plane kernels (or the bf16-storage ones); *Alt: contractions that ran on the
+// fp32-storage kernels instead (a load-time fall-back of that contraction, or a forced gemm_variant / attn_variant);
+// kKcConvert: the fp32 -> planes hand-over between the two kinds
+enum KernelClass { kKcGemm = 0, kKcEncAttn, kKcLayerNorm, kKcTranspose, kKcGemmAlt, kKcEncAttnAlt, kKcConvert, kKcCount };
 
 struct AttnWeights {
   const float *wqkv = nullptr, *bqkv = nullptr;  // fused [3d][d] (self attention)
@@ -54,13 +57,18 @@ struct DecBlockWeights {
   TiledW w1, w2;
 };
 
+// Opens a .wtw file and checks header, tensor table and length without touching a GPU; throws wt::Error (kErrIo /
+// kErrFormat).  wt_engine_create uses it to decide whether a .wtw next to a .tflite pair must be rebuilt.
+void check_wtw_file(const std::string& path);
+
 class Engine {
  public:
   // Throws std::runtime_error with a message; the C ABI maps it to a status code.
   // monolith: the reference's other engine type (whisper.h:165-179) routed to the same encoder / decoder
   // kernels; it differs in the prompt only (prompt(), engine.cpp)
+  // weights_path: the .wtw to load; empty = model_prefix + ".wtw"
   Engine(const std::string& model_prefix, const std::string& vocab_path, bool multilingual,
-         int device_id, bool monolith = false);
+         int device_id, bool monolith = false, const std::string& weights_path = "");
   // front end only: log-mel kernels over `filters` (80 x 201), no weights; encode()/decode() must not be called
   Engine(const FilterBank& filters, int device_id);
   ~Engine();
@@ -84,10 +92,10 @@ class Engine {
   // prologue per (clip, head) measured 121.2 k audio-sec/s against 119.0 k with two chunks and 113.8 k with four; a
   // single clip needs the chunks to spread its 6 heads over the chip)
   long cross_chunks = 0;
-  long attn_variant = 4;  // encoder attention: 0 = fp32 MFMA, 1/2 = bf16 x3 split, 3 = bf16 operands, 4 = fp16 x2 split
+  long attn_variant = 4;  // encoder attention: 4 = two fp16 planes (default), 1 = three bf16 planes (full range), 0 = fp32 MFMA
   long fc2_ksplit = 2;  // decoder fc2 (K = 4 d_model) over twice the blocks, halves summed by the consumer
   long use_graphs = 1;  // replay the decoder's launch sequence from a captured hipGraph
-  long gemm_variant = -1;  // encoder GEMM tile variant (k_gemm.hip); -1 = per-shape choice
+  long gemm_variant = -1;  // -1 = plane GEMM (per-contraction fall-back to 13/16); 0 = fp32 MFMA, 13 / 16 = three bf16 planes
   // 1 = bf16 STORAGE mode (BASELINE configs[3]): bf16 weights, activations and both KV caches, fp32 accumulation,
   // fp32 residual stream; k_gemm_bf16.hip and the BF variants of the attention / decoder kernels.  Set through
   // set_bf16(): the first switch uploads the bf16 weight copies.
@@ -126,6 +134,11 @@ class Engine {
   int in_flight() const { return int(inflight_.size()); }
   // contractions that were given the full-range bf16 three-plane kernels at load time (bound slack, engine.cpp)
   int f16_fallbacks() const { return n_f16_fallbacks_; }
+  // Test hook (option "force_fallback"): bit i treats contraction i — launch order: conv1, conv2, then per layer
+  // qkv, attention, out, fc1, fc2, and last the cross-KV projection — as flagged by the load-time slack check, on top
+  // of the contractions that check flagged itself.  Exercises every plane <-> fall-back hand-over on any weights.
+  void set_force_fallback(long mask);
+  long force_fallback() const { return force_fallback_; }
   // throws unless no submitted batch is waiting for collect(): every synchronous entry point calls it first
   void require_idle() const;
   void sync();
@@ -235,10 +248,6 @@ class Engine {
   std::vector<EncLayerPlanes> enc_planes_;
   PlaneW upload_planes(const float* W, int N, int K, int Kpad, float scale);
   int conv1_kpad_p_ = 0;  // conv1's K padded to the plane GEMM's k-tile
-  void encode_enqueue_planes(const float* d_mel, int batch);
-  // the plane kernels are the default encoder; an explicit gemm_variant / attn_variant, or a contraction the load-time
-  // slack check gave the full-range form, selects the fp32-storage kernels of k_gemm.hip / k_attention.hip
-  bool use_planes() const { return gemm_variant < 0 && attn_variant == 4 && n_f16_fallbacks_ == 0; }
   const float* enc_pos = nullptr;
   std::vector<BlockWeights> enc_blocks_;
   std::vector<DecBlockWeights> dec_blocks_;
@@ -252,6 +261,9 @@ class Engine {
     float a = 1.0f, w = 64.0f;
     bool f16_ok = true;  // false: the operand's bound is too far above its typical magnitude (upload_weights)
   };
+  // Per contraction: the plane kernels unless the load-time slack check gave that contraction the full-range form
+  // (GemmScale::f16_ok) or an explicit gemm_variant / attn_variant selects the fp32-storage kernels for all of them
+  bool gemm_on_planes(const GemmScale& sc) const { return gemm_variant < 0 && sc.f16_ok; }
   struct EncLayerScales {
     GemmScale qkv, out, fc1, fc2;
     float q = 1.0f, k = 1.0f, v = 1.0f;
@@ -260,10 +272,14 @@ class Engine {
   static constexpr float kMelBound = 8.0f;
   static constexpr float kF16Slack = 4096.0f;  // largest bound / typical ratio the two-plane fp16 form is used for
   int n_f16_fallbacks_ = 0;
-  int enc_gemm_variant(const GemmScale& sc) const {
+  long force_fallback_ = 0;
+  std::vector<bool> load_ok_;  // the slack check's own verdicts, in contraction order (set_force_fallback)
+  std::vector<bool*> ok_flags();  // the f16_ok / attn_f16_ok members in contraction order
+  // the fp32-storage GEMM a contraction falls back to: the forced variant, else three bf16 planes (13; 16 = the same
+  // at two blocks per CU beside the decoders of the pipeline)
+  int alt_gemm_variant() const {
     if (gemm_variant >= 0) return int(gemm_variant);
-    const bool two_per_cu = stream_ == stream_masked_ && stream_masked_;
-    return sc.f16_ok ? (two_per_cu ? 18 : 17) : (two_per_cu ? 16 : 13);  // load-time fall-back to the full-range form
+    return (stream_ == stream_masked_ && stream_masked_) ? 16 : 13;
   }
   GemmScale sc_conv1_, sc_conv2_, sc_cross_kv_;
   std::vector<EncLayerScales> sc_layers_;
@@ -278,7 +294,7 @@ class Engine {
 
   struct DecWorkspace {  // one per decoder stream
     float *xb = nullptr, *xpart = nullptr;  // fc2's K-split: first-half result / second-half partial
-    float *xd = nullptr, *lnd = nullptr, *qkvd = nullptr, *attd = nullptr,
+    float *xd = nullptr, *qkvd = nullptr, *attd = nullptr,
           *hd = nullptr, *cross_ws = nullptr, *self_kv = nullptr, *logits = nullptr;
     unsigned long long* best = nullptr;
     long long* ids = nullptr;
@@ -291,6 +307,8 @@ class Engine {
     // plane path (fp16 hi | lo planes; ln / qkv / att / hid reuse the fp32 buffers above, same bytes): the two
     // zero-padded convolution inputs need buffers of their own (their pad rows sit elsewhere in the plane layout)
     unsigned short *melTp = nullptr, *h1pp = nullptr;
+    // planes made by launch_f32_to_planes from the fp32 output of a fall-back contraction ([B T][4 d] elements)
+    unsigned short* cvt = nullptr;
     // front end
     float *pcm_pad = nullptr, *spec = nullptr, *pw = nullptr, *melacc = nullptr;
     unsigned* clip_max = nullptr;
@@ -303,10 +321,10 @@ class Engine {
   void kt_begin(int cls, double flops, double bytes);
   void kt_end();
   void resolve_kernel_stats(int slot);
-  KernelStat kstats_[kKcCount] = {{"gemm_f32_128x128", 0, 0, 0, 0},
-                                  {"encoder_attention_f32", 0, 0, 0, 0},
-                                  {"layernorm_rows", 0, 0, 0, 0},
-                                  {"mel_transpose", 0, 0, 0, 0}};
+  KernelStat kstats_[kKcCount] = {{"gemm_planes_tile", 0, 0, 0, 0},     {"encoder_attention_planes", 0, 0, 0, 0},
+                                  {"layernorm_rows", 0, 0, 0, 0},       {"mel_transpose", 0, 0, 0, 0},
+                                  {"gemm_split16_tile", 0, 0, 0, 0},    {"encoder_attention_split", 0, 0, 0, 0},
+                                  {"f32_to_planes", 0, 0, 0, 0}};
   int self_cap_ = 32;
   static constexpr int kDecRowsMax = 128;  // rows of one decoder pass (k_decoder.hip: up to four 32-row tiles)
 };

@@ -768,19 +768,13 @@ void launch_encoder_attention(const float* qkv, float* out, int batch, int T, in
                               hipStream_t s, float q_scale, float k_scale, float v_scale) {
   const int q_blocks = (T + AQ - 1) / AQ;
   const dim3 grid(batch * heads * q_blocks);
+  (void)q_scale; (void)k_scale; (void)v_scale;
   if (variant == 0) {
     hipLaunchKernelGGL(encoder_attention_f32, grid, dim3(256), 0, s, qkv, out, T, heads);
-  } else if (variant == 2) {  // 8 wavefronts = 256 queries per block
-    const int qb8 = (T + 255) / 256;
-    hipLaunchKernelGGL((encoder_attention_split<8, 3>), dim3(batch * heads * qb8), dim3(512), 0, s, qkv, out, T, heads,
-                       1.0f, 1.0f, 1.0f);
-  } else if (variant == 4) {  // two fp16 planes, three products
-    hipLaunchKernelGGL((encoder_attention_split<4, 2>), grid, dim3(256), 0, s, qkv, out, T, heads, q_scale, k_scale,
-                       v_scale);
-  } else if (variant == 3) {  // bf16 compute mode: operands and probabilities rounded to bf16
-    hipLaunchKernelGGL((encoder_attention_split<4, 1>), grid, dim3(256), 0, s, qkv, out, T, heads, 1.0f, 1.0f, 1.0f);
-  } else {
+  } else if (variant == 1) {  // three bf16 planes, six products: full fp32 operand range (the engine's fall-back form)
     hipLaunchKernelGGL((encoder_attention_split<4, 3>), grid, dim3(256), 0, s, qkv, out, T, heads, 1.0f, 1.0f, 1.0f);
+  } else {
+    throw Error(kErrInvalidArg, "fp32-storage encoder attention: variant must be 0 (fp32 MFMA) or 1 (three bf16 planes)");
   }
 }
 

@@ -11,9 +11,10 @@
 // through that XCD's L2.  The epilogue goes through a per-wavefront LDS transpose (16-byte
 // global accesses).  tools/mfma_probe.hip measures what bounds this loop.
 //
-// This translation unit holds the three supported forms of the fp32-in / fp32-out GEMM
-// (variant 0 = fp32 MFMA, 13/16 = three bf16 planes, 17/18 = two fp16 planes) and the bf16 compute
-// mode (variant 11).  Tile-shape experiments and timing ablations live in tools/gemm_lab.hip only.
+// This translation unit holds the fp32-in / fp32-out GEMMs: variant 0 = fp32 MFMA (bench.py's exact-fp32 leg, the
+// reference form of the accuracy tests) and 13 / 16 = fp32 operands split into three bf16 planes inside the loop
+// (full fp32 operand range: the log-mel front end's two GEMMs and the per-contraction fall-back of the encoder,
+// engine.cpp).  The encoder's default GEMM is k_gemm_planes.hip.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -235,11 +236,6 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using half8 = __attribute__((ext_vector_type(8))) _Float16;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
-__device__ __forceinline__ void round_store8(const f32x4& lo, const f32x4& hi, unsigned short* dst) {
-  const float x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  *reinterpret_cast<u32x4_t*>(dst) = round8_bf16(x);
-}
-
 template <int NS>
 __device__ __forceinline__ void split_store8(const f32x4& lo, const f32x4& hi, unsigned short* dst, int plane_stride) {
   static_assert(NS == 3, "three bf16 planes");
@@ -250,110 +246,6 @@ __device__ __forceinline__ void split_store8(const f32x4& lo, const f32x4& hi, u
   for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(dst + p * plane_stride) = o[p];
 }
 
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_tile(GemmDev g) {
-  constexpr int BM = 128, BN = 128, BK = 32, MI = 2, NI = 2;
-  constexpr int LD = BK + 8;            // bf16 per LDS row: 80 B, an odd multiple of 16 B
-  constexpr int PLANE = BM * LD;        // bf16 per operand
-  constexpr int kTileBytes = 2 * PLANE * 2, kStageBytes = 4 * 32 * (NI * 32 + 4) * 4;
-  __shared__ __attribute__((aligned(16))) unsigned char smem_raw[kTileBytes > kStageBytes ? kTileBytes : kStageBytes];
-  unsigned short* const As = reinterpret_cast<unsigned short*>(smem_raw);
-  unsigned short* const Bs = As + PLANE;
-
-  const int nb = gridDim.x, bid = blockIdx.x;
-  const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7;
-  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int n_tiles = g.N / BN;
-  const int m0 = (logical / n_tiles) * BM;
-  const int n0 = (logical % n_tiles) * BN;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 1, wn = wid & 1;
-  const int l31 = lane & 31, lh = lane >> 5;
-
-  // staging: 4 threads per row, 8 consecutive k each (two float4), 64 rows per pass
-  const int srow = tid >> 2, scol = (tid & 3) * 8;
-  const float* a_ptr[2];
-  const float* w_ptr[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    int m = m0 + srow + 64 * i;
-    m = m < g.M ? m : g.M - 1;  // clamp: rows past M are computed and discarded
-    a_ptr[i] = g.A + (long)(m / g.a_rpb) * g.a_bs + (long)(m % g.a_rpb) * g.lda + scol;
-    w_ptr[i] = g.W + (long)(n0 + srow + 64 * i) * g.K + scol;
-  }
-
-  f32x16 acc[MI][NI];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NI; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-  f32x4 st0[8], st1[8];  // two register stages: {A pass 0, A pass 1, W pass 0, W pass 1} x 2 float4
-  auto load_into = [&](f32x4* st, int kt) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      st[2 * i] = *reinterpret_cast<const f32x4*>(a_ptr[i] + kt * BK);
-      st[2 * i + 1] = *reinterpret_cast<const f32x4*>(a_ptr[i] + kt * BK + 4);
-      st[4 + 2 * i] = *reinterpret_cast<const f32x4*>(w_ptr[i] + kt * BK);
-      st[4 + 2 * i + 1] = *reinterpret_cast<const f32x4*>(w_ptr[i] + kt * BK + 4);
-    }
-  };
-  auto store_from = [&](const f32x4* st) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      round_store8(st[2 * i], st[2 * i + 1], As + (srow + 64 * i) * LD + scol);
-      round_store8(st[4 + 2 * i], st[4 + 2 * i + 1], Bs + (srow + 64 * i) * LD + scol);
-    }
-  };
-  auto compute = [&]() {
-    const unsigned short* Ab = As + (wm * 64 + l31) * LD + 8 * lh;
-    const unsigned short* Bb = Bs + (wn * 64 + l31) * LD + 8 * lh;
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      // lane (row l31, half lh) holds k = 16*ks + 8*lh + 0..7 of its row, for A and W alike
-      bf16x8 af[MI], bf[NI];
-#pragma unroll
-      for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * LD + ks * 16);
-#pragma unroll
-      for (int j = 0; j < NI; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * LD + ks * 16);
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-    }
-  };
-
-  const int nkt = g.K / BK;
-  load_into(st0, 0);
-  if (nkt > 1) load_into(st1, 1);
-  for (int kt = 0; kt < nkt; kt += 2) {
-    store_from(st0);
-    __syncthreads();
-    if (kt + 2 < nkt) load_into(st0, kt + 2);
-    compute();
-    __syncthreads();
-    if (kt + 1 < nkt) {
-      store_from(st1);
-      __syncthreads();
-      if (kt + 3 < nkt) load_into(st1, kt + 3);
-      compute();
-      __syncthreads();
-    }
-  }
-  tile_epilogue<EPI, BM, BN, MI, NI>(g, acc, reinterpret_cast<float*>(smem_raw), m0, n0);
-}
-
-template <int EPI>
-void launch_bf16(const GemmDev& g, hipStream_t s) {
-  const int blocks = ((g.M + 127) / 128) * (g.N / 128);
-  hipLaunchKernelGGL((gemm_bf16_tile<EPI>), dim3(blocks), dim3(256), 0, s, g);
-}
-
 // gemm_split16_tile: the 3-plane split GEMM software-pipelined inside each wavefront.  k-tiles of
 // 16 with two LDS buffers (73.7 KB, 2 blocks per CU): while the 24 MFMAs of k-tile t run, the
 // same wavefront splits the registers of k-tile t+1 and writes them to the other buffer (the
@@ -361,12 +253,9 @@ void launch_bf16(const GemmDev& g, hipStream_t s) {
 // global loads of k-tile t+3 are in flight.  One barrier per k-tile.
 // PAD2: LDS padded to 54 KB so that exactly two blocks share a CU (pipelined mode: leaves registers and LDS
 // to co-resident decoder blocks; results unchanged).
-template <int EPI, bool PAD2 = false, bool F16 = false>
+template <int EPI, bool PAD2 = false>
 __global__ __launch_bounds__(256, 2) void gemm_split16_tile(GemmDev g) {
-  // F16: two fp16 planes and three products (bf16_split.h, split8_f16x2) instead of three bf16 planes and
-  // six; A and W are scaled by powers of two (GemmArgs::a_scale, w_scale: from operand bounds) into fp16's
-  // normal range and the accumulators are scaled back before the epilogue
-  constexpr int BM = 128, BN = 128, BK = 16, MI = 2, NI = 2, NS = F16 ? 2 : 3;
+  constexpr int BM = 128, BN = 128, BK = 16, MI = 2, NI = 2, NS = 3;
   // bf16 per LDS row: 32 B, unpadded. The two 16-byte chunks of a row are stored swapped when bit 3
   // of the row is set: a 16-lane group of a ds_read_b128 (16 consecutive rows, same k half) then
   // covers all 64 banks once, and the staging writes (both chunks of 4 consecutive rows per 8
@@ -414,19 +303,6 @@ __global__ __launch_bounds__(256, 2) void gemm_split16_tile(GemmDev g) {
     st[3] = *reinterpret_cast<const f32x4*>(w_ptr + kt * BK + 4);
   };
   auto store_from = [&](const f32x4* st, int buf) {
-    if (F16) {
-      const float xa[8] = {st[0][0], st[0][1], st[0][2], st[0][3], st[1][0], st[1][1], st[1][2], st[1][3]};
-      const float xw[8] = {st[2][0], st[2][1], st[2][2], st[2][3], st[3][0], st[3][1], st[3][2], st[3][3]};
-      u32x4_t oa[3], ow[3];
-      split8_f16x2(xa, g.a_scale, oa);
-      split8_f16x2(xw, g.w_scale, ow);
-#pragma unroll
-      for (int p = 0; p < NS; ++p) {
-        *reinterpret_cast<u32x4_t*>(lds + buf * BUF + p * PLANE + st_off) = oa[p];
-        *reinterpret_cast<u32x4_t*>(lds + buf * BUF + (NS + p) * PLANE + st_off) = ow[p];
-      }
-      return;
-    }
     split_store8<3>(st[0], st[1], lds + buf * BUF + st_off, PLANE);
     split_store8<3>(st[2], st[3], lds + buf * BUF + NS * PLANE + st_off, PLANE);
   };
@@ -454,12 +330,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split16_tile(GemmDev g) {
         for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int j = 0; j < NI; ++j)
-            if (F16) {
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, af[i][pa]),
-                                                                 __builtin_bit_cast(half8, bf[j][pb]), acc[i][j], 0, 0, 0);
-            } else {
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][pa], bf[j][pb], acc[i][j], 0, 0, 0);
-            }
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][pa], bf[j][pb], acc[i][j], 0, 0, 0);
       }
   };
   const int nkt = g.K / BK;
@@ -497,19 +368,13 @@ __global__ __launch_bounds__(256, 2) void gemm_split16_tile(GemmDev g) {
       __syncthreads();
     }
   }
-  if (F16) {
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NI; ++j) acc[i][j] *= g.descale;
-  }
   tile_epilogue<EPI, BM, BN, MI, NI>(g, acc, reinterpret_cast<float*>(smem_raw), m0, n0);
 }
 
-template <int EPI, bool PAD2, bool F16>
+template <int EPI, bool PAD2>
 void launch_split16(const GemmDev& g, hipStream_t s) {
   const int blocks = ((g.M + 127) / 128) * (g.N / 128);
-  hipLaunchKernelGGL((gemm_split16_tile<EPI, PAD2, F16>), dim3(blocks), dim3(256), 0, s, g);
+  hipLaunchKernelGGL((gemm_split16_tile<EPI, PAD2>), dim3(blocks), dim3(256), 0, s, g);
 }
 
 template <int EPI>
@@ -520,27 +385,23 @@ void launch_gemm_t(const GemmDev& g, int variant, hipStream_t s) {
       hipLaunchKernelGGL((gemm_f32_tile<EPI, 128, 128, 32>), dim3(blocks), dim3(256), 0, s, g);
       break;
     }
-    case 11: launch_bf16<EPI>(g, s); break;                   // operands rounded to bf16 (configs[3] compute mode)
-    case 13: launch_split16<EPI, false, false>(g, s); break;  // three bf16 planes, six products: full fp32 range
-    case 16: launch_split16<EPI, true, false>(g, s); break;   // same at 2 blocks per CU
-    case 17: launch_split16<EPI, false, true>(g, s); break;   // two fp16 planes, three products (22-bit operands)
-    case 18: launch_split16<EPI, true, true>(g, s); break;    // same at 2 blocks per CU
-    default: throw Error(kErrInvalidArg, "gemm_variant must be one of 0, 11, 13, 16, 17, 18");
+    case 13: launch_split16<EPI, false>(g, s); break;  // three bf16 planes, six products: full fp32 range
+    case 16: launch_split16<EPI, true>(g, s); break;   // same at 2 blocks per CU
+    default: throw Error(kErrInvalidArg, "gemm_variant must be one of 0, 13, 16");
   }
 }
 
 }  // namespace
 
 bool gemm_variant_supported(int variant) {
-  return variant == 0 || variant == 11 || variant == 13 || variant == 16 || variant == 17 || variant == 18;
+  return variant == 0 || variant == 13 || variant == 16;
 }
 
 int gemm_occupancy(int variant) {
   int n = -1;
   switch (variant) {
     case 0: (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_f32_tile<kEpiBias, 128, 128, 32>, 256, 0); break;
-    case 13: (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_split16_tile<kEpiBias, false, false>, 256, 0); break;
-    case 17: (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_split16_tile<kEpiBias, false, true>, 256, 0); break;
+    case 13: (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_split16_tile<kEpiBias, false>, 256, 0); break;
     default: break;
   }
   return n;

@@ -338,6 +338,7 @@ void launch_gemm_planes(const PlaneGemmArgs& a, int epi, hipStream_t s) {
   }
   switch (epi | (planes ? 256 : 0)) {
     case kEpiBias: launch_planes<kEpiBias, false>(g, a.n_cu, s); break;
+    case kEpiBias | kEpiGelu: launch_planes<kEpiBias | kEpiGelu, false>(g, a.n_cu, s); break;  // fp32 for a fall-back consumer
     case kEpiBias | kEpiResidual: launch_planes<kEpiBias | kEpiResidual, false>(g, a.n_cu, s); break;
     case kEpiBias | kEpiGelu | kEpiPos: launch_planes<kEpiBias | kEpiGelu | kEpiPos, false>(g, a.n_cu, s); break;
     case kEpiBias | kEpiKvLayout: launch_planes<kEpiBias | kEpiKvLayout, false>(g, a.n_cu, s); break;

@@ -3,6 +3,8 @@
 // and the decoder's token embedding / greedy selection (whisper.cpp:346-361, :392-399).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "bf16_split.h"
 #include "kernels.h"
 
@@ -119,6 +121,28 @@ __global__ __launch_bounds__(256) void layernorm_rows_planes(const float* __rest
       *reinterpret_cast<half4*>(yp + row * d + c) = hi;
       *reinterpret_cast<half4*>(yp + plane + row * d + c) = lo;
     }
+  }
+}
+
+// fp32 rows [M][ld] -> two fp16 planes of x * scale (hi at yp, lo at yp + plane), column n scaled by
+// scale[n / seg]: the hand-over from a contraction that ran on the full-range fp32-storage kernels (a load-time
+// fall-back, engine.cpp) to the next one, which takes its operand as planes.  4 columns per thread.
+struct SegScales {
+  float s[3];
+};
+__global__ __launch_bounds__(256) void f32_to_planes(const float* __restrict__ x, _Float16* __restrict__ yp, long plane,
+                                                     SegScales sc, int seg, int ld, long n4) {
+  using f32x4 = __attribute__((ext_vector_type(4))) float;
+  using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * i);
+    const int col = (int)((4 * i) % ld);
+    const float s = sc.s[col / seg];
+    unsigned h0, l0, h1, l1;
+    split_f16x2(v[0] * s, v[1] * s, &h0, &l0);
+    split_f16x2(v[2] * s, v[3] * s, &h1, &l1);
+    *reinterpret_cast<u32x2*>(yp + 4 * i) = u32x2{h0, h1};
+    *reinterpret_cast<u32x2*>(yp + plane + 4 * i) = u32x2{l0, l1};
   }
 }
 
@@ -324,6 +348,16 @@ void launch_layernorm_planes(const float* x, unsigned short* yp, long plane, flo
   } else {
     launch_ln_planes<false>(x, y, plane, scale, y32, g, b, M, d, s, nonfinite);
   }
+}
+
+void launch_f32_to_planes(const float* x, unsigned short* yp, long plane, long M, int ld, const float* scales, int seg,
+                          hipStream_t s) {
+  if (seg <= 0) seg = ld;
+  if (M < 1 || ld % 4 != 0 || seg % 4 != 0 || (ld + seg - 1) / seg > 3) throw Error(kErrInvalidArg, "f32_to_planes: bad shape");
+  SegScales sc{{scales[0], (ld + seg - 1) / seg > 1 ? scales[1] : 1.0f, (ld + seg - 1) / seg > 2 ? scales[2] : 1.0f}};
+  const long n4 = M * ld / 4;
+  const unsigned blocks = (unsigned)std::min<long>((n4 + 255) / 256, 256 * 32);
+  hipLaunchKernelGGL(f32_to_planes, dim3(blocks), dim3(256), 0, s, x, reinterpret_cast<_Float16*>(yp), plane, sc, seg, ld, n4);
 }
 
 void launch_mel_transpose_planes(const float* mel, unsigned short* out, long plane, float scale, int batch, int n_mels,

@@ -165,6 +165,11 @@ void launch_layernorm(const float* x, float* y, const float* g, const float* b, 
 void launch_layernorm_planes(const float* x, unsigned short* yp, long plane, float scale, float* y32, const float* g,
                              const float* b, int M, int d, hipStream_t s, int* nonfinite = nullptr, bool bf16 = false);
 
+// fp32 rows [M][ld] (contiguous) -> planes of x * scales[n / seg] (seg = 0: one segment), hi at yp, lo at yp + plane:
+// the operand hand-over between a contraction on the fp32-storage fall-back kernels and one on the plane kernels
+void launch_f32_to_planes(const float* x, unsigned short* yp, long plane, long M, int ld, const float* scales, int seg,
+                          hipStream_t s);
+
 // ------------------------------------------------------ encoder attention ---
 // qkv [B*T][3*d] (q | k | v, heads of 64 inside each third) -> out [B*T][d].
 // Non-causal softmax(q k^T / 8) v per (clip, head), flash-style; `variant`: 0 fp32 MFMA, 1/2 three bf16

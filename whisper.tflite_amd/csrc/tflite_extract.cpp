@@ -46,6 +46,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <vector>
@@ -155,6 +157,7 @@ struct Constant {
   std::vector<int> shape;
   std::vector<float> data;  // de-quantised
   int first_use = 1 << 30;  // index of the first operator that reads it
+  int first_use_slot = 0;   // its position among that operator's inputs
   int first_use_opcode = -1;
   bool used = false;
   size_t numel() const { return data.size(); }
@@ -288,6 +291,7 @@ std::vector<Constant> read_constants(const std::string& path) {
       Constant& c = out[size_t(const_of_tensor[ti])];
       if (int(oi) < c.first_use) {
         c.first_use = int(oi);
+        c.first_use_slot = int(k);
         c.first_use_opcode = ci < opcode.size() ? opcode[ci] : -1;
       }
     }
@@ -375,7 +379,7 @@ bool name_matches(const std::string& tensor_name, const std::string& param, cons
 }
 
 void assign_graph(std::vector<Constant>& consts, const std::string& graph, std::vector<wtw::NamedTensor>& tensors,
-                  const std::string& path) {
+                  const std::string& path, std::vector<std::string>* report) {
   // (1) by name
   for (wtw::NamedTensor& t : tensors) {
     if (t.name.compare(0, graph.size() + 1, graph + ".") != 0 || !t.data.empty()) continue;
@@ -383,26 +387,43 @@ void assign_graph(std::vector<Constant>& consts, const std::string& graph, std::
       if (c.used || !name_matches(c.name, t.name, graph)) continue;
       if (to_torch_layout(c, t.shape, &t.data)) {
         c.used = true;
+        if (report) report->push_back(t.name + " <- \"" + c.name + "\" (rule 1: name)");
         break;
       }
     }
   }
-  // (2) by order of first use and element count
+  // (2) by order of first use — operator index, then position among that operator's inputs (a FULLY_CONNECTED carries
+  // its weight at input 1 and its bias at input 2) — and element count
   std::vector<Constant*> order;
   for (Constant& c : consts)
     if (!c.used && c.first_use < (1 << 30)) order.push_back(&c);
-  std::stable_sort(order.begin(), order.end(), [](const Constant* a, const Constant* b) { return a->first_use < b->first_use; });
-  size_t cursor = 0;
+  std::stable_sort(order.begin(), order.end(), [](const Constant* a, const Constant* b) {
+    return a->first_use != b->first_use ? a->first_use < b->first_use : a->first_use_slot < b->first_use_slot;
+  });
   for (wtw::NamedTensor& t : tensors) {
     if (t.name.compare(0, graph.size() + 1, graph + ".") != 0 || !t.data.empty()) continue;
     bool found = false;
-    for (size_t i = cursor; i < order.size() && !found; ++i) {
+    for (size_t i = 0; i < order.size() && !found; ++i) {
       if (order[i]->used || order[i]->numel() != numel_of(t.shape)) continue;
+      // Parameters of equal size are told apart by first-use order only.  Two unnamed candidates that ONE operator
+      // reads (a folded LayerNorm's gain and shift, a fused q|k|v) have no order to go by: refuse rather than guess.
+      for (size_t j = i + 1; j < order.size(); ++j) {
+        if (order[j]->used || order[j]->numel() != order[i]->numel()) continue;
+        if (order[j]->first_use == order[i]->first_use) {
+          throw Error(kErrFormat, path + ": cannot tell which constant is " + t.name + ": operator #" +
+                                      std::to_string(order[i]->first_use) + " reads several unnamed constants of " +
+                                      std::to_string(order[i]->numel()) + " elements (\"" + order[i]->name + "\", \"" +
+                                      order[j]->name + "\")");
+        }
+        break;  // the next candidate of this size belongs to a later operator
+      }
       if (to_torch_layout(*order[i], t.shape, &t.data)) {
         order[i]->used = true;
-        // parameters of equal size are told apart by order only: never look behind the last match of that size
-        cursor = (t.shape.size() == 1) ? cursor : cursor;
         found = true;
+        if (report) {
+          report->push_back(t.name + " <- \"" + order[i]->name + "\" (rule 2: first use, operator #" +
+                            std::to_string(order[i]->first_use) + " input " + std::to_string(order[i]->first_use_slot) + ")");
+        }
       }
     }
     if (!found) throw Error(kErrFormat, path + ": no constant found for " + t.name);
@@ -436,8 +457,13 @@ void convert_tflite(const std::string& model_prefix, const std::string& out_path
     throw Error(kErrFormat, model_prefix + ": the .tflite pair matches none of the supported architectures (tiny, tiny.en, base)");
   }
   std::vector<wtw::NamedTensor> tensors = wtw::tensor_specs(dims);
-  assign_graph(enc, "encoder", tensors, enc_path);
-  assign_graph(dec, "decoder", tensors, dec_path);
+  // WT_VERBOSE: which rule matched each parameter (a real converter file orders and names constants its own way;
+  // this mapping is what to read first when a transcript comes out as garbage)
+  std::vector<std::string> report;
+  const bool verbose = getenv("WT_VERBOSE") != nullptr;
+  assign_graph(enc, "encoder", tensors, enc_path, verbose ? &report : nullptr);
+  assign_graph(dec, "decoder", tensors, dec_path, verbose ? &report : nullptr);
+  for (const std::string& line : report) std::fprintf(stderr, "[wt-convert] %s\n", line.c_str());
   std::string err;
   const int rc = wtw::write_tensors(out_path.c_str(), dims, tensors, 0, &err);
   if (rc != 0) throw Error(rc == 1 ? kErrFormat : kErrIo, err);

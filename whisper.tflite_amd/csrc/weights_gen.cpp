@@ -8,6 +8,8 @@
 // element are used, so the bytes do not depend on libm or the host CPU.
 #include "weights_gen.h"
 
+#include <unistd.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -187,9 +189,12 @@ int write_tensors(const char* path, const Dims& dims, const std::vector<NamedTen
   }
   hdr.file_bytes = off;
 
-  FILE* f = std::fopen(path, "wb");
+  // Written next to the target under a name of its own and renamed into place: a reader (another rank converting
+  // the same .tflite pair, a later wt_engine_create) sees either no file or a complete one, never a short write.
+  const std::string tmp = std::string(path) + ".tmp." + std::to_string(static_cast<long>(::getpid()));
+  FILE* f = std::fopen(tmp.c_str(), "wb");
   if (!f) {
-    if (err) *err = std::string("cannot open for writing: ") + path;
+    if (err) *err = std::string("cannot open for writing: ") + tmp;
     return 2;
   }
   bool ok = std::fwrite(&hdr, sizeof(hdr), 1, f) == 1;
@@ -210,9 +215,16 @@ int write_tensors(const char* path, const Dims& dims, const std::vector<NamedTen
     pos += n * sizeof(float);
   }
   pad_to(hdr.file_bytes);
+  ok = ok && std::fflush(f) == 0 && ::fsync(::fileno(f)) == 0;
   ok = (std::fclose(f) == 0) && ok;
   if (!ok) {
-    if (err) *err = std::string("short write: ") + path;
+    ::unlink(tmp.c_str());
+    if (err) *err = std::string("short write: ") + tmp;
+    return 2;
+  }
+  if (::rename(tmp.c_str(), path) != 0) {  // two writers racing for the same name both succeed: same bytes
+    ::unlink(tmp.c_str());
+    if (err) *err = std::string("cannot rename into place: ") + path;
     return 2;
   }
   return 0;

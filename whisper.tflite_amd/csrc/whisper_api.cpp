@@ -125,8 +125,12 @@ std::string remove_extra_spaces(const std::string& input) { return wt::remove_ex
 template <class Int>
 std::string decode(const Vocab& vocab, const Int* begin, const Int* end, bool omit_special_tokens) {
   std::vector<int64_t> ids(begin, end);
-  bool missing = false;  // the reference asserts on an unknown id (whisper.cpp:642); it is skipped here
-  return wt::decode_tokens(to_data(vocab), ids.data(), int(ids.size()), omit_special_tokens, &missing);
+  // An id without a vocabulary entry: the reference asserts (whisper.cpp:642; undefined behaviour in a release
+  // build).  Here it is an exception, in line with the C ABI, where wt_vocab_decode returns WT_ERR_INVALID_ARG.
+  bool missing = false;
+  std::string text = wt::decode_tokens(to_data(vocab), ids.data(), int(ids.size()), omit_special_tokens, &missing);
+  if (missing) throw std::out_of_range("whisper::decode: token id without a vocabulary entry");
+  return text;
 }
 template std::string decode(const Vocab& vocab, const int* begin, const int* end, bool omit_special_tokens);
 template std::string decode(const Vocab& vocab, const int64_t* begin, const int64_t* end, bool omit_special_tokens);
@@ -144,9 +148,10 @@ std::vector<float> wav_read_legacy(const char* filename) {
 // --------------------------------------------------------------- front end ---
 bool log_mel_spectrogram(const float* samples, int n_samples, int sample_rate, int fft_size, int fft_step,
                          int n_mel, int /*n_threads*/, Filters& filters, Mel& mel) {
-  if (sample_rate != kSampleRate || fft_size != kNFFT || fft_step != kHopLength || n_mel != filters.n_mel ||
+  (void)sample_rate;  // the reference never reads it either (whisper.cpp:109-216)
+  if (fft_size != kNFFT || fft_step != kHopLength || n_mel != filters.n_mel ||
       size_t(filters.n_mel) * size_t(filters.n_fft) != filters.data.size()) {
-    std::cerr << "log_mel_spectrogram: only the reference's fixed geometry (16 kHz, fft 400, hop 160) runs on the GPU front end\n";
+    std::cerr << "log_mel_spectrogram: only the reference's fixed geometry (fft 400, hop 160, 80 x 201 filters) runs on the GPU front end\n";
     return false;
   }
   mel.n_mel = n_mel;
