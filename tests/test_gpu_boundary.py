@@ -165,6 +165,116 @@ def test_unsupported_weight_files_and_options_return_status_codes(pkg, assets, t
     unknown GEMM variant.  Each must come back as a status code with a message — the process survives
     (before: abort() inside launch_ln / launch_gemm_t, SIGFPE in upload_weights)."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from wtw import read_wtw, write_wtw
+    prefix, vocab = assets("micro")
+    dims, t = read_wtw(prefix + ".wtw")
+    L = pkg.lib()
+
+    def create(path_prefix):
+        h = ctypes.c_void_p()
+        rc = L.wt_engine_create(1, path_prefix.encode(), vocab.encode(), 1, 0, ctypes.byref(h))
+        assert not h.value
+        return rc, L.wt_last_error(None).decode()
+
+    def variant(name, **over):
+        d = dict(dims)
+        d.update(over)
+        p = str(tmp_path / name)
+        write_wtw(p + ".wtw", d, t)
+        return p
+
+    rc, msg = create(variant("d256", n_audio_state=256, n_text_state=256, n_audio_head=4, n_text_head=4))
+    assert rc == 3 and "d_model" in msg                      # WT_ERR_FORMAT
+    rc, msg = create(variant("heads0", n_audio_head=0))
+    assert rc == 3 and "heads" in msg
+    rc, msg = create(variant("ctx8", n_audio_ctx=8))
+    assert rc == 3
+    rc, msg = create(variant("tctx16", n_text_ctx=16))
+    assert rc == 3
+    rc, msg = create(variant("vocab0", n_vocab=0))
+    assert rc == 3
+    # tensor table: offset + nbytes wraps around 2^64 / payload not 4-byte aligned
+    raw = bytearray(open(prefix + ".wtw", "rb").read())
+    e0 = 128
+    bad = bytearray(raw)
+    struct.pack_into("<QQ", bad, e0 + 104, 2 ** 64 - 4, 8)
+    (tmp_path / "wrap.wtw").write_bytes(bad)
+    assert create(str(tmp_path / "wrap"))[0] == 3
+    bad = bytearray(raw)
+    off, nb = struct.unpack_from("<QQ", raw, e0 + 104)
+    struct.pack_into("<QQ", bad, e0 + 104, off + 2, nb - 4)
+    (tmp_path / "unaligned.wtw").write_bytes(bad)
+    assert create(str(tmp_path / "unaligned"))[0] == 3
+    (tmp_path / "trunc.wtw").write_bytes(raw[:1000])
+    assert create(str(tmp_path / "trunc"))[0] == 3
+    assert create(str(tmp_path / "missing"))[0] == 2          # WT_ERR_IO
+    # options: variants that do not exist are refused when they are set, not when a kernel is launched
+    e = pkg.Engine(prefix, vocab, True)
+    for bad_v in (12, 1, 10, 11, 14, 17, 18, 19, -2):
+        with pytest.raises(pkg.WtError) as ei:
+            e.set_option("gemm_variant", bad_v)
+        assert ei.value.code == 1
+    for bad_v in (2, 3, 5, -1):
+        with pytest.raises(pkg.WtError):
+            e.set_option("attn_variant", bad_v)
+    e.set_prompt([3, 5, 7, 11])
+    mel = np.random.default_rng(1).uniform(-1, 1.5, size=(1,) + e.mel_shape).astype(np.float32)
+    ids, n = e.encdec_tokens_batch(mel)  # and the engine works after the refused options
+    assert n[0] >= 5
+    # kernel-level taps: shapes outside a kernel's contract are errors too
+    with pytest.raises(pkg.WtError):
+        e.dbg_layernorm(np.zeros((4, 600), np.float32), np.ones(600, np.float32), np.zeros(600, np.float32))
+    with pytest.raises(pkg.WtError):
+        e.dbg_dec_gemm(np.zeros((4, 96), np.float32), np.zeros((64, 96), np.float32), mode=2, R=np.zeros((4, 64), np.float32))
+    e.close()
+
+
+def test_sync_call_with_batches_in_flight_is_refused_before_any_work(pkg, assets):
+    """With the pipeline FULL (6 uncollected batches) a synchronous call used to enqueue its encoder first — onto
+    the oldest uncollected slot, overwriting that batch — and throw only at decode().  Now every synchronous entry
+    point checks first: error, nothing enqueued, and the later collects return the ORIGINAL ids (also when the
+    refused call carried a larger batch than the submitted ones)."""
+    prefix, vocab = assets("micro")
+    e = pkg.Engine(prefix, vocab, True)
+    e.set_option("stop_at_eot", 0)
+    e.set_prompt([3, 5, 7, 11])
+    rng = np.random.default_rng(21)
+    mels = [rng.uniform(-1.0, 1.5, size=(3,) + e.mel_shape).astype(np.float32) for _ in range(6)]
+    big = rng.uniform(-1.0, 1.5, size=(9,) + e.mel_shape).astype(np.float32)
+    want = [e.encdec_tokens_batch(m) for m in mels]
+    e.encdec_tokens_batch(big)  # grows the workspace now, not while batches are in flight
+    dev = [DevBuf(m) for m in mels]
+    d_big = DevBuf(big)
+    pcm = DevBuf(np.zeros((9, e.pcm_len), np.float32))
+    for d in dev:
+        e.pipeline_submit_dev(d.data_ptr(), 3)
+    assert e.get_option("in_flight") == 6
+    for call in (lambda: e.encdec_tokens_batch(big), lambda: e.encdec_tokens_batch_dev(d_big.data_ptr(), 9),
+                 lambda: e.encdec_debug_batch(big), lambda: e.transcribe(np.zeros(1000, np.float32)),
+                 lambda: e.logmel_batch(np.zeros((1, e.pcm_len), np.float32)),
+                 lambda: e.transcribe_tokens_batch_dev(pcm.data_ptr(), 9),
+                 lambda: e.transcribe_long(np.zeros(1000, np.float32))):
+        with pytest.raises(pkg.WtError) as ei:
+            call()
+        assert ei.value.code == 1 and "collect" in str(ei.value)
+    with pytest.raises(pkg.WtError):
+        e.pipeline_submit_dev(dev[0].data_ptr(), 3)  # a seventh submit: pipeline full
+    assert e.get_option("in_flight") == 6
+    for k in range(6):
+        ids, n = e.pipeline_collect()
+        assert ids.shape == (3, 32) and np.array_equal(ids, want[k][0]) and np.array_equal(n, want[k][1]), k
+    ids, n = e.encdec_tokens_batch(mels[2])  # synchronous calls work again
+    assert np.array_equal(ids, want[2][0])
+    e.close()
+
+
+# ----------------------------------------------------- fp16 two-plane kernels, adversarial weights ---
+
+def _adversarial_tiny(assets, tmp_path, name, ln_gain=30.0, heavy=True, v_row_scale=1.0):
+    """whisper-tiny random-init weights with the statistics a trained checkpoint can have and N(0, 1/fan_in) does
+    not (tools/wtw.py adversarial_weights: LayerNorm-gain outliers, LayerNorm shifts, heavy-tailed rows, one value
+    channel `v_row_scale` x larger with its out-projection column that much smaller)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
     from wtw import adversarial_weights
     prefix, vocab = assets("tiny")
     p = str(tmp_path / name)

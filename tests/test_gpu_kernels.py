@@ -459,6 +459,24 @@ def test_bf16_gemm_is_exact_on_integers(eng):
 
 
 @pytest.mark.parametrize("B,T,H", [(1, 64, 1), (2, 100, 2), (1, 1500, 8), (3, 333, 2)])
+@pytest.mark.parametrize("growth", [0.5, 2.9, 3.1, 9.0])
+def test_encoder_attention_planes_deferred_maximum(eng, growth):
+    """The kernel raises its running maximum only when a tile's maximum exceeds it by more than 3 (log2 domain); below
+    that the tile's probabilities exceed 1 (up to 2^3) and must still come out right — also when the excess accumulates
+    over several tiles before the rescale fires.  Scores that grow by `growth` (log2 units) per 64-key tile, against
+    the full fp64 softmax: just under and just over the threshold, far under, far over."""
+    rng = np.random.default_rng(int(growth * 10))
+    T, d = 400, 64
+    qkv = (rng.standard_normal((T, 3 * d)) * 0.05).astype(np.float32)
+    qkv[:, 0:d] += 1.0                                           # q ~ ones: |q|^2 ~ 64
+    ramp = growth / (64 * 1.4426950408889634) * np.arange(T)     # score of key j ~ ramp[j] after the 1/8 scaling
+    qkv[:, d:2 * d] += (ramp / 8.0)[:, None].astype(np.float32)  # k_j ~ ramp_j / 8 * ones -> q.k / 8 = ramp_j
+    out = eng.dbg_encoder_attention_planes(qkv, 1, T, 1)
+    q = qkv.astype(np.float64)
+    ref = attn_ref(q[:, 0:64], q[:, 64:128], q[:, 128:192])
+    assert np.abs(out - ref).max() < 2e-5, growth
+
+
 def test_encoder_attention_bf16_storage(eng, B, T, H):
     """encoder_attention_planes<true>: q, k, v read as bf16, probabilities rounded to bf16 for the PV product, fp32
     accumulation and softmax statistics.  Against fp64 attention on the bf16-rounded inputs what is left is the

@@ -3,14 +3,20 @@
 // "swapped" products S^T = K . Q^T and O^T += V^T . P^T so that a softmax row sits on a lane, both contractions
 // as three v_mfma_f32_32x32x16_f16 plane products with fp32 accumulation — but q, k and v ARRIVE as two fp16
 // planes each (written by the qkv GEMM's epilogue, q already multiplied by d_head^-1/2 * log2(e)), so that
-//   * staging a K/V tile is a plain copy (16-byte global load -> ds_write_b128): round 1's kernel re-split every
-//     K and V element on the VALU in each of the 12 query blocks that stream it, and wrote the V^T image with
-//     scattered 4-byte LDS stores (the bank-conflict source rocprof showed: SQ_LDS_BANK_CONFLICT = LDS-active cycles);
+//   * a K/V tile goes global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write, no VALU;
+//     round 2 moved it through 32 VGPRs + ds_write_b128, round 1 re-split every element on the VALU in each of the 12
+//     query blocks that stream it).  K is double-buffered, V single: 48 KB per block and 164 VGPRs, so THREE blocks
+//     share a CU (three wavefronts per SIMD to overlap one's softmax with another's MFMAs; round 2: two);
 //   * V stays row-major [key][d] in LDS and its transposed MFMA fragments come from ds_read_b64_tr_b16, the hardware
 //     transpose read of gfx950 (each 16-lane group fetches a 4-key x 16-d block column-major);
 //   * both LDS images are XOR-swizzled in 16-byte chunks so that the fragment reads are conflict-free:
 //     K rows (128 B): chunk ^= (key >> 1) & 7 (ds_read_b128, 16-lane groups); V rows: chunk ^= ((key >> 1) & 1) << 2
-//     (a 32-lane half of the tr read covers 4 keys x 64 B = one 256-byte bank row);
+//     (a 32-lane half of the tr read covers 4 keys x 64 B = one 256-byte bank row) — applied to the per-lane SOURCE
+//     address of the DMA, whose LDS destination is lane-linear;
+//   * the running maximum is only raised when a tile's maximum exceeds it by more than kDefer = 3 (in the log2
+//     domain): probabilities then reach at most 2^3, their fp16 planes 2^(12 + 3) < 65504, and the 32 multiplies per
+//     lane that rescale O disappear from almost every tile (with 32 query rows per wavefront SOME row used to raise
+//     its maximum in most tiles);
 //   * the result leaves as two fp16 planes scaled for the out-projection GEMM.
 // Only the probabilities P = exp2(S^T - m) are split in registers (they are born there).
 #include <hip/hip_runtime.h>
@@ -37,12 +43,20 @@ __device__ __forceinline__ int crow(int r, int h) { return (r & 3) + 8 * (r >> 2
 // BF: bf16 storage mode — q, k, v and the output are ONE bf16 plane each (plane offsets unused), one
 // v_mfma_f32_32x32x16_bf16 per product, probabilities rounded to bf16; s_inv then carries the softmax scale itself
 // (d_head^-1/2 * log2 e: the qkv GEMM does not pre-scale q in that mode) and o_scale is 1.
+constexpr float kDefer = 3.0f;   // log2 of the factor a tile's maximum may exceed the running maximum by without a rescale
+constexpr float kPShift = 12.0f;  // probabilities are scaled by 2^12 before their fp16 split: 2^(12 + kDefer) < 65504
+
 template <bool BF>
-__global__ __launch_bounds__(256, 2) void encoder_attention_planes(const _Float16* __restrict__ qkv, long plane,
+__global__ __launch_bounds__(256, BF ? 4 : 3) void encoder_attention_planes(const _Float16* __restrict__ qkv, long plane,
                                                                    _Float16* __restrict__ out, long out_plane, int T,
                                                                    int heads, float s_inv, float o_scale) {
-  // [K hi][K lo][V hi][V lo], 8 KB each; bf16 mode: [K][unused][V][unused]
-  __shared__ __attribute__((aligned(16))) unsigned char lds[4 * kPlaneBytes];
+  // [K0 hi][K0 lo][K1 hi][K1 lo][V hi][V lo], 8 KB each (K double-buffered): 48 KB, three blocks per CU; bf16 mode
+  // has one plane per tensor ([K0][K1][V]: 24 KB, four blocks per CU)
+  // (dynamic LDS: with a static __shared__ array hipcc knows that the DMA in flight writes the array its ds_reads
+  // come from and puts an s_waitcnt vmcnt(0) in front of them, which would wait for every prefetch right at its issue)
+  constexpr int NP = BF ? 1 : 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int kVOff = 2 * NP * kPlaneBytes;
   using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
   const int d_model = heads * 64, ld = 3 * d_model;
@@ -74,43 +88,25 @@ __global__ __launch_bounds__(256, 2) void encoder_attention_planes(const _Float1
   for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.0f;
   float m_run = -1e30f, l_run = 0.0f;
 
-  // staging: a tile is 4 planes x 64 rows x 8 chunks of 16 B = 2048 chunks, 8 per thread: thread = (row tid >> 2,
-  // chunk pair tid & 3) for each plane
-  const int srow = tid >> 2, sc0 = (tid & 3) * 2;
-  // ds_write_b128 is served in groups of 8 consecutive lanes (= two rows of this mapping) over 32 banks = 128 B: the
-  // two rows of a group must write DIFFERENT chunks, so odd rows take their chunk pair in the opposite order (their
-  // swizzle terms are equal: both depend on row >> 1)
-  const int e0 = (srow & 1) * 8, e1 = 8 - e0;  // element offsets of the first / second chunk this thread moves
-  const _Float16* kbase = base + d_model + sc0 * 8;
-  const _Float16* vbase = base + 2 * d_model + sc0 * 8;
-  u32x4 st[8];
-  auto load_tile = [&](int kt) {
-    const int key = kt * AK + srow;
-    const long ro = (long)(key < T ? key : T - 1) * ld;  // rows past T re-read row T - 1; their scores are masked
-    st[0] = *reinterpret_cast<const u32x4*>(kbase + ro + e0);
-    st[1] = *reinterpret_cast<const u32x4*>(kbase + ro + e1);
-    if (!BF) {
-      st[2] = *reinterpret_cast<const u32x4*>(kbase + plane + ro + e0);
-      st[3] = *reinterpret_cast<const u32x4*>(kbase + plane + ro + e1);
-    }
-    st[4] = *reinterpret_cast<const u32x4*>(vbase + ro + e0);
-    st[5] = *reinterpret_cast<const u32x4*>(vbase + ro + e1);
-    if (!BF) {
-      st[6] = *reinterpret_cast<const u32x4*>(vbase + plane + ro + e0);
-      st[7] = *reinterpret_cast<const u32x4*>(vbase + plane + ro + e1);
-    }
-  };
-  const int kx = (srow >> 1) & 7, vx = ((srow >> 1) & 1) << 2;
-  auto store_tile = [&]() {
-    unsigned char* row = lds + srow * 128;
+  // LDS-DMA of a K or V tile: one wave-instruction copies 8 rows x 128 B (1 KiB) of one plane; LDS slot (row
+  // lane >> 3, chunk lane & 7) of instruction (plane p, row group g) is base + p * 8 KB + g * 1 KB + lane * 16 (the
+  // destination is lane-linear), and takes the global chunk (lane & 7) ^ swizzle(row) of that row.  Wave w issues
+  // (p, g) = (0, w), (0, w + 4) and, with two planes, (1, w), (1, w + 4): rows 8 w + (lane >> 3) and 32 more.
+  const int drow = 8 * wid + (lane >> 3);                       // + 32 for the second row group
+  const int kch = (lane & 7) ^ ((drow >> 1) & 7);               // (row + 32) >> 1 has the same low three bits
+  const int vch = (lane & 7) ^ (((drow >> 1) & 1) << 2);
+  const _Float16* const kbase = base + d_model + kch * 8;
+  const _Float16* const vbase = base + 2 * d_model + vch * 8;
+  auto dma_tile = [&](const _Float16* src, int kt, unsigned char* dst) {
+    const int k0 = kt * AK + drow, k1 = k0 + 32;
+    const long r0 = (long)(k0 < T ? k0 : T - 1) * ld, r1 = (long)(k1 < T ? k1 : T - 1) * ld;  // rows past T re-read row T - 1; their scores are masked
+    unsigned char* d = dst + wid * 1024;
 #pragma unroll
     for (int p = 0; p < (BF ? 1 : 2); ++p) {
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int ch = sc0 + (e ^ (srow & 1));
-        *reinterpret_cast<u32x4*>(row + p * kPlaneBytes + ((ch ^ kx) << 4)) = st[2 * p + e];
-        *reinterpret_cast<u32x4*>(row + (2 + p) * kPlaneBytes + ((ch ^ vx) << 4)) = st[4 + 2 * p + e];
-      }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + p * plane + r0),
+                                       (__attribute__((address_space(3))) void*)(d + p * kPlaneBytes), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + p * plane + r1),
+                                       (__attribute__((address_space(3))) void*)(d + p * kPlaneBytes + 4096), 16, 0, 0);
     }
   };
   // fragment addresses.  K: lane (key l31 (+32), half lh), k-step c -> chunk 2c + lh of its row.
@@ -120,12 +116,16 @@ __global__ __launch_bounds__(256, 2) void encoder_attention_planes(const _Float1
   const int vq = (lane >> 2) & 3, vp = lane & 3, vg = (lane >> 4) & 1;
 
   const int n_tiles = (T + AK - 1) / AK;
-  load_tile(0);
+  // Schedule per tile t (two barriers, the loads never waited for right after their issue):
+  //   QK_t from K buffer t & 1 | softmax | vmcnt(0) + barrier: V_t and K_t+1 have landed, everybody is done with K_t
+  //   | PV_t | barrier: everybody is done with V_t -> issue V_t+1, and K_t+2 into buffer t & 1
+  dma_tile(kbase, 0, lds);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // K_0 (and this wave's Q fragments)
+  __builtin_amdgcn_s_barrier();
+  dma_tile(vbase, 0, lds + kVOff);
+  if (n_tiles > 1) dma_tile(kbase, 1, lds + NP * kPlaneBytes);
   for (int kt = 0; kt < n_tiles; ++kt) {
-    store_tile();
-    __syncthreads();
-    if (kt + 1 < n_tiles) load_tile(kt + 1);
-
+    const unsigned char* const kb = lds + (kt & 1) * NP * kPlaneBytes;
     // S^T for the two 32-key halves of the tile
     f32x16 s0, s1;
 #pragma unroll
@@ -133,15 +133,15 @@ __global__ __launch_bounds__(256, 2) void encoder_attention_planes(const _Float1
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int slot = ((2 * c + lh) ^ kfx) << 4;
-      const half8 k0h = *reinterpret_cast<const half8*>(lds + l31 * 128 + slot);
-      const half8 k1h = *reinterpret_cast<const half8*>(lds + (32 + l31) * 128 + slot);
+      const half8 k0h = *reinterpret_cast<const half8*>(kb + l31 * 128 + slot);
+      const half8 k1h = *reinterpret_cast<const half8*>(kb + (32 + l31) * 128 + slot);
       if constexpr (BF) {
         s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, k0h), __builtin_bit_cast(bf16x8, qh[c]), s0, 0, 0, 0);
         s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, k1h), __builtin_bit_cast(bf16x8, qh[c]), s1, 0, 0, 0);
         continue;
       }
-      const half8 k0l = *reinterpret_cast<const half8*>(lds + kPlaneBytes + l31 * 128 + slot);
-      const half8 k1l = *reinterpret_cast<const half8*>(lds + kPlaneBytes + (32 + l31) * 128 + slot);
+      const half8 k0l = *reinterpret_cast<const half8*>(kb + kPlaneBytes + l31 * 128 + slot);
+      const half8 k1l = *reinterpret_cast<const half8*>(kb + kPlaneBytes + (32 + l31) * 128 + slot);
       s0 = WT_MM16(k0h, ql[c], s0);
       s0 = WT_MM16(k0l, qh[c], s0);
       s0 = WT_MM16(k0h, qh[c], s0);
@@ -158,25 +158,16 @@ __global__ __launch_bounds__(256, 2) void encoder_attention_planes(const _Float1
     }
     // online softmax; the row (query) lives on lanes l and l ^ 32.  The scores still carry the operand scales of
     // the planes (s_inv > 0 takes them out): the maximum is taken on the raw values, and s_inv, the running maximum
-    // and the 2^14 that puts the probabilities into fp16's normal range all go into ONE fma per score in front of
-    // the exp2.  l_run and O then both carry the 2^14, which cancels in O / l.
-    float tmax = s0[0];
+    // and the 2^12 that puts the probabilities into fp16's normal range all go into ONE fma per score in front of
+    // the exp2.  l_run and O then both carry the 2^12, which cancels in O / l.
+    float tmax = fmaxf(s0[0], s1[0]);
 #pragma unroll
-    for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s0[r]);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s1[r]);
+    for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, fmaxf(s0[r], s1[r]));
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * s_inv;
-    const float m_new = fmaxf(m_run, tmax);
-    const float shift = (BF ? 0.0f : 14.0f) - m_new;
-    float psum = 0.0f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      s0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], s_inv, shift));
-      s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], s_inv, shift));
-      psum += s0[r] + s1[r];
-    }
-    psum += __shfl_xor(psum, 32, 64);
-    if (__any(m_new != m_run)) {
+    // deferred maximum: raise m_run (and rescale O, l) only when some row's tile maximum exceeds it by more than
+    // kDefer; otherwise the probabilities of this tile are at most 2^kDefer, which the planes hold
+    if (__any(tmax > m_run + kDefer)) {
+      const float m_new = fmaxf(m_run, tmax);
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       l_run *= alpha;
 #pragma unroll
@@ -186,7 +177,20 @@ __global__ __launch_bounds__(256, 2) void encoder_attention_planes(const _Float1
       }
       m_run = m_new;
     }
+    const float shift = (BF ? 0.0f : kPShift) - m_run;
+    float psum = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], s_inv, shift));
+      s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], s_inv, shift));
+      psum += s0[r] + s1[r];
+    }
+    psum += __shfl_xor(psum, 32, 64);
     l_run += psum;
+    // V_t and K_t+1 have landed (this wave's parts: vmcnt; everybody's: the barrier), and every wave is done with K_t
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
     // O^T += V^T . P^T, 16 keys per step: registers 8 s2 .. 8 s2 + 7 of S^T are, unmoved, the B fragment
     auto pv_half = [&](const f32x16& sp, const int hf) {
 #pragma unroll
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void encoder_attention_planes(const _Float1
           const int key = key0 + 8 * ri + vq;
           const int vsw = ((key >> 1) & 1) << 2;
           // d tile 0: chunk = 2 vg + (vp >> 1) (+ 4 for d tile 1), byte 8 (vp & 1) inside the chunk
-          const unsigned char* r0 = lds + 2 * kPlaneBytes + key * 128 + ((vp & 1) << 3);
+          const unsigned char* r0 = lds + kVOff + key * 128 + ((vp & 1) << 3);
           const int c0 = ((2 * vg + (vp >> 1)) ^ vsw) << 4, c1 = ((4 + 2 * vg + (vp >> 1)) ^ vsw) << 4;
           const i16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(r0 + c0));
           const i16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(r0 + c1));
@@ -249,11 +253,19 @@ __global__ __launch_bounds__(256, 2) void encoder_attention_planes(const _Float1
     };
     pv_half(s0, 0);
     pv_half(s1, 1);
-    __syncthreads();
+    // every wave is done with V_t (its fragment reads were consumed by the MFMAs above); K_t+2 stays in flight
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // (K_t+2 could go out one phase earlier, right after the barrier above; hipcc then puts an s_waitcnt vmcnt(0) of
+    // its own in front of the V fragment reads — it cannot see that the DMA targets the other buffer — and the
+    // prefetch would be waited for at its issue)
+    if (kt + 1 < n_tiles) dma_tile(vbase, kt + 1, lds + kVOff);
+    if (kt + 2 < n_tiles) dma_tile(kbase, kt + 2, lds + (kt & 1) * NP * kPlaneBytes);
   }
 
   if (q_row < T) {
-    const float inv = o_scale / l_run;  // o_scale = out_scale / v_scale (the 2^14 of the probabilities is in l_run too)
+    const float inv = o_scale / l_run;  // o_scale = out_scale / v_scale (the 2^12 of the probabilities is in l_run too)
     _Float16* orow = out + ((long)b * T + q_row) * d_model + h * 64;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -287,7 +299,7 @@ void launch_encoder_attention_planes(const unsigned short* qkv, long plane, unsi
                                      float out_scale, hipStream_t stream) {
   if (batch < 1 || T < 1 || heads < 1 || (3 * heads * 64) % 8 != 0) throw Error(kErrInvalidArg, "encoder attention: bad shape");
   const int q_blocks = (T + 127) / 128;
-  hipLaunchKernelGGL(encoder_attention_planes<false>, dim3(batch * heads * q_blocks), dim3(256), 0, stream,
+  hipLaunchKernelGGL(encoder_attention_planes<false>, dim3(batch * heads * q_blocks), dim3(256), 6 * kPlaneBytes, stream,
                      reinterpret_cast<const _Float16*>(qkv), plane, reinterpret_cast<_Float16*>(out), out_plane, T, heads,
                      1.0f / (q_scale * k_scale), out_scale / v_scale);
 }
@@ -296,7 +308,7 @@ void launch_encoder_attention_bf16(const unsigned short* qkv, unsigned short* ou
                                    hipStream_t stream) {
   if (batch < 1 || T < 1 || heads < 1) throw Error(kErrInvalidArg, "encoder attention: bad shape");
   const int q_blocks = (T + 127) / 128;
-  hipLaunchKernelGGL(encoder_attention_planes<true>, dim3(batch * heads * q_blocks), dim3(256), 0, stream,
+  hipLaunchKernelGGL(encoder_attention_planes<true>, dim3(batch * heads * q_blocks), dim3(256), 3 * kPlaneBytes, stream,
                      reinterpret_cast<const _Float16*>(qkv), 0L, reinterpret_cast<_Float16*>(out), 0L, T, heads,
                      0.125f * 1.44269504088896340736f, 1.0f);
 }
