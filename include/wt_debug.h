@@ -16,6 +16,13 @@ int wt_dbg_gemm(wt_engine* h, int M, int N, int K, const float* A, const float* 
 int wt_dbg_gemm_planes(wt_engine* h, int M, int N, int K, const float* A, const float* W, const float* bias,
                        const float* R, const float* pos, int pos_period, int epi, int planes_out, int iters, float* C,
                        float* avg_ms, int n_cu /* CUs the tile choice assumes; 0 = all */);
+/* the same GEMM (N = 384, fp32 output C, epi = bias | residual (5) or bias | gelu | pos (11)) with the LayerNorm of the
+ * finished rows fused into its epilogue: ln_out [M][384] = LayerNorm(C row) * ln_g + ln_b reconstructed from the planes
+ * the kernel wrote, ln_y32 (optional) its fp32 copy; *fused = 1 when a 384-column tile did it, 0 when the tile choice
+ * (n_cu, M) took the narrow tile and nothing was written */
+int wt_dbg_gemm_planes_ln(wt_engine* h, int M, int K, const float* A, const float* W, const float* bias, const float* R,
+                          const float* pos, int pos_period, int epi, const float* ln_g, const float* ln_b, int n_cu,
+                          float* C, float* ln_out, float* ln_y32, int* fused);
 /* encoder attention on planes (k_attention_planes.hip): qkv fp32 [B*T][3*heads*64] is split on the host the way the
  * qkv GEMM's epilogue writes it; out [B*T][heads*64] reconstructed from the output planes */
 int wt_dbg_encoder_attention_planes(wt_engine* h, int batch, int T, int heads, const float* qkv, int iters, float* out,

@@ -103,6 +103,41 @@ def test_plane_gemm_epilogues(eng, epi):
     assert rel_err(C, ref) < 3e-6
 
 
+@pytest.mark.parametrize("M,K,epi,n_cu", [(500, 384, 5, 0), (700, 1536, 5, 224), (3000, 96, 11, 0), (193, 384, 5, 0),
+                                          (48000, 384, 5, 224), (48000, 384, 5, 256)])
+def test_plane_gemm_with_fused_layernorm(eng, M, K, epi, n_cu):
+    """The N = 384 residual GEMMs (out-projection, fc2) and conv2 write the NEXT LayerNorm's planes from their epilogue
+    (the 384-column tile owns whole rows: two-pass statistics exchanged between the four wavefront columns through LDS).
+    Checked against fp64: C as before, LayerNorm(C) * g + b to the LayerNorm kernel's own tolerance, the fp32 copy, and
+    both 384-column tile heights (192 rows; 256 rows, which the 224-CU pipelined stream picks at 48000 rows)."""
+    rng = np.random.default_rng(M + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((384, K)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(384).astype(np.float32)
+    R = (rng.standard_normal((M, 384)) * 3 + 0.7).astype(np.float32) if epi & 4 else None
+    pos = rng.standard_normal((150, 384)).astype(np.float32) if epi & 8 else None
+    g = (1.0 + 0.3 * rng.standard_normal(384)).astype(np.float32)
+    b = rng.standard_normal(384).astype(np.float32)
+    if M > 10000:  # tile heights at the engine's size: force the 384-column tile the cost model would pick there
+        A[:] = A[:1000].repeat(48, axis=0)[:M]
+    C, ln, y32, fused = eng.dbg_gemm_planes_ln(A, W, bias, g, b, R=R, pos=pos, epi=epi, n_cu=n_cu)
+    ref = A.astype(np.float64) @ W.astype(np.float64).T + bias
+    if epi & 2:
+        ref = gelu(ref)
+    if epi & 8:
+        ref = ref + pos[np.arange(M) % 150]
+    if epi & 4:
+        ref = ref + R
+    assert rel_err(C, ref) < 3e-6
+    if M > 10000:
+        assert fused  # at the engine's size a 384-column tile is always the choice
+    if not fused:  # small M: the cost model may prefer the narrow tile, and the engine then launches the LayerNorm
+        return     # kernel itself (covered by the path tests)
+    lnref = (ref - ref.mean(1, keepdims=True)) / np.sqrt(ref.var(1, keepdims=True) + 1e-5) * g + b
+    assert np.abs(ln - lnref).max() < 1e-5 and np.abs(y32 - lnref).max() < 1e-5
+    assert np.abs(ln - y32).max() < 4e-6  # the planes carry 22 bits of the same values
+
+
 def test_plane_gemm_is_exact_on_integers(eng):
     """A = I (padded) against an ASYMMETRIC integer W catches a swapped C/D row-col map or a wrong LDS swizzle."""
     K, N = 128, 256
@@ -458,7 +493,6 @@ def test_bf16_gemm_is_exact_on_integers(eng):
     assert np.array_equal(C, (A.astype(np.float64) @ W.astype(np.float64).T).astype(np.float32))
 
 
-@pytest.mark.parametrize("B,T,H", [(1, 64, 1), (2, 100, 2), (1, 1500, 8), (3, 333, 2)])
 @pytest.mark.parametrize("growth", [0.5, 2.9, 3.1, 9.0])
 def test_encoder_attention_planes_deferred_maximum(eng, growth):
     """The kernel raises its running maximum only when a tile's maximum exceeds it by more than 3 (log2 domain); below
@@ -477,6 +511,7 @@ def test_encoder_attention_planes_deferred_maximum(eng, growth):
     assert np.abs(out - ref).max() < 2e-5, growth
 
 
+@pytest.mark.parametrize("B,T,H", [(1, 64, 1), (2, 100, 2), (1, 1500, 8), (3, 333, 2)])
 def test_encoder_attention_bf16_storage(eng, B, T, H):
     """encoder_attention_planes<true>: q, k, v read as bf16, probabilities rounded to bf16 for the PV product, fp32
     accumulation and softmax statistics.  Against fp64 attention on the bf16-rounded inputs what is left is the

@@ -46,7 +46,7 @@ CAPI_SYMBOLS = [
     "wt_vocab_decode", "wt_log_mel_spectrogram", "wt_convert_tflite", "wt_shutdown",
 ]
 DEBUG_SYMBOLS = [
-    "wt_dbg_gemm", "wt_dbg_gemm_bench", "wt_dbg_dec_gemm_bench", "wt_dbg_dec_gemm", "wt_dbg_dec_ln_gemm", "wt_dbg_layernorm", "wt_dbg_encoder_attention",
+    "wt_dbg_gemm_planes_ln", "wt_dbg_gemm", "wt_dbg_gemm_bench", "wt_dbg_dec_gemm_bench", "wt_dbg_dec_gemm", "wt_dbg_dec_ln_gemm", "wt_dbg_layernorm", "wt_dbg_encoder_attention",
     "wt_dbg_cross_attention", "wt_dbg_self_attention", "wt_dbg_interference", "wt_dbg_concurrency",
     "wt_dbg_gemm_planes", "wt_dbg_encoder_attention_planes", "wt_dbg_gemm_bf16", "wt_dbg_encoder_attention_bf16",
 ]
@@ -139,6 +139,8 @@ def lib() -> ctypes.CDLL:
         L.wt_dbg_gemm_planes.argtypes = [c_void_p, c_int, c_int, c_int, fp, fp, fp, fp, fp, c_int, c_int, c_int, c_int, fp,
                                          POINTER(c_float), c_int]
         L.wt_dbg_encoder_attention_planes.argtypes = [c_void_p, c_int, c_int, c_int, fp, c_int, fp, POINTER(c_float)]
+        L.wt_dbg_gemm_planes_ln.argtypes = [c_void_p, c_int, c_int, fp, fp, fp, fp, fp, c_int, c_int, fp, fp, c_int, fp, fp, fp,
+                                            POINTER(c_int)]
         L.wt_dbg_gemm_bf16.argtypes = [c_void_p, c_int, c_int, c_int, fp, fp, fp, fp, fp, c_int, c_int, c_int, c_int, fp,
                                        POINTER(c_float)]
         L.wt_dbg_encoder_attention_bf16.argtypes = [c_void_p, c_int, c_int, c_int, fp, c_int, fp, POINTER(c_float)]
@@ -474,6 +476,23 @@ class Engine:
                                              pos.shape[0] if pos is not None else 0, epi, int(planes_out), iters, _fp(C),
                                              byref(ms), int(n_cu)))
         return (C, ms.value) if iters > 0 else C
+
+    def dbg_gemm_planes_ln(self, A, W, bias, ln_g, ln_b, R=None, pos=None, epi=5, n_cu=0, want_y32=True):
+        """The plane GEMM (N = 384) with the LayerNorm of its output rows fused into the epilogue.  Returns
+        (C, ln_out, ln_y32, fused)."""
+        A, W = _f32(A), _f32(W)
+        M, K = A.shape
+        assert W.shape[0] == 384
+        C = np.zeros((M, 384), np.float32)
+        ln = np.zeros((M, 384), np.float32)
+        y32 = np.zeros((M, 384), np.float32) if want_y32 else None
+        R = _f32(R) if R is not None else None
+        pos = _f32(pos) if pos is not None else None
+        fused = ctypes.c_int(0)
+        self._check(lib().wt_dbg_gemm_planes_ln(self._h, M, K, _fp(A), _fp(W), _fp(_f32(bias)), _fp(R), _fp(pos),
+                                                pos.shape[0] if pos is not None else 0, epi, _fp(_f32(ln_g)), _fp(_f32(ln_b)),
+                                                int(n_cu), _fp(C), _fp(ln), _fp(y32) if y32 is not None else None, byref(fused)))
+        return C, ln, y32, bool(fused.value)
 
     def dbg_encoder_attention_planes(self, qkv, batch, T, heads, iters=0):
         qkv = _f32(qkv)

@@ -774,7 +774,7 @@ int wt_dbg_gemm_planes(wt_engine* h, int M, int N, int K, const float* A, const 
     wt::launch_gemm_planes(g, epi, st);
     h->impl->sync();
     if (planes_out) dO.to_host(C, size_t(M) * N, so); else dC.to_host(C, size_t(M) * N);
-    if (avg_ms && iters > 0 && !(epi & wt::kEpiResidual)) {
+    if (avg_ms && iters > 0) {  // (C has been copied out: a residual epilogue may keep accumulating in place)
       hipEvent_t e0, e1;
       hipchk(hipEventCreate(&e0), "event");
       hipchk(hipEventCreate(&e1), "event");
@@ -788,6 +788,35 @@ int wt_dbg_gemm_planes(wt_engine* h, int M, int N, int K, const float* A, const 
       *avg_ms = ms / iters;
       (void)hipEventDestroy(e0);
       (void)hipEventDestroy(e1);
+    }
+  });
+}
+
+int wt_dbg_gemm_planes_ln(wt_engine* h, int M, int K, const float* A, const float* W, const float* bias, const float* R,
+                          const float* pos, int pos_period, int epi, const float* ln_g, const float* ln_b, int n_cu,
+                          float* C, float* ln_out, float* ln_y32, int* fused) {
+  const int N = 384;
+  if (!h || !A || !W || !C || !ln_g || !ln_b || !ln_out || !fused || K % 32 || M < 1 || n_cu < 0) return WT_ERR_INVALID_ARG;
+  return guarded(h, [&] {
+    const float sa = wt::f16_scale_for(max_abs(A, size_t(M) * K)), sw = wt::f16_scale_for(max_abs(W, size_t(N) * K));
+    const DevPlanes dA(A, size_t(M) * K, sa), dW(W, size_t(N) * K, sw);
+    DevBuf dB(bias, N), dC(R ? R : nullptr, size_t(M) * N), dP(pos, pos ? size_t(pos_period) * N : 0), dG(ln_g, N), dS(ln_b, N),
+        dY(size_t(M) * N), dF(1);
+    hipchk(hipMemset(dF.p, 0, 4), "memset");
+    const float so = 64.0f;  // LayerNorm output is O(|g| sqrt(N))
+    DevPlanes dO(nullptr, size_t(M) * N, 1.0f);
+    wt::PlaneGemmArgs g;
+    g.A = dA.ptr(); g.a_plane = dA.plane; g.lda = K; g.W = dW.ptr(); g.w_plane = dW.plane; g.bias = dB.p;
+    g.C = dC.p; g.R = dC.p; g.ldc = N; g.pos = dP.p; g.pos_period = pos_period > 0 ? pos_period : 1;
+    g.M = M; g.N = N; g.K = K; g.a_scale = sa; g.w_scale = sw; g.n_cu = n_cu;
+    g.ln_g = dG.p; g.ln_b = dS.p; g.ln_P = dO.ptr(); g.ln_plane = dO.plane; g.ln_scale = so;
+    g.ln_y32 = ln_y32 ? dY.p : nullptr; g.nonfinite = reinterpret_cast<int*>(dF.p);
+    *fused = wt::launch_gemm_planes(g, epi, h->impl->stream()) ? 1 : 0;
+    h->impl->sync();
+    dC.to_host(C, size_t(M) * N);
+    if (*fused) {
+      dO.to_host(ln_out, size_t(M) * N, so);
+      if (ln_y32) dY.to_host(ln_y32, size_t(M) * N);
     }
   });
 }
@@ -900,7 +929,7 @@ int wt_dbg_gemm_bf16(wt_engine* h, int M, int N, int K, const float* A, const fl
     wt::launch_gemm_bf16_planes(g, epi, st);
     h->impl->sync();
     if (bf16_out) dO.to_host(C, size_t(M) * N); else dC.to_host(C, size_t(M) * N);
-    if (avg_ms && iters > 0 && !(epi & wt::kEpiResidual)) {
+    if (avg_ms && iters > 0) {  // (C has been copied out: a residual epilogue may keep accumulating in place)
       *avg_ms = time_launches(st, iters, [&] { wt::launch_gemm_bf16_planes(g, epi, st); });
     }
   });

@@ -1066,8 +1066,16 @@ void Engine::encode_enqueue(const float* d_mel, int batch) {
   auto plane_gemm = [&](PlaneGemmArgs& g, const GemmScale& sc, int epi, double flops) {
     g.n_cu = cus; g.a_scale = sc.a; g.w_scale = sc.w;
     kt_begin(kKcGemm, flops, 0);
-    launch_gemm_planes(g, epi, stream_);
+    const bool ln_fused = launch_gemm_planes(g, epi, stream_);
     kt_end();
+    return ln_fused;
+  };
+  // The LayerNorm that follows a GEMM whose output is the residual stream x (conv2, out-projection, fc2) is made by
+  // that GEMM's epilogue when its 384-column tile owns whole rows and both sides run on planes; ln_done then tells the
+  // consumer's side not to launch the LayerNorm kernel.
+  bool ln_done = false;
+  auto fuse_ln = [&](PlaneGemmArgs& g, const float* gain, const float* shift, float scale) {
+    g.ln_g = gain; g.ln_b = shift; g.ln_P = lnp; g.ln_plane = ln_plane; g.ln_scale = scale;
   };
   auto alt_gemm = [&](GemmArgs& g, const GemmScale& sc, int epi, double flops) {
     g.variant = alt; g.a_scale = sc.a; g.w_scale = sc.w;
@@ -1118,7 +1126,8 @@ void Engine::encode_enqueue(const float* d_mel, int batch) {
     g.A = ws_.h1pp; g.a_plane = h1p_plane; g.a_rpb = T; g.a_bs = long(T0 + 2) * d; g.lda = 2 * d;
     g.W = conv2_p_.w; g.w_plane = conv2_p_.plane; g.bias = conv2_b; g.pos = enc_pos; g.pos_period = T;
     g.C = ws_.x; g.ldc = d; g.M = M; g.N = d; g.K = 3 * d;
-    plane_gemm(g, sc_conv2_, kEpiBias | kEpiGelu | kEpiPos, 2.0 * g.M * g.N * g.K);
+    if (gemm_on_planes(sc_layers_[0].qkv)) fuse_ln(g, enc_blocks_[0].attn_ln_g, enc_blocks_[0].attn_ln_b, sc_layers_[0].qkv.a);
+    ln_done = plane_gemm(g, sc_conv2_, kEpiBias | kEpiGelu | kEpiPos, 2.0 * g.M * g.N * g.K);
   } else {
     GemmArgs g;
     g.A = ws_.h1p; g.a_rpb = T; g.a_bs = long(T0 + 2) * d; g.lda = 2 * d;
@@ -1128,6 +1137,10 @@ void Engine::encode_enqueue(const float* d_mel, int batch) {
   }
   constexpr float kQScale = 0.125f * 1.44269504088896340736f;  // d_head^-1/2 * log2(e): softmax as exp2
   auto layernorm_for = [&](bool planes, float scale, const float* g, const float* b) {
+    if (ln_done) {  // the producing GEMM's epilogue has written these planes
+      ln_done = false;
+      return;
+    }
     kt_begin(kKcLayerNorm, 0, 2.0 * M * d * 4);
     if (planes) {
       launch_layernorm_planes(ws_.x, lnp, ln_plane, scale, nullptr, g, b, M, d, stream_);
@@ -1190,7 +1203,8 @@ void Engine::encode_enqueue(const float* d_mel, int batch) {
       PlaneGemmArgs o;
       o.A = att_src; o.a_plane = att_src_plane; o.lda = d; o.W = wp.out.w; o.w_plane = wp.out.plane; o.bias = w.attn.bo;
       o.C = ws_.x; o.R = ws_.x; o.ldc = d; o.M = M; o.N = d; o.K = d;
-      plane_gemm(o, sc.out, kEpiBias | kEpiResidual, 2.0 * o.M * o.N * o.K);
+      if (f1p) fuse_ln(o, w.mlp_ln_g, w.mlp_ln_b, sc.fc1.a);
+      ln_done = plane_gemm(o, sc.out, kEpiBias | kEpiResidual, 2.0 * o.M * o.N * o.K);
     } else {
       GemmArgs o;
       o.A = ws_.att; o.lda = d; o.W = w.attn.wo; o.bias = w.attn.bo; o.C = ws_.x; o.R = ws_.x; o.ldc = d;
@@ -1224,7 +1238,13 @@ void Engine::encode_enqueue(const float* d_mel, int batch) {
       PlaneGemmArgs f2;
       f2.A = hid_src; f2.a_plane = hid_src_plane; f2.lda = 4 * d; f2.W = wp.fc2.w; f2.w_plane = wp.fc2.plane; f2.bias = w.b2;
       f2.C = ws_.x; f2.R = ws_.x; f2.ldc = d; f2.M = M; f2.N = d; f2.K = 4 * d;
-      plane_gemm(f2, sc.fc2, kEpiBias | kEpiResidual, 2.0 * f2.M * f2.N * f2.K);
+      if (l + 1 < c.n_audio_layer) {
+        if (gemm_on_planes(sc_layers_[l + 1].qkv)) fuse_ln(f2, enc_blocks_[l + 1].attn_ln_g, enc_blocks_[l + 1].attn_ln_b, sc_layers_[l + 1].qkv.a);
+      } else if (gemm_on_planes(sc_cross_kv_)) {  // the encoder's final LayerNorm: also the API's fp32 enc_out and the non-finite flag
+        fuse_ln(f2, enc_ln_post_g, enc_ln_post_b, sc_cross_kv_.a);
+        f2.ln_y32 = ws_.enc_out; f2.nonfinite = slot.d_flag;
+      }
+      ln_done = plane_gemm(f2, sc.fc2, kEpiBias | kEpiResidual, 2.0 * f2.M * f2.N * f2.K);
     } else {
       GemmArgs f2;
       f2.A = ws_.hid; f2.lda = 4 * d; f2.W = w.w2; f2.bias = w.b2; f2.C = ws_.x; f2.R = ws_.x; f2.ldc = d;
@@ -1233,15 +1253,19 @@ void Engine::encode_enqueue(const float* d_mel, int batch) {
     }
   }
   const bool kp = gemm_on_planes(sc_cross_kv_);
-  kt_begin(kKcLayerNorm, 0, 2.0 * M * d * 4);
-  if (kp) {
-    launch_layernorm_planes(ws_.x, lnp, ln_plane, sc_cross_kv_.a, ws_.enc_out, enc_ln_post_g, enc_ln_post_b, M, d, stream_,
-                            slot.d_flag);
+  if (ln_done) {
+    ln_done = false;
   } else {
-    launch_layernorm(ws_.x, ws_.enc_out, enc_ln_post_g, enc_ln_post_b, M, d, stream_, slot.d_flag);
+    kt_begin(kKcLayerNorm, 0, 2.0 * M * d * 4);
+    if (kp) {
+      launch_layernorm_planes(ws_.x, lnp, ln_plane, sc_cross_kv_.a, ws_.enc_out, enc_ln_post_g, enc_ln_post_b, M, d, stream_,
+                              slot.d_flag);
+    } else {
+      launch_layernorm(ws_.x, ws_.enc_out, enc_ln_post_g, enc_ln_post_b, M, d, stream_, slot.d_flag);
+    }
+    kt_end();
   }
   HIPCHK(hipMemcpyAsync(slot.h_flag, slot.d_flag, sizeof(int), hipMemcpyDeviceToHost, stream_));
-  kt_end();
   HIPCHK(hipEventRecord(slot.enc_mid, stream_));
   // cross-attention K/V of every decoder layer, projected once per clip into the persistent cache
   // [layer][k|v][clip][head][t][64] (the reference recomputes them inside every decoder Invoke(), whisper.cpp:375)

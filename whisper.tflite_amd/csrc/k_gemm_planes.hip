@@ -55,6 +55,14 @@ struct PlaneGemmDev {
   float descale;       // 1 / (a_scale * w_scale)
   float out_scale[3];  // plane output: column n is multiplied by out_scale[n / seg] before the split
   int seg;
+  // LN: LayerNorm of the finished rows (N == BN: a block owns whole rows), written as planes for the next GEMM
+  const float* ln_g;
+  const float* ln_b;
+  _Float16* ln_P;      // hi plane [M][N]; lo plane at ln_P + ln_plane
+  long ln_plane;
+  float ln_scale;
+  float* ln_y32;       // optional fp32 copy of the LayerNorm output (the encoder's enc_out)
+  int* nonfinite;      // optional flag word: a row with a non-finite mean or variance sets it
 };
 
 // Block tile 192 x BN with BN = WN * NI * 32: 2 x WN wavefronts, each owning 3 x NI MFMA tiles.
@@ -67,8 +75,9 @@ struct PlaneGemmDev {
 //   MI = 32-row MFMA tiles per wavefront (two wavefront rows): 3 -> 192 block rows; 4 -> 256 rows x 384 columns, the
 //   whole register file (255 VGPRs) and all 160 KB of LDS, 230 FLOP per staged byte — used where 188 row tiles fill the
 //   available CUs in fewer rounds than 250 (the CU-masked stream of the pipeline on the N = d_model shapes).
-template <int EPI, bool PLANES_OUT, int WN, int NI, int MI>
+template <int EPI, bool PLANES_OUT, int WN, int NI, int MI, bool LN = false>
 __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 2) void gemm_planes_tile(PlaneGemmDev g) {
+  static_assert(!LN || (!PLANES_OUT && WN == 4 && NI == 3), "LayerNorm fusion: fp32 output, 384-column tile");
   constexpr int BN = WN * NI * 32, NW = 2 * WN, BM = 64 * MI;
   constexpr int kAPlane = BM * BK * 2, kWPlane = BN * BK * 2;  // bytes of one plane of a stage
   constexpr int kStage = 2 * kAPlane + 2 * kWPlane;
@@ -260,29 +269,105 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 2) void gemm_planes_tile(Pl
             f32x4 out = {v[0], v[1], v[2], v[3]};
             if (EPI & kEpiResidual) out += *reinterpret_cast<const f32x4*>(g.R + o);
             *reinterpret_cast<f32x4*>(g.C + o) = out;
+            if constexpr (LN) {  // the accumulator registers of this tile are dead: they keep the finished row-major values
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc[mi][ni][4 * p + e] = out[e];
+            }
           }
+        } else if constexpr (LN) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[mi][ni][4 * p + e] = 0.0f;  // rows past M: no part in anything
         }
       }
     }
   }
+  if constexpr (LN) {
+    // LayerNorm of the rows this block has just finished (N == BN = 384: whole rows), written as the planes the
+    // next GEMM reads: the separate LayerNorm launch re-read and re-wrote the residual stream (147 MB per launch at 32
+    // clips).  acc[mi][ni][4 p + e] now holds row (mi, p * 8 + prow), columns 32 (wn NI + ni) + c0 + e of the finished
+    // values.  Two-pass statistics like layernorm_rows_planes: the four wavefront columns of a block row exchange
+    // their partial sums through LDS (behind the epilogue's stage area), first of the values, then of the squared
+    // deviations.
+    float* const part = reinterpret_cast<float*>(smem) + NW * (32 * SLD);  // [BM][4] partial sums, twice
+    const int rbase = wm * (32 * MI) + prow;
+    float mean[MI][4], rstd[MI][4];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          float t = 0.0f;
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float x = acc[mi][ni][4 * p + e] - (pass ? mean[mi][p] : 0.0f);
+              t += pass ? x * x : x;
+            }
+          t += __shfl_xor(t, 1, 64);
+          t += __shfl_xor(t, 2, 64);
+          t += __shfl_xor(t, 4, 64);
+          if ((lane & 7) == 0) part[pass * (BM * 4) + (rbase + mi * 32 + p * 8) * 4 + wn] = t;
+        }
+      __syncthreads();
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const f32x4 q = *reinterpret_cast<const f32x4*>(&part[pass * (BM * 4) + (rbase + mi * 32 + p * 8) * 4]);
+          const float tot = ((q[0] + q[1]) + (q[2] + q[3])) * (1.0f / (float)BN);
+          if (pass == 0) {
+            mean[mi][p] = tot;
+          } else {
+            if (g.nonfinite != nullptr && (lane & 7) == 0 && wn == 0 && !(fabsf(mean[mi][p]) <= 3.0e38f && tot <= 3.0e38f)) atomicOr(g.nonfinite, 1);
+            rstd[mi][p] = rsqrtf(tot + 1e-5f);
+          }
+        }
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int n = n0 + (wn * NI + ni) * 32 + c0;
+      const f32x4 gg = *reinterpret_cast<const f32x4*>(g.ln_g + n), bb = *reinterpret_cast<const f32x4*>(g.ln_b + n);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int m = m0 + rbase + mi * 32 + p * 8;
+          if (m >= g.M) continue;
+          f32x4 y;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) y[e] = (acc[mi][ni][4 * p + e] - mean[mi][p]) * rstd[mi][p] * gg[e] + bb[e];
+          const long o = (long)m * BN + n;
+          if (g.ln_y32 != nullptr) __builtin_nontemporal_store(y, reinterpret_cast<f32x4*>(g.ln_y32 + o));
+          unsigned h0, l0, h1, l1;
+          split_f16x2(y[0] * g.ln_scale, y[1] * g.ln_scale, &h0, &l0);
+          split_f16x2(y[2] * g.ln_scale, y[3] * g.ln_scale, &h1, &l1);
+          using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+          *reinterpret_cast<u32x2*>(g.ln_P + o) = u32x2{h0, h1};
+          *reinterpret_cast<u32x2*>(g.ln_P + g.ln_plane + o) = u32x2{l0, l1};
+        }
+    }
+  }
 }
 
-template <int EPI, bool PLANES_OUT, int WN, int NI, int MI = 3>
+template <int EPI, bool PLANES_OUT, int WN, int NI, int MI = 3, bool LN = false>
 void launch_planes_shape(const PlaneGemmDev& g, hipStream_t s) {
   constexpr int BN = WN * NI * 32, BM = 64 * MI;
   const int blocks = ((g.M + BM - 1) / BM) * (g.N / BN);
   constexpr size_t smem = 2 * (2 * BM * BK * 2 + 2 * BN * BK * 2);  // two stages; the epilogue stages fit inside
   static const bool raised = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_planes_tile<EPI, PLANES_OUT, WN, NI, MI>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_planes_tile<EPI, PLANES_OUT, WN, NI, MI, LN>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return true;
   }();
   (void)raised;
-  hipLaunchKernelGGL((gemm_planes_tile<EPI, PLANES_OUT, WN, NI, MI>), dim3(blocks), dim3(128 * WN), smem, s, g);
+  hipLaunchKernelGGL((gemm_planes_tile<EPI, PLANES_OUT, WN, NI, MI, LN>), dim3(blocks), dim3(128 * WN), smem, s, g);
 }
 
+// returns true when the launch also wrote the LayerNorm planes (g.ln_P set and a 384-column tile chosen)
 template <int EPI, bool PLANES_OUT>
-void launch_planes(const PlaneGemmDev& g, int n_cu, hipStream_t s) {
+bool launch_planes(const PlaneGemmDev& g, int n_cu, hipStream_t s) {
   static const int forced = [] {
     const char* v = getenv("WT_PLANE_TILE");  // measurement knob (tools/gemm_planes_bench.py): 128 / 384 = that tile only
     return v ? atoi(v) : 0;
@@ -303,6 +388,16 @@ void launch_planes(const PlaneGemmDev& g, int n_cu, hipStream_t s) {
   if (forced == 128) pick = 0;
   if (forced == 384 && can_wide) pick = 1;
   if (forced == 256 && can_wide) pick = 2;
+  if constexpr (!PLANES_OUT && (EPI == (kEpiBias | kEpiResidual) || EPI == (kEpiBias | kEpiGelu | kEpiPos))) {
+    if (g.ln_P != nullptr && g.N == 384 && pick != 0) {  // whole rows in one block: LayerNorm fused into the epilogue
+      if (pick == 2) {
+        launch_planes_shape<EPI, false, 4, 3, 4, true>(g, s);
+      } else {
+        launch_planes_shape<EPI, false, 4, 3, 3, true>(g, s);
+      }
+      return true;
+    }
+  }
   if (pick == 2) {
     launch_planes_shape<EPI, PLANES_OUT, 4, 3, 4>(g, s);
   } else if (pick == 1) {
@@ -310,11 +405,12 @@ void launch_planes(const PlaneGemmDev& g, int n_cu, hipStream_t s) {
   } else {
     launch_planes_shape<EPI, PLANES_OUT, 2, 2, 3>(g, s);
   }
+  return false;
 }
 
 }  // namespace
 
-void launch_gemm_planes(const PlaneGemmArgs& a, int epi, hipStream_t s) {
+bool launch_gemm_planes(const PlaneGemmArgs& a, int epi, hipStream_t s) {
   PlaneGemmDev g{};
   g.A = reinterpret_cast<const _Float16*>(a.A); g.a_plane = a.a_plane;
   g.W = reinterpret_cast<const _Float16*>(a.W); g.w_plane = a.w_plane;
@@ -328,6 +424,11 @@ void launch_gemm_planes(const PlaneGemmArgs& a, int epi, hipStream_t s) {
   g.descale = 1.0f / (a.a_scale * a.w_scale);
   g.out_scale[0] = a.out_scale[0]; g.out_scale[1] = a.out_scale[1]; g.out_scale[2] = a.out_scale[2];
   g.seg = a.seg > 0 ? a.seg : a.N;
+  g.ln_g = a.ln_g; g.ln_b = a.ln_b; g.ln_P = reinterpret_cast<_Float16*>(a.ln_P); g.ln_plane = a.ln_plane;
+  g.ln_scale = a.ln_scale; g.ln_y32 = a.ln_y32; g.nonfinite = a.nonfinite;
+  if (a.ln_P && (!a.ln_g || !a.ln_b || a.P || a.c_rpb < a.M || a.ldc != a.N || !(a.ln_scale > 0.0f))) {
+    throw Error(kErrInvalidArg, "plane GEMM LayerNorm fusion: needs gain and shift, fp32 output, contiguous [M][N] rows");
+  }
   const bool planes = a.P != nullptr;
   // shape contract of the kernel (16-byte chunks, whole k-tiles; the epilogue wraps clip / position rows at most once
   // per 32 rows; 8 output columns never straddle a scale segment)
@@ -337,13 +438,13 @@ void launch_gemm_planes(const PlaneGemmArgs& a, int epi, hipStream_t s) {
     throw Error(kErrInvalidArg, "plane GEMM shape outside the kernel contract");
   }
   switch (epi | (planes ? 256 : 0)) {
-    case kEpiBias: launch_planes<kEpiBias, false>(g, a.n_cu, s); break;
-    case kEpiBias | kEpiGelu: launch_planes<kEpiBias | kEpiGelu, false>(g, a.n_cu, s); break;  // fp32 for a fall-back consumer
-    case kEpiBias | kEpiResidual: launch_planes<kEpiBias | kEpiResidual, false>(g, a.n_cu, s); break;
-    case kEpiBias | kEpiGelu | kEpiPos: launch_planes<kEpiBias | kEpiGelu | kEpiPos, false>(g, a.n_cu, s); break;
-    case kEpiBias | kEpiKvLayout: launch_planes<kEpiBias | kEpiKvLayout, false>(g, a.n_cu, s); break;
-    case kEpiBias | 256: launch_planes<kEpiBias, true>(g, a.n_cu, s); break;
-    case kEpiBias | kEpiGelu | 256: launch_planes<kEpiBias | kEpiGelu, true>(g, a.n_cu, s); break;
+    case kEpiBias: return launch_planes<kEpiBias, false>(g, a.n_cu, s);
+    case kEpiBias | kEpiGelu: return launch_planes<kEpiBias | kEpiGelu, false>(g, a.n_cu, s);  // fp32 for a fall-back consumer
+    case kEpiBias | kEpiResidual: return launch_planes<kEpiBias | kEpiResidual, false>(g, a.n_cu, s);
+    case kEpiBias | kEpiGelu | kEpiPos: return launch_planes<kEpiBias | kEpiGelu | kEpiPos, false>(g, a.n_cu, s);
+    case kEpiBias | kEpiKvLayout: return launch_planes<kEpiBias | kEpiKvLayout, false>(g, a.n_cu, s);
+    case kEpiBias | 256: return launch_planes<kEpiBias, true>(g, a.n_cu, s);
+    case kEpiBias | kEpiGelu | 256: return launch_planes<kEpiBias | kEpiGelu, true>(g, a.n_cu, s);
     default: throw Error(kErrInvalidArg, "unsupported plane GEMM epilogue combination");
   }
 }

@@ -90,8 +90,19 @@ struct PlaneGemmArgs {
   float out_scale[3] = {1.0f, 1.0f, 1.0f};
   int seg = 0;  // columns per out_scale segment (0 = one segment)
   int n_cu = 256;  // CUs the launching stream may use (tile choice, k_gemm_planes.hip)
+  // LayerNorm fusion (fp32 output C with kEpiBias | kEpiResidual or kEpiBias | kEpiGelu | kEpiPos, N = 384, contiguous
+  // [M][N] rows): the block that finishes a 384-column row also writes LayerNorm(row) * ln_g + ln_b, times ln_scale,
+  // as planes (hi at ln_P, lo at ln_P + ln_plane) — the A operand of the next GEMM — and optionally as fp32 (ln_y32)
+  // with the non-finite flag of launch_layernorm.  Only the 384-column tiles can do it: launch_gemm_planes returns
+  // whether it did (false: the caller launches the LayerNorm kernel).
+  const float *ln_g = nullptr, *ln_b = nullptr;
+  unsigned short* ln_P = nullptr;
+  long ln_plane = 0;
+  float ln_scale = 1.0f;
+  float* ln_y32 = nullptr;
+  int* nonfinite = nullptr;
 };
-void launch_gemm_planes(const PlaneGemmArgs& a, int epi, hipStream_t s);
+bool launch_gemm_planes(const PlaneGemmArgs& a, int epi, hipStream_t s);
 // bf16 storage mode (k_gemm_bf16.hip): A, W single bf16 matrices (the plane offsets and scales of the struct are
 // unused), K a multiple of 64; P set = bf16 output (row-major, or the cross-KV cache layout with kEpiKvLayout),
 // else fp32 output C
