@@ -253,6 +253,8 @@ def main() -> None:
     ap.add_argument("--depth", type=int, default=5, choices=tuple(range(1, 7)), help="batches in flight (pipelined mode)")
     ap.add_argument("--attn-variant", type=int, default=None, choices=(0, 1, 2, 3, 4))
     ap.add_argument("--cross-chunks", type=int, default=None, choices=(1, 2, 4, 8))
+    ap.add_argument("--cross-absorb", type=int, default=None, choices=(0, 1),
+                    help="0 = round 2's cross-KV cache instead of the absorbed cross-attention (default 1)")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the extra fp32-MFMA-only measurement")
     ap.add_argument("--no-graphs", action="store_true", help="launch the decoder eagerly instead of replaying its hipGraph")
     ap.add_argument("--gemm-variant", type=int, default=None, help="encoder GEMM tile variant (k_gemm.hip)")
@@ -307,6 +309,8 @@ def main() -> None:
         eng.set_option("attn_variant", args.attn_variant)
     if args.cross_chunks:
         eng.set_option("cross_chunks", args.cross_chunks)
+    if args.cross_absorb is not None:
+        eng.set_option("cross_absorb", args.cross_absorb)
     if args.no_graphs:
         eng.set_option("use_graphs", 0)
     if args.gemm_variant is not None:

@@ -46,7 +46,7 @@ CAPI_SYMBOLS = [
     "wt_vocab_decode", "wt_log_mel_spectrogram", "wt_convert_tflite", "wt_shutdown",
 ]
 DEBUG_SYMBOLS = [
-    "wt_dbg_gemm_planes_ln", "wt_dbg_gemm", "wt_dbg_gemm_bench", "wt_dbg_dec_gemm_bench", "wt_dbg_dec_gemm", "wt_dbg_dec_ln_gemm", "wt_dbg_layernorm", "wt_dbg_encoder_attention",
+    "wt_dbg_cross_absorbed", "wt_dbg_gemm_planes_ln", "wt_dbg_gemm", "wt_dbg_gemm_bench", "wt_dbg_dec_gemm_bench", "wt_dbg_dec_gemm", "wt_dbg_dec_ln_gemm", "wt_dbg_layernorm", "wt_dbg_encoder_attention",
     "wt_dbg_cross_attention", "wt_dbg_self_attention", "wt_dbg_interference", "wt_dbg_concurrency",
     "wt_dbg_gemm_planes", "wt_dbg_encoder_attention_planes", "wt_dbg_gemm_bf16", "wt_dbg_encoder_attention_bf16",
 ]
@@ -139,6 +139,7 @@ def lib() -> ctypes.CDLL:
         L.wt_dbg_gemm_planes.argtypes = [c_void_p, c_int, c_int, c_int, fp, fp, fp, fp, fp, c_int, c_int, c_int, c_int, fp,
                                          POINTER(c_float), c_int]
         L.wt_dbg_encoder_attention_planes.argtypes = [c_void_p, c_int, c_int, c_int, fp, c_int, fp, POINTER(c_float)]
+        L.wt_dbg_cross_absorbed.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, fp, fp, fp]
         L.wt_dbg_gemm_planes_ln.argtypes = [c_void_p, c_int, c_int, fp, fp, fp, fp, fp, c_int, c_int, fp, fp, c_int, fp, fp, fp,
                                             POINTER(c_int)]
         L.wt_dbg_gemm_bf16.argtypes = [c_void_p, c_int, c_int, c_int, fp, fp, fp, fp, fp, c_int, c_int, c_int, c_int, fp,
@@ -493,6 +494,14 @@ class Engine:
                                                 pos.shape[0] if pos is not None else 0, epi, _fp(_f32(ln_g)), _fp(_f32(ln_b)),
                                                 int(n_cu), _fp(C), _fp(ln), _fp(y32) if y32 is not None else None, byref(fused)))
         return C, ln, y32, bool(fused.value)
+
+    def dbg_cross_absorbed(self, qp, E, batch, heads, T, chunks, nq):
+        """Absorbed cross-attention + chunk combine: qp [nq * batch][heads * d], E [batch][T][d] -> [nq * batch][heads * d]"""
+        qp, E = _f32(qp), _f32(E)
+        d = heads * 64
+        out = np.zeros((nq * batch, heads * d), np.float32)
+        self._check(lib().wt_dbg_cross_absorbed(self._h, batch, heads, T, chunks, nq, _fp(qp), _fp(E), _fp(out)))
+        return out
 
     def dbg_encoder_attention_planes(self, qkv, batch, T, heads, iters=0):
         qkv = _f32(qkv)

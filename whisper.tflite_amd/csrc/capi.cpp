@@ -167,6 +167,8 @@ int wt_engine_set_option(wt_engine* h, const char* key, long value) {
     e.fc2_ksplit = value;
   } else if (k == "use_graphs") {
     e.use_graphs = value != 0;
+  } else if (k == "cross_absorb") {
+    e.cross_absorb = value != 0;
   } else if (k == "gemm_variant") {
     if (value != -1 && !wt::gemm_variant_supported(int(value))) {
       return fail(h, WT_ERR_INVALID_ARG, "gemm_variant must be -1 (default: plane GEMM), 0 (fp32 MFMA), 13 or 16 (three bf16 planes)");
@@ -215,6 +217,8 @@ int wt_engine_get_option(const wt_engine* h, const char* key, long* value) {
   else if (k == "cross_chunks") *value = e.cross_chunks;
   else if (k == "gemm_variant") *value = e.gemm_variant;
   else if (k == "use_graphs") *value = e.use_graphs;
+  else if (k == "cross_absorb") *value = e.cross_absorb;
+  else if (k == "cross_absorb_active") *value = e.absorb_active() ? 1 : 0;  // read-only
   else if (k == "bf16") *value = e.bf16;
   else if (k == "kernel_timers") *value = e.kernel_timers;
   else if (k == "fc2_ksplit") *value = e.fc2_ksplit;
@@ -1190,6 +1194,27 @@ int wt_dbg_cross_attention(wt_engine* h, int batch, int heads, int T, int chunks
     wt::launch_dec_gemm(g, wt::kProCombine, wt::kDecResid, h->impl->stream());
     h->impl->sync();
     dout.to_host(out, rows * d);
+  });
+}
+
+int wt_dbg_cross_absorbed(wt_engine* h, int batch, int heads, int T, int chunks, int nq, const float* qp, const float* E,
+                          float* out) {
+  if (!h || !qp || !E || !out || batch < 1 || heads < 1 || T < 1 || nq < 1 || chunks < 1 || chunks > 16) return WT_ERR_INVALID_ARG;
+  return guarded(h, [&] {
+    const size_t d = size_t(heads) * 64, rows = size_t(nq) * batch;
+    const float se = wt::f16_scale_for(max_abs(E, size_t(batch) * T * d));
+    const DevPlanes dE(E, size_t(batch) * T * d, se);
+    DevBuf dq(qp, rows * heads * d), dws(rows * heads * chunks * (d + 4)), dout(rows * heads * d);
+    const int nq_max = wt::cross_absorbed_max_nq(heads);
+    for (int p0 = 0; p0 < nq; p0 += nq_max) {
+      wt::CrossAbsorbedArgs a;
+      a.qp = dq.p; a.e = dE.ptr(); a.e_plane = dE.plane; a.e_scale = se; a.ws = dws.p;
+      a.batch = batch; a.heads = heads; a.d_model = int(d); a.T = T; a.chunks = chunks; a.nq = std::min(nq_max, nq - p0); a.p0 = p0;
+      wt::launch_cross_absorbed(a, h->impl->stream());
+    }
+    wt::launch_cross_absorbed_combine(dws.p, dout.p, int(rows), heads, chunks, int(d), h->impl->stream());
+    h->impl->sync();
+    dout.to_host(out, rows * heads * d);
   });
 }
 

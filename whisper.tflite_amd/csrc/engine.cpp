@@ -339,6 +339,57 @@ void Engine::upload_weights(const std::string& path) {
     bw.cross_bq = up(blk + ".cross_attn.query.bias", d);
     bw.cross_wo = upload_tiled(H(blk + ".cross_attn.out.weight", dd), d, d);
     bw.cross_bo = up(blk + ".cross_attn.out.bias", d);
+    {
+      // Absorbed cross-attention (k_cross_absorbed.hip): scores q_h . (Wk_h e) = (Wk_h^T q_h) . e and contexts
+      // sum_j p_j (Wv_h e_j + bv_h) = Wv_h (sum_j p_j e_j) + bv_h, so the decoder works on the encoder output e itself.
+      // Folded once, in double: A_h = c0 Wk_h^T Wq_h (c0 = d_head^-1/2 log2 e: the kernel's softmax is an exp2),
+      // a_h = c0 Wk_h^T bq_h; W'[n][h d + c] = sum_i Wo[n][64 h + i] Wv[64 h + i][c], b' = bo + Wo bv.
+      const int Hh = c.n_text_head;
+      const float* wq = H(blk + ".cross_attn.query.weight", dd);
+      const float* bq = H(blk + ".cross_attn.query.bias", d);
+      const float* wk = H(blk + ".cross_attn.key.weight", dd);
+      const float* wv = H(blk + ".cross_attn.value.weight", dd);
+      const float* bv = H(blk + ".cross_attn.value.bias", d);
+      const float* wo = H(blk + ".cross_attn.out.weight", dd);
+      const float* bo = H(blk + ".cross_attn.out.bias", d);
+      const double c0 = 0.125 * 1.44269504088896340736;
+      std::vector<float> A(size_t(Hh) * d * d), av(size_t(Hh) * d), Wp(size_t(d) * Hh * d), bp(d);
+      std::vector<double> acc(d);
+      for (int h = 0; h < Hh; ++h) {
+        for (int cc = 0; cc < d; ++cc) {
+          std::fill(acc.begin(), acc.end(), 0.0);
+          double ab = 0.0;
+          for (int i = 0; i < 64; ++i) {
+            const double kv = wk[size_t(h * 64 + i) * d + cc];
+            const float* qrow = wq + size_t(h * 64 + i) * d;
+            for (int j = 0; j < d; ++j) acc[j] += kv * qrow[j];
+            ab += kv * bq[h * 64 + i];
+          }
+          float* arow = A.data() + (size_t(h) * d + cc) * d;
+          for (int j = 0; j < d; ++j) arow[j] = float(c0 * acc[j]);
+          av[size_t(h) * d + cc] = float(c0 * ab);
+        }
+        for (int n = 0; n < d; ++n) {
+          std::fill(acc.begin(), acc.end(), 0.0);
+          for (int i = 0; i < 64; ++i) {
+            const double ov = wo[size_t(n) * d + h * 64 + i];
+            const float* vrow = wv + size_t(h * 64 + i) * d;
+            for (int cc = 0; cc < d; ++cc) acc[cc] += ov * vrow[cc];
+          }
+          float* prow = Wp.data() + size_t(n) * Hh * d + size_t(h) * d;
+          for (int cc = 0; cc < d; ++cc) prow[cc] = float(acc[cc]);
+        }
+      }
+      for (int n = 0; n < d; ++n) {
+        double t = bo[n];
+        for (int k = 0; k < d; ++k) t += double(wo[size_t(n) * d + k]) * bv[k];
+        bp[n] = float(t);
+      }
+      bw.wq_abs = upload_tiled(A.data(), Hh * d, d);
+      bw.bq_abs = upload(av);
+      bw.wo_abs = upload_tiled(Wp.data(), d, Hh * d);
+      bw.bo_abs = upload(bp);
+    }
     // all layers' cross K/V projections act on the same encoder output: one GEMM
     std::memcpy(ckv_w.data() + (size_t(l) * 2 + 0) * dd, H(blk + ".cross_attn.key.weight", dd), dd * 4);
     std::memcpy(ckv_w.data() + (size_t(l) * 2 + 1) * dd, H(blk + ".cross_attn.value.weight", dd), dd * 4);
@@ -706,7 +757,16 @@ void Engine::create_streams() {
   stream_ = stream_full_;
   HIPCHK(hipEventCreate(&ev_switch_));
   if (const char* v = getenv("WT_DEC_STREAMS")) n_dec_streams_ = std::min(std::max(atoi(v), 1), kDecStreams);
-  for (auto& ds : dstream_) HIPCHK(hipStreamCreateWithPriority(&ds, hipStreamNonBlocking, prio_hi));
+  // WT_DEC_PARTITION=1 (measurement knob): the decoder streams are confined to the CUs the pipelined encoder stream
+  // leaves free — a strict partition instead of "decoders may run anywhere"
+  const char* part = getenv("WT_DEC_PARTITION");
+  if (part && atoi(part) == 1 && enc_cus_masked_ > 0 && enc_cus_masked_ < n_cu) {
+    std::vector<uint32_t> dmask((n_cu + 31) / 32, 0u);
+    for (int i = enc_cus_masked_; i < n_cu; ++i) dmask[i / 32] |= 1u << (i % 32);
+    for (auto& ds : dstream_) HIPCHK(hipExtStreamCreateWithCUMask(&ds, uint32_t(dmask.size()), dmask.data()));
+  } else {
+    for (auto& ds : dstream_) HIPCHK(hipStreamCreateWithPriority(&ds, hipStreamNonBlocking, prio_hi));
+  }
   for (auto& e : ev_) HIPCHK(hipEventCreate(&e));
   for (Slot& sl : slots_) {
     for (hipEvent_t* e : {&sl.enc_begin, &sl.enc_mid, &sl.enc_done, &sl.dec_begin, &sl.dec_done}) {
@@ -865,6 +925,7 @@ void Engine::ensure_batch(int batch) {
   ws_.cvt = reinterpret_cast<unsigned short*>(alloc(B * T * 4 * d, false));
   for (Slot& sl : slots_) {
     sl.cross_kv = alloc(size_t(c.n_text_layer) * 2 * B * T * d, false);
+    sl.e_planes = reinterpret_cast<unsigned short*>(alloc(B * T * d, false));  // two planes of halfs
     sl.used = false;
   }
   // decoder rows: one position of the batch, or all prompt positions of a <= 32-clip batch in one pass
@@ -877,6 +938,9 @@ void Engine::ensure_batch(int batch) {
     dw.attd = alloc(R * d, false);
     dw.hd = alloc(R * 4 * d, false);
     dw.cross_ws = alloc(R * c.n_text_head * 8 * 68, false);
+    dw.qp = alloc(R * c.n_text_head * d, false);
+    dw.abs_ws = alloc(R * c.n_text_head * 16 * (d + 4), false);
+    dw.cabs = alloc(R * c.n_text_head * d, false);
     dw.self_kv = alloc(size_t(c.n_text_layer) * 2 * B * self_cap_ * d, true);
     dw.logits = alloc(B * c.n_vocab, false);
     dw.best = reinterpret_cast<unsigned long long*>(alloc(B * 2 * size_t((c.n_vocab + 31) / 32), true));
@@ -1061,6 +1125,8 @@ void Engine::encode_enqueue(const float* d_mel, int batch) {
   unsigned short* const hidp = reinterpret_cast<unsigned short*>(ws_.hid);
   const long melT_plane = Bw * (T0 + 2) * nm + 128, h1p_plane = Bw * (T0 + 2) * d + 128;
   const long ln_plane = Bw * T * d, qkv_plane = Bw * T * 3 * d, hid_plane = Bw * T * 4 * d, cvt_plane = Bw * T * 4 * d;
+  const long e_plane = Bw * T * d;
+  const bool absorb = absorb_active();
   const int alt = alt_gemm_variant();
 
   auto plane_gemm = [&](PlaneGemmArgs& g, const GemmScale& sc, int epi, double flops) {
@@ -1243,6 +1309,9 @@ void Engine::encode_enqueue(const float* d_mel, int batch) {
       } else if (gemm_on_planes(sc_cross_kv_)) {  // the encoder's final LayerNorm: also the API's fp32 enc_out and the non-finite flag
         fuse_ln(f2, enc_ln_post_g, enc_ln_post_b, sc_cross_kv_.a);
         f2.ln_y32 = ws_.enc_out; f2.nonfinite = slot.d_flag;
+        if (absorb) {  // absorbed cross-attention: these planes ARE what the decoder streams (no cross-KV projection)
+          f2.ln_P = slot.e_planes; f2.ln_plane = e_plane;
+        }
       }
       ln_done = plane_gemm(f2, sc.fc2, kEpiBias | kEpiResidual, 2.0 * f2.M * f2.N * f2.K);
     } else {
@@ -1258,8 +1327,8 @@ void Engine::encode_enqueue(const float* d_mel, int batch) {
   } else {
     kt_begin(kKcLayerNorm, 0, 2.0 * M * d * 4);
     if (kp) {
-      launch_layernorm_planes(ws_.x, lnp, ln_plane, sc_cross_kv_.a, ws_.enc_out, enc_ln_post_g, enc_ln_post_b, M, d, stream_,
-                              slot.d_flag);
+      launch_layernorm_planes(ws_.x, absorb ? slot.e_planes : lnp, absorb ? e_plane : ln_plane, sc_cross_kv_.a, ws_.enc_out,
+                              enc_ln_post_g, enc_ln_post_b, M, d, stream_, slot.d_flag);
     } else {
       launch_layernorm(ws_.x, ws_.enc_out, enc_ln_post_g, enc_ln_post_b, M, d, stream_, slot.d_flag);
     }
@@ -1268,8 +1337,11 @@ void Engine::encode_enqueue(const float* d_mel, int batch) {
   HIPCHK(hipMemcpyAsync(slot.h_flag, slot.d_flag, sizeof(int), hipMemcpyDeviceToHost, stream_));
   HIPCHK(hipEventRecord(slot.enc_mid, stream_));
   // cross-attention K/V of every decoder layer, projected once per clip into the persistent cache
-  // [layer][k|v][clip][head][t][64] (the reference recomputes them inside every decoder Invoke(), whisper.cpp:375)
-  if (kp) {
+  // [layer][k|v][clip][head][t][64] (the reference recomputes them inside every decoder Invoke(), whisper.cpp:375) —
+  // unless the decoder runs the absorbed form, which needs the planes of the encoder output and nothing else
+  slot.absorbed = absorb;
+  if (absorb) {
+  } else if (kp) {
     PlaneGemmArgs g;
     g.A = lnp; g.a_plane = ln_plane; g.lda = d; g.W = cross_kv_p_.w; g.w_plane = cross_kv_p_.plane; g.bias = cross_kv_b;
     g.C = slot.cross_kv; g.M = M; g.N = c.n_text_layer * 2 * d; g.K = d;
@@ -1373,6 +1445,7 @@ void Engine::encode_enqueue_bf16(const float* d_mel, int batch) {
   HIPCHK(hipMemcpyAsync(slot.h_flag, slot.d_flag, sizeof(int), hipMemcpyDeviceToHost, stream_));
   kt_end();
   HIPCHK(hipEventRecord(slot.enc_mid, stream_));
+  slot.absorbed = false;
   {
     PlaneGemmArgs g;  // cross-attention K/V of every decoder layer into the slot's cache, as bf16
     g.A = lnp; g.lda = d; g.W = bf_.cross_kv; g.bias = cross_kv_b;
@@ -1480,6 +1553,10 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
     chunks = 1;
     while (chunks < 8 && batch * H * chunks < 192) chunks *= 2;
   }
+  // key chunks of the absorbed form: clips x chunks ~ 256 blocks, a chunk a whole number of 32-key tiles
+  const bool absorbed = slot.absorbed;  // the form this slot's encoder pass prepared (the same for every slot of a graph set)
+  int abs_chunks = std::min(16, std::max(1, (256 + batch - 1) / batch));
+  abs_chunks = std::min(abs_chunks, (T + 31) / 32);
   int steps = 0;
   // WT_DEC_KERNEL_TIMERS=1 (diagnostics, eager launches only): event pairs around every decoder launch
   static const bool dec_timers = getenv("WT_DEC_KERNEL_TIMERS") != nullptr;
@@ -1557,6 +1634,29 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
         o.bias = w.bo; o.R = x; o.Y = x; o.ldy = d;
         DT(2, launch_dec_gemm(o, kProNone, kDecResid, stream_));
 
+        if (absorbed) {
+          // Cross attention against the encoder output itself (k_cross_absorbed.hip): LN + absorbed query projection
+          // q'_h = c0 Wk_h^T (Wq_h LN(x) + bq_h) for all heads in one GEMM, the matrix-core sweep of E per key chunk
+          // (positions in groups of 16 / heads query columns), the chunk combine, and the out-projection with
+          // Wo . Wv_h folded.
+          DecGemmArgs qa;
+          qa.Wt = w.wq_abs.w; qa.w_scale = w.wq_abs.scale; qa.N = H * d; qa.K = d; qa.B = batch; qa.M = M;
+          qa.xin = x; qa.ln_g = w.cross_ln_g; qa.ln_b = w.cross_ln_b; qa.bias = w.bq_abs; qa.Y = dw.qp; qa.ldy = H * d;
+          DT(3, launch_dec_gemm(qa, kProLn, kDecBias, stream_));
+          const int nq_max = cross_absorbed_max_nq(H);
+          for (int p0 = 0; p0 < np; p0 += nq_max) {
+            CrossAbsorbedArgs ca;
+            ca.qp = dw.qp; ca.e = slot.e_planes; ca.e_plane = long(ws_.batch) * T * d; ca.e_scale = sc_cross_kv_.a;
+            ca.ws = dw.abs_ws; ca.batch = batch; ca.heads = H; ca.d_model = d; ca.T = T; ca.chunks = abs_chunks;
+            ca.nq = std::min(nq_max, np - p0); ca.p0 = p0;
+            DT(4, launch_cross_absorbed(ca, stream_));
+          }
+          DT(8, launch_cross_absorbed_combine(dw.abs_ws, dw.cabs, M, H, abs_chunks, d, stream_));
+          DecGemmArgs co;
+          co.Wt = w.wo_abs.w; co.w_scale = w.wo_abs.scale; co.N = d; co.K = H * d; co.B = batch; co.M = M;
+          co.X = dw.cabs; co.ldx = H * d; co.bias = w.bo_abs; co.R = x; co.Y = x; co.ldy = d;
+          DT(5, launch_dec_gemm(co, kProNone, kDecResid, stream_));
+        } else {
         CrossAttnArgs ca;  // LN + query projection + attention over the cached encoder keys, per key chunk
         ca.x = x; ca.ln_g = w.cross_ln_g; ca.ln_b = w.cross_ln_b; ca.wq_t = w.cross_wq_t; ca.bq = w.cross_bq;
         ca.kc = cache_at(slot.cross_kv, (size_t(l) * 2 + 0) * kv_slab); ca.vc = cache_at(slot.cross_kv, (size_t(l) * 2 + 1) * kv_slab);
@@ -1569,6 +1669,7 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
         co.cross_ws = dw.cross_ws; co.heads = H; co.chunks = chunks;
         co.bias = w.cross_bo; co.R = x; co.Y = x; co.ldy = d;
         DT(5, launch_dec_gemm(co, kProCombine, kDecResid, stream_));
+        }
 
         DecGemmArgs f1;  // LN + fc1 + GELU
         f1.bf16 = bf;
@@ -1614,7 +1715,7 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
   // kernels' one-time attribute set-up) and then captures one hipGraph per slot; later calls
   // replay the slot's graph: one host call instead of ~1100. The logits tap stays eager.
   auto key_of = [&](int si) {
-    return std::vector<long long>{si, batch, max_pos, n_prompt, chunks, long(stop_at_eot), fc2_ksplit, bf16};
+    return std::vector<long long>{si, batch, max_pos, n_prompt, chunks, long(stop_at_eot), fc2_ksplit, bf16, absorbed ? 1 : 0};
   };
   hipGraphExec_t exec = nullptr;
   if (use_graphs && !logits_host) {
@@ -1727,8 +1828,8 @@ void Engine::decode_collect(int slot_idx, int64_t* ids, int32_t* n_ids) {
   if (hipEventElapsedTime(&ms, slot.dec_begin, slot.dec_done) == hipSuccess) timings_.decoder_ms = ms;
   if (hipEventElapsedTime(&ms, slot.enc_begin, slot.dec_done) == hipSuccess) timings_.total_ms = ms;
   if (!slot.dt_cls.empty()) {
-    static const char* kNames[11] = {"qkv(LN)", "self_attn", "o_proj", "cq(LN)", "cross_attn", "combine+co",
-                                     "fc1(LN)", "fc2", "final_ln", "logits", "select"};
+    static const char* kNames[11] = {"qkv(LN)", "self_attn", "o_proj", "q_abs(LN)", "cross_attn", "co",
+                                     "fc1(LN)", "fc2", "abs_combine", "logits", "select"};
     double tot[11] = {0};
     int cnt[11] = {0};
     for (size_t i = 0; i < slot.dt_cls.size(); ++i) {

@@ -53,6 +53,11 @@ struct DecBlockWeights {
   TiledW wqkv, wo;
   const float *cross_ln_g, *cross_ln_b, *cross_wq_t, *cross_bq, *cross_bo;  // cross_wq_t: cross_q_layout()
   TiledW cross_wo;
+  // absorbed cross-attention (k_cross_absorbed.hip): the key projection folded into the query side, A_h = c0 Wk_h^T Wq_h
+  // stacked over heads [H d][d] with its bias c0 Wk_h^T bq_h, and the value projection folded into the output side,
+  // W'[n][h d + c] = sum_i Wo[n][64 h + i] Wv[64 h + i][c] with bias bo + Wo bv (upload_weights)
+  TiledW wq_abs, wo_abs;
+  const float *bq_abs = nullptr, *bo_abs = nullptr;
   const float *mlp_ln_g, *mlp_ln_b, *b1, *b2;
   TiledW w1, w2;
 };
@@ -95,6 +100,11 @@ class Engine {
   long attn_variant = 4;  // encoder attention: 4 = two fp16 planes (default), 1 = three bf16 planes (full range), 0 = fp32 MFMA
   long fc2_ksplit = 2;  // decoder fc2 (K = 4 d_model) over twice the blocks, halves summed by the consumer
   long use_graphs = 1;  // replay the decoder's launch sequence from a captured hipGraph
+  // 1 = decoder cross-attention against the encoder output itself, K / V projections absorbed into the query and
+  // output sides (k_cross_absorbed.hip: half the bytes per decoder position, no cross-KV GEMM in the encoder);
+  // 0 = round 2's cross-KV cache.  The bf16 storage mode and a flagged ln_post operand always take the cache.
+  long cross_absorb = 1;
+  bool absorb_active() const { return cross_absorb != 0 && bf16 == 0 && gemm_variant < 0 && sc_cross_kv_.f16_ok; }
   long gemm_variant = -1;  // -1 = plane GEMM (per-contraction fall-back to 13/16); 0 = fp32 MFMA, 13 / 16 = three bf16 planes
   // 1 = bf16 STORAGE mode (BASELINE configs[3]): bf16 weights, activations and both KV caches, fp32 accumulation,
   // fp32 residual stream; k_gemm_bf16.hip and the BF variants of the attention / decoder kernels.  Set through
@@ -202,6 +212,8 @@ class Engine {
   hipEvent_t ev_[2] = {nullptr, nullptr};  // front end begin / end
   struct Slot {
     float* cross_kv = nullptr;  // [layer][k|v][clip][head][t][64]
+    unsigned short* e_planes = nullptr;  // absorbed cross-attention: planes of the encoder output [clip][T][d]
+    bool absorbed = false;               // which of the two this slot's encoder pass filled
     hipEvent_t enc_begin = nullptr, enc_mid = nullptr, enc_done = nullptr;
     hipEvent_t dec_begin = nullptr, dec_done = nullptr;
     long long* h_ids = nullptr;  // pinned [4096][32]
@@ -296,6 +308,7 @@ class Engine {
     float *xb = nullptr, *xpart = nullptr;  // fc2's K-split: first-half result / second-half partial
     float *xd = nullptr, *qkvd = nullptr, *attd = nullptr,
           *hd = nullptr, *cross_ws = nullptr, *self_kv = nullptr, *logits = nullptr;
+    float *qp = nullptr, *abs_ws = nullptr, *cabs = nullptr;  // absorbed queries, per-chunk records, combined contexts
     unsigned long long* best = nullptr;
     long long* ids = nullptr;
     int *n_ids = nullptr, *finished = nullptr;

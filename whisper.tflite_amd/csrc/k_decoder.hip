@@ -746,7 +746,7 @@ void launch_dec_gemm(const DecGemmArgs& a, int pro, int epi, hipStream_t s) {
   const bool resid = epi == kDecResid;  // N = d_model: 8 wavefronts split K
   const int waves = resid ? 8 : 4;
   const int kblock = a.K / ksplit;
-  if (!a.Wt || a.B < 1 || M < a.B || M > 128 || M % a.B != 0 || a.K > 2048 || a.K % 16 != 0 || !(a.w_scale > 0.0f) ||
+  if (!a.Wt || a.B < 1 || M < a.B || M > 128 || M % a.B != 0 || a.K > 4096 || a.K % 16 != 0 || !(a.w_scale > 0.0f) ||
       ksplit > 2 || kblock % (16 * waves) != 0 ||
       (pro == kProCombine && a.K != a.heads * 64) || (resid && (!a.R || !a.Y))) {
     throw Error(kErrInvalidArg, "decoder GEMM shape outside the kernel contract");

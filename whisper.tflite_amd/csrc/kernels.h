@@ -241,6 +241,23 @@ struct CrossAttnArgs {
   bool bf16 = false;
 };
 void launch_cross_attention(const CrossAttnArgs& a, hipStream_t s);
+// Cross attention with the K / V projections absorbed (k_cross_absorbed.hip): scores and context are taken against
+// the encoder output E itself (planes: hi at e, lo at e + e_plane, scaled by the power of two e_scale; [clip][T][d]),
+// shared by all heads and layers.  qp [rows][heads * d]: absorbed queries q'_h = c0 Wk_h^T (Wq_h LN(x) + bq_h) with
+// c0 = d_head^-1/2 log2(e) (row = p * batch + b; this launch handles positions p0 .. p0 + nq - 1, nq * heads <= 16).
+// ws [rows][heads][chunks][d + 4]: per key chunk the unnormalised context c[d], m (natural log), l.
+struct CrossAbsorbedArgs {
+  const float* qp = nullptr;
+  const unsigned short* e = nullptr;
+  long e_plane = 0;
+  float e_scale = 1.0f;
+  float* ws = nullptr;
+  int batch = 0, heads = 0, d_model = 0, T = 0, chunks = 1, nq = 1, p0 = 0;
+};
+void launch_cross_absorbed(const CrossAbsorbedArgs& a, hipStream_t s);
+int cross_absorbed_max_nq(int heads);  // positions one launch can take
+// out [rows][heads * d] = chunk-combined, normalised contexts (the A operand of the folded Wo . Wv_h projection)
+void launch_cross_absorbed_combine(const float* ws, float* out, int rows, int heads, int chunks, int d_model, hipStream_t s);
 // Greedy selection after the logits GEMM: reduces the per-tile (value, column) records
 // best[B][n_tiles], appends to ids and applies the EOT stop (reference whisper.cpp:397-399).
 void launch_select_token(const unsigned long long* best, int n_tiles, long long* ids, int ids_stride,
