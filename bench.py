@@ -255,6 +255,7 @@ def main() -> None:
     ap.add_argument("--cross-chunks", type=int, default=None, choices=(1, 2, 4, 8))
     ap.add_argument("--cross-absorb", type=int, default=None, choices=(0, 1),
                     help="0 = round 2's cross-KV cache instead of the absorbed cross-attention (default 1)")
+    ap.add_argument("--abs-chunks", type=int, default=None, help="key chunks per clip of the absorbed cross-attention (0 = automatic)")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the extra fp32-MFMA-only measurement")
     ap.add_argument("--no-graphs", action="store_true", help="launch the decoder eagerly instead of replaying its hipGraph")
     ap.add_argument("--gemm-variant", type=int, default=None, help="encoder GEMM tile variant (k_gemm.hip)")
@@ -311,6 +312,8 @@ def main() -> None:
         eng.set_option("cross_chunks", args.cross_chunks)
     if args.cross_absorb is not None:
         eng.set_option("cross_absorb", args.cross_absorb)
+    if args.abs_chunks is not None:
+        eng.set_option("abs_chunks", args.abs_chunks)
     if args.no_graphs:
         eng.set_option("use_graphs", 0)
     if args.gemm_variant is not None:

@@ -63,11 +63,12 @@ int wt_dbg_cross_attention(wt_engine* h, int batch, int heads, int T, int chunks
                            const float* ln_g, const float* ln_b, const float* wq, const float* bq, const float* kc,
                            const float* vc, float* out);
 /* qkv [npos*B][3d] (row = p * B + b); caches [B][cap][d] updated in place at rows pos .. pos+npos-1; out [npos*B][d] */
-/* absorbed cross-attention (k_cross_absorbed.hip) + chunk combine: qp [nq * batch][heads * d] absorbed queries (log2
- * domain), E [batch][T][d] encoder output (split into planes on the host); out [nq * batch][heads * d] =
- * sum_j softmax2_j(qp_h . e_j) e_j per (row, head); d = 64 * heads */
+/* absorbed cross-attention (k_cross_absorbed.hip) + chunk combine with the heads' value projections: qp [nq * batch]
+ * [heads * d] absorbed queries (log2 domain), E [batch][T][d] encoder output (split into planes on the host), wv [d][d],
+ * bv [d]; out [nq * batch][d]: out[r][64 h + j] = Wv[64 h + j] . (sum_k softmax2_k(qp_h . e_k) e_k) + bv[64 h + j];
+ * d = 64 * heads.  iters > 0 also times the attention launch. */
 int wt_dbg_cross_absorbed(wt_engine* h, int batch, int heads, int T, int chunks, int nq, const float* qp, const float* E,
-                          float* out);
+                          const float* wv, const float* bv, float* out, int iters, float* avg_us);
 int wt_dbg_self_attention(wt_engine* h, int batch, int heads, int cap, int pos, int npos, const float* qkv,
                           float* kcache, float* vcache, float* out);
 /* bf16 storage mode kernels (option "bf16"): operands are rounded to bf16 on the host, contracted by

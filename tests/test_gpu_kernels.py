@@ -552,8 +552,8 @@ def test_plane_gemm_every_tile_shape_gives_the_same_result(eng, n_cu, expect):
 @pytest.mark.parametrize("B,H,T,chunks,nq", [(1, 6, 1500, 8, 1), (3, 6, 333, 4, 2), (2, 2, 100, 2, 4), (2, 8, 200, 3, 2),
                                               (1, 6, 64, 2, 1), (2, 6, 1500, 16, 4), (5, 6, 97, 1, 1)])
 def test_cross_attention_absorbed(eng, B, H, T, chunks, nq):
-    """k_cross_absorbed.hip: per (row, head) sum_j softmax_j(q' . e_j) e_j over the encoder output itself (scores in
-    the log2 domain), key chunks combined — against fp64.  Covers d_model 384 / 128 / 512 (6 / 2 / 8 heads), ragged
+    """k_cross_absorbed.hip: per (row, head) Wv_h (sum_j softmax_j(q' . e_j) e_j) + bv_h over the encoder output
+    itself (scores in the log2 domain), key chunks combined — against fp64.  Covers d_model 384 / 128 / 512 (6 / 2 / 8 heads), ragged
     last tiles and chunks, one to four positions per clip (positions beyond 16 / heads query columns take a second
     launch), a single chunk, and the full 1500-key sweep."""
     rng = np.random.default_rng(B * 1000 + T + H + nq)
@@ -561,12 +561,15 @@ def test_cross_attention_absorbed(eng, B, H, T, chunks, nq):
     E = rng.standard_normal((B, T, d)).astype(np.float32)
     qp = (rng.standard_normal((nq * B, H * d)) * (3.0 / np.sqrt(d))).astype(np.float32)  # scores O(3) in log2 units
     qp[0, :d] *= 4.0          # one peaky query column: its running maximum jumps
-    out = eng.dbg_cross_absorbed(qp, E, B, H, T, chunks, nq)
+    wv = (rng.standard_normal((d, d)) / np.sqrt(d)).astype(np.float32)
+    bv = rng.standard_normal(d).astype(np.float32)
+    out = eng.dbg_cross_absorbed(qp, E, wv, bv, B, H, T, chunks, nq)
     E64 = E.astype(np.float64)
     for r in range(nq * B):
         b = r % B                                   # row = p * B + b
         for h in range(H):
             s = E64[b] @ qp[r, h * d:(h + 1) * d].astype(np.float64)
             p = np.exp2(s - s.max())
-            ref = (p[:, None] * E64[b]).sum(0) / p.sum()
-            assert np.abs(out[r, h * d:(h + 1) * d] - ref).max() < 2e-5, (r, h)
+            c = (p[:, None] * E64[b]).sum(0) / p.sum()
+            ref = wv[h * 64:(h + 1) * 64].astype(np.float64) @ c + bv[h * 64:(h + 1) * 64]
+            assert np.abs(out[r, h * 64:(h + 1) * 64] - ref).max() < 2e-5, (r, h)

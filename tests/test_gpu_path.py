@@ -274,6 +274,50 @@ def test_pipeline_submit_collect_matches_sync(tiny):
     assert np.array_equal(e.encdec_tokens_batch(mels[3])[0], want[3][0])  # sync call works again
 
 
+def test_pipeline_pairs_two_batches_per_decoder_chain(tiny):
+    """Option dec_pair (default): two consecutive submitted batches of equal size are decoded by ONE decoder chain
+    (64 rows per pass, each half reading its own batch's encoder-output planes).  Every batch must come back in
+    submission order with exactly the ids of the synchronous call — for full pairs, for a batch whose partner never
+    arrives (collected first: decoded alone), for an odd number of submissions, for unequal sizes (never paired),
+    with hipGraph replay and without, and with the pairing switched off."""
+    from conftest import DevBuf
+    e, _ = tiny
+    rng = np.random.default_rng(2024)
+    mels = [rng.uniform(-1.0, 1.5, size=(b, 80, 3000)).astype(np.float32) for b in (4, 4, 4, 4, 4, 3, 3)]
+    e.set_option("dec_pair", 0)
+    want = [e.encdec_tokens_batch(m) for m in mels]
+    dev = [DevBuf(m) for m in mels]
+
+    def run(order, depth):
+        got, in_flight = [], 0
+        for k in order:
+            e.pipeline_submit_dev(dev[k].data_ptr(), mels[k].shape[0])
+            in_flight += 1
+            if in_flight == depth:
+                got.append(e.pipeline_collect())
+                in_flight -= 1
+        while in_flight:
+            got.append(e.pipeline_collect())
+            in_flight -= 1
+        for k, (ids_g, n_g) in zip(order, got):
+            assert np.array_equal(want[k][0], ids_g) and np.array_equal(want[k][1], n_g), (order, depth, k)
+
+    for pair in (1, 0, 1):
+        e.set_option("dec_pair", pair)
+        for graphs in (1, 0):
+            e.set_option("use_graphs", graphs)
+            run([0, 1, 2, 3], 4)          # two full pairs
+            run([0, 1, 2, 3, 4], 2)       # pairs, then a single at the end
+            run([0], 1)                   # partner never comes
+            run([0, 1, 2], 1)             # every batch collected before the next is submitted: all decoded alone
+            run([0, 5, 6, 1, 2, 5], 3)    # unequal sizes are not paired; equal neighbours are
+            run([4, 3, 2, 1, 0, 1], 6)    # pipeline full
+        e.set_option("use_graphs", 1)
+    e.set_option("dec_pair", 1)
+    for d in dev:
+        d.free()
+
+
 def test_config3_second_weight_set_multilingual_prompt(pkg, assets, orc):
     """BASELINE configs[2] (whisper-tiny-german): same graph, a different weight set (seed 1
     stands in for the fine-tune) and the multilingual vocab path (sot 50258, <|de|> 50261,

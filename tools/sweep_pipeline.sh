@@ -1,6 +1,6 @@
-# pipeline knobs A/B on one box (GPU): reserve (CUs per XCD kept free of pipelined encoder work), strict partition
+# pipeline knobs A/B on one box (GPU)
 set -o pipefail
-run() { name=$1; shift; env "$@" python bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-fp32-leg ${EXTRA} > gpurun_out/sw_$name.json 2> gpurun_out/sw_$name.err; python - "$name" <<'PY'
+run() { name=$1; shift; env "$@" python bench.py --steps 40 --warmup 4 --no-cpu-baseline --no-fp32-leg ${EXTRA} > gpurun_out/sw_$name.json 2> gpurun_out/sw_$name.err; python - "$name" <<'PY'
 import json,sys
 n=sys.argv[1]
 try:
@@ -10,13 +10,11 @@ except Exception as e:
     print(n,'ERR',e, open(f'gpurun_out/sw_{n}.err').read()[-300:])
 PY
 }
-EXTRA="" run res4 WT_ENC_CU_RESERVE=4
-EXTRA="" run res8 WT_ENC_CU_RESERVE=8
-EXTRA="" run res8part WT_ENC_CU_RESERVE=8 WT_DEC_PARTITION=1
-EXTRA="" run res10part WT_ENC_CU_RESERVE=10 WT_DEC_PARTITION=1
-EXTRA="" run res6part WT_ENC_CU_RESERVE=6 WT_DEC_PARTITION=1
-EXTRA="" run res8part_dec4 WT_ENC_CU_RESERVE=8 WT_DEC_PARTITION=1 WT_DEC_STREAMS=4
-EXTRA="" run res8_cc2 WT_ENC_CU_RESERVE=8
-EXTRA="--cross-chunks 2" run res8part_cc2 WT_ENC_CU_RESERVE=8 WT_DEC_PARTITION=1
-EXTRA="" run res9 WT_ENC_CU_RESERVE=9
-EXTRA="" run res8b WT_ENC_CU_RESERVE=8
+EXTRA="--abs-chunks 4" run b32_c4_res8 WT_ENC_CU_RESERVE=8
+EXTRA="--batch 64 --abs-chunks 4" run b64_c4_res8 WT_ENC_CU_RESERVE=8
+EXTRA="--batch 64 --abs-chunks 2" run b64_c2_res8 WT_ENC_CU_RESERVE=8
+EXTRA="--batch 64 --abs-chunks 2" run b64_c2_res4 WT_ENC_CU_RESERVE=4
+EXTRA="--batch 64 --abs-chunks 4" run b64_c4_res4 WT_ENC_CU_RESERVE=4
+EXTRA="--batch 64 --abs-chunks 2" run b64_c2_res6 WT_ENC_CU_RESERVE=6
+EXTRA="--batch 64 --abs-chunks 2 --depth 3" run b64_c2_res4_d3 WT_ENC_CU_RESERVE=4
+EXTRA="--batch 64 --abs-chunks 2" run b64_c2_res4_dec2 WT_ENC_CU_RESERVE=4 WT_DEC_STREAMS=2

@@ -139,7 +139,7 @@ def lib() -> ctypes.CDLL:
         L.wt_dbg_gemm_planes.argtypes = [c_void_p, c_int, c_int, c_int, fp, fp, fp, fp, fp, c_int, c_int, c_int, c_int, fp,
                                          POINTER(c_float), c_int]
         L.wt_dbg_encoder_attention_planes.argtypes = [c_void_p, c_int, c_int, c_int, fp, c_int, fp, POINTER(c_float)]
-        L.wt_dbg_cross_absorbed.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, fp, fp, fp]
+        L.wt_dbg_cross_absorbed.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, fp, fp, fp, fp, fp, c_int, POINTER(c_float)]
         L.wt_dbg_gemm_planes_ln.argtypes = [c_void_p, c_int, c_int, fp, fp, fp, fp, fp, c_int, c_int, fp, fp, c_int, fp, fp, fp,
                                             POINTER(c_int)]
         L.wt_dbg_gemm_bf16.argtypes = [c_void_p, c_int, c_int, c_int, fp, fp, fp, fp, fp, c_int, c_int, c_int, c_int, fp,
@@ -495,13 +495,16 @@ class Engine:
                                                 int(n_cu), _fp(C), _fp(ln), _fp(y32) if y32 is not None else None, byref(fused)))
         return C, ln, y32, bool(fused.value)
 
-    def dbg_cross_absorbed(self, qp, E, batch, heads, T, chunks, nq):
-        """Absorbed cross-attention + chunk combine: qp [nq * batch][heads * d], E [batch][T][d] -> [nq * batch][heads * d]"""
-        qp, E = _f32(qp), _f32(E)
+    def dbg_cross_absorbed(self, qp, E, wv, bv, batch, heads, T, chunks, nq, iters=0):
+        """Absorbed cross-attention + chunk combine + value projection: qp [nq * batch][heads * d], E [batch][T][d],
+        wv [d][d], bv [d] -> [nq * batch][d] (and the average microseconds of the attention launch when iters > 0)"""
+        qp, E, wv, bv = _f32(qp), _f32(E), _f32(wv), _f32(bv)
         d = heads * 64
-        out = np.zeros((nq * batch, heads * d), np.float32)
-        self._check(lib().wt_dbg_cross_absorbed(self._h, batch, heads, T, chunks, nq, _fp(qp), _fp(E), _fp(out)))
-        return out
+        out = np.zeros((nq * batch, d), np.float32)
+        us = c_float(0)
+        self._check(lib().wt_dbg_cross_absorbed(self._h, batch, heads, T, chunks, nq, _fp(qp), _fp(E), _fp(wv), _fp(bv), _fp(out),
+                                                iters, byref(us)))
+        return (out, us.value) if iters > 0 else out
 
     def dbg_encoder_attention_planes(self, qkv, batch, T, heads, iters=0):
         qkv = _f32(qkv)

@@ -169,6 +169,12 @@ int wt_engine_set_option(wt_engine* h, const char* key, long value) {
     e.use_graphs = value != 0;
   } else if (k == "cross_absorb") {
     e.cross_absorb = value != 0;
+  } else if (k == "dec_pair") {
+    if (h->impl->in_flight() > 0) return fail(h, WT_ERR_INVALID_ARG, "collect the submitted batches before changing dec_pair");
+    e.dec_pair = value != 0;
+  } else if (k == "abs_chunks") {
+    if (value < 0 || value > 16) return fail(h, WT_ERR_INVALID_ARG, "abs_chunks must be 0 (automatic) or 1..16");
+    e.abs_chunks = value;
   } else if (k == "gemm_variant") {
     if (value != -1 && !wt::gemm_variant_supported(int(value))) {
       return fail(h, WT_ERR_INVALID_ARG, "gemm_variant must be -1 (default: plane GEMM), 0 (fp32 MFMA), 13 or 16 (three bf16 planes)");
@@ -218,6 +224,8 @@ int wt_engine_get_option(const wt_engine* h, const char* key, long* value) {
   else if (k == "gemm_variant") *value = e.gemm_variant;
   else if (k == "use_graphs") *value = e.use_graphs;
   else if (k == "cross_absorb") *value = e.cross_absorb;
+  else if (k == "abs_chunks") *value = e.abs_chunks;
+  else if (k == "dec_pair") *value = e.dec_pair;
   else if (k == "cross_absorb_active") *value = e.absorb_active() ? 1 : 0;  // read-only
   else if (k == "bf16") *value = e.bf16;
   else if (k == "kernel_timers") *value = e.kernel_timers;
@@ -1198,13 +1206,14 @@ int wt_dbg_cross_attention(wt_engine* h, int batch, int heads, int T, int chunks
 }
 
 int wt_dbg_cross_absorbed(wt_engine* h, int batch, int heads, int T, int chunks, int nq, const float* qp, const float* E,
-                          float* out) {
-  if (!h || !qp || !E || !out || batch < 1 || heads < 1 || T < 1 || nq < 1 || chunks < 1 || chunks > 16) return WT_ERR_INVALID_ARG;
+                          const float* wv, const float* bv, float* out, int iters, float* avg_us) {
+  if (!h || !qp || !E || !wv || !bv || !out || batch < 1 || heads < 1 || T < 1 || nq < 1 || chunks < 1 || chunks > 16) return WT_ERR_INVALID_ARG;
   return guarded(h, [&] {
     const size_t d = size_t(heads) * 64, rows = size_t(nq) * batch;
     const float se = wt::f16_scale_for(max_abs(E, size_t(batch) * T * d));
     const DevPlanes dE(E, size_t(batch) * T * d, se);
-    DevBuf dq(qp, rows * heads * d), dws(rows * heads * chunks * (d + 4)), dout(rows * heads * d);
+    const std::vector<float> wvt = wt::cross_q_layout(wv, int(d));
+    DevBuf dq(qp, rows * heads * d), dws(rows * heads * chunks * (d + 4)), dout(rows * d), dwv(wvt.data(), wvt.size()), dbv(bv, d);
     const int nq_max = wt::cross_absorbed_max_nq(heads);
     for (int p0 = 0; p0 < nq; p0 += nq_max) {
       wt::CrossAbsorbedArgs a;
@@ -1212,9 +1221,28 @@ int wt_dbg_cross_absorbed(wt_engine* h, int batch, int heads, int T, int chunks,
       a.batch = batch; a.heads = heads; a.d_model = int(d); a.T = T; a.chunks = chunks; a.nq = std::min(nq_max, nq - p0); a.p0 = p0;
       wt::launch_cross_absorbed(a, h->impl->stream());
     }
-    wt::launch_cross_absorbed_combine(dws.p, dout.p, int(rows), heads, chunks, int(d), h->impl->stream());
+    wt::launch_cross_absorbed_combine(dws.p, dwv.p, dbv.p, dout.p, int(rows), heads, chunks, int(d), h->impl->stream());
     h->impl->sync();
-    dout.to_host(out, rows * heads * d);
+    dout.to_host(out, rows * d);
+    if (iters > 0 && avg_us) {
+      wt::CrossAbsorbedArgs a;
+      a.qp = dq.p; a.e = dE.ptr(); a.e_plane = dE.plane; a.e_scale = se; a.ws = dws.p;
+      a.batch = batch; a.heads = heads; a.d_model = int(d); a.T = T; a.chunks = chunks; a.nq = std::min(nq_max, nq); a.p0 = 0;
+      hipStream_t st = h->impl->stream();
+      hipEvent_t e0, e1;
+      hipchk(hipEventCreate(&e0), "event");
+      hipchk(hipEventCreate(&e1), "event");
+      for (int i = 0; i < 3; ++i) wt::launch_cross_absorbed(a, st);
+      hipchk(hipEventRecord(e0, st), "record");
+      for (int i = 0; i < iters; ++i) wt::launch_cross_absorbed(a, st);
+      hipchk(hipEventRecord(e1, st), "record");
+      hipchk(hipEventSynchronize(e1), "sync");
+      float ms = 0;
+      hipchk(hipEventElapsedTime(&ms, e0, e1), "elapsed");
+      *avg_us = 1e3f * ms / iters;
+      (void)hipEventDestroy(e0);
+      (void)hipEventDestroy(e1);
+    }
   });
 }
 

@@ -343,17 +343,15 @@ void Engine::upload_weights(const std::string& path) {
       // Absorbed cross-attention (k_cross_absorbed.hip): scores q_h . (Wk_h e) = (Wk_h^T q_h) . e and contexts
       // sum_j p_j (Wv_h e_j + bv_h) = Wv_h (sum_j p_j e_j) + bv_h, so the decoder works on the encoder output e itself.
       // Folded once, in double: A_h = c0 Wk_h^T Wq_h (c0 = d_head^-1/2 log2 e: the kernel's softmax is an exp2),
-      // a_h = c0 Wk_h^T bq_h; W'[n][h d + c] = sum_i Wo[n][64 h + i] Wv[64 h + i][c], b' = bo + Wo bv.
+      // a_h = c0 Wk_h^T bq_h.  Wv_h and bv_h are applied to each head's combined context (cross_absorbed_combine).
       const int Hh = c.n_text_head;
       const float* wq = H(blk + ".cross_attn.query.weight", dd);
       const float* bq = H(blk + ".cross_attn.query.bias", d);
       const float* wk = H(blk + ".cross_attn.key.weight", dd);
       const float* wv = H(blk + ".cross_attn.value.weight", dd);
       const float* bv = H(blk + ".cross_attn.value.bias", d);
-      const float* wo = H(blk + ".cross_attn.out.weight", dd);
-      const float* bo = H(blk + ".cross_attn.out.bias", d);
       const double c0 = 0.125 * 1.44269504088896340736;
-      std::vector<float> A(size_t(Hh) * d * d), av(size_t(Hh) * d), Wp(size_t(d) * Hh * d), bp(d);
+      std::vector<float> A(size_t(Hh) * d * d), av(size_t(Hh) * d);
       std::vector<double> acc(d);
       for (int h = 0; h < Hh; ++h) {
         for (int cc = 0; cc < d; ++cc) {
@@ -369,26 +367,11 @@ void Engine::upload_weights(const std::string& path) {
           for (int j = 0; j < d; ++j) arow[j] = float(c0 * acc[j]);
           av[size_t(h) * d + cc] = float(c0 * ab);
         }
-        for (int n = 0; n < d; ++n) {
-          std::fill(acc.begin(), acc.end(), 0.0);
-          for (int i = 0; i < 64; ++i) {
-            const double ov = wo[size_t(n) * d + h * 64 + i];
-            const float* vrow = wv + size_t(h * 64 + i) * d;
-            for (int cc = 0; cc < d; ++cc) acc[cc] += ov * vrow[cc];
-          }
-          float* prow = Wp.data() + size_t(n) * Hh * d + size_t(h) * d;
-          for (int cc = 0; cc < d; ++cc) prow[cc] = float(acc[cc]);
-        }
-      }
-      for (int n = 0; n < d; ++n) {
-        double t = bo[n];
-        for (int k = 0; k < d; ++k) t += double(wo[size_t(n) * d + k]) * bv[k];
-        bp[n] = float(t);
       }
       bw.wq_abs = upload_tiled(A.data(), Hh * d, d);
       bw.bq_abs = upload(av);
-      bw.wo_abs = upload_tiled(Wp.data(), d, Hh * d);
-      bw.bo_abs = upload(bp);
+      bw.cross_wv_t = upload(cross_q_layout(wv, d));
+      bw.cross_bv = upload(std::vector<float>(bv, bv + d));
     }
     // all layers' cross K/V projections act on the same encoder output: one GEMM
     std::memcpy(ckv_w.data() + (size_t(l) * 2 + 0) * dd, H(blk + ".cross_attn.key.weight", dd), dd * 4);
@@ -1486,30 +1469,69 @@ void Engine::decode(int batch, int64_t* ids, int32_t* n_ids, float* logits_host,
   decode_collect(last_enc_slot_, ids, n_ids);
 }
 
+void Engine::flush_pending() {
+  if (pending_slot_ < 0) return;
+  const int p = pending_slot_;
+  pending_slot_ = -1;
+  decode_enqueue(slots_[p].batch, p, nullptr, 0, -1, true);
+}
+
+// decoder side of a pipelined submit: alone, or together with the previous submit's batch (dec_pair)
+static bool can_pair(const Engine& e, int batch) { return e.dec_pair != 0 && e.absorb_active() && batch <= 32; }
+
 void Engine::submit(const float* d_mel, int batch) {
   if (int(inflight_.size()) >= kSlots) throw Error(1, "pipeline is full (6 batches in flight): collect() first");
   if (batch > 64) throw Error(1, "decoder batches are limited to 64 clips per call");
   select_stream(true);
+  if (can_pair(*this, batch) && inflight_.empty()) ensure_batch(2 * batch);  // the pair's decoder rows; never grown in flight
   encode_enqueue(d_mel, batch);
-  decode_enqueue(batch, last_enc_slot_, nullptr, 0);
-  inflight_.push_back(last_enc_slot_);
+  const int s = last_enc_slot_;
+  if (can_pair(*this, batch) && ws_.batch >= 2 * batch) {
+    if (pending_slot_ >= 0 && slots_[pending_slot_].batch == batch) {
+      const int a = pending_slot_;
+      pending_slot_ = -1;
+      decode_enqueue(batch, a, nullptr, 0, s, true);
+    } else {
+      flush_pending();
+      pending_slot_ = s;
+    }
+  } else {
+    flush_pending();
+    decode_enqueue(batch, s, nullptr, 0, -1, true);
+  }
+  inflight_.push_back(s);
 }
 
 void Engine::submit_pcm(const float* d_pcm, int batch) {
   if (int(inflight_.size()) >= kSlots) throw Error(1, "pipeline is full (6 batches in flight): collect() first");
   if (batch > 64) throw Error(1, "decoder batches are limited to 64 clips per call");
   select_stream(true);
+  if (can_pair(*this, batch) && inflight_.empty()) ensure_batch(2 * batch);
   // one staging mel buffer: the front end of batch k+1 follows the encoder of batch k on the same stream
   float* d_mel = staging_mel(batch);
   logmel(d_pcm, batch, d_mel);
   encode_enqueue(d_mel, batch);
-  decode_enqueue(batch, last_enc_slot_, nullptr, 0);
-  inflight_.push_back(last_enc_slot_);
+  const int s = last_enc_slot_;
+  if (can_pair(*this, batch) && ws_.batch >= 2 * batch) {
+    if (pending_slot_ >= 0 && slots_[pending_slot_].batch == batch) {
+      const int a = pending_slot_;
+      pending_slot_ = -1;
+      decode_enqueue(batch, a, nullptr, 0, s, true);
+    } else {
+      flush_pending();
+      pending_slot_ = s;
+    }
+  } else {
+    flush_pending();
+    decode_enqueue(batch, s, nullptr, 0, -1, true);
+  }
+  inflight_.push_back(s);
 }
 
 void Engine::collect(int64_t* ids, int32_t* n_ids) {
   if (inflight_.empty()) throw Error(1, "collect() without a submitted batch");
   const int slot = inflight_.front();
+  if (slot == pending_slot_) flush_pending();  // its partner never came: decode it alone now
   inflight_.erase(inflight_.begin());
   decode_collect(slot, ids, n_ids);
 }
@@ -1525,14 +1547,23 @@ std::vector<long long> Engine::prompt() const {
   return {vocab_.token_sot, 50259 + language, vocab_.token_transcribe, vocab_.token_not};
 }
 
-void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int logits_steps_cap) {
+void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int logits_steps_cap, int slot_b, bool pipelined) {
+  const bool paired = slot_b >= 0;
+  const int per = batch;          // clips per encoder batch
+  if (paired) batch = 2 * per;    // the chain decodes both: rows / clips below count the pair
   if (batch > 64) throw Error(1, "decoder batches are limited to 64 clips per call");  // before any stream operation
+  if (paired && (slot_b != (slot_idx + 1) % kSlots || !slots_[slot_idx].absorbed || !slots_[slot_b].absorbed || logits_host)) {
+    throw Error(kErrInvalidArg, "decoder pairing: consecutive slots of the absorbed form only");
+  }
   ensure_batch(batch);
   Slot& slot = slots_[slot_idx];
   slot.dec = slot_idx % n_dec_streams_;  // fixed pairing keeps the number of captured graphs small
+  slot.pair_leader = -1;
+  slot.pair_off = 0;
   DecWorkspace& dw = dws_[slot.dec];
   hipStream_t const stream_ = dstream_[slot.dec];  // everything below runs on this decoder stream
   HIPCHK(hipStreamWaitEvent(stream_, slot.enc_done, 0));
+  if (paired) HIPCHK(hipStreamWaitEvent(stream_, slots_[slot_b].enc_done, 0));
   HIPCHK(hipEventRecord(slot.dec_begin, stream_));
   long long* const h_ids_ = slot.h_ids;
   int* const h_n_ = slot.h_n;
@@ -1555,8 +1586,11 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
   }
   // key chunks of the absorbed form: clips x chunks ~ 256 blocks, a chunk a whole number of 32-key tiles
   const bool absorbed = slot.absorbed;  // the form this slot's encoder pass prepared (the same for every slot of a graph set)
-  int abs_chunks = std::min(16, std::max(1, (256 + batch - 1) / batch));
-  abs_chunks = std::min(abs_chunks, (T + 31) / 32);
+  // (option abs_chunks; 0 = 256 / clips: one block per CU when the decoder has the chip; pipelined 128 / clips — fewer,
+  // longer blocks: a block costs ~9 us before its first tile, and the decoders share the CUs the encoder leaves)
+  const int abs_blocks = pipelined ? 128 : 256;
+  int n_abs = abs_chunks > 0 ? int(abs_chunks) : std::min(16, std::max(1, (abs_blocks + batch - 1) / batch));
+  n_abs = std::min(n_abs, (T + 31) / 32);
   int steps = 0;
   // WT_DEC_KERNEL_TIMERS=1 (diagnostics, eager launches only): event pairs around every decoder launch
   static const bool dec_timers = getenv("WT_DEC_KERNEL_TIMERS") != nullptr;
@@ -1584,6 +1618,7 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
   (void)dw;
   auto enqueue_all = [&](int si) {
     Slot& slot = slots_[si];
+    const Slot& slot2 = slots_[(si + 1) % kSlots];  // the pair's second batch (paired only)
     DecWorkspace& dw = dws_[si % n_dec_streams_];
     hipStream_t const stream_ = dstream_[si % n_dec_streams_];
     long long* const h_ids_ = slot.h_ids;
@@ -1637,8 +1672,8 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
         if (absorbed) {
           // Cross attention against the encoder output itself (k_cross_absorbed.hip): LN + absorbed query projection
           // q'_h = c0 Wk_h^T (Wq_h LN(x) + bq_h) for all heads in one GEMM, the matrix-core sweep of E per key chunk
-          // (positions in groups of 16 / heads query columns), the chunk combine, and the out-projection with
-          // Wo . Wv_h folded.
+          // (positions in groups of 16 / heads query columns), the chunk combine with the heads' value projections,
+          // and the ordinary out-projection.
           DecGemmArgs qa;
           qa.Wt = w.wq_abs.w; qa.w_scale = w.wq_abs.scale; qa.N = H * d; qa.K = d; qa.B = batch; qa.M = M;
           qa.xin = x; qa.ln_g = w.cross_ln_g; qa.ln_b = w.cross_ln_b; qa.bias = w.bq_abs; qa.Y = dw.qp; qa.ldy = H * d;
@@ -1647,14 +1682,15 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
           for (int p0 = 0; p0 < np; p0 += nq_max) {
             CrossAbsorbedArgs ca;
             ca.qp = dw.qp; ca.e = slot.e_planes; ca.e_plane = long(ws_.batch) * T * d; ca.e_scale = sc_cross_kv_.a;
-            ca.ws = dw.abs_ws; ca.batch = batch; ca.heads = H; ca.d_model = d; ca.T = T; ca.chunks = abs_chunks;
+            if (paired) ca.e2 = slot2.e_planes, ca.split = per;
+            ca.ws = dw.abs_ws; ca.batch = batch; ca.heads = H; ca.d_model = d; ca.T = T; ca.chunks = n_abs;
             ca.nq = std::min(nq_max, np - p0); ca.p0 = p0;
             DT(4, launch_cross_absorbed(ca, stream_));
           }
-          DT(8, launch_cross_absorbed_combine(dw.abs_ws, dw.cabs, M, H, abs_chunks, d, stream_));
-          DecGemmArgs co;
-          co.Wt = w.wo_abs.w; co.w_scale = w.wo_abs.scale; co.N = d; co.K = H * d; co.B = batch; co.M = M;
-          co.X = dw.cabs; co.ldx = H * d; co.bias = w.bo_abs; co.R = x; co.Y = x; co.ldy = d;
+          DT(8, launch_cross_absorbed_combine(dw.abs_ws, w.cross_wv_t, w.cross_bv, dw.cabs, M, H, n_abs, d, stream_));
+          DecGemmArgs co;  // x += o . Wco^T + bco
+          co.Wt = w.cross_wo.w; co.w_scale = w.cross_wo.scale; co.N = d; co.K = d; co.B = batch; co.M = M;
+          co.X = dw.cabs; co.ldx = d; co.bias = w.cross_bo; co.R = x; co.Y = x; co.ldy = d;
           DT(5, launch_dec_gemm(co, kProNone, kDecResid, stream_));
         } else {
         CrossAttnArgs ca;  // LN + query projection + attention over the cached encoder keys, per key chunk
@@ -1715,7 +1751,7 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
   // kernels' one-time attribute set-up) and then captures one hipGraph per slot; later calls
   // replay the slot's graph: one host call instead of ~1100. The logits tap stays eager.
   auto key_of = [&](int si) {
-    return std::vector<long long>{si, batch, max_pos, n_prompt, chunks, long(stop_at_eot), fc2_ksplit, bf16, absorbed ? 1 : 0};
+    return std::vector<long long>{si, batch, max_pos, n_prompt, chunks, long(stop_at_eot), fc2_ksplit, bf16, absorbed ? 1 : 0, n_abs, paired ? 1 : 0};
   };
   hipGraphExec_t exec = nullptr;
   if (use_graphs && !logits_host) {
@@ -1737,6 +1773,11 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
     // fail, so that submit() / collect() stay consistent whatever happens to the captures below
     HIPCHK(hipEventRecord(slot.dec_done, stream_));
     slot.steps = eager_steps;
+    if (paired) {
+      Slot& sb = slots_[slot_b];
+      HIPCHK(hipEventRecord(sb.dec_done, stream_));
+      sb.pair_leader = slot_idx, sb.pair_off = per, sb.steps = eager_steps, sb.dec = slot.dec;
+    }
     if (use_graphs && !logits_host) {
       // A capture or instantiation failure is not fatal: the decoder keeps launching eagerly (same kernels, same
       // results, more host time per batch) and the engine stops trying.
@@ -1773,6 +1814,11 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
   }
   HIPCHK(hipEventRecord(slot.dec_done, stream_));
   slot.steps = steps;
+  if (paired) {
+    Slot& sb = slots_[slot_b];
+    HIPCHK(hipEventRecord(sb.dec_done, stream_));
+    sb.pair_leader = slot_idx, sb.pair_off = per, sb.steps = steps, sb.dec = slot.dec;
+  }
 }
 
 #undef DT
@@ -1814,10 +1860,13 @@ void Engine::decode_collect(int slot_idx, int64_t* ids, int32_t* n_ids) {
                    "attn_variant 1 (bf16 three-plane split) have the full fp32 range");
   }
   const int batch = slot.batch, stride = 32;
+  // a batch decoded by its pair leader's chain: the ids are in the leader's buffers behind the leader's own clips
+  const Slot& src = slot.pair_leader >= 0 ? slots_[slot.pair_leader] : slot;
+  const size_t off = slot.pair_leader >= 0 ? size_t(slot.pair_off) : 0;
   for (int b = 0; b < batch; ++b) {
-    n_ids[b] = slot.h_n[b];
+    n_ids[b] = src.h_n[off + b];
     for (int i = 0; i < stride; ++i)
-      ids[size_t(b) * stride + i] = i < slot.h_n[b] ? slot.h_ids[size_t(b) * stride + i] : 0;
+      ids[size_t(b) * stride + i] = i < src.h_n[off + b] ? src.h_ids[(off + b) * stride + i] : 0;
   }
   resolve_kernel_stats(slot_idx);
   float ms = 0;
@@ -1825,7 +1874,7 @@ void Engine::decode_collect(int slot_idx, int64_t* ids, int32_t* n_ids) {
   timings_.decoder_steps = slot.steps;
   if (hipEventElapsedTime(&ms, slot.enc_begin, slot.enc_mid) == hipSuccess) timings_.encoder_ms = ms;
   if (hipEventElapsedTime(&ms, slot.enc_mid, slot.enc_done) == hipSuccess) timings_.cross_kv_ms = ms;
-  if (hipEventElapsedTime(&ms, slot.dec_begin, slot.dec_done) == hipSuccess) timings_.decoder_ms = ms;
+  if (hipEventElapsedTime(&ms, src.dec_begin, slot.dec_done) == hipSuccess) timings_.decoder_ms = ms;
   if (hipEventElapsedTime(&ms, slot.enc_begin, slot.dec_done) == hipSuccess) timings_.total_ms = ms;
   if (!slot.dt_cls.empty()) {
     static const char* kNames[11] = {"qkv(LN)", "self_attn", "o_proj", "q_abs(LN)", "cross_attn", "co",

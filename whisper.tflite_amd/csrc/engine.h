@@ -54,10 +54,10 @@ struct DecBlockWeights {
   const float *cross_ln_g, *cross_ln_b, *cross_wq_t, *cross_bq, *cross_bo;  // cross_wq_t: cross_q_layout()
   TiledW cross_wo;
   // absorbed cross-attention (k_cross_absorbed.hip): the key projection folded into the query side, A_h = c0 Wk_h^T Wq_h
-  // stacked over heads [H d][d] with its bias c0 Wk_h^T bq_h, and the value projection folded into the output side,
-  // W'[n][h d + c] = sum_i Wo[n][64 h + i] Wv[64 h + i][c] with bias bo + Wo bv (upload_weights)
-  TiledW wq_abs, wo_abs;
-  const float *bq_abs = nullptr, *bo_abs = nullptr;
+  // stacked over heads [H d][d] with its bias c0 Wk_h^T bq_h (upload_weights); the value projection is applied to the
+  // combined context of each head by cross_absorbed_combine
+  TiledW wq_abs;
+  const float *bq_abs = nullptr, *cross_wv_t = nullptr, *cross_bv = nullptr;  // cross_wv_t: cross_q_layout(Wv)
   const float *mlp_ln_g, *mlp_ln_b, *b1, *b2;
   TiledW w1, w2;
 };
@@ -104,6 +104,12 @@ class Engine {
   // output sides (k_cross_absorbed.hip: half the bytes per decoder position, no cross-KV GEMM in the encoder);
   // 0 = round 2's cross-KV cache.  The bf16 storage mode and a flagged ln_post operand always take the cache.
   long cross_absorb = 1;
+  long abs_chunks = 0;  // key chunks per clip of the absorbed form: 1..16, 0 = by batch size and mode (decode_enqueue)
+  // 1 = the pipeline decodes TWO consecutive submitted batches of equal size (<= 32 clips each, absorbed form) with
+  // one decoder chain: the chain's ~1000 dependent launches then serve 64 clips, and the decoder streams stop being
+  // what the pipeline waits for.  Results and their order are unchanged; a batch whose partner has
+  // not been submitted yet is decoded alone as soon as it is collected.
+  long dec_pair = 1;
   bool absorb_active() const { return cross_absorb != 0 && bf16 == 0 && gemm_variant < 0 && sc_cross_kv_.f16_ok; }
   long gemm_variant = -1;  // -1 = plane GEMM (per-contraction fall-back to 13/16); 0 = fp32 MFMA, 13 / 16 = three bf16 planes
   // 1 = bf16 STORAGE mode (BASELINE configs[3]): bf16 weights, activations and both KV caches, fp32 accumulation,
@@ -191,7 +197,10 @@ class Engine {
   TiledW upload_tiled(const float* W, int N, int K);
   void build_frontend_tables();
 
-  void decode_enqueue(int batch, int slot, float* logits_host, int logits_steps_cap);
+  // slot_b >= 0: the decoder chain takes the batches of slot and slot_b (same size) together
+  void decode_enqueue(int batch, int slot, float* logits_host, int logits_steps_cap, int slot_b = -1, bool pipelined = false);
+  int pending_slot_ = -1;  // submitted, encoder enqueued, decoder waiting for a partner batch
+  void flush_pending();
   void decode_collect(int slot, int64_t* ids, int32_t* n_ids);
 
   int enc_cus_masked_ = 0;  // CUs the pipelined encoder stream may use
@@ -214,6 +223,7 @@ class Engine {
     float* cross_kv = nullptr;  // [layer][k|v][clip][head][t][64]
     unsigned short* e_planes = nullptr;  // absorbed cross-attention: planes of the encoder output [clip][T][d]
     bool absorbed = false;               // which of the two this slot's encoder pass filled
+    int pair_leader = -1, pair_off = 0;  // decoded by another slot's chain: its ids sit in that slot's buffers at pair_off
     hipEvent_t enc_begin = nullptr, enc_mid = nullptr, enc_done = nullptr;
     hipEvent_t dec_begin = nullptr, dec_done = nullptr;
     long long* h_ids = nullptr;  // pinned [4096][32]

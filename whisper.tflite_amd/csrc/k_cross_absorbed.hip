@@ -24,8 +24,11 @@
 // applied to the DMA's per-lane SOURCE address.  Wave w computes the scores of key sub-tile w & 1 over d-half w >> 1
 // (the halves are added through LDS), every wave then holds all 32 x 16 probabilities and accumulates its own
 // quarter of the d range.  Output per (row, head, chunk): unnormalised c[d_model], m, l — combined over chunks by
-// cross_absorbed_combine, then out-projected with Wo . Wv_h folded (engine.cpp).
+// cross_absorbed_combine, which also applies the head's value projection Wv_h c + bv_h; the ordinary cross
+// out-projection follows.
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
 
 #include "bf16_split.h"
 #include "kernels.h"
@@ -41,6 +44,8 @@ using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
 struct CrossAbsDev {
   const float* qp;       // [rows][heads * DM] absorbed queries (log2 domain: d_head^-1/2 * log2 e folded in)
   const _Float16* e;     // E planes: hi [clips * T][DM], lo at e + e_plane
+  const _Float16* e2;    // clips >= split: a second encoder batch (two batches decoded by one chain), indexed from 0
+  int split;
   long e_plane;
   float e_scale;         // power of two baked into the planes
   float* ws;             // [rows][heads][chunks][DM + 4]: c[DM], m (natural log units), l, pad
@@ -104,6 +109,36 @@ __global__ __launch_bounds__(256) void cross_absorbed_attention(CrossAbsDev a) {
   const int qpos = q_ok ? qc / a.H : 0, qh_i = q_ok ? qc % a.H : 0;
   const long row = (long)(a.p0 + qpos) * a.B + b;
 
+  // ---- key range of this chunk, in tiles of 32
+  const int key_lo = ck * a.tiles_per_chunk * 32;
+  int key_hi = key_lo + a.tiles_per_chunk * 32;
+  key_hi = key_hi < a.T ? key_hi : a.T;
+  const int n_tiles = key_hi > key_lo ? (key_hi - key_lo + 31) / 32 : 0;
+
+  // ---- LDS-DMA: instruction i of a tile (i = wid + 4 j) copies 4 keys x 256 B of (plane, panel): LDS slot
+  // (key lane >> 4, chunk lane & 15) takes the global chunk (lane & 15) ^ ((key & 7) << 1) of that key row
+  const _Float16* const ebase = b < a.split ? a.e + (long)b * a.T * DM : a.e2 + (long)(b - a.split) * a.T * DM;
+  auto dma_tile = [&](int t, int stage) {
+    const int tt = t < n_tiles ? t : (n_tiles > 0 ? n_tiles - 1 : 0);  // past the end: a harmless re-load (uniform vmcnt)
+    unsigned char* const sbase = lds + stage * kStage;
+#pragma unroll
+    for (int j = 0; j < IPW; ++j) {
+      const int i = wid + 4 * j;
+      const int plane = i / (8 * P), rem = i % (8 * P), panel = rem / 8, kg = rem % 8;
+      const int key = 4 * kg + lq;
+      int gk = key_lo + tt * 32 + key;
+      gk = gk < a.T ? gk : a.T - 1;  // keys past T re-read the last row; their scores are masked
+      const int chunk = (lane & 15) ^ ((key & 7) << 1);
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(ebase + plane * a.e_plane + (long)gk * DM + panel * 128 + chunk * 8),
+          (__attribute__((address_space(3))) void*)(sbase + plane * kPlane + panel * 8192 + kg * 1024), 16, 0, 0);
+    }
+  };
+
+  // the stream starts before anything else: the first NST - 1 tiles are in flight while the queries are prepared
+#pragma unroll
+  for (int st0 = 0; st0 < NST - 1; ++st0) dma_tile(st0, st0);
+
   // ---- Q' planes of this lane's query column: dynamic power-of-two scale from the column's largest element
   u32x4 qh[KS], ql[KS];
   float s_inv;
@@ -138,32 +173,6 @@ __global__ __launch_bounds__(256) void cross_absorbed_attention(CrossAbsDev a) {
     }
   }
 
-  // ---- key range of this chunk, in tiles of 32
-  const int key_lo = ck * a.tiles_per_chunk * 32;
-  int key_hi = key_lo + a.tiles_per_chunk * 32;
-  key_hi = key_hi < a.T ? key_hi : a.T;
-  const int n_tiles = key_hi > key_lo ? (key_hi - key_lo + 31) / 32 : 0;
-
-  // ---- LDS-DMA: instruction i of a tile (i = wid + 4 j) copies 4 keys x 256 B of (plane, panel): LDS slot
-  // (key lane >> 4, chunk lane & 15) takes the global chunk (lane & 15) ^ ((key & 7) << 1) of that key row
-  const _Float16* const ebase = a.e + (long)b * a.T * DM;
-  auto dma_tile = [&](int t, int stage) {
-    const int tt = t < n_tiles ? t : (n_tiles > 0 ? n_tiles - 1 : 0);  // past the end: a harmless re-load (uniform vmcnt)
-    unsigned char* const sbase = lds + stage * kStage;
-#pragma unroll
-    for (int j = 0; j < IPW; ++j) {
-      const int i = wid + 4 * j;
-      const int plane = i / (8 * P), rem = i % (8 * P), panel = rem / 8, kg = rem % 8;
-      const int key = 4 * kg + lq;
-      int gk = key_lo + tt * 32 + key;
-      gk = gk < a.T ? gk : a.T - 1;  // keys past T re-read the last row; their scores are masked
-      const int chunk = (lane & 15) ^ ((key & 7) << 1);
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(ebase + plane * a.e_plane + (long)gk * DM + panel * 128 + chunk * 8),
-          (__attribute__((address_space(3))) void*)(sbase + plane * kPlane + panel * 8192 + kg * 1024), 16, 0, 0);
-    }
-  };
-
   f32x4 cacc[DT];
 #pragma unroll
   for (int t = 0; t < DT; ++t) cacc[t] = f32x4{0, 0, 0, 0};
@@ -175,8 +184,6 @@ __global__ __launch_bounds__(256) void cross_absorbed_attention(CrossAbsDev a) {
   const int tq = (lane >> 2) & 3, tp = lane & 3;          // transposed read: lane 4 q + p of its 16-lane group
   const unsigned lds0 = lds_addr(lds);
 
-#pragma unroll
-  for (int s = 0; s < NST - 1; ++s) dma_tile(s, s);
   for (int t = 0; t < n_tiles; ++t) {
     // tile t has landed (this wave's pieces: the counted wait, which leaves the NST - 2 younger tiles in flight;
     // everybody's: the barrier), and every wave has finished tile t - 1, whose stage is refilled now
@@ -287,26 +294,44 @@ __global__ __launch_bounds__(256) void cross_absorbed_attention(CrossAbsDev a) {
   }
 }
 
-// c[row][head * DM + d] = sum_k w_k c_k[d] / sum_k w_k l_k,  w_k = exp(m_k - max m): one block per (row, head)
-__global__ __launch_bounds__(128) void cross_absorbed_combine(const float* __restrict__ ws, float* __restrict__ out, int H,
+// One block per (row, head): c[d] = sum_k w_k c_k[d] / sum_k w_k l_k with w_k = exp(m_k - max m) (the key chunks'
+// partials), then the head's value projection o[64 h + j] = Wv_h[j] . c + bv[64 h + j] — 64 x d multiply-adds on
+// weights in cross_q_layout() order ([head][d / 4][64 outputs][4]: a wavefront reads 1 KiB contiguous per step).
+// out [rows][heads * 64]: the A operand of the ordinary cross out-projection.
+__global__ __launch_bounds__(256) void cross_absorbed_combine(const float* __restrict__ ws, const float* __restrict__ wv_t,
+                                                              const float* __restrict__ bv, float* __restrict__ out, int H,
                                                               int chunks, int DM) {
+  __shared__ __attribute__((aligned(16))) float cs[512];
+  __shared__ float part[4][64];
   const long rh = blockIdx.x;
+  const int h = (int)(rh % H);
   const float* rec = ws + rh * chunks * (long)(DM + 4);
+  const int tid = threadIdx.x;
   float mx = -3.0e38f;
   for (int k = 0; k < chunks; ++k) mx = fmaxf(mx, rec[k * (DM + 4) + DM]);
-  const int j = threadIdx.x;
-  if (4 * j >= DM) return;
-  f32x4 acc = {0, 0, 0, 0};
-  float l = 0.0f;
-  for (int k = 0; k < chunks; ++k) {
-    const float* r = rec + k * (long)(DM + 4);
-    const float w = __expf(r[DM] - mx);
-    acc += w * *reinterpret_cast<const f32x4*>(r + 4 * j);
-    l += w * r[DM + 1];
+  if (4 * tid < DM) {
+    f32x4 acc = {0, 0, 0, 0};
+    float l = 0.0f;
+    for (int k = 0; k < chunks; ++k) {
+      const float* r = rec + k * (long)(DM + 4);
+      const float w = __expf(r[DM] - mx);
+      acc += w * *reinterpret_cast<const f32x4*>(r + 4 * tid);
+      l += w * r[DM + 1];
+    }
+    *reinterpret_cast<f32x4*>(&cs[4 * tid]) = acc * (1.0f / l);
   }
-  const float inv = 1.0f / l;
-  const long row = rh / H, h = rh % H;
-  *reinterpret_cast<f32x4*>(out + (row * H + h) * DM + 4 * j) = acc * inv;
+  __syncthreads();
+  const int j = tid & 63, cq = tid >> 6, c4n = DM / 16;  // float4 steps of this k-quarter
+  const float* w = wv_t + ((long)h * (DM / 4) + cq * c4n) * 256 + j * 4;
+  float acc = 0.0f;
+  for (int c = 0; c < c4n; ++c) {
+    const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (long)c * 256);
+    const f32x4 x = *reinterpret_cast<const f32x4*>(&cs[(cq * c4n + c) * 4]);
+    acc += (wv[0] * x[0] + wv[1] * x[1]) + (wv[2] * x[2] + wv[3] * x[3]);
+  }
+  part[cq][j] = acc;
+  __syncthreads();
+  if (tid < 64) out[(rh / H) * (long)(H * 64) + h * 64 + tid] = ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid])) + bv[h * 64 + tid];
 }
 
 template <int DM, int NST>
@@ -328,12 +353,14 @@ int cross_absorbed_max_nq(int heads) { return heads > 0 ? 16 / heads : 0; }
 void launch_cross_absorbed(const CrossAbsorbedArgs& a, hipStream_t s) {
   const int dm = a.d_model;
   if (!a.qp || !a.e || !a.ws || a.batch < 1 || a.heads < 1 || a.heads * 64 != dm || a.T < 1 || a.chunks < 1 || a.chunks > 16 ||
-      a.nq < 1 || a.nq * a.heads > 16 || a.p0 < 0 || !(a.e_scale > 0.0f) || a.e_plane < (long)a.batch * a.T * dm) {
+      a.nq < 1 || a.nq * a.heads > 16 || a.p0 < 0 || !(a.e_scale > 0.0f) || a.e_plane < (long)(a.e2 ? std::max(a.split, a.batch - a.split) : a.batch) * a.T * dm) {
     throw Error(kErrInvalidArg, "absorbed cross-attention: shape outside the kernel contract");
   }
   const int tiles = (a.T + 31) / 32;
-  CrossAbsDev g{a.qp, reinterpret_cast<const _Float16*>(a.e), a.e_plane, a.e_scale, a.ws, a.batch, a.heads, a.T, a.chunks, a.nq,
-                a.p0, (tiles + a.chunks - 1) / a.chunks};
+  const int split = a.e2 ? a.split : a.batch;
+  if (split < 1 || split > a.batch) throw Error(kErrInvalidArg, "absorbed cross-attention: bad batch split");
+  CrossAbsDev g{a.qp, reinterpret_cast<const _Float16*>(a.e), reinterpret_cast<const _Float16*>(a.e2 ? a.e2 : a.e), split, a.e_plane,
+                a.e_scale, a.ws, a.batch, a.heads, a.T, a.chunks, a.nq, a.p0, (tiles + a.chunks - 1) / a.chunks};
   switch (dm) {
     case 128: launch_abs<128, 3>(g, s); break;
     case 384: launch_abs<384, 3>(g, s); break;
@@ -342,11 +369,12 @@ void launch_cross_absorbed(const CrossAbsorbedArgs& a, hipStream_t s) {
   }
 }
 
-void launch_cross_absorbed_combine(const float* ws, float* out, int rows, int heads, int chunks, int d_model, hipStream_t s) {
-  if (!ws || !out || rows < 1 || heads < 1 || chunks < 1 || d_model % 4 != 0 || d_model > 512) {
+void launch_cross_absorbed_combine(const float* ws, const float* wv_t, const float* bv, float* out, int rows, int heads,
+                                   int chunks, int d_model, hipStream_t s) {
+  if (!ws || !wv_t || !bv || !out || rows < 1 || heads < 1 || chunks < 1 || d_model != heads * 64 || d_model > 512) {
     throw Error(kErrInvalidArg, "absorbed cross-attention combine: bad shape");
   }
-  hipLaunchKernelGGL(cross_absorbed_combine, dim3(rows * heads), dim3(128), 0, s, ws, out, heads, chunks, d_model);
+  hipLaunchKernelGGL(cross_absorbed_combine, dim3(rows * heads), dim3(256), 0, s, ws, wv_t, bv, out, heads, chunks, d_model);
 }
 
 }  // namespace wt

@@ -249,6 +249,8 @@ void launch_cross_attention(const CrossAttnArgs& a, hipStream_t s);
 struct CrossAbsorbedArgs {
   const float* qp = nullptr;
   const unsigned short* e = nullptr;
+  const unsigned short* e2 = nullptr;  // set: clips [split, batch) belong to a second encoder batch whose planes start here
+  int split = 0;
   long e_plane = 0;
   float e_scale = 1.0f;
   float* ws = nullptr;
@@ -256,8 +258,10 @@ struct CrossAbsorbedArgs {
 };
 void launch_cross_absorbed(const CrossAbsorbedArgs& a, hipStream_t s);
 int cross_absorbed_max_nq(int heads);  // positions one launch can take
-// out [rows][heads * d] = chunk-combined, normalised contexts (the A operand of the folded Wo . Wv_h projection)
-void launch_cross_absorbed_combine(const float* ws, float* out, int rows, int heads, int chunks, int d_model, hipStream_t s);
+// out [rows][heads * 64] = Wv_h (chunk-combined, normalised context of head h) + bv_h: the A operand of the ordinary
+// cross out-projection.  wv_t = cross_q_layout(Wv).
+void launch_cross_absorbed_combine(const float* ws, const float* wv_t, const float* bv, float* out, int rows, int heads,
+                                   int chunks, int d_model, hipStream_t s);
 // Greedy selection after the logits GEMM: reduces the per-tile (value, column) records
 // best[B][n_tiles], appends to ids and applies the EOT stop (reference whisper.cpp:397-399).
 void launch_select_token(const unsigned long long* best, int n_tiles, long long* ids, int ids_stride,
