@@ -250,7 +250,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="synchronous steps (encoder then decoder) instead of the two-deep pipeline")
-    ap.add_argument("--depth", type=int, default=5, choices=tuple(range(1, 7)), help="batches in flight (pipelined mode)")
+    ap.add_argument("--depth", type=int, default=10, choices=tuple(range(1, 13)), help="batches in flight (pipelined mode)")
     ap.add_argument("--attn-variant", type=int, default=None, choices=(0, 1, 2, 3, 4))
     ap.add_argument("--cross-chunks", type=int, default=None, choices=(1, 2, 4, 8))
     ap.add_argument("--cross-absorb", type=int, default=None, choices=(0, 1),

@@ -139,7 +139,7 @@ int wt_transcribe_tokens_batch_dev(wt_engine* h, const float* d_pcm, int batch, 
  * the MFMA-bound encoder of the newest batch shares the chip with the latency/HBM-bound
  * decoder chains of the previous ones.  d_mel must stay valid until that batch is collected.
  * At most WT_PIPELINE_DEPTH uncollected submits; batch <= 64. */
-#define WT_PIPELINE_DEPTH 6
+#define WT_PIPELINE_DEPTH 12
 int wt_pipeline_submit_dev(wt_engine* h, const float* d_mel, int batch);
 /* Same from device-resident PCM [batch][480000]: the log-mel front end (whisper.cpp:109-216) runs
  * on the pipeline's encoder stream ahead of the encoder; d_pcm may be reused once the call returns

@@ -230,7 +230,7 @@ def test_unsupported_weight_files_and_options_return_status_codes(pkg, assets, t
 
 
 def test_sync_call_with_batches_in_flight_is_refused_before_any_work(pkg, assets):
-    """With the pipeline FULL (6 uncollected batches) a synchronous call used to enqueue its encoder first — onto
+    """With the pipeline FULL (WT_PIPELINE_DEPTH uncollected batches) a synchronous call used to enqueue its encoder first — onto
     the oldest uncollected slot, overwriting that batch — and throw only at decode().  Now every synchronous entry
     point checks first: error, nothing enqueued, and the later collects return the ORIGINAL ids (also when the
     refused call carried a larger batch than the submitted ones)."""
@@ -239,7 +239,8 @@ def test_sync_call_with_batches_in_flight_is_refused_before_any_work(pkg, assets
     e.set_option("stop_at_eot", 0)
     e.set_prompt([3, 5, 7, 11])
     rng = np.random.default_rng(21)
-    mels = [rng.uniform(-1.0, 1.5, size=(3,) + e.mel_shape).astype(np.float32) for _ in range(6)]
+    D = 12  # WT_PIPELINE_DEPTH
+    mels = [rng.uniform(-1.0, 1.5, size=(3,) + e.mel_shape).astype(np.float32) for _ in range(D)]
     big = rng.uniform(-1.0, 1.5, size=(9,) + e.mel_shape).astype(np.float32)
     want = [e.encdec_tokens_batch(m) for m in mels]
     e.encdec_tokens_batch(big)  # grows the workspace now, not while batches are in flight
@@ -248,7 +249,7 @@ def test_sync_call_with_batches_in_flight_is_refused_before_any_work(pkg, assets
     pcm = DevBuf(np.zeros((9, e.pcm_len), np.float32))
     for d in dev:
         e.pipeline_submit_dev(d.data_ptr(), 3)
-    assert e.get_option("in_flight") == 6
+    assert e.get_option("in_flight") == D
     for call in (lambda: e.encdec_tokens_batch(big), lambda: e.encdec_tokens_batch_dev(d_big.data_ptr(), 9),
                  lambda: e.encdec_debug_batch(big), lambda: e.transcribe(np.zeros(1000, np.float32)),
                  lambda: e.logmel_batch(np.zeros((1, e.pcm_len), np.float32)),
@@ -258,9 +259,9 @@ def test_sync_call_with_batches_in_flight_is_refused_before_any_work(pkg, assets
             call()
         assert ei.value.code == 1 and "collect" in str(ei.value)
     with pytest.raises(pkg.WtError):
-        e.pipeline_submit_dev(dev[0].data_ptr(), 3)  # a seventh submit: pipeline full
-    assert e.get_option("in_flight") == 6
-    for k in range(6):
+        e.pipeline_submit_dev(dev[0].data_ptr(), 3)  # one submit too many: pipeline full
+    assert e.get_option("in_flight") == D
+    for k in range(D):
         ids, n = e.pipeline_collect()
         assert ids.shape == (3, 32) and np.array_equal(ids, want[k][0]) and np.array_equal(n, want[k][1]), k
     ids, n = e.encdec_tokens_batch(mels[2])  # synchronous calls work again

@@ -237,7 +237,7 @@ def test_pipeline_submit_collect_matches_sync(tiny):
     mels = [rng.uniform(-1.0, 1.5, size=(b, 80, 3000)).astype(np.float32) for b in (3, 5, 2, 4)]
     want = [e.encdec_tokens_batch(m) for m in mels]
     dev = [Dev(m) for m in mels]
-    for depth in (2, 3, 6):  # keep `depth` batches in flight over a sequence of 8
+    for depth in (2, 3, 6, 8):  # keep `depth` batches in flight over a sequence of 8
         got, in_flight = [], 0
         order = [0, 1, 2, 3, 1, 0, 3, 2]
         for k in order:
@@ -261,14 +261,15 @@ def test_pipeline_submit_collect_matches_sync(tiny):
     for k in (0, 1, 1, 0):
         ids_g, n_g = e.pipeline_collect()
         assert np.array_equal(want_pcm[k][0], ids_g) and np.array_equal(want_pcm[k][1], n_g)
-    # a seventh uncollected submit (WT_PIPELINE_DEPTH = 6) is refused, and so is a sync call with batches in flight
-    for k in range(6):
+    # one uncollected submit more than WT_PIPELINE_DEPTH is refused, and so is a sync call with batches in flight
+    D = 12
+    for k in range(D):
         e.pipeline_submit_dev(dev[k % 4].data_ptr(), mels[k % 4].shape[0])
     with pytest.raises(Exception):
         e.pipeline_submit_dev(dev[3].data_ptr(), 4)
     with pytest.raises(Exception):
         e.encdec_tokens_batch(mels[0])
-    for k in range(6):
+    for k in range(D):
         ids_g, n_g = e.pipeline_collect()
         assert np.array_equal(ids_g, want[k % 4][0])
     assert np.array_equal(e.encdec_tokens_batch(mels[3])[0], want[3][0])  # sync call works again

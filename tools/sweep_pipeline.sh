@@ -1,6 +1,6 @@
 # pipeline knobs A/B on one box (GPU)
 set -o pipefail
-run() { name=$1; shift; env "$@" python bench.py --steps 40 --warmup 4 --no-cpu-baseline --no-fp32-leg ${EXTRA} > gpurun_out/sw_$name.json 2> gpurun_out/sw_$name.err; python - "$name" <<'PY'
+run() { name=$1; shift; env "$@" python bench.py --steps 72 --warmup 12 --no-cpu-baseline --no-fp32-leg ${EXTRA} > gpurun_out/sw_$name.json 2> gpurun_out/sw_$name.err; python - "$name" <<'PY'
 import json,sys
 n=sys.argv[1]
 try:
@@ -10,11 +10,12 @@ except Exception as e:
     print(n,'ERR',e, open(f'gpurun_out/sw_{n}.err').read()[-300:])
 PY
 }
-EXTRA="--abs-chunks 4" run b32_c4_res8 WT_ENC_CU_RESERVE=8
-EXTRA="--batch 64 --abs-chunks 4" run b64_c4_res8 WT_ENC_CU_RESERVE=8
-EXTRA="--batch 64 --abs-chunks 2" run b64_c2_res8 WT_ENC_CU_RESERVE=8
-EXTRA="--batch 64 --abs-chunks 2" run b64_c2_res4 WT_ENC_CU_RESERVE=4
-EXTRA="--batch 64 --abs-chunks 4" run b64_c4_res4 WT_ENC_CU_RESERVE=4
-EXTRA="--batch 64 --abs-chunks 2" run b64_c2_res6 WT_ENC_CU_RESERVE=6
-EXTRA="--batch 64 --abs-chunks 2 --depth 3" run b64_c2_res4_d3 WT_ENC_CU_RESERVE=4
-EXTRA="--batch 64 --abs-chunks 2" run b64_c2_res4_dec2 WT_ENC_CU_RESERVE=4 WT_DEC_STREAMS=2
+EXTRA="--depth 6" run d6_res8 WT_ENC_CU_RESERVE=8
+EXTRA="--depth 8" run d8_res8 WT_ENC_CU_RESERVE=8
+EXTRA="--depth 10" run d10_res8 WT_ENC_CU_RESERVE=8
+EXTRA="--depth 12" run d12_res8 WT_ENC_CU_RESERVE=8
+EXTRA="--depth 10" run d10_res4 WT_ENC_CU_RESERVE=4
+EXTRA="--depth 10" run d10_res6 WT_ENC_CU_RESERVE=6
+EXTRA="--depth 10 --abs-chunks 3" run d10_res8_c3 WT_ENC_CU_RESERVE=8
+EXTRA="--depth 10 --abs-chunks 4" run d10_res8_c4 WT_ENC_CU_RESERVE=8
+EXTRA="--depth 10" run d10_res10 WT_ENC_CU_RESERVE=10

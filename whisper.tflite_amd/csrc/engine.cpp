@@ -725,7 +725,7 @@ void Engine::create_streams() {
   // to an encoder that owns every CU stretch it by 2.5 ms per batch, next to one that owns
   // 224 of 256 CUs by 0.9 ms; with the faster encoder kernels 4..8 CUs per XCD measure
   // within 2 % of each other. Synchronous calls keep the whole chip.
-  int reserve = 4;
+  int reserve = 8;  // 192 CUs for the pipelined encoder: 188 row tiles of 256 and 2304 / 3 attention blocks fill whole rounds
   if (const char* v = getenv("WT_ENC_CU_RESERVE")) reserve = std::min(std::max(atoi(v), 0), 16);
   reserve_ = reserve;
   const int n_cu = n_cu_;
@@ -1480,7 +1480,7 @@ void Engine::flush_pending() {
 static bool can_pair(const Engine& e, int batch) { return e.dec_pair != 0 && e.absorb_active() && batch <= 32; }
 
 void Engine::submit(const float* d_mel, int batch) {
-  if (int(inflight_.size()) >= kSlots) throw Error(1, "pipeline is full (6 batches in flight): collect() first");
+  if (int(inflight_.size()) >= kSlots) throw Error(1, "pipeline is full (12 batches in flight): collect() first");
   if (batch > 64) throw Error(1, "decoder batches are limited to 64 clips per call");
   select_stream(true);
   if (can_pair(*this, batch) && inflight_.empty()) ensure_batch(2 * batch);  // the pair's decoder rows; never grown in flight
@@ -1503,7 +1503,7 @@ void Engine::submit(const float* d_mel, int batch) {
 }
 
 void Engine::submit_pcm(const float* d_pcm, int batch) {
-  if (int(inflight_.size()) >= kSlots) throw Error(1, "pipeline is full (6 batches in flight): collect() first");
+  if (int(inflight_.size()) >= kSlots) throw Error(1, "pipeline is full (12 batches in flight): collect() first");
   if (batch > 64) throw Error(1, "decoder batches are limited to 64 clips per call");
   select_stream(true);
   if (can_pair(*this, batch) && inflight_.empty()) ensure_batch(2 * batch);
@@ -1801,7 +1801,7 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
           if (ie != hipSuccess) throw Error(kErrDevice, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie));
           fresh[key_of(si)] = GraphEntry{ge, steps};
         }
-        for (auto& g : fresh) graphs_[g.first] = g.second;  // all six slots or none
+        for (auto& g : fresh) graphs_[g.first] = g.second;  // all slots or none
       } catch (const std::exception& e) {
         for (auto& g : fresh) (void)hipGraphExecDestroy(g.second.exec);
         (void)hipGetLastError();
@@ -1830,7 +1830,7 @@ void Engine::debug_concurrency(const float* d_mel, int batch, int n_dec, int n_e
   ensure_batch(batch);
   sync();
   for (int i = 0; i < n_dec; ++i)
-    if (!slots_[i].used) throw Error(1, "debug_concurrency: run six batches first so every slot holds a cross-KV cache");
+    if (!slots_[i].used) throw Error(1, "debug_concurrency: run a batch per slot first so every slot holds a cross-KV cache");
   select_stream(true);
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0));

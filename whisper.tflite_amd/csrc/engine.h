@@ -213,8 +213,10 @@ class Engine {
   // default encoder GEMM: the k16 split kernel in its two-plane fp16 form, at 2 blocks per CU when decoders
   // share the chip (pipelined), at 3 blocks per CU otherwise
   void encode_enqueue(const float* d_mel, int batch);
-  static constexpr int kDecStreams = 8, kSlots = 6;  // slots: a multiple of the 3 decoder streams in use, so
-                                                     // batches rotate evenly over them (WT_PIPELINE_DEPTH)
+  // slots (WT_PIPELINE_DEPTH): a multiple of twice the 3 decoder streams in use, so single batches AND pair leaders
+  // (every second slot) rotate evenly over them; a pair's chain holds two slots for ~4 pipeline periods, so the
+  // encoder needs that many slots ahead of it to keep running
+  static constexpr int kDecStreams = 8, kSlots = 12;
   int n_dec_streams_ = 3;  // decoder streams in use: one hardware queue each (the runtime multiplexes
                            // streams onto 4 queues per priority; two decoders sharing one serialise)
   hipStream_t dstream_[kDecStreams] = {};  // decoders (batches rotate over them)
