@@ -748,7 +748,9 @@ void Engine::create_streams() {
     for (int i = enc_cus_masked_; i < n_cu; ++i) dmask[i / 32] |= 1u << (i % 32);
     for (auto& ds : dstream_) HIPCHK(hipExtStreamCreateWithCUMask(&ds, uint32_t(dmask.size()), dmask.data()));
   } else {
-    for (auto& ds : dstream_) HIPCHK(hipStreamCreateWithPriority(&ds, hipStreamNonBlocking, prio_hi));
+    const char* dp = getenv("WT_DEC_PRIO");  // measurement knob: "lo" = decoder streams at the encoder's priority
+    const int prio = dp && dp[0] == 'l' ? prio_lo : prio_hi;
+    for (auto& ds : dstream_) HIPCHK(hipStreamCreateWithPriority(&ds, hipStreamNonBlocking, prio));
   }
   for (auto& e : ev_) HIPCHK(hipEventCreate(&e));
   for (Slot& sl : slots_) {
@@ -1123,7 +1125,9 @@ void Engine::encode_enqueue(const float* d_mel, int batch) {
   // that GEMM's epilogue when its 384-column tile owns whole rows and both sides run on planes; ln_done then tells the
   // consumer's side not to launch the LayerNorm kernel.
   bool ln_done = false;
+  static const bool no_ln_fuse = getenv("WT_NO_LN_FUSE") != nullptr;  // measurement knob: separate LayerNorm launches
   auto fuse_ln = [&](PlaneGemmArgs& g, const float* gain, const float* shift, float scale) {
+    if (no_ln_fuse) return;
     g.ln_g = gain; g.ln_b = shift; g.ln_P = lnp; g.ln_plane = ln_plane; g.ln_scale = scale;
   };
   auto alt_gemm = [&](GemmArgs& g, const GemmScale& sc, int epi, double flops) {
@@ -1292,9 +1296,10 @@ void Engine::encode_enqueue(const float* d_mel, int batch) {
       } else if (gemm_on_planes(sc_cross_kv_)) {  // the encoder's final LayerNorm: also the API's fp32 enc_out and the non-finite flag
         fuse_ln(f2, enc_ln_post_g, enc_ln_post_b, sc_cross_kv_.a);
         f2.ln_y32 = ws_.enc_out; f2.nonfinite = slot.d_flag;
-        if (absorb) {  // absorbed cross-attention: these planes ARE what the decoder streams (no cross-KV projection)
+        if (absorb && f2.ln_P) {  // absorbed cross-attention: these planes ARE what the decoder streams (no cross-KV projection)
           f2.ln_P = slot.e_planes; f2.ln_plane = e_plane;
         }
+        if (!f2.ln_P) f2.ln_y32 = nullptr, f2.nonfinite = nullptr;
       }
       ln_done = plane_gemm(f2, sc.fc2, kEpiBias | kEpiResidual, 2.0 * f2.M * f2.N * f2.K);
     } else {
