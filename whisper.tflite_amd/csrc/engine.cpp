@@ -1014,6 +1014,8 @@ void Engine::logmel(const float* d_pcm, int batch, float* d_mel, int valid_frame
 
 // ------------------------------------------------------- kernel timer ---
 
+thread_local LaunchTimer g_launch_timer;
+
 void Engine::kt_begin(int cls, double flops, double bytes) {
   if (!kt_on_) return;
   Slot& sl = slots_[enc_slot_];
@@ -1026,11 +1028,21 @@ void Engine::kt_begin(int cls, double flops, double bytes) {
   sl.kt_cls.push_back(cls);
   sl.kt_flops.push_back(flops);
   sl.kt_bytes.push_back(bytes);
+  // the default contraction kernels take the pair on the dispatch itself (kernels.h, LaunchTimer): kernel begin -> end
+  if (cls == kKcGemm || cls == kKcEncAttn) {
+    g_launch_timer.start = sl.kt_events[idx];
+    g_launch_timer.stop = sl.kt_events[idx + 1];
+    return;
+  }
   HIPCHK(hipEventRecord(sl.kt_events[idx], stream_));
 }
 
 void Engine::kt_end() {
   if (!kt_on_) return;
+  if (g_launch_timer.start) {
+    g_launch_timer = LaunchTimer{};
+    return;
+  }
   Slot& sl = slots_[enc_slot_];
   HIPCHK(hipEventRecord(sl.kt_events[(sl.kt_cls.size() - 1) * 2 + 1], stream_));
 }
@@ -1481,13 +1493,20 @@ void Engine::flush_pending() {
   decode_enqueue(slots_[p].batch, p, nullptr, 0, -1, true);
 }
 
+// An encoder pass that no decoder chain will run beside (the first one or two of a pipeline fill, or a
+// submit/collect loop of depth one) keeps the whole chip; every other pipelined pass runs on the CU-masked stream.
+bool Engine::decoders_enqueued() const {
+  static const bool always = [] { const char* v = getenv("WT_ENC_MASK_ALWAYS"); return v && atoi(v) == 1; }();
+  return always || int(inflight_.size()) - (pending_slot_ >= 0 ? 1 : 0) > 0;
+}
+
 // decoder side of a pipelined submit: alone, or together with the previous submit's batch (dec_pair)
 static bool can_pair(const Engine& e, int batch) { return e.dec_pair != 0 && e.absorb_active() && batch <= 32; }
 
 void Engine::submit(const float* d_mel, int batch) {
   if (int(inflight_.size()) >= kSlots) throw Error(1, "pipeline is full (12 batches in flight): collect() first");
   if (batch > 64) throw Error(1, "decoder batches are limited to 64 clips per call");
-  select_stream(true);
+  select_stream(decoders_enqueued());
   if (can_pair(*this, batch) && inflight_.empty()) ensure_batch(2 * batch);  // the pair's decoder rows; never grown in flight
   encode_enqueue(d_mel, batch);
   const int s = last_enc_slot_;
@@ -1510,7 +1529,7 @@ void Engine::submit(const float* d_mel, int batch) {
 void Engine::submit_pcm(const float* d_pcm, int batch) {
   if (int(inflight_.size()) >= kSlots) throw Error(1, "pipeline is full (12 batches in flight): collect() first");
   if (batch > 64) throw Error(1, "decoder batches are limited to 64 clips per call");
-  select_stream(true);
+  select_stream(decoders_enqueued());
   if (can_pair(*this, batch) && inflight_.empty()) ensure_batch(2 * batch);
   // one staging mel buffer: the front end of batch k+1 follows the encoder of batch k on the same stream
   float* d_mel = staging_mel(batch);
@@ -1903,8 +1922,9 @@ void Engine::decode_collect(int slot_idx, int64_t* ids, int32_t* n_ids) {
   if (trace) {  // device timeline of the batch relative to the first traced batch, for pipeline analysis
     hipEvent_t base = trace_base_;
     float t[4] = {0, 0, 0, 0};
-    hipEvent_t evs[4] = {slot.enc_begin, slot.enc_done, slot.dec_begin, slot.dec_done};
+    hipEvent_t evs[4] = {slot.enc_begin, slot.enc_done, src.dec_begin, slot.dec_done};  // a paired batch: its leader's chain
     for (int i = 0; i < 4; ++i) (void)hipEventElapsedTime(&t[i], base, evs[i]);
+    (void)hipGetLastError();
     fprintf(stderr, "[wt-trace] slot %d enc %.3f..%.3f dec %.3f..%.3f\n", slot_idx, t[0], t[1], t[2], t[3]);
   }
   if (timings_.logmel_ms < 0) {

@@ -299,7 +299,7 @@ void launch_encoder_attention_planes(const unsigned short* qkv, long plane, unsi
                                      float out_scale, hipStream_t stream) {
   if (batch < 1 || T < 1 || heads < 1 || (3 * heads * 64) % 8 != 0) throw Error(kErrInvalidArg, "encoder attention: bad shape");
   const int q_blocks = (T + 127) / 128;
-  hipLaunchKernelGGL(encoder_attention_planes<false>, dim3(batch * heads * q_blocks), dim3(256), 6 * kPlaneBytes, stream,
+  WT_LAUNCH_TIMED(encoder_attention_planes<false>, dim3(batch * heads * q_blocks), dim3(256), 6 * kPlaneBytes, stream,
                      reinterpret_cast<const _Float16*>(qkv), plane, reinterpret_cast<_Float16*>(out), out_plane, T, heads,
                      1.0f / (q_scale * k_scale), out_scale / v_scale);
 }
@@ -308,7 +308,7 @@ void launch_encoder_attention_bf16(const unsigned short* qkv, unsigned short* ou
                                    hipStream_t stream) {
   if (batch < 1 || T < 1 || heads < 1) throw Error(kErrInvalidArg, "encoder attention: bad shape");
   const int q_blocks = (T + 127) / 128;
-  hipLaunchKernelGGL(encoder_attention_planes<true>, dim3(batch * heads * q_blocks), dim3(256), 3 * kPlaneBytes, stream,
+  WT_LAUNCH_TIMED(encoder_attention_planes<true>, dim3(batch * heads * q_blocks), dim3(256), 3 * kPlaneBytes, stream,
                      reinterpret_cast<const _Float16*>(qkv), 0L, reinterpret_cast<_Float16*>(out), 0L, T, heads,
                      0.125f * 1.44269504088896340736f, 1.0f);
 }

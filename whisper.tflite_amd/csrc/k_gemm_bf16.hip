@@ -224,7 +224,7 @@ void launch_shape(const Bf16GemmDev& g, hipStream_t s) {
     return true;
   }();
   (void)raised;
-  hipLaunchKernelGGL((gemm_bf16_planes<EPI, BF_OUT, WN, NI>), dim3(blocks), dim3(128 * WN), smem, s, g);
+  WT_LAUNCH_TIMED((gemm_bf16_planes<EPI, BF_OUT, WN, NI>), dim3(blocks), dim3(128 * WN), smem, s, g);
 }
 
 template <int EPI, bool BF_OUT>

@@ -362,7 +362,7 @@ void launch_planes_shape(const PlaneGemmDev& g, hipStream_t s) {
     return true;
   }();
   (void)raised;
-  hipLaunchKernelGGL((gemm_planes_tile<EPI, PLANES_OUT, WN, NI, MI, LN>), dim3(blocks), dim3(128 * WN), smem, s, g);
+  WT_LAUNCH_TIMED((gemm_planes_tile<EPI, PLANES_OUT, WN, NI, MI, LN>), dim3(blocks), dim3(128 * WN), smem, s, g);
 }
 
 // returns true when the launch also wrote the LayerNorm planes (g.ln_P set and a 384-column tile chosen)

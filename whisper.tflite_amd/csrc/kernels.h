@@ -4,6 +4,7 @@
 // A shape outside a kernel's contract throws wt::Error (never abort()).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdint>
 #include <vector>
@@ -11,6 +12,25 @@
 #include "error.h"
 
 namespace wt {
+
+// Kernel-exact timing for the roofline figures (bench.py): while `start` is set, the launchers of the encoder's
+// contraction kernels attach the two events to the dispatch itself (hipExtLaunchKernelGGL), so their difference is the
+// kernel's own begin -> end interval, the figure rocprofv3 --kernel-trace reports.  An event pair recorded around the
+// launch on the stream also counts the wait for CUs that decoder chains hold and the barrier packets of the events.
+struct LaunchTimer {
+  hipEvent_t start = nullptr, stop = nullptr;
+};
+extern thread_local LaunchTimer g_launch_timer;
+
+#define WT_LAUNCH_TIMED(kernel, grid, block, smem, stream, ...)                                                      \
+  do {                                                                                                                \
+    if (::wt::g_launch_timer.start) {                                                                                 \
+      hipExtLaunchKernelGGL(kernel, grid, block, smem, stream, ::wt::g_launch_timer.start, ::wt::g_launch_timer.stop, \
+                            0, __VA_ARGS__);                                                                          \
+    } else {                                                                                                          \
+      hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__);                                             \
+    }                                                                                                                 \
+  } while (0)
 
 // ------------------------------------------------------------------ GEMM ---
 // C = epilogue(A . W^T): A [M][K] activations (row m at
