@@ -1493,20 +1493,13 @@ void Engine::flush_pending() {
   decode_enqueue(slots_[p].batch, p, nullptr, 0, -1, true);
 }
 
-// An encoder pass that no decoder chain will run beside (the first one or two of a pipeline fill, or a
-// submit/collect loop of depth one) keeps the whole chip; every other pipelined pass runs on the CU-masked stream.
-bool Engine::decoders_enqueued() const {
-  static const bool always = [] { const char* v = getenv("WT_ENC_MASK_ALWAYS"); return v && atoi(v) == 1; }();
-  return always || int(inflight_.size()) - (pending_slot_ >= 0 ? 1 : 0) > 0;
-}
-
 // decoder side of a pipelined submit: alone, or together with the previous submit's batch (dec_pair)
 static bool can_pair(const Engine& e, int batch) { return e.dec_pair != 0 && e.absorb_active() && batch <= 32; }
 
 void Engine::submit(const float* d_mel, int batch) {
   if (int(inflight_.size()) >= kSlots) throw Error(1, "pipeline is full (12 batches in flight): collect() first");
   if (batch > 64) throw Error(1, "decoder batches are limited to 64 clips per call");
-  select_stream(decoders_enqueued());
+  select_stream(true);
   if (can_pair(*this, batch) && inflight_.empty()) ensure_batch(2 * batch);  // the pair's decoder rows; never grown in flight
   encode_enqueue(d_mel, batch);
   const int s = last_enc_slot_;
@@ -1529,7 +1522,7 @@ void Engine::submit(const float* d_mel, int batch) {
 void Engine::submit_pcm(const float* d_pcm, int batch) {
   if (int(inflight_.size()) >= kSlots) throw Error(1, "pipeline is full (12 batches in flight): collect() first");
   if (batch > 64) throw Error(1, "decoder batches are limited to 64 clips per call");
-  select_stream(decoders_enqueued());
+  select_stream(true);
   if (can_pair(*this, batch) && inflight_.empty()) ensure_batch(2 * batch);
   // one staging mel buffer: the front end of batch k+1 follows the encoder of batch k on the same stream
   float* d_mel = staging_mel(batch);

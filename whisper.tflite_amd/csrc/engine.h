@@ -199,7 +199,6 @@ class Engine {
 
   // slot_b >= 0: the decoder chain takes the batches of slot and slot_b (same size) together
   void decode_enqueue(int batch, int slot, float* logits_host, int logits_steps_cap, int slot_b = -1, bool pipelined = false);
-  bool decoders_enqueued() const;  // a decoder chain is (or will be) running next to the encoder pass about to be enqueued
   int pending_slot_ = -1;  // submitted, encoder enqueued, decoder waiting for a partner batch
   void flush_pending();
   void decode_collect(int slot, int64_t* ids, int32_t* n_ids);
