@@ -5,6 +5,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <chrono>
 #include <cmath>
 #include <complex>
 #include <cstdio>
@@ -752,6 +753,7 @@ void Engine::create_streams() {
     const int prio = dp && dp[0] == 'l' ? prio_lo : prio_hi;
     for (auto& ds : dstream_) HIPCHK(hipStreamCreateWithPriority(&ds, hipStreamNonBlocking, prio));
   }
+  pick_decoder_streams();
   for (auto& e : ev_) HIPCHK(hipEventCreate(&e));
   for (Slot& sl : slots_) {
     for (hipEvent_t* e : {&sl.enc_begin, &sl.enc_mid, &sl.enc_done, &sl.dec_begin, &sl.dec_done}) {
@@ -850,6 +852,47 @@ void Engine::release() noexcept {
     ds = nullptr;
   }
   stream_ = nullptr;
+}
+
+// The runtime multiplexes the streams of a process onto a few hardware queues, and two streams that share a queue run
+// their kernels one after the other.  Which streams share depends on everything the process created before (a second
+// engine in one process measured 108 k instead of 131 k audio-sec/s: one of its decoder streams sat on the encoder
+// stream's queue).  So the engine does not trust creation order: it times a 300 us one-wavefront kernel on pairs of
+// streams (concurrent ~0.3 ms, serialised ~0.6 ms) and moves to the front of dstream_ decoder streams that overlap with
+// the pipelined encoder stream and with each other.  ~10 ms at engine creation; WT_NO_STREAM_PROBE=1 skips it.
+void Engine::pick_decoder_streams() {
+  if (getenv("WT_NO_STREAM_PROBE") || getenv("WT_DEC_PARTITION")) return;
+  hipStream_t enc = stream_masked_ ? stream_masked_ : stream_full_;
+  constexpr int kSpinUs = 20, kChain = 30;  // a chain of dependent short kernels per stream, like a decoder chain
+  const bool trace = getenv("WT_STREAM_PROBE_TRACE") != nullptr;
+  auto chain_us = [&](hipStream_t a, hipStream_t b) {
+    HIPCHK(hipStreamSynchronize(a));
+    if (b) HIPCHK(hipStreamSynchronize(b));
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < kChain; ++i) {
+      launch_spin(kSpinUs, a);
+      if (b) launch_spin(kSpinUs, b);
+    }
+    HIPCHK(hipStreamSynchronize(a));
+    if (b) HIPCHK(hipStreamSynchronize(b));
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+  };
+  launch_spin(50, enc);  // first launch of the kernel (code object load) outside the timed pairs
+  const double alone = chain_us(enc, nullptr);
+  auto serialised = [&](hipStream_t a, hipStream_t b) {
+    const double us = chain_us(a, b);
+    if (trace) std::fprintf(stderr, "[wt] stream probe: pair %p %p %.0f us (one chain alone %.0f us)\n", (void*)a, (void*)b, us, alone);
+    return us > 1.5 * alone;
+  };
+  int chosen = 0;
+  for (int i = 0; i < kDecStreams && chosen < n_dec_streams_; ++i) {
+    bool clash = serialised(enc, dstream_[i]);
+    for (int j = 0; j < chosen && !clash; ++j) clash = serialised(dstream_[j], dstream_[i]);
+    if (clash) continue;
+    std::swap(dstream_[chosen], dstream_[i]);
+    ++chosen;
+  }
+  if (trace) std::fprintf(stderr, "[wt] stream probe: %d of %d decoder streams run beside the encoder stream\n", chosen, n_dec_streams_);
 }
 
 void Engine::select_stream(bool pipelined) {
@@ -1574,7 +1617,9 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
   }
   ensure_batch(batch);
   Slot& slot = slots_[slot_idx];
-  slot.dec = slot_idx % n_dec_streams_;  // fixed pairing keeps the number of captured graphs small
+  // fixed slot -> stream map (few captured graphs); pair leaders are the even slots, so a pair counts as one
+  auto dec_of = [&](int si) { return (paired ? si / 2 : si) % n_dec_streams_; };
+  slot.dec = dec_of(slot_idx);
   slot.pair_leader = -1;
   slot.pair_off = 0;
   DecWorkspace& dw = dws_[slot.dec];
@@ -1636,8 +1681,8 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
   auto enqueue_all = [&](int si) {
     Slot& slot = slots_[si];
     const Slot& slot2 = slots_[(si + 1) % kSlots];  // the pair's second batch (paired only)
-    DecWorkspace& dw = dws_[si % n_dec_streams_];
-    hipStream_t const stream_ = dstream_[si % n_dec_streams_];
+    DecWorkspace& dw = dws_[dec_of(si)];
+    hipStream_t const stream_ = dstream_[dec_of(si)];
     long long* const h_ids_ = slot.h_ids;
     int* const h_n_ = slot.h_n;
     steps = 0;
@@ -1801,7 +1846,7 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
       std::map<std::vector<long long>, GraphEntry> fresh;
       try {
         for (int si = 0; si < kSlots; ++si) {
-          hipStream_t cs = dstream_[si % n_dec_streams_];
+          hipStream_t cs = dstream_[dec_of(si)];
           hipGraph_t graph = nullptr;
           hipGraphExec_t ge = nullptr;
           HIPCHK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));

@@ -210,6 +210,7 @@ class Engine {
   hipStream_t stream_full_ = nullptr, stream_masked_ = nullptr;
   hipEvent_t ev_switch_ = nullptr;
   void select_stream(bool pipelined);
+  void pick_decoder_streams();  // decoder streams that do not share a hardware queue with the encoder stream
   // default encoder GEMM: the k16 split kernel in its two-plane fp16 form, at 2 blocks per CU when decoders
   // share the chip (pipelined), at 3 blocks per CU otherwise
   void encode_enqueue(const float* d_mel, int batch);

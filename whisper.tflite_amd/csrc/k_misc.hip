@@ -412,4 +412,20 @@ void launch_select_token(const unsigned long long* best, int n_tiles, long long*
                      n_ids, finished, eot, stop_at_eot);
 }
 
+
+// One wavefront that holds a CU for `ticks` periods of the 100 MHz constant clock: the probe Engine::create_streams uses
+// to find out which of its streams the runtime mapped onto the same hardware queue (two such streams run it one after
+// the other, independent ones at the same time).  Bounded: the loop ends after `ticks` whatever happens.
+__global__ __launch_bounds__(64) void spin_ticks(unsigned long long ticks) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  for (int i = 0; i < (1 << 22); ++i) {
+    if (__builtin_amdgcn_s_memrealtime() - t0 >= ticks) break;
+    __builtin_amdgcn_s_sleep(8);
+  }
+}
+
+void launch_spin(int microseconds, hipStream_t s) {
+  hipLaunchKernelGGL(spin_ticks, dim3(1), dim3(64), 0, s, (unsigned long long)(microseconds) * 100ull);
+}
+
 }  // namespace wt

@@ -198,6 +198,9 @@ void launch_layernorm_planes(const float* x, unsigned short* yp, long plane, flo
 
 // fp32 rows [M][ld] (contiguous) -> planes of x * scales[n / seg] (seg = 0: one segment), hi at yp, lo at yp + plane:
 // the operand hand-over between a contraction on the fp32-storage fall-back kernels and one on the plane kernels
+// probe kernel of Engine::create_streams: one wavefront busy for `microseconds` (k_misc.hip)
+void launch_spin(int microseconds, hipStream_t s);
+
 void launch_f32_to_planes(const float* x, unsigned short* yp, long plane, long M, int ld, const float* scales, int seg,
                           hipStream_t s);
 
