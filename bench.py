@@ -182,10 +182,12 @@ def add_stats(acc, ks):
             a[k] += v[k]
 
 
-def pipeline_run(eng, ptr, batch, k, depth, on_collect=None):
+def pipeline_run(eng, ptr, batch, k, depth, on_collect=None, tail=2):
     """k pipelined passes of the hot path over the device-resident batch at `ptr`; returns the last (ids, n)"""
     in_flight, out = 0, None
-    for _ in range(k):
+    for i in range(k):
+        if tail and k - i == tail:
+            eng.set_option("last_batches", tail)  # the job's last batches drain as one decoder chain per batch
         eng.pipeline_submit_dev(ptr, batch)
         in_flight += 1
         if in_flight == depth:
@@ -251,6 +253,9 @@ def main() -> None:
     ap.add_argument("--no-pipeline", action="store_true",
                     help="synchronous steps (encoder then decoder) instead of the two-deep pipeline")
     ap.add_argument("--depth", type=int, default=10, choices=tuple(range(1, 13)), help="batches in flight (pipelined mode)")
+    ap.add_argument("--tail", type=int, default=2, choices=(0, 1, 2, 3, 4),
+                    help="announce the last N batches of every run of steps to the engine (option last_batches: one decoder "
+                         "chain per batch while the pipeline drains); 0 = never")
     ap.add_argument("--attn-variant", type=int, default=None, choices=(0, 1, 2, 3, 4))
     ap.add_argument("--cross-chunks", type=int, default=None, choices=(1, 2, 4, 8))
     ap.add_argument("--cross-absorb", type=int, default=None, choices=(0, 1),
@@ -377,7 +382,10 @@ def main() -> None:
             flush_gather()
             return out[0], out[1], gathered["rec"]
         in_flight = 0
-        for _ in range(k):
+        for i in range(k):
+            if args.tail and k - i == args.tail:
+                # the job's last batches: one decoder chain per batch (option last_batches, DESIGN section 5 "drain")
+                eng.set_option("last_batches", args.tail)
             t_h = time.perf_counter()
             eng.pipeline_submit_dev(d_mel.data_ptr(), B)
             host["submit_s"] += time.perf_counter() - t_h

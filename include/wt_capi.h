@@ -86,12 +86,21 @@ int wt_engine_dims(const wt_engine* h, wt_dims* out);
  * 1 = three bf16 planes; 0 = fp32 MFMA),
  * "fc2_ksplit" (2 = default: the decoder's fc2 GEMM over twice the blocks, halves added by the
  * consumer; 1 = one block per column tile), "use_graphs" (1 = default: the decoder's launch sequence is replayed from a hipGraph).
+ * Decoder form: "cross_absorb" (1 = default: cross-attention scores the decoder's queries, pre-multiplied by Wk, directly
+ * against the encoder output planes and applies Wv after the softmax, so no cross K/V cache is projected or streamed;
+ * 0 = the cross-KV cache of whisper.cpp's graph; fp32-accurate mode only, "cross_absorb_active" reads what is in
+ * effect), "abs_chunks" (key chunks per clip of that form, 0 = by batch size), "dec_pair" (1 = default: two consecutive
+ * pipelined batches of equal size <= 32 share one decoder chain; change only with nothing in flight),
+ * "last_batches" (N = the next N pipelined submits are the last of a job: they are decoded one chain per batch, the very
+ * last on the encoder's stream, so the pipeline drains sooner; counts down to 0 by itself, may be set with batches in
+ * flight), "force_fallback" (test hook: bit mask of contractions sent to the full-range kernels, nothing in flight).
  * Read-only (wt_engine_get_option): "f16_fallbacks" = contractions that were given the full-range bf16
  * three-plane kernels at load time because an operand's weight-derived bound lies more than 2^12 above its
  * typical magnitude (csrc/engine.cpp, upload_weights) — only those leave the plane kernels, the others keep them; "in_flight" = submitted, uncollected batches.
  * Environment, read at wt_engine_create: WT_ENC_CU_RESERVE (CUs per XCD the pipelined encoder
- * stream leaves to the decoders, default 4, 0 = none), WT_DEC_STREAMS (decoder streams, default 3),
- * WT_TRACE_PIPELINE (per-batch device timeline on stderr). */
+ * stream leaves to the decoders, default 8, 0 = none), WT_DEC_STREAMS (decoder streams, default 3),
+ * WT_TRACE_PIPELINE (per-batch device timeline on stderr), WT_NO_STREAM_PROBE (skip the ~10 ms probe that picks decoder
+ * streams which do not share a hardware queue with the encoder stream or with each other). */
 int wt_engine_set_option(wt_engine* h, const char* key, long value);
 int wt_engine_get_option(const wt_engine* h, const char* key, long* value);
 /* Replaces the reference's hard-coded prompt [sot, 50259+language, transcribe, notimestamps]

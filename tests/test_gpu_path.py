@@ -319,6 +319,41 @@ def test_pipeline_pairs_two_batches_per_decoder_chain(tiny):
         d.free()
 
 
+def test_pipeline_last_batches_drain_in_latency_form(pkg, tiny):
+    """Option last_batches = N: the next N submits are announced as the last of a job and are decoded one chain per batch
+    (the very last one on the encoder's own stream) instead of in pairs, so the pipeline drains sooner.  Same ids as the
+    synchronous call in submission order; the counter runs down to 0; submitting more batches afterwards still works and
+    pairs again."""
+    from conftest import DevBuf
+    e, _ = tiny
+    rng = np.random.default_rng(77)
+    mels = [rng.uniform(-1.0, 1.5, size=(4, 80, 3000)).astype(np.float32) for _ in range(6)]
+    want = [e.encdec_tokens_batch(m) for m in mels]
+    dev = [DevBuf(m) for m in mels]
+    with pytest.raises(pkg.WtError):
+        e.set_option("last_batches", 13)
+    for graphs in (1, 0, 1):
+        e.set_option("use_graphs", graphs)
+        for tail in (1, 2, 3):
+            for k in range(6):
+                if 6 - k == tail:
+                    e.set_option("last_batches", tail)
+                e.pipeline_submit_dev(dev[k].data_ptr(), 4)
+            assert e.get_option("last_batches") == 0
+            for k in range(6):
+                ids_g, n_g = e.pipeline_collect()
+                assert np.array_equal(want[k][0], ids_g) and np.array_equal(want[k][1], n_g), (graphs, tail, k)
+        # after a drained job the next submits pair as usual
+        for k in (0, 1):
+            e.pipeline_submit_dev(dev[k].data_ptr(), 4)
+        for k in (0, 1):
+            ids_g, n_g = e.pipeline_collect()
+            assert np.array_equal(want[k][0], ids_g) and np.array_equal(want[k][1], n_g)
+    e.set_option("use_graphs", 1)
+    for d in dev:
+        d.free()
+
+
 def test_config3_second_weight_set_multilingual_prompt(pkg, assets, orc):
     """BASELINE configs[2] (whisper-tiny-german): same graph, a different weight set (seed 1
     stands in for the fine-tune) and the multilingual vocab path (sot 50258, <|de|> 50261,

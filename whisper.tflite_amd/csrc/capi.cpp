@@ -169,6 +169,9 @@ int wt_engine_set_option(wt_engine* h, const char* key, long value) {
     e.use_graphs = value != 0;
   } else if (k == "cross_absorb") {
     e.cross_absorb = value != 0;
+  } else if (k == "last_batches") {
+    if (value < 0 || value > 12) return fail(h, WT_ERR_INVALID_ARG, "last_batches: 0..12");
+    e.last_batches = value;
   } else if (k == "dec_pair") {
     if (h->impl->in_flight() > 0) return fail(h, WT_ERR_INVALID_ARG, "collect the submitted batches before changing dec_pair");
     e.dec_pair = value != 0;
@@ -226,6 +229,7 @@ int wt_engine_get_option(const wt_engine* h, const char* key, long* value) {
   else if (k == "cross_absorb") *value = e.cross_absorb;
   else if (k == "abs_chunks") *value = e.abs_chunks;
   else if (k == "dec_pair") *value = e.dec_pair;
+  else if (k == "last_batches") *value = e.last_batches;
   else if (k == "cross_absorb_active") *value = e.absorb_active() ? 1 : 0;  // read-only
   else if (k == "bf16") *value = e.bf16;
   else if (k == "kernel_timers") *value = e.kernel_timers;

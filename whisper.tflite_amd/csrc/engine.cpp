@@ -885,14 +885,16 @@ void Engine::pick_decoder_streams() {
     return us > 1.5 * alone;
   };
   int chosen = 0;
-  for (int i = 0; i < kDecStreams && chosen < n_dec_streams_; ++i) {
+  const int want = std::min(kDecStreams, n_dec_streams_ + 2);  // + spare streams for the latency form (submit_decoder)
+  for (int i = 0; i < kDecStreams && chosen < want; ++i) {
     bool clash = serialised(enc, dstream_[i]);
     for (int j = 0; j < chosen && !clash; ++j) clash = serialised(dstream_[j], dstream_[i]);
     if (clash) continue;
     std::swap(dstream_[chosen], dstream_[i]);
     ++chosen;
   }
-  if (trace) std::fprintf(stderr, "[wt] stream probe: %d of %d decoder streams run beside the encoder stream\n", chosen, n_dec_streams_);
+  n_spare_streams_ = std::max(0, chosen - n_dec_streams_);
+  if (trace) std::fprintf(stderr, "[wt] stream probe: %d decoder streams (%d wanted + spares) run beside the encoder stream\n", chosen, n_dec_streams_);
 }
 
 void Engine::select_stream(bool pipelined) {
@@ -1539,14 +1541,14 @@ void Engine::flush_pending() {
 // decoder side of a pipelined submit: alone, or together with the previous submit's batch (dec_pair)
 static bool can_pair(const Engine& e, int batch) { return e.dec_pair != 0 && e.absorb_active() && batch <= 32; }
 
-void Engine::submit(const float* d_mel, int batch) {
-  if (int(inflight_.size()) >= kSlots) throw Error(1, "pipeline is full (12 batches in flight): collect() first");
-  if (batch > 64) throw Error(1, "decoder batches are limited to 64 clips per call");
-  select_stream(true);
-  if (can_pair(*this, batch) && inflight_.empty()) ensure_batch(2 * batch);  // the pair's decoder rows; never grown in flight
-  encode_enqueue(d_mel, batch);
-  const int s = last_enc_slot_;
-  if (can_pair(*this, batch) && ws_.batch >= 2 * batch) {
+// Throughput form: two consecutive batches share one decoder chain.  Latency form — the last `last_batches` submits of
+// a job (option, counted down here): a chain per batch, on spare decoder streams when the probe found any, so that the
+// pipeline drains in one short chain instead of a long paired one behind two others (measured on the driver's 20-step
+// command: 16.7 ms from the last encoder pass to the last token with the paired form).
+void Engine::submit_decoder(int batch, int s) {
+  const bool tail = last_batches > 0;
+  if (tail) --last_batches;
+  if (!tail && can_pair(*this, batch) && ws_.batch >= 2 * batch) {
     if (pending_slot_ >= 0 && slots_[pending_slot_].batch == batch) {
       const int a = pending_slot_;
       pending_slot_ = -1;
@@ -1557,9 +1559,25 @@ void Engine::submit(const float* d_mel, int batch) {
     }
   } else {
     flush_pending();
-    decode_enqueue(batch, s, nullptr, 0, -1, true);
+    int spare = -1;
+    // The very last batch decodes on the encoder's own stream, right behind its encoder pass: that hardware queue has
+    // nothing else to do once the last encoder pass is through, and the decoder streams are still busy with earlier
+    // chains.  (Submitting more batches after "the last" is allowed: their encoder passes queue behind that chain.)
+    // The batches before it use a spare decoder stream when the probe found one.
+    if (tail && last_batches == 0) spare = kEncAsDec;
+    else if (tail && n_spare_streams_ > 0) spare = n_dec_streams_ + int(last_batches % n_spare_streams_);
+    decode_enqueue(batch, s, nullptr, 0, -1, true, spare);
   }
   inflight_.push_back(s);
+}
+
+void Engine::submit(const float* d_mel, int batch) {
+  if (int(inflight_.size()) >= kSlots) throw Error(1, "pipeline is full (12 batches in flight): collect() first");
+  if (batch > 64) throw Error(1, "decoder batches are limited to 64 clips per call");
+  select_stream(true);
+  if (can_pair(*this, batch) && inflight_.empty()) ensure_batch(2 * batch);  // the pair's decoder rows; never grown in flight
+  encode_enqueue(d_mel, batch);
+  submit_decoder(batch, last_enc_slot_);
 }
 
 void Engine::submit_pcm(const float* d_pcm, int batch) {
@@ -1571,21 +1589,7 @@ void Engine::submit_pcm(const float* d_pcm, int batch) {
   float* d_mel = staging_mel(batch);
   logmel(d_pcm, batch, d_mel);
   encode_enqueue(d_mel, batch);
-  const int s = last_enc_slot_;
-  if (can_pair(*this, batch) && ws_.batch >= 2 * batch) {
-    if (pending_slot_ >= 0 && slots_[pending_slot_].batch == batch) {
-      const int a = pending_slot_;
-      pending_slot_ = -1;
-      decode_enqueue(batch, a, nullptr, 0, s, true);
-    } else {
-      flush_pending();
-      pending_slot_ = s;
-    }
-  } else {
-    flush_pending();
-    decode_enqueue(batch, s, nullptr, 0, -1, true);
-  }
-  inflight_.push_back(s);
+  submit_decoder(batch, last_enc_slot_);
 }
 
 void Engine::collect(int64_t* ids, int32_t* n_ids) {
@@ -1607,7 +1611,8 @@ std::vector<long long> Engine::prompt() const {
   return {vocab_.token_sot, 50259 + language, vocab_.token_transcribe, vocab_.token_not};
 }
 
-void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int logits_steps_cap, int slot_b, bool pipelined) {
+void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int logits_steps_cap, int slot_b, bool pipelined,
+                            int stream_override) {
   const bool paired = slot_b >= 0;
   const int per = batch;          // clips per encoder batch
   if (paired) batch = 2 * per;    // the chain decodes both: rows / clips below count the pair
@@ -1618,12 +1623,13 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
   ensure_batch(batch);
   Slot& slot = slots_[slot_idx];
   // fixed slot -> stream map (few captured graphs); pair leaders are the even slots, so a pair counts as one
-  auto dec_of = [&](int si) { return (paired ? si / 2 : si) % n_dec_streams_; };
+  // (stream_override: a spare stream + workspace for a batch decoded in the latency form, submit_decoder)
+  auto dec_of = [&](int si) { return stream_override >= 0 ? stream_override : (paired ? si / 2 : si) % n_dec_streams_; };
   slot.dec = dec_of(slot_idx);
   slot.pair_leader = -1;
   slot.pair_off = 0;
   DecWorkspace& dw = dws_[slot.dec];
-  hipStream_t const stream_ = dstream_[slot.dec];  // everything below runs on this decoder stream
+  hipStream_t const stream_ = dec_stream_at(slot.dec);  // everything below runs on this decoder stream
   HIPCHK(hipStreamWaitEvent(stream_, slot.enc_done, 0));
   if (paired) HIPCHK(hipStreamWaitEvent(stream_, slots_[slot_b].enc_done, 0));
   HIPCHK(hipEventRecord(slot.dec_begin, stream_));
@@ -1682,7 +1688,7 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
     Slot& slot = slots_[si];
     const Slot& slot2 = slots_[(si + 1) % kSlots];  // the pair's second batch (paired only)
     DecWorkspace& dw = dws_[dec_of(si)];
-    hipStream_t const stream_ = dstream_[dec_of(si)];
+    hipStream_t const stream_ = dec_stream_at(dec_of(si));
     long long* const h_ids_ = slot.h_ids;
     int* const h_n_ = slot.h_n;
     steps = 0;
@@ -1813,7 +1819,7 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
   // kernels' one-time attribute set-up) and then captures one hipGraph per slot; later calls
   // replay the slot's graph: one host call instead of ~1100. The logits tap stays eager.
   auto key_of = [&](int si) {
-    return std::vector<long long>{si, batch, max_pos, n_prompt, chunks, long(stop_at_eot), fc2_ksplit, bf16, absorbed ? 1 : 0, n_abs, paired ? 1 : 0};
+    return std::vector<long long>{si, batch, max_pos, n_prompt, chunks, long(stop_at_eot), fc2_ksplit, bf16, absorbed ? 1 : 0, n_abs, paired ? 1 : 0, stream_override};
   };
   hipGraphExec_t exec = nullptr;
   if (use_graphs && !logits_host) {
@@ -1846,7 +1852,7 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
       std::map<std::vector<long long>, GraphEntry> fresh;
       try {
         for (int si = 0; si < kSlots; ++si) {
-          hipStream_t cs = dstream_[dec_of(si)];
+          hipStream_t cs = dec_stream_at(dec_of(si));
           hipGraph_t graph = nullptr;
           hipGraphExec_t ge = nullptr;
           HIPCHK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));

@@ -110,6 +110,7 @@ class Engine {
   // what the pipeline waits for.  Results and their order are unchanged; a batch whose partner has
   // not been submitted yet is decoded alone as soon as it is collected.
   long dec_pair = 1;
+  long last_batches = 0;  // the next N submits are the last of a job: decoded one chain per batch (latency form); counts down
   bool absorb_active() const { return cross_absorb != 0 && bf16 == 0 && gemm_variant < 0 && sc_cross_kv_.f16_ok; }
   long gemm_variant = -1;  // -1 = plane GEMM (per-contraction fall-back to 13/16); 0 = fp32 MFMA, 13 / 16 = three bf16 planes
   // 1 = bf16 STORAGE mode (BASELINE configs[3]): bf16 weights, activations and both KV caches, fp32 accumulation,
@@ -198,7 +199,10 @@ class Engine {
   void build_frontend_tables();
 
   // slot_b >= 0: the decoder chain takes the batches of slot and slot_b (same size) together
-  void decode_enqueue(int batch, int slot, float* logits_host, int logits_steps_cap, int slot_b = -1, bool pipelined = false);
+  void decode_enqueue(int batch, int slot, float* logits_host, int logits_steps_cap, int slot_b = -1, bool pipelined = false,
+                      int stream_override = -1);
+  void submit_decoder(int batch, int slot);  // decoder side of submit / submit_pcm: paired, alone, or latency form
+  int n_spare_streams_ = 0;  // probe-selected decoder streams beyond n_dec_streams_ (latency form of the last batches)
   int pending_slot_ = -1;  // submitted, encoder enqueued, decoder waiting for a partner batch
   void flush_pending();
   void decode_collect(int slot, int64_t* ids, int32_t* n_ids);
@@ -221,6 +225,8 @@ class Engine {
   int n_dec_streams_ = 3;  // decoder streams in use: one hardware queue each (the runtime multiplexes
                            // streams onto 4 queues per priority; two decoders sharing one serialise)
   hipStream_t dstream_[kDecStreams] = {};  // decoders (batches rotate over them)
+  static constexpr int kEncAsDec = kDecStreams;  // decoder-stream index meaning "the pipelined encoder stream" (submit_decoder)
+  hipStream_t dec_stream_at(int i) const { return i == kEncAsDec ? (stream_masked_ ? stream_masked_ : stream_full_) : dstream_[i]; }
   hipEvent_t ev_[2] = {nullptr, nullptr};  // front end begin / end
   struct Slot {
     float* cross_kv = nullptr;  // [layer][k|v][clip][head][t][64]
@@ -325,7 +331,7 @@ class Engine {
     unsigned long long* best = nullptr;
     long long* ids = nullptr;
     int *n_ids = nullptr, *finished = nullptr;
-  } dws_[kDecStreams];
+  } dws_[kDecStreams + 1];  // one per decoder stream, + one for a chain on the encoder stream (kEncAsDec)
   struct Workspace {
     int batch = 0;
     float *melT = nullptr, *h1p = nullptr, *x = nullptr, *ln = nullptr, *qkv = nullptr,
