@@ -31,4 +31,24 @@ for k, cs in out.items():
         res[k]["hbm_read_bytes_per_launch"] = 2 * 1024 * cs["FETCH_SIZE"] / launches[k]["FETCH_SIZE"]
     if "WRITE_SIZE" in cs:
         res[k]["hbm_write_bytes_per_launch"] = 1024 * cs["WRITE_SIZE"] / launches[k]["WRITE_SIZE"]
+    pl = {c: v / launches[k][c] for c, v in cs.items()}
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in pl and pl.get("GRBM_GUI_ACTIVE"):
+        res[k]["mfma_busy_frac"] = round(pl["SQ_VALU_MFMA_BUSY_CYCLES"] / (pl["GRBM_GUI_ACTIVE"] / 8 * 1024), 3)
+    if "SQ_LDS_BANK_CONFLICT" in pl and pl.get("SQ_LDS_IDX_ACTIVE"):
+        res[k]["lds_conflict_frac"] = round(pl["SQ_LDS_BANK_CONFLICT"] / pl["SQ_LDS_IDX_ACTIVE"], 4)
+    if pl.get("SQ_WAVE_CYCLES"):
+        for c, name in (("SQ_WAIT_ANY", "wave_wait_any_frac"), ("SQ_WAIT_INST_ANY", "wave_wait_inst_frac"),
+                        ("SQ_ACTIVE_INST_ANY", "wave_issuing_frac")):
+            if c in pl:
+                res[k][name] = round(pl[c] / pl["SQ_WAVE_CYCLES"], 3)
+res["_notes"] = {
+    "mfma_busy_frac": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs): share of the launch's GPU-active "
+                      "cycles in which a SIMD's matrix pipe was busy, chip average",
+    "lds_conflict_frac": "SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE (extra LDS-array cycles / all LDS-array cycles)",
+    "wave_wait_any_frac / wave_wait_inst_frac / wave_issuing_frac": "SQ_WAIT_ANY, SQ_WAIT_INST_ANY, SQ_ACTIVE_INST_ANY over "
+        "SQ_WAVE_CYCLES: share of a resident wave's cycles spent waiting on anything (counters, barriers), waiting to "
+        "issue, and issuing",
+    "run": "separate --pmc passes over a serial 2-step bench run (tools/collect_profiles.sh); never combined with other "
+           "trace domains",
+}
 print(json.dumps(res, indent=1))
