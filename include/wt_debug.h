@@ -69,6 +69,9 @@ int wt_dbg_cross_attention(wt_engine* h, int batch, int heads, int T, int chunks
  * d = 64 * heads.  iters > 0 also times the attention launch. */
 int wt_dbg_cross_absorbed(wt_engine* h, int batch, int heads, int T, int chunks, int nq, const float* qp, const float* E,
                           const float* wv, const float* bv, float* out, int iters, float* avg_us);
+/* the same with E as ONE bf16 plane (bf16 storage mode): queries and probabilities rounded to bf16 in the kernel */
+int wt_dbg_cross_absorbed_bf16(wt_engine* h, int batch, int heads, int T, int chunks, int nq, const float* qp, const float* E,
+                               const float* wv, const float* bv, float* out, int iters, float* avg_us);
 int wt_dbg_self_attention(wt_engine* h, int batch, int heads, int cap, int pos, int npos, const float* qkv,
                           float* kcache, float* vcache, float* out);
 /* bf16 storage mode kernels (option "bf16"): operands are rounded to bf16 on the host, contracted by

@@ -573,3 +573,36 @@ def test_cross_attention_absorbed(eng, B, H, T, chunks, nq):
             c = (p[:, None] * E64[b]).sum(0) / p.sum()
             ref = wv[h * 64:(h + 1) * 64].astype(np.float64) @ c + bv[h * 64:(h + 1) * 64]
             assert np.abs(out[r, h * 64:(h + 1) * 64] - ref).max() < 2e-5, (r, h)
+
+
+def _bf16_round(x):
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32).reshape(np.shape(x))
+
+
+@pytest.mark.parametrize("B,H,T,chunks,nq", [(2, 8, 1500, 4, 2), (3, 6, 333, 4, 2), (2, 2, 100, 2, 4), (1, 8, 64, 2, 1),
+                                              (5, 6, 97, 1, 1)])
+def test_cross_attention_absorbed_bf16_storage(eng, B, H, T, chunks, nq):
+    """The bf16 storage variant of the absorbed cross-attention (BASELINE configs[3]): E is one bf16 plane, queries and
+    probabilities are rounded to bf16 in the kernel, one bf16 MFMA per product, fp32 accumulation.  Against fp64 on the
+    bf16-ROUNDED E and queries the only remaining difference is the rounding of the probabilities (2^-9 relative each,
+    averaging out over the keys) and fp32 accumulation: 4e-3 absolute on O(1) outputs; d_model 512 / 384 / 128."""
+    rng = np.random.default_rng(B * 77 + T + H + nq)
+    d = 64 * H
+    E = _bf16_round(rng.standard_normal((B, T, d)).astype(np.float32))
+    qp = _bf16_round((rng.standard_normal((nq * B, H * d)) * (3.0 / np.sqrt(d))).astype(np.float32))
+    wv = (rng.standard_normal((d, d)) / np.sqrt(d)).astype(np.float32)
+    bv = rng.standard_normal(d).astype(np.float32)
+    out = eng.dbg_cross_absorbed(qp, E, wv, bv, B, H, T, chunks, nq, bf16=True)
+    E64 = E.astype(np.float64)
+    worst = 0.0
+    for r in range(nq * B):
+        b = r % B
+        for h in range(H):
+            s = E64[b] @ qp[r, h * d:(h + 1) * d].astype(np.float64)
+            p = np.exp2(s - s.max())
+            c = (p[:, None] * E64[b]).sum(0) / p.sum()
+            ref = wv[h * 64:(h + 1) * 64].astype(np.float64) @ c + bv[h * 64:(h + 1) * 64]
+            worst = max(worst, np.abs(out[r, h * 64:(h + 1) * 64] - ref).max())
+    assert worst < 4e-3, worst

@@ -609,6 +609,22 @@ def test_bf16_storage_mode_micro_and_tiny(micro, tiny, orc):
     # deterministic, and the pipelined path runs the same kernels
     ids_p, n_p = e.encdec_tokens_batch(mel)
     assert np.array_equal(ids_p, ids16) and np.array_equal(n_p, n16)
+    # the mode runs the absorbed cross-attention on one bf16 plane of the encoder output; the cached form (bf16 K/V) is
+    # the same function up to bf16 rounding: ids agree wherever the fp32 margin allows (checked against fp32 above), and
+    # two pipelined batches share one decoder chain exactly like in the default mode
+    assert e.get_option("cross_absorb_active") == 1
+    from conftest import DevBuf
+    dev = DevBuf(mel)
+    for _ in range(2):
+        e.pipeline_submit_dev(dev.data_ptr(), 5)
+    for _ in range(2):
+        ids_q, n_q = e.pipeline_collect()
+        assert np.array_equal(ids_q, ids16) and np.array_equal(n_q, n16)
+    dev.free()
+    e.set_option("cross_absorb", 0)
+    assert e.get_option("cross_absorb_active") == 0
+    _bf16_vs_fp32(e, mel, enc_ref)
+    e.set_option("cross_absorb", 1)
     # switching back restores the fp32 results bit for bit (the two modes lay their padded buffers out differently)
     e.set_option("bf16", 0)
     ids_b, n_b = e.encdec_tokens_batch(mel)

@@ -47,7 +47,7 @@ CAPI_SYMBOLS = [
     "wt_vocab_decode", "wt_log_mel_spectrogram", "wt_convert_tflite", "wt_shutdown",
 ]
 DEBUG_SYMBOLS = [
-    "wt_dbg_cross_absorbed", "wt_dbg_gemm_planes_ln", "wt_dbg_gemm", "wt_dbg_gemm_bench", "wt_dbg_dec_gemm_bench", "wt_dbg_dec_gemm", "wt_dbg_dec_ln_gemm", "wt_dbg_layernorm", "wt_dbg_encoder_attention",
+    "wt_dbg_cross_absorbed", "wt_dbg_cross_absorbed_bf16", "wt_dbg_gemm_planes_ln", "wt_dbg_gemm", "wt_dbg_gemm_bench", "wt_dbg_dec_gemm_bench", "wt_dbg_dec_gemm", "wt_dbg_dec_ln_gemm", "wt_dbg_layernorm", "wt_dbg_encoder_attention",
     "wt_dbg_cross_attention", "wt_dbg_self_attention", "wt_dbg_interference", "wt_dbg_concurrency",
     "wt_dbg_gemm_planes", "wt_dbg_encoder_attention_planes", "wt_dbg_gemm_bf16", "wt_dbg_encoder_attention_bf16",
 ]
@@ -141,6 +141,7 @@ def lib() -> ctypes.CDLL:
                                          POINTER(c_float), c_int]
         L.wt_dbg_encoder_attention_planes.argtypes = [c_void_p, c_int, c_int, c_int, fp, c_int, fp, POINTER(c_float)]
         L.wt_dbg_cross_absorbed.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, fp, fp, fp, fp, fp, c_int, POINTER(c_float)]
+        L.wt_dbg_cross_absorbed_bf16.argtypes = L.wt_dbg_cross_absorbed.argtypes
         L.wt_dbg_gemm_planes_ln.argtypes = [c_void_p, c_int, c_int, fp, fp, fp, fp, fp, c_int, c_int, fp, fp, c_int, fp, fp, fp,
                                             POINTER(c_int)]
         L.wt_dbg_gemm_bf16.argtypes = [c_void_p, c_int, c_int, c_int, fp, fp, fp, fp, fp, c_int, c_int, c_int, c_int, fp,
@@ -496,15 +497,15 @@ class Engine:
                                                 int(n_cu), _fp(C), _fp(ln), _fp(y32) if y32 is not None else None, byref(fused)))
         return C, ln, y32, bool(fused.value)
 
-    def dbg_cross_absorbed(self, qp, E, wv, bv, batch, heads, T, chunks, nq, iters=0):
+    def dbg_cross_absorbed(self, qp, E, wv, bv, batch, heads, T, chunks, nq, iters=0, bf16=False):
         """Absorbed cross-attention + chunk combine + value projection: qp [nq * batch][heads * d], E [batch][T][d],
         wv [d][d], bv [d] -> [nq * batch][d] (and the average microseconds of the attention launch when iters > 0)"""
         qp, E, wv, bv = _f32(qp), _f32(E), _f32(wv), _f32(bv)
         d = heads * 64
         out = np.zeros((nq * batch, d), np.float32)
         us = c_float(0)
-        self._check(lib().wt_dbg_cross_absorbed(self._h, batch, heads, T, chunks, nq, _fp(qp), _fp(E), _fp(wv), _fp(bv), _fp(out),
-                                                iters, byref(us)))
+        fn = lib().wt_dbg_cross_absorbed_bf16 if bf16 else lib().wt_dbg_cross_absorbed
+        self._check(fn(self._h, batch, heads, T, chunks, nq, _fp(qp), _fp(E), _fp(wv), _fp(bv), _fp(out), iters, byref(us)))
         return (out, us.value) if iters > 0 else out
 
     def dbg_encoder_attention_planes(self, qkv, batch, T, heads, iters=0):

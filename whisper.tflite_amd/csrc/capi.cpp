@@ -1209,19 +1209,21 @@ int wt_dbg_cross_attention(wt_engine* h, int batch, int heads, int T, int chunks
   });
 }
 
-int wt_dbg_cross_absorbed(wt_engine* h, int batch, int heads, int T, int chunks, int nq, const float* qp, const float* E,
-                          const float* wv, const float* bv, float* out, int iters, float* avg_us) {
+static int dbg_cross_absorbed_impl(wt_engine* h, int batch, int heads, int T, int chunks, int nq, const float* qp, const float* E,
+                                   const float* wv, const float* bv, float* out, int iters, float* avg_us, bool bf) {
   if (!h || !qp || !E || !wv || !bv || !out || batch < 1 || heads < 1 || T < 1 || nq < 1 || chunks < 1 || chunks > 16) return WT_ERR_INVALID_ARG;
   return guarded(h, [&] {
     const size_t d = size_t(heads) * 64, rows = size_t(nq) * batch;
-    const float se = wt::f16_scale_for(max_abs(E, size_t(batch) * T * d));
-    const DevPlanes dE(E, size_t(batch) * T * d, se);
+    const float se = bf ? 1.0f : wt::f16_scale_for(max_abs(E, size_t(batch) * T * d));
+    const DevPlanes dEp(bf ? nullptr : E, bf ? 0 : size_t(batch) * T * d, se);
+    const DevBf16 dEb(bf ? E : nullptr, bf ? size_t(batch) * T * d : 0);
+    struct { const unsigned short* p; long plane; const unsigned short* ptr() const { return p; } } dE{bf ? dEb.ptr() : dEp.ptr(), bf ? 0 : dEp.plane};
     const std::vector<float> wvt = wt::cross_q_layout(wv, int(d));
     DevBuf dq(qp, rows * heads * d), dws(rows * heads * chunks * (d + 4)), dout(rows * d), dwv(wvt.data(), wvt.size()), dbv(bv, d);
     const int nq_max = wt::cross_absorbed_max_nq(heads);
     for (int p0 = 0; p0 < nq; p0 += nq_max) {
       wt::CrossAbsorbedArgs a;
-      a.qp = dq.p; a.e = dE.ptr(); a.e_plane = dE.plane; a.e_scale = se; a.ws = dws.p;
+      a.qp = dq.p; a.e = dE.ptr(); a.e_plane = dE.plane; a.e_scale = se; a.ws = dws.p; a.bf16 = bf;
       a.batch = batch; a.heads = heads; a.d_model = int(d); a.T = T; a.chunks = chunks; a.nq = std::min(nq_max, nq - p0); a.p0 = p0;
       wt::launch_cross_absorbed(a, h->impl->stream());
     }
@@ -1230,7 +1232,7 @@ int wt_dbg_cross_absorbed(wt_engine* h, int batch, int heads, int T, int chunks,
     dout.to_host(out, rows * d);
     if (iters > 0 && avg_us) {
       wt::CrossAbsorbedArgs a;
-      a.qp = dq.p; a.e = dE.ptr(); a.e_plane = dE.plane; a.e_scale = se; a.ws = dws.p;
+      a.qp = dq.p; a.e = dE.ptr(); a.e_plane = dE.plane; a.e_scale = se; a.ws = dws.p; a.bf16 = bf;
       a.batch = batch; a.heads = heads; a.d_model = int(d); a.T = T; a.chunks = chunks; a.nq = std::min(nq_max, nq); a.p0 = 0;
       hipStream_t st = h->impl->stream();
       hipEvent_t e0, e1;
@@ -1248,6 +1250,16 @@ int wt_dbg_cross_absorbed(wt_engine* h, int batch, int heads, int T, int chunks,
       (void)hipEventDestroy(e1);
     }
   });
+}
+
+int wt_dbg_cross_absorbed(wt_engine* h, int batch, int heads, int T, int chunks, int nq, const float* qp, const float* E,
+                          const float* wv, const float* bv, float* out, int iters, float* avg_us) {
+  return dbg_cross_absorbed_impl(h, batch, heads, T, chunks, nq, qp, E, wv, bv, out, iters, avg_us, false);
+}
+
+int wt_dbg_cross_absorbed_bf16(wt_engine* h, int batch, int heads, int T, int chunks, int nq, const float* qp, const float* E,
+                               const float* wv, const float* bv, float* out, int iters, float* avg_us) {
+  return dbg_cross_absorbed_impl(h, batch, heads, T, chunks, nq, qp, E, wv, bv, out, iters, avg_us, true);
 }
 
 int wt_dbg_self_attention(wt_engine* h, int batch, int heads, int cap, int pos, int npos, const float* qkv,

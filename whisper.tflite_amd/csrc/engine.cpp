@@ -228,6 +228,32 @@ void check_wtw_file(const std::string& path) {
   }
 }
 
+// The fused query matrix of the absorbed cross-attention, folded once, in double: A_h = c0 Wk_h^T Wq_h stacked over the
+// heads ([heads * d][d]: row (h, c) gives column c of head h's d-wide query) and a_h = c0 Wk_h^T bq_h, with
+// c0 = d_head^-1/2 log2 e (the kernel's softmax is an exp2).
+static void absorbed_query_matrix(const float* wq, const float* bq, const float* wk, int heads, int d, std::vector<float>* A,
+                                  std::vector<float>* av) {
+  const double c0 = 0.125 * 1.44269504088896340736;
+  A->assign(size_t(heads) * d * d, 0.0f);
+  av->assign(size_t(heads) * d, 0.0f);
+  std::vector<double> acc(d);
+  for (int h = 0; h < heads; ++h) {
+    for (int cc = 0; cc < d; ++cc) {
+      std::fill(acc.begin(), acc.end(), 0.0);
+      double ab = 0.0;
+      for (int i = 0; i < 64; ++i) {
+        const double kv = wk[size_t(h * 64 + i) * d + cc];
+        const float* qrow = wq + size_t(h * 64 + i) * d;
+        for (int j = 0; j < d; ++j) acc[j] += kv * qrow[j];
+        ab += kv * bq[h * 64 + i];
+      }
+      float* arow = A->data() + (size_t(h) * d + cc) * d;
+      for (int j = 0; j < d; ++j) arow[j] = float(c0 * acc[j]);
+      (*av)[size_t(h) * d + cc] = float(c0 * ab);
+    }
+  }
+}
+
 void Engine::upload_weights(const std::string& path) {
   // Replaces Atom::Atom (whisper.cpp:261-271): instead of mmapping a .tflite FlatBuffer and
   // building an interpreter, the flat .wtw payload is mapped, re-laid-out for the kernels
@@ -343,32 +369,13 @@ void Engine::upload_weights(const std::string& path) {
     {
       // Absorbed cross-attention (k_cross_absorbed.hip): scores q_h . (Wk_h e) = (Wk_h^T q_h) . e and contexts
       // sum_j p_j (Wv_h e_j + bv_h) = Wv_h (sum_j p_j e_j) + bv_h, so the decoder works on the encoder output e itself.
-      // Folded once, in double: A_h = c0 Wk_h^T Wq_h (c0 = d_head^-1/2 log2 e: the kernel's softmax is an exp2),
-      // a_h = c0 Wk_h^T bq_h.  Wv_h and bv_h are applied to each head's combined context (cross_absorbed_combine).
+      // Wv_h and bv_h are applied to each head's combined context (cross_absorbed_combine).
       const int Hh = c.n_text_head;
-      const float* wq = H(blk + ".cross_attn.query.weight", dd);
-      const float* bq = H(blk + ".cross_attn.query.bias", d);
-      const float* wk = H(blk + ".cross_attn.key.weight", dd);
       const float* wv = H(blk + ".cross_attn.value.weight", dd);
       const float* bv = H(blk + ".cross_attn.value.bias", d);
-      const double c0 = 0.125 * 1.44269504088896340736;
-      std::vector<float> A(size_t(Hh) * d * d), av(size_t(Hh) * d);
-      std::vector<double> acc(d);
-      for (int h = 0; h < Hh; ++h) {
-        for (int cc = 0; cc < d; ++cc) {
-          std::fill(acc.begin(), acc.end(), 0.0);
-          double ab = 0.0;
-          for (int i = 0; i < 64; ++i) {
-            const double kv = wk[size_t(h * 64 + i) * d + cc];
-            const float* qrow = wq + size_t(h * 64 + i) * d;
-            for (int j = 0; j < d; ++j) acc[j] += kv * qrow[j];
-            ab += kv * bq[h * 64 + i];
-          }
-          float* arow = A.data() + (size_t(h) * d + cc) * d;
-          for (int j = 0; j < d; ++j) arow[j] = float(c0 * acc[j]);
-          av[size_t(h) * d + cc] = float(c0 * ab);
-        }
-      }
+      std::vector<float> A, av;
+      absorbed_query_matrix(H(blk + ".cross_attn.query.weight", dd), H(blk + ".cross_attn.query.bias", d),
+                            H(blk + ".cross_attn.key.weight", dd), Hh, d, &A, &av);
       bw.wq_abs = upload_tiled(A.data(), Hh * d, d);
       bw.bq_abs = upload(av);
       bw.cross_wv_t = upload(cross_q_layout(wv, d));
@@ -607,6 +614,10 @@ void Engine::ensure_bf16_weights() {
     bw.cross_wo = TiledW{up16(tile_weights_bf16(H(blk + ".cross_attn.out.weight", dd), d, d)), 1.0f};
     bw.w1 = TiledW{up16(tile_weights_bf16(H(blk + ".mlp.0.weight", 4 * dd), 4 * d, d)), 1.0f};
     bw.w2 = TiledW{up16(tile_weights_bf16(H(blk + ".mlp.2.weight", 4 * dd), d, 4 * d)), 1.0f};
+    std::vector<float> A, av;  // absorbed cross-attention: the fused query matrix as bf16 (bq_abs, Wv, bv stay fp32: shared)
+    absorbed_query_matrix(H(blk + ".cross_attn.query.weight", dd), H(blk + ".cross_attn.query.bias", d),
+                          H(blk + ".cross_attn.key.weight", dd), c.n_text_head, d, &A, &av);
+    bw.wq_abs = TiledW{up16(tile_weights_bf16(A.data(), c.n_text_head * d, d)), 1.0f};
   }
   bf_.cross_kv = up16(round_weights_bf16(ckv_w.data(), c.n_text_layer * 2 * d, d, d));
   tok_emb_tiled_bf_ = TiledW{up16(tile_weights_bf16(H("decoder.token_embedding.weight", size_t(c.n_vocab) * d), c.n_vocab, d)), 1.0f};
@@ -1485,13 +1496,15 @@ void Engine::encode_enqueue_bf16(const float* d_mel, int batch) {
     launch_gemm_bf16_planes(f2, kEpiBias | kEpiResidual, stream_);
     kt_end();
   }
+  const bool absorb = absorb_active();  // the decoder streams the encoder output itself (one bf16 plane per slot): no cross-KV GEMM
   kt_begin(kKcLayerNorm, 0, 2.5 * M * d * 4);
-  launch_layernorm_planes(ws_.x, lnp, 0, 1.0f, ws_.enc_out, enc_ln_post_g, enc_ln_post_b, M, d, stream_, slot.d_flag, true);
+  launch_layernorm_planes(ws_.x, absorb ? slot.e_planes : lnp, 0, 1.0f, ws_.enc_out, enc_ln_post_g, enc_ln_post_b, M, d, stream_,
+                          slot.d_flag, true);
   HIPCHK(hipMemcpyAsync(slot.h_flag, slot.d_flag, sizeof(int), hipMemcpyDeviceToHost, stream_));
   kt_end();
   HIPCHK(hipEventRecord(slot.enc_mid, stream_));
-  slot.absorbed = false;
-  {
+  slot.absorbed = absorb;
+  if (!absorb) {
     PlaneGemmArgs g;  // cross-attention K/V of every decoder layer into the slot's cache, as bf16
     g.A = lnp; g.lda = d; g.W = bf_.cross_kv; g.bias = cross_kv_b;
     g.P = reinterpret_cast<unsigned short*>(slot.cross_kv); g.M = M; g.N = c.n_text_layer * 2 * d; g.K = d;
@@ -1656,7 +1669,8 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
   const bool absorbed = slot.absorbed;  // the form this slot's encoder pass prepared (the same for every slot of a graph set)
   // (option abs_chunks; 0 = 256 / clips: one block per CU when the decoder has the chip; pipelined 128 / clips — fewer,
   // longer blocks: a block costs ~9 us before its first tile, and the decoders share the CUs the encoder leaves)
-  const int abs_blocks = pipelined ? 128 : 256;
+  // (bf16 storage mode: half the bytes per key row, so half as many blocks again: 122.5 k against 120.5 k on configs[3])
+  const int abs_blocks = pipelined ? (bf16 ? 64 : 128) : 256;
   int n_abs = abs_chunks > 0 ? int(abs_chunks) : std::min(16, std::max(1, (abs_blocks + batch - 1) / batch));
   n_abs = std::min(n_abs, (T + 31) / 32);
   int steps = 0;
@@ -1744,12 +1758,14 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
           // and the ordinary out-projection.
           DecGemmArgs qa;
           qa.Wt = w.wq_abs.w; qa.w_scale = w.wq_abs.scale; qa.N = H * d; qa.K = d; qa.B = batch; qa.M = M;
+          qa.bf16 = bf;
           qa.xin = x; qa.ln_g = w.cross_ln_g; qa.ln_b = w.cross_ln_b; qa.bias = w.bq_abs; qa.Y = dw.qp; qa.ldy = H * d;
           DT(3, launch_dec_gemm(qa, kProLn, kDecBias, stream_));
           const int nq_max = cross_absorbed_max_nq(H);
           for (int p0 = 0; p0 < np; p0 += nq_max) {
             CrossAbsorbedArgs ca;
             ca.qp = dw.qp; ca.e = slot.e_planes; ca.e_plane = long(ws_.batch) * T * d; ca.e_scale = sc_cross_kv_.a;
+            ca.bf16 = bf;
             if (paired) ca.e2 = slot2.e_planes, ca.split = per;
             ca.ws = dw.abs_ws; ca.batch = batch; ca.heads = H; ca.d_model = d; ca.T = T; ca.chunks = n_abs;
             ca.nq = std::min(nq_max, np - p0); ca.p0 = p0;
@@ -1757,6 +1773,7 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
           }
           DT(8, launch_cross_absorbed_combine(dw.abs_ws, w.cross_wv_t, w.cross_bv, dw.cabs, M, H, n_abs, d, stream_));
           DecGemmArgs co;  // x += o . Wco^T + bco
+          co.bf16 = bf;
           co.Wt = w.cross_wo.w; co.w_scale = w.cross_wo.scale; co.N = d; co.K = d; co.B = batch; co.M = M;
           co.X = dw.cabs; co.ldx = d; co.bias = w.cross_bo; co.R = x; co.Y = x; co.ldy = d;
           DT(5, launch_dec_gemm(co, kProNone, kDecResid, stream_));

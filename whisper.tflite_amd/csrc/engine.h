@@ -111,7 +111,9 @@ class Engine {
   // not been submitted yet is decoded alone as soon as it is collected.
   long dec_pair = 1;
   long last_batches = 0;  // the next N submits are the last of a job: decoded one chain per batch (latency form); counts down
-  bool absorb_active() const { return cross_absorb != 0 && bf16 == 0 && gemm_variant < 0 && sc_cross_kv_.f16_ok; }
+  // absorbed cross-attention in effect: the default mode needs E as fp16 planes (no fall-back on that operand); bf16
+  // storage mode streams E as one bf16 plane
+  bool absorb_active() const { return cross_absorb != 0 && (bf16 != 0 || (gemm_variant < 0 && sc_cross_kv_.f16_ok)); }
   long gemm_variant = -1;  // -1 = plane GEMM (per-contraction fall-back to 13/16); 0 = fp32 MFMA, 13 / 16 = three bf16 planes
   // 1 = bf16 STORAGE mode (BASELINE configs[3]): bf16 weights, activations and both KV caches, fp32 accumulation,
   // fp32 residual stream; k_gemm_bf16.hip and the BF variants of the attention / decoder kernels.  Set through

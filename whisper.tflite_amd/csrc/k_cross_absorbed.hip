@@ -43,7 +43,7 @@ using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
 
 struct CrossAbsDev {
   const float* qp;       // [rows][heads * DM] absorbed queries (log2 domain: d_head^-1/2 * log2 e folded in)
-  const _Float16* e;     // E planes: hi [clips * T][DM], lo at e + e_plane
+  const _Float16* e;     // E planes: hi [clips * T][DM], lo at e + e_plane (bf16 storage mode: ONE bf16 plane)
   const _Float16* e2;    // clips >= split: a second encoder batch (two batches decoded by one chain), indexed from 0
   int split;
   long e_plane;
@@ -81,22 +81,42 @@ __device__ __forceinline__ void ds_read_tr16_x2(unsigned a0, unsigned a1, unsign
       : "memory");
 }
 
+// the same for ONE plane (bf16 storage mode): four reads
+__device__ __forceinline__ void ds_read_tr16_x2_one_plane(unsigned a0, unsigned a1, unsigned b0, unsigned b1, TrFrag& x, TrFrag& y) {
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %4\n\t"
+      "ds_read_b64_tr_b16 %1, %5\n\t"
+      "ds_read_b64_tr_b16 %2, %6\n\t"
+      "ds_read_b64_tr_b16 %3, %7\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(x.h0), "=&v"(x.h1), "=&v"(y.h0), "=&v"(y.h1)
+      : "v"(a0), "v"(a1), "v"(b0), "v"(b1)
+      : "memory");
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
-  static_assert(N == 0 || N == 4 || N == 12, "ring depths in use");
+  static_assert(N == 0 || N == 2 || N == 4 || N == 6 || N == 8 || N == 12, "ring depths in use");
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
 }
 
-template <int DM, int NST>
+// BF: bf16 storage mode (BASELINE configs[3]) — E is ONE bf16 plane, Q' and P are rounded to bf16 in registers, one
+// v_mfma_f32_16x16x32_bf16 per product instead of three f16 ones, no operand scales (bf16 has the fp32 range).
+template <int DM, int NST, bool BF>
 __global__ __launch_bounds__(256) void cross_absorbed_attention(CrossAbsDev a) {
+  using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
   constexpr int P = DM / 128;                  // column panels of 128 halfs (256-byte LDS rows)
   constexpr int kPlane = P * 8192;             // bytes of one plane of a 32-key tile
-  constexpr int kStage = 2 * kPlane;
+  constexpr int NP = BF ? 1 : 2;
+  constexpr int kStage = NP * kPlane;
   constexpr int KS = DM / 64;                  // 32-deep k-steps of one d-half (score product)
   constexpr int DT = DM / 64;                  // 16-wide d tiles per wavefront (context product)
-  constexpr int IPW = 4 * P;                   // LDS-DMA instructions per wavefront and tile
+  constexpr int IPW = 2 * NP * P;              // LDS-DMA instructions per wavefront and tile
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   float* const xch = reinterpret_cast<float*>(lds + NST * kStage);  // [2][4 waves][64 lanes][4]
 
@@ -163,13 +183,23 @@ __global__ __launch_bounds__(256) void cross_absorbed_attention(CrossAbsDev a) {
     const unsigned ex = (__float_as_uint(mx) >> 23) & 0xFFu;
     const float sc = ex < 32u ? 1.0f : __uint_as_float((268u - ex) << 23);  // largest element -> [2^14, 2^15)
     const float inv = ex < 32u ? 1.0f : __uint_as_float((ex - 14u) << 23);
-    s_inv = inv / a.e_scale;
+    if constexpr (BF) {
+      s_inv = 1.0f;
 #pragma unroll
-    for (int c = 0; c < KS; ++c) {
-      u32x4_t pl[3];
-      split8_f16x2(own[c], sc, pl);
-      qh[c] = pl[0];
-      ql[c] = pl[1];
+      for (int c = 0; c < KS; ++c) {
+        qh[c] = u32x4{pack_bf16x2(own[c][0], own[c][1]), pack_bf16x2(own[c][2], own[c][3]), pack_bf16x2(own[c][4], own[c][5]),
+                      pack_bf16x2(own[c][6], own[c][7])};
+        ql[c] = u32x4{0, 0, 0, 0};
+      }
+    } else {
+      s_inv = inv / a.e_scale;
+#pragma unroll
+      for (int c = 0; c < KS; ++c) {
+        u32x4_t pl[3];
+        split8_f16x2(own[c], sc, pl);
+        qh[c] = pl[0];
+        ql[c] = pl[1];
+      }
     }
   }
 
@@ -200,10 +230,14 @@ __global__ __launch_bounds__(256) void cross_absorbed_attention(CrossAbsDev a) {
       const int cg = khalf * KS + c;  // k-step of the whole row: columns 32 cg .. 32 cg + 31
       const int off = (cg >> 2) * 8192 + skey * 256 + ((((cg & 3) * 4 + lq) ^ sswz) << 4);
       const half8 eh = *reinterpret_cast<const half8*>(st + off);
-      const half8 el = *reinterpret_cast<const half8*>(st + kPlane + off);
-      sp = __builtin_amdgcn_mfma_f32_16x16x32_f16(eh, __builtin_bit_cast(half8, ql[c]), sp, 0, 0, 0);
-      sp = __builtin_amdgcn_mfma_f32_16x16x32_f16(el, __builtin_bit_cast(half8, qh[c]), sp, 0, 0, 0);
-      sp = __builtin_amdgcn_mfma_f32_16x16x32_f16(eh, __builtin_bit_cast(half8, qh[c]), sp, 0, 0, 0);
+      if constexpr (BF) {
+        sp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, eh), __builtin_bit_cast(bf16x8, qh[c]), sp, 0, 0, 0);
+      } else {
+        const half8 el = *reinterpret_cast<const half8*>(st + kPlane + off);
+        sp = __builtin_amdgcn_mfma_f32_16x16x32_f16(eh, __builtin_bit_cast(half8, ql[c]), sp, 0, 0, 0);
+        sp = __builtin_amdgcn_mfma_f32_16x16x32_f16(el, __builtin_bit_cast(half8, qh[c]), sp, 0, 0, 0);
+        sp = __builtin_amdgcn_mfma_f32_16x16x32_f16(eh, __builtin_bit_cast(half8, qh[c]), sp, 0, 0, 0);
+      }
     }
     float* const xb = xch + (t & 1) * 1024;
     *reinterpret_cast<f32x4*>(xb + (wid * 64 + lane) * 4) = sp;
@@ -246,11 +280,18 @@ __global__ __launch_bounds__(256) void cross_absorbed_attention(CrossAbsDev a) {
     psum += __shfl_xor(psum, 32, 64);
     l_run += psum;
     // P^T B fragment: element j of this lane = key 4 lq + j (j < 4, sub-tile 0) / 16 + 4 lq + j - 4 (sub-tile 1)
-    unsigned ph[4], pl[4];
-    split_f16x2(s0[0], s0[1], &ph[0], &pl[0]);
-    split_f16x2(s0[2], s0[3], &ph[1], &pl[1]);
-    split_f16x2(s1[0], s1[1], &ph[2], &pl[2]);
-    split_f16x2(s1[2], s1[3], &ph[3], &pl[3]);
+    unsigned ph[4], pl[4] = {0, 0, 0, 0};
+    if constexpr (BF) {
+      ph[0] = pack_bf16x2(s0[0], s0[1]);
+      ph[1] = pack_bf16x2(s0[2], s0[3]);
+      ph[2] = pack_bf16x2(s1[0], s1[1]);
+      ph[3] = pack_bf16x2(s1[2], s1[3]);
+    } else {
+      split_f16x2(s0[0], s0[1], &ph[0], &pl[0]);
+      split_f16x2(s0[2], s0[3], &ph[1], &pl[1]);
+      split_f16x2(s1[0], s1[1], &ph[2], &pl[2]);
+      split_f16x2(s1[2], s1[3], &ph[3], &pl[3]);
+    }
     const half8 pH = __builtin_bit_cast(half8, u32x4{ph[0], ph[1], ph[2], ph[3]});
     const half8 pL = __builtin_bit_cast(half8, u32x4{pl[0], pl[1], pl[2], pl[3]});
     // -- context: this wave's DT d tiles; E^T fragments by transposed reads, keys in the same order as P^T
@@ -268,14 +309,23 @@ __global__ __launch_bounds__(256) void cross_absorbed_attention(CrossAbsDev a) {
         ad[u][1] = sa + col + (unsigned)(k1 * 256 + (((dtg & 7) ^ (k1 & 7)) << 5));
       }
       TrFrag f[2];
-      ds_read_tr16_x2(ad[0][0], ad[0][1], ad[1][0], ad[1][1], (unsigned)kPlane, f[0], f[1]);
+      if constexpr (BF) {
+        ds_read_tr16_x2_one_plane(ad[0][0], ad[0][1], ad[1][0], ad[1][1], f[0], f[1]);
+      } else {
+        ds_read_tr16_x2(ad[0][0], ad[0][1], ad[1][0], ad[1][1], (unsigned)kPlane, f[0], f[1]);
+      }
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const half8 eh = __builtin_bit_cast(half8, u32x4{f[u].h0[0], f[u].h0[1], f[u].h1[0], f[u].h1[1]});
-        const half8 el = __builtin_bit_cast(half8, u32x4{f[u].g0[0], f[u].g0[1], f[u].g1[0], f[u].g1[1]});
-        cacc[d + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(eh, pL, cacc[d + u], 0, 0, 0);
-        cacc[d + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(el, pH, cacc[d + u], 0, 0, 0);
-        cacc[d + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(eh, pH, cacc[d + u], 0, 0, 0);
+        if constexpr (BF) {
+          cacc[d + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, eh), __builtin_bit_cast(bf16x8, pH),
+                                                                cacc[d + u], 0, 0, 0);
+        } else {
+          const half8 el = __builtin_bit_cast(half8, u32x4{f[u].g0[0], f[u].g0[1], f[u].g1[0], f[u].g1[1]});
+          cacc[d + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(eh, pL, cacc[d + u], 0, 0, 0);
+          cacc[d + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(el, pH, cacc[d + u], 0, 0, 0);
+          cacc[d + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(eh, pH, cacc[d + u], 0, 0, 0);
+        }
       }
     }
   }
@@ -334,16 +384,17 @@ __global__ __launch_bounds__(256) void cross_absorbed_combine(const float* __res
   if (tid < 64) out[(rh / H) * (long)(H * 64) + h * 64 + tid] = ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid])) + bv[h * 64 + tid];
 }
 
-template <int DM, int NST>
+template <int DM, int NST, bool BF = false>
 void launch_abs(const CrossAbsDev& g, hipStream_t s) {
-  constexpr size_t smem = (size_t)NST * 2 * (DM / 128) * 8192 + 8192;
+  constexpr size_t smem = (size_t)NST * (BF ? 1 : 2) * (DM / 128) * 8192 + 8192;
+  static_assert(smem <= 160 * 1024, "ring + exchange buffer fit the CU's LDS");
   static const bool raised = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_absorbed_attention<DM, NST>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_absorbed_attention<DM, NST, BF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return true;
   }();
   (void)raised;
-  hipLaunchKernelGGL((cross_absorbed_attention<DM, NST>), dim3(g.B * g.chunks), dim3(256), smem, s, g);
+  hipLaunchKernelGGL((cross_absorbed_attention<DM, NST, BF>), dim3(g.B * g.chunks), dim3(256), smem, s, g);
 }
 
 }  // namespace
@@ -353,18 +404,19 @@ int cross_absorbed_max_nq(int heads) { return heads > 0 ? 16 / heads : 0; }
 void launch_cross_absorbed(const CrossAbsorbedArgs& a, hipStream_t s) {
   const int dm = a.d_model;
   if (!a.qp || !a.e || !a.ws || a.batch < 1 || a.heads < 1 || a.heads * 64 != dm || a.T < 1 || a.chunks < 1 || a.chunks > 16 ||
-      a.nq < 1 || a.nq * a.heads > 16 || a.p0 < 0 || !(a.e_scale > 0.0f) || a.e_plane < (long)(a.e2 ? std::max(a.split, a.batch - a.split) : a.batch) * a.T * dm) {
+      a.nq < 1 || a.nq * a.heads > 16 || a.p0 < 0 || !(a.e_scale > 0.0f) ||
+      (!a.bf16 && a.e_plane < (long)(a.e2 ? std::max(a.split, a.batch - a.split) : a.batch) * a.T * dm)) {
     throw Error(kErrInvalidArg, "absorbed cross-attention: shape outside the kernel contract");
   }
   const int tiles = (a.T + 31) / 32;
   const int split = a.e2 ? a.split : a.batch;
   if (split < 1 || split > a.batch) throw Error(kErrInvalidArg, "absorbed cross-attention: bad batch split");
   CrossAbsDev g{a.qp, reinterpret_cast<const _Float16*>(a.e), reinterpret_cast<const _Float16*>(a.e2 ? a.e2 : a.e), split, a.e_plane,
-                a.e_scale, a.ws, a.batch, a.heads, a.T, a.chunks, a.nq, a.p0, (tiles + a.chunks - 1) / a.chunks};
+                a.bf16 ? 1.0f : a.e_scale, a.ws, a.batch, a.heads, a.T, a.chunks, a.nq, a.p0, (tiles + a.chunks - 1) / a.chunks};
   switch (dm) {
-    case 128: launch_abs<128, 3>(g, s); break;
-    case 384: launch_abs<384, 3>(g, s); break;
-    case 512: launch_abs<512, 2>(g, s); break;
+    case 128: a.bf16 ? launch_abs<128, 3, true>(g, s) : launch_abs<128, 3>(g, s); break;
+    case 384: a.bf16 ? launch_abs<384, 3, true>(g, s) : launch_abs<384, 3>(g, s); break;
+    case 512: a.bf16 ? launch_abs<512, 3, true>(g, s) : launch_abs<512, 2>(g, s); break;
     default: throw Error(kErrFormat, "absorbed cross-attention supports d_model 128, 384 or 512");
   }
 }

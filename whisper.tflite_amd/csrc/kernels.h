@@ -278,6 +278,7 @@ struct CrossAbsorbedArgs {
   float e_scale = 1.0f;
   float* ws = nullptr;
   int batch = 0, heads = 0, d_model = 0, T = 0, chunks = 1, nq = 1, p0 = 0;
+  bool bf16 = false;  // bf16 storage mode: e (and e2) are ONE bf16 plane [clips * T][d_model]; e_plane and e_scale unused
 };
 void launch_cross_absorbed(const CrossAbsorbedArgs& a, hipStream_t s);
 int cross_absorbed_max_nq(int heads);  // positions one launch can take
