@@ -334,9 +334,10 @@ def test_fp16_split_falls_back_per_contraction_when_a_bound_is_far_above_typical
     smaller) puts the weight-derived bound of V — the scale of the fp16 planes of the whole tensor — more than 2^12
     above V's typical magnitude: typical elements would lose their second fp16 plane to the subnormal range.  The
     engine must give THOSE contractions (layer 0's attention and its out-projection) the bf16 three-plane kernels by
-    itself at load time (f16_fallbacks >= 2) — and only those: the other 17 GEMMs (of 18: conv1, conv2, four per
-    layer; the absorbed cross-attention needs no cross-KV projection) and 3 attentions of the pass stay on the plane
-    kernels (wt_last_kernel_stats), the hand-over being the fp32 output form of the qkv plane GEMM.
+    itself at load time (f16_fallbacks >= 2) — and only those: the other 18 GEMMs (of 19: conv1, conv2, four per
+    layer, and the cross-KV projection of a synchronous one-clip call — pipelined batches run the absorbed
+    cross-attention and have 18) and 3 attentions of the pass stay on the plane kernels (wt_last_kernel_stats), the
+    hand-over being the fp32 output form of the qkv plane GEMM.
     The result stays at the fp32 instruction's error level."""
     mel = np.random.default_rng(10).uniform(-1.0, 1.5, size=(1, 80, 3000)).astype(np.float32)
     prefix, vocab = _adversarial_tiny(assets, tmp_path, "tiny-vrow", ln_gain=1.0, heavy=False, v_row_scale=1.0e4)
@@ -349,7 +350,7 @@ def test_fp16_split_falls_back_per_contraction_when_a_bound_is_far_above_typical
     e.set_option("kernel_timers", 1)
     e.encdec_tokens_batch(mel)
     ks = e.kernel_stats()
-    assert ks["gemm_planes_tile"]["launches"] == 18 - 1 and ks["gemm_split16_tile"]["launches"] == 1, ks
+    assert ks["gemm_planes_tile"]["launches"] == 19 - 1 and ks["gemm_split16_tile"]["launches"] == 1, ks
     assert ks["encoder_attention_planes"]["launches"] == 3 and ks["encoder_attention_split"]["launches"] == 1, ks
     assert ks["f32_to_planes"]["launches"] == 0  # fall-back feeds fall-back here: no conversion needed
     # a fall-back producer in front of a plane consumer: forcing only the attention off the plane kernel makes every
@@ -358,7 +359,7 @@ def test_fp16_split_falls_back_per_contraction_when_a_bound_is_far_above_typical
     ids_a, _, enc_a, _ = e.encdec_debug_batch(mel, want_logits=False)
     ks = e.kernel_stats()
     assert ks["encoder_attention_split"]["launches"] == 4 and ks["encoder_attention_planes"]["launches"] == 0, ks
-    assert ks["f32_to_planes"]["launches"] == 3 and ks["gemm_planes_tile"]["launches"] == 17, ks
+    assert ks["f32_to_planes"]["launches"] == 3 and ks["gemm_planes_tile"]["launches"] == 18, ks
     e.set_option("attn_variant", 4)
     ids_b, _, enc_b, _ = e.encdec_debug_batch(mel, want_logits=False)
     assert np.abs(enc_a - enc_b).max() < 6.0 * min(err["oracle"], err["fp32_mfma"]) + 2e-6 * scale

@@ -874,7 +874,7 @@ void Engine::release() noexcept {
 void Engine::pick_decoder_streams() {
   if (getenv("WT_NO_STREAM_PROBE") || getenv("WT_DEC_PARTITION")) return;
   hipStream_t enc = stream_masked_ ? stream_masked_ : stream_full_;
-  constexpr int kSpinUs = 20, kChain = 30;  // a chain of dependent short kernels per stream, like a decoder chain
+  constexpr int kSpinUs = 10, kChain = 20;  // a chain of dependent short kernels per stream, like a decoder chain
   const bool trace = getenv("WT_STREAM_PROBE_TRACE") != nullptr;
   auto chain_us = [&](hipStream_t a, hipStream_t b) {
     HIPCHK(hipStreamSynchronize(a));
@@ -909,6 +909,7 @@ void Engine::pick_decoder_streams() {
 }
 
 void Engine::select_stream(bool pipelined) {
+  pipelined_call_ = pipelined;
   hipStream_t target = pipelined && stream_masked_ ? stream_masked_ : stream_full_;
   if (target == stream_) return;
   // everything already enqueued on the old stream stays ahead of what follows on the new one
@@ -1179,7 +1180,7 @@ void Engine::encode_enqueue(const float* d_mel, int batch) {
   const long melT_plane = Bw * (T0 + 2) * nm + 128, h1p_plane = Bw * (T0 + 2) * d + 128;
   const long ln_plane = Bw * T * d, qkv_plane = Bw * T * 3 * d, hid_plane = Bw * T * 4 * d, cvt_plane = Bw * T * 4 * d;
   const long e_plane = Bw * T * d;
-  const bool absorb = absorb_active();
+  const bool absorb = absorb_for(batch);
   const int alt = alt_gemm_variant();
 
   auto plane_gemm = [&](PlaneGemmArgs& g, const GemmScale& sc, int epi, double flops) {
@@ -1496,7 +1497,7 @@ void Engine::encode_enqueue_bf16(const float* d_mel, int batch) {
     launch_gemm_bf16_planes(f2, kEpiBias | kEpiResidual, stream_);
     kt_end();
   }
-  const bool absorb = absorb_active();  // the decoder streams the encoder output itself (one bf16 plane per slot): no cross-KV GEMM
+  const bool absorb = absorb_for(batch);  // the decoder streams the encoder output itself (one bf16 plane per slot): no cross-KV GEMM
   kt_begin(kKcLayerNorm, 0, 2.5 * M * d * 4);
   launch_layernorm_planes(ws_.x, absorb ? slot.e_planes : lnp, 0, 1.0f, ws_.enc_out, enc_ln_post_g, enc_ln_post_b, M, d, stream_,
                           slot.d_flag, true);

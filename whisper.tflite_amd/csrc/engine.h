@@ -114,6 +114,10 @@ class Engine {
   // absorbed cross-attention in effect: the default mode needs E as fp16 planes (no fall-back on that operand); bf16
   // storage mode streams E as one bf16 plane
   bool absorb_active() const { return cross_absorb != 0 && (bf16 != 0 || (gemm_variant < 0 && sc_cross_kv_.f16_ok)); }
+  // ... and chosen for a call: every pipelined batch (throughput: half the decoder's stream bytes, no cross-KV GEMM);
+  // synchronous calls only from 32 clips on — below that the cached form's 7 launches per decoder layer beat the absorbed
+  // form's 9 (single clip 7.2 against 9.0 ms, 16 clips 11.1 against 12.1 ms, 32 clips 15.2 against 15.0 ms)
+  bool absorb_for(int batch) const { return absorb_active() && (pipelined_call_ || batch >= 32); }
   long gemm_variant = -1;  // -1 = plane GEMM (per-contraction fall-back to 13/16); 0 = fp32 MFMA, 13 / 16 = three bf16 planes
   // 1 = bf16 STORAGE mode (BASELINE configs[3]): bf16 weights, activations and both KV caches, fp32 accumulation,
   // fp32 residual stream; k_gemm_bf16.hip and the BF variants of the attention / decoder kernels.  Set through
@@ -205,6 +209,7 @@ class Engine {
                       int stream_override = -1);
   void submit_decoder(int batch, int slot);  // decoder side of submit / submit_pcm: paired, alone, or latency form
   int n_spare_streams_ = 0;  // probe-selected decoder streams beyond n_dec_streams_ (latency form of the last batches)
+  bool pipelined_call_ = false;  // set by select_stream: the batch being enqueued belongs to submit(), not to a synchronous call
   int pending_slot_ = -1;  // submitted, encoder enqueued, decoder waiting for a partner batch
   void flush_pending();
   void decode_collect(int slot, int64_t* ids, int32_t* n_ids);
