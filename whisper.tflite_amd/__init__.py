@@ -25,7 +25,7 @@ from ctypes import (POINTER, byref, c_char_p, c_float, c_int, c_int32, c_int64, 
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libwhisper-tflite.so")
+LIB_PATH = os.environ.get("WT_LIB_PATH") or os.path.join(_HERE, "lib", "libwhisper-tflite.so")  # WT_LIB_PATH: A/B runs of two builds
 
 WT_OK = 0
 WT_MAX_IDS = 32
