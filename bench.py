@@ -646,10 +646,12 @@ def main() -> None:
                        "argmax_steps": 27, "parallelism": f"clip-parallel dp{world}, one RCCL all_gather of id records per {GATHER_EVERY} batches",
                        "pipelined": pipelined, "batches_in_flight": args.depth if pipelined else 1,
                        "decoder": "two consecutive steps' batches share one decoder chain (dec_pair)" if (pipelined and eng.get_option("dec_pair") and eng.get_option("cross_absorb_active") and B <= 32) else "one decoder chain per step",
+                       "last_batches_announced": args.tail if pipelined else 0,
                        "priming_batches": 1,
-                       "compute": "bf16 storage mode: weights, activations, cross- and self-attention KV caches stored as bf16; every "
-                                  "contraction one bf16 MFMA product with fp32 accumulation; residual streams, softmax statistics, "
-                                  "LayerNorm, biases and the cross-attention query projection fp32" if args.bf16 else
+                       "compute": "bf16 storage mode: weights, activations, the encoder output the decoder's cross-attention streams and the "
+                                  "self-attention KV cache stored as bf16; every contraction one bf16 MFMA product with fp32 "
+                                  "accumulation; residual streams, softmax statistics, LayerNorm, biases and the cross-attention value "
+                                  "projection fp32" if args.bf16 else
                                   "every contraction (encoder GEMMs and attention, decoder GEMMs and logits): operands as 2 fp16 "
                                   "planes (22 significand bits: hi + lo, 4 bytes per element like fp32), 3 f16-MFMA products, "
                                   "fp32 accumulate (measured error at or below the fp32-MFMA kernel's, tests/test_gpu_kernels.py; "
