@@ -16,6 +16,7 @@
 // group of a ds_read_b128 covers all 64 banks once.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 
 #include "bf16_split.h"
@@ -104,7 +105,14 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 2) void gemm_planes_tile(Pl
   // q = w, w + NW, ...  Lane i fills LDS slot (row i >> 2, chunk i & 3) of its instruction with the global chunk
   // (i & 3) ^ ((row >> 2) & 3) of that row: the XOR swizzle lives on the SOURCE side.
   const int srow = lane >> 2;
-  const _Float16* src[QPW];
+  // Addresses as (uniform base) + (32-bit per-lane byte offset): the LDS-DMA then takes its base from SGPRs that SALU
+  // instructions advance per k-tile, and its issue needs NO vector instruction.  With per-lane 64-bit pointers every
+  // issue was preceded by a v_lshl_add_u64 — and on this part a wavefront's VALU instruction does not slip into the
+  // other wavefront's MFMA burst (tools/mfma_valu_overlap.hip), so the loads of the next k-tile left a whole MFMA
+  // phase late: the main loop took MFMA time + DMA time (profiles/r03_gemm_mainloop_ablation.txt).
+  unsigned voff[QPW];
+  const unsigned char* ubase[QPW];
+  const unsigned lds_base = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)smem;
 #pragma unroll
   for (int j = 0; j < QPW; ++j) {
     const int q = wid + NW * j;
@@ -116,19 +124,25 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 2) void gemm_planes_tile(Pl
     if (is_a) {
       int m = m0 + row;
       m = m < g.M ? m : g.M - 1;  // clamp: rows past M are computed and discarded
-      src[j] = g.A + (lo ? g.a_plane : 0) + (long)(m / g.a_rpb) * g.a_bs + (long)(m % g.a_rpb) * g.lda + chunk * 8;
+      voff[j] = (unsigned)(2 * ((lo ? g.a_plane : 0) + (long)(m / g.a_rpb) * g.a_bs + (long)(m % g.a_rpb) * g.lda + chunk * 8));
+      ubase[j] = reinterpret_cast<const unsigned char*>(g.A);
     } else {
-      src[j] = g.W + (lo ? g.w_plane : 0) + (long)(n0 + row) * g.K + chunk * 8;
+      voff[j] = (unsigned)(2 * ((lo ? g.w_plane : 0) + (long)(n0 + row) * g.K + chunk * 8));
+      ubase[j] = reinterpret_cast<const unsigned char*>(g.W);
     }
   }
   auto issue_stage = [&](int kt, int buf) {
     unsigned char* base = smem + buf * kStage;
-    const int ko = kt * BK;
+    const size_t ko = (size_t)kt * (BK * 2);  // bytes
 #pragma unroll
     for (int j = 0; j < QPW; ++j) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + ko),
-                                       (__attribute__((address_space(3))) void*)(base + (wid + NW * j) * 1024), 16, 0, 0);
+      // global_load_lds_dwordx4 in its SGPR-base form, written out: the builtin only selects the 64-bit per-lane address
+      // form (a v_lshl_add_u64 in front of every issue, even with the base held in SGPRs)
+      const unsigned long long sb = reinterpret_cast<unsigned long long>(ubase[j]) + ko;
+      const unsigned dst = lds_base + (unsigned)(buf * kStage + (wid + NW * j) * 1024);
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff[j]), "s"(sb), "s"(dst) : "memory", "m0");
     }
+    (void)base;
   };
 
   f32x16 acc[MI][NI];
@@ -436,6 +450,14 @@ bool launch_gemm_planes(const PlaneGemmArgs& a, int epi, hipStream_t s) {
       a.a_bs % 8 != 0 || a.ldc % 8 != 0 || a.c_bs % 8 != 0 || (planes && (g.seg % 8 != 0 || (a.N + g.seg - 1) / g.seg > 3)) ||
       (!planes && !a.C) || !(a.a_scale > 0.0f) || !(a.w_scale > 0.0f)) {
     throw Error(kErrInvalidArg, "plane GEMM shape outside the kernel contract");
+  }
+  // the kernel addresses both operands as a uniform base + 32-bit per-lane byte offset (see gemm_planes_tile)
+  {
+    const long a_span = a.a_plane + (long)((a.M - 1) / a.a_rpb) * a.a_bs + (long)std::min(a.a_rpb, a.M) * a.lda + a.K + 64;
+    const long w_span = a.w_plane + (long)a.N * a.K + 64;
+    if (a.a_plane < 0 || a.w_plane < 0 || a.a_bs < 0 || 2 * a_span >= (1L << 32) || 2 * w_span >= (1L << 32)) {
+      throw Error(kErrInvalidArg, "plane GEMM operand spans more than the 4 GiB its 32-bit offsets reach");
+    }
   }
   switch (epi | (planes ? 256 : 0)) {
     case kEpiBias: return launch_planes<kEpiBias, false>(g, a.n_cu, s);
