@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256, BF ? 4 : 3) void encoder_attention_planes(cons
   const int bh = logical / q_blocks, qb = logical % q_blocks;
   const int b = bh / heads, h = bh % heads;
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lh = lane >> 5;
   const _Float16* base = qkv + (long)b * T * ld + h * 64;
 
@@ -95,18 +95,39 @@ __global__ __launch_bounds__(256, BF ? 4 : 3) void encoder_attention_planes(cons
   const int drow = 8 * wid + (lane >> 3);                       // + 32 for the second row group
   const int kch = (lane & 7) ^ ((drow >> 1) & 7);               // (row + 32) >> 1 has the same low three bits
   const int vch = (lane & 7) ^ (((drow >> 1) & 1) << 2);
-  const _Float16* const kbase = base + d_model + kch * 8;
-  const _Float16* const vbase = base + 2 * d_model + vch * 8;
-  auto dma_tile = [&](const _Float16* src, int kt, unsigned char* dst) {
-    const int k0 = kt * AK + drow, k1 = k0 + 32;
-    const long r0 = (long)(k0 < T ? k0 : T - 1) * ld, r1 = (long)(k1 < T ? k1 : T - 1) * ld;  // rows past T re-read row T - 1; their scores are masked
-    unsigned char* d = dst + wid * 1024;
+  // The loads are issued in the SGPR-base form of global_load_lds_dwordx4, written out (the builtin only selects the
+  // per-lane 64-bit address form): base = this (clip, head)'s rows of tile kt (+ plane), advanced by scalar
+  // instructions; the per-lane part is a 32-bit byte offset that never changes — row drow (+ 32) of the tile, the q / k /
+  // v column block, the swizzled 16-byte chunk.  So NO vector instruction stands in front of a load: on this part a
+  // wavefront's VALU instruction waits for the other wavefronts' MFMA bursts (tools/mfma_valu_overlap.hip), and the
+  // row * ld multiplies, clamps and readfirstlanes of the per-lane form delayed every prefetch by such a burst.
+  // Only the sequence's last tile has rows past T: it uses offsets clamped to row T - 1 (their scores are masked).
+  const unsigned row_b = 2u * (unsigned)ld;  // bytes per row
+  const unsigned offK0 = (unsigned)drow * row_b + 2u * (unsigned)(d_model + kch * 8), offK1 = offK0 + 32u * row_b;
+  const unsigned offV0 = (unsigned)drow * row_b + 2u * (unsigned)(2 * d_model + vch * 8), offV1 = offV0 + 32u * row_b;
+  const int last0 = ((T + AK - 1) / AK - 1) * AK;
+  const unsigned c0r = (unsigned)((last0 + drow < T ? last0 + drow : T - 1) - last0);
+  const unsigned c1r = (unsigned)((last0 + drow + 32 < T ? last0 + drow + 32 : T - 1) - last0);
+  const unsigned offK0c = c0r * row_b + 2u * (unsigned)(d_model + kch * 8), offK1c = c1r * row_b + 2u * (unsigned)(d_model + kch * 8);
+  const unsigned offV0c = c0r * row_b + 2u * (unsigned)(2 * d_model + vch * 8), offV1c = c1r * row_b + 2u * (unsigned)(2 * d_model + vch * 8);
+  const unsigned lds0 = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)lds;
+  auto dma16 = [&](unsigned voff, unsigned long long sb, unsigned dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sb), "s"(dst) : "memory", "m0");
+  };
+  auto dma_tile = [&](const bool is_v, int kt, unsigned char* dst) {
+    const unsigned long long sb = reinterpret_cast<unsigned long long>(base) + (unsigned long long)kt * (unsigned long long)(AK * 2) * (unsigned long long)ld;
+    const unsigned d = lds0 + (unsigned)(dst - lds) + (unsigned)wid * 1024u;
+    const bool lastp = kt * AK + AK > T;
 #pragma unroll
     for (int p = 0; p < (BF ? 1 : 2); ++p) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + p * plane + r0),
-                                       (__attribute__((address_space(3))) void*)(d + p * kPlaneBytes), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + p * plane + r1),
-                                       (__attribute__((address_space(3))) void*)(d + p * kPlaneBytes + 4096), 16, 0, 0);
+      const unsigned long long sbp = sb + (unsigned long long)p * 2ull * (unsigned long long)plane;
+      if (lastp) {
+        dma16(is_v ? offV0c : offK0c, sbp, d + p * kPlaneBytes);
+        dma16(is_v ? offV1c : offK1c, sbp, d + p * kPlaneBytes + 4096);
+      } else {
+        dma16(is_v ? offV0 : offK0, sbp, d + p * kPlaneBytes);
+        dma16(is_v ? offV1 : offK1, sbp, d + p * kPlaneBytes + 4096);
+      }
     }
   };
   // fragment addresses.  K: lane (key l31 (+32), half lh), k-step c -> chunk 2c + lh of its row.
@@ -119,11 +140,11 @@ __global__ __launch_bounds__(256, BF ? 4 : 3) void encoder_attention_planes(cons
   // Schedule per tile t (two barriers, the loads never waited for right after their issue):
   //   QK_t from K buffer t & 1 | softmax | vmcnt(0) + barrier: V_t and K_t+1 have landed, everybody is done with K_t
   //   | PV_t | barrier: everybody is done with V_t -> issue V_t+1, and K_t+2 into buffer t & 1
-  dma_tile(kbase, 0, lds);
+  dma_tile(false, 0, lds);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // K_0 (and this wave's Q fragments)
   __builtin_amdgcn_s_barrier();
-  dma_tile(vbase, 0, lds + kVOff);
-  if (n_tiles > 1) dma_tile(kbase, 1, lds + NP * kPlaneBytes);
+  dma_tile(true, 0, lds + kVOff);
+  if (n_tiles > 1) dma_tile(false, 1, lds + NP * kPlaneBytes);
   for (int kt = 0; kt < n_tiles; ++kt) {
     const unsigned char* const kb = lds + (kt & 1) * NP * kPlaneBytes;
     // S^T for the two 32-key halves of the tile
@@ -260,8 +281,8 @@ __global__ __launch_bounds__(256, BF ? 4 : 3) void encoder_attention_planes(cons
     // (K_t+2 could go out one phase earlier, right after the barrier above; hipcc then puts an s_waitcnt vmcnt(0) of
     // its own in front of the V fragment reads — it cannot see that the DMA targets the other buffer — and the
     // prefetch would be waited for at its issue)
-    if (kt + 1 < n_tiles) dma_tile(vbase, kt + 1, lds + kVOff);
-    if (kt + 2 < n_tiles) dma_tile(kbase, kt + 2, lds + (kt & 1) * NP * kPlaneBytes);
+    if (kt + 1 < n_tiles) dma_tile(true, kt + 1, lds + kVOff);
+    if (kt + 2 < n_tiles) dma_tile(false, kt + 2, lds + (kt & 1) * NP * kPlaneBytes);
   }
 
   if (q_row < T) {
