@@ -74,7 +74,11 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_bf16_planes(Bf16GemmDev g) {
   // LDS-DMA: instruction q copies rows 8 q .. 8 q + 7 of the A tile (q < QA) or of the W tile; lane i fills slot
   // (row i >> 3, chunk i & 7) with the global chunk (i & 7) ^ ((row >> 1) & 7) of that row
   const int srow = lane >> 3;
-  const unsigned short* src[QPW];
+  // (uniform base) + (32-bit per-lane byte offset), issued in the SGPR-base form of global_load_lds_dwordx4 written out:
+  // no vector instruction in front of a load (k_gemm_planes.hip explains why that matters on this part)
+  unsigned voff[QPW];
+  const unsigned char* ubase[QPW];
+  const unsigned lds_base = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)smem;
 #pragma unroll
   for (int j = 0; j < QPW; ++j) {
     const int q = wid + NW * j;
@@ -84,18 +88,20 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_bf16_planes(Bf16GemmDev g) {
     if (is_a) {
       int m = m0 + row;
       m = m < g.M ? m : g.M - 1;
-      src[j] = g.A + (long)(m / g.a_rpb) * g.a_bs + (long)(m % g.a_rpb) * g.lda + chunk * 8;
+      voff[j] = (unsigned)(2 * ((long)(m / g.a_rpb) * g.a_bs + (long)(m % g.a_rpb) * g.lda + chunk * 8));
+      ubase[j] = reinterpret_cast<const unsigned char*>(g.A);
     } else {
-      src[j] = g.W + (long)(n0 + row) * g.K + chunk * 8;
+      voff[j] = (unsigned)(2 * ((long)(n0 + row) * g.K + chunk * 8));
+      ubase[j] = reinterpret_cast<const unsigned char*>(g.W);
     }
   }
   auto issue_stage = [&](int kt, int buf) {
-    unsigned char* base = smem + buf * kStage;
-    const int ko = kt * BK;
+    const size_t ko = (size_t)kt * (BK * 2);  // bytes
 #pragma unroll
     for (int j = 0; j < QPW; ++j) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + ko),
-                                       (__attribute__((address_space(3))) void*)(base + (wid + NW * j) * 1024), 16, 0, 0);
+      const unsigned long long sb = reinterpret_cast<unsigned long long>(ubase[j]) + ko;
+      const unsigned dst = lds_base + (unsigned)(buf * kStage + (wid + NW * j) * 1024);
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff[j]), "s"(sb), "s"(dst) : "memory", "m0");
     }
   };
 
@@ -260,6 +266,13 @@ void launch_gemm_bf16_planes(const PlaneGemmArgs& a, int epi, hipStream_t s) {
       a.a_bs % 8 != 0 || a.ldc % 8 != 0 || a.c_bs % 8 != 0 || (!bf_out && !a.C) ||
       ((epi & kEpiKvLayout) && (!bf_out || a.kv_dmodel % 64 != 0))) {
     throw Error(kErrInvalidArg, "bf16 GEMM shape outside the kernel contract");
+  }
+  {  // both operands are addressed as a uniform base + 32-bit per-lane byte offset
+    const long a_span = (long)((a.M - 1) / a.a_rpb) * a.a_bs + (long)(a.a_rpb < a.M ? a.a_rpb : a.M) * a.lda + a.K + 64;
+    const long w_span = (long)a.N * a.K + 64;
+    if (a.a_bs < 0 || 2 * a_span >= (1L << 32) || 2 * w_span >= (1L << 32)) {
+      throw Error(kErrInvalidArg, "bf16 GEMM operand spans more than the 4 GiB its 32-bit offsets reach");
+    }
   }
   switch (epi | (bf_out ? 256 : 0)) {
     case kEpiBias: launch_bf16_planes<kEpiBias, false>(g, s); break;
