@@ -186,4 +186,17 @@ __device__ __forceinline__ unsigned round2_bf16(float lo, float hi) {
   return __builtin_amdgcn_perm(b, a, 0x07060302u);
 }
 
+// global -> LDS copy of 16 bytes per lane (LDS-DMA) in the instruction's SGPR-base form: address = sbase (uniform, scalar
+// registers) + voff (32-bit per-lane byte offset), LDS destination = lds_dst + lane * 16 (M0).  Written out because the
+// builtin __builtin_amdgcn_global_load_lds only selects the per-lane 64-bit address form, which puts a vector instruction
+// in front of every issue — and on this part a wavefront's vector instruction waits for the SIMD's other wavefronts'
+// MFMA bursts (tools/mfma_valu_overlap.hip), so prefetches left late.  M0 is not used by
+// anything else in the kernels that call this (gfx9+ LDS instructions do not need it).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void lds_dma16_sgpr(unsigned voff, unsigned long long sbase, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+
 }  // namespace wt

@@ -111,9 +111,7 @@ __global__ __launch_bounds__(256, BF ? 4 : 3) void encoder_attention_planes(cons
   const unsigned offK0c = c0r * row_b + 2u * (unsigned)(d_model + kch * 8), offK1c = c1r * row_b + 2u * (unsigned)(d_model + kch * 8);
   const unsigned offV0c = c0r * row_b + 2u * (unsigned)(2 * d_model + vch * 8), offV1c = c1r * row_b + 2u * (unsigned)(2 * d_model + vch * 8);
   const unsigned lds0 = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)lds;
-  auto dma16 = [&](unsigned voff, unsigned long long sb, unsigned dst) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sb), "s"(dst) : "memory", "m0");
-  };
+  auto dma16 = [&](unsigned voff, unsigned long long sb, unsigned dst) { lds_dma16_sgpr(voff, sb, dst); };
   auto dma_tile = [&](const bool is_v, int kt, unsigned char* dst) {
     const unsigned long long sb = reinterpret_cast<unsigned long long>(base) + (unsigned long long)kt * (unsigned long long)(AK * 2) * (unsigned long long)ld;
     const unsigned d = lds0 + (unsigned)(dst - lds) + (unsigned)wid * 1024u;

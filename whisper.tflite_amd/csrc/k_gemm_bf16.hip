@@ -101,7 +101,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_bf16_planes(Bf16GemmDev g) {
     for (int j = 0; j < QPW; ++j) {
       const unsigned long long sb = reinterpret_cast<unsigned long long>(ubase[j]) + ko;
       const unsigned dst = lds_base + (unsigned)(buf * kStage + (wid + NW * j) * 1024);
-      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff[j]), "s"(sb), "s"(dst) : "memory", "m0");
+      lds_dma16_sgpr(voff[j], sb, dst);
     }
   };
 

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 2) void gemm_planes_tile(Pl
       // form (a v_lshl_add_u64 in front of every issue, even with the base held in SGPRs)
       const unsigned long long sb = reinterpret_cast<unsigned long long>(ubase[j]) + ko;
       const unsigned dst = lds_base + (unsigned)(buf * kStage + (wid + NW * j) * 1024);
-      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff[j]), "s"(sb), "s"(dst) : "memory", "m0");
+      lds_dma16_sgpr(voff[j], sb, dst);
     }
     (void)base;
   };
