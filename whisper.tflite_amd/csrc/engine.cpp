@@ -755,9 +755,11 @@ void Engine::create_streams() {
   // WT_DEC_PARTITION=1 (measurement knob): the decoder streams are confined to the CUs the pipelined encoder stream
   // leaves free — a strict partition instead of "decoders may run anywhere"
   const char* part = getenv("WT_DEC_PARTITION");
-  if (part && atoi(part) == 1 && enc_cus_masked_ > 0 && enc_cus_masked_ < n_cu) {
+  if (part && atoi(part) >= 1 && enc_cus_masked_ > 0 && enc_cus_masked_ < n_cu) {
+    // 1 = the reserved CUs only; N > 1 = the reserved CUs and the N CUs of the encoder's share next to them (soft partition)
+    const int shared = atoi(part) > 1 ? std::min(atoi(part), enc_cus_masked_) : 0;
     std::vector<uint32_t> dmask((n_cu + 31) / 32, 0u);
-    for (int i = enc_cus_masked_; i < n_cu; ++i) dmask[i / 32] |= 1u << (i % 32);
+    for (int i = enc_cus_masked_ - shared; i < n_cu; ++i) dmask[i / 32] |= 1u << (i % 32);
     for (auto& ds : dstream_) HIPCHK(hipExtStreamCreateWithCUMask(&ds, uint32_t(dmask.size()), dmask.data()));
   } else {
     const char* dp = getenv("WT_DEC_PRIO");  // measurement knob: "lo" = decoder streams at the encoder's priority

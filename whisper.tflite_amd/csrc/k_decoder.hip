@@ -22,6 +22,8 @@
 //     makes hipcc branch around it and wait vmcnt(0) per element (measured: 6x slower).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "bf16_split.h"
 #include "kernels.h"
 
@@ -601,7 +603,12 @@ template <bool BF, int LNMODE>
 bool launch_logits_persistent(const DecGemmDev& g, hipStream_t s) {
   if (g.K % 64 != 0 || g.ksplit != 1) return false;
   const int n_tiles = (g.N + 31) / 32, m_tiles = (g.M + 31) / 32;
-  const int per = 512 / m_tiles;  // 512 resident blocks in all
+  static const int total = [] {  // measurement knob: resident blocks in all (default 512 = two per CU)
+    const char* v = getenv("WT_LOGITS_BLOCKS");
+    const int n = v ? atoi(v) : 512;
+    return n >= 32 && n <= 1024 ? n : 512;
+  }();
+  const int per = total / m_tiles;
   const dim3 grid(n_tiles < per ? n_tiles : per, m_tiles);
   switch (g.K / 64) {
     case 2: hipLaunchKernelGGL((dec_logits_persistent<2, BF, LNMODE>), grid, dim3(256), 0, s, g); return true;
