@@ -1816,6 +1816,7 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
         const size_t off = size_t(np - 1) * batch * d;
         DecGemmArgs lg;  // final LayerNorm (of x, or of the two halves a K-split fc2 left) + logits + argmax records
         lg.bf16 = bf;
+        lg.logits_blocks = pipelined ? 256 : 0;
         lg.Wt = (bf ? tok_emb_tiled_bf_ : tok_emb_tiled).w; lg.w_scale = (bf ? tok_emb_tiled_bf_ : tok_emb_tiled).scale; lg.N = V; lg.K = d; lg.B = batch;
         lg.xin = (split ? dw.xb : x) + off; lg.xpart = split ? dw.xpart + off : nullptr; lg.ln_g = dec_ln_g; lg.ln_b = dec_ln_b;
         lg.Y = logits_host ? dw.logits : nullptr; lg.ldy = V; lg.best = dw.best;

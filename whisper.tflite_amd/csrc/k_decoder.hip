@@ -600,14 +600,16 @@ __global__ __launch_bounds__(256, 2) void dec_logits_persistent(DecGemmDev g) {
 }
 
 template <bool BF, int LNMODE>
-bool launch_logits_persistent(const DecGemmDev& g, hipStream_t s) {
+bool launch_logits_persistent(const DecGemmDev& g, hipStream_t s, int blocks = 0) {
   if (g.K % 64 != 0 || g.ksplit != 1) return false;
   const int n_tiles = (g.N + 31) / 32, m_tiles = (g.M + 31) / 32;
-  static const int total = [] {  // measurement knob: resident blocks in all (default 512 = two per CU)
+  static const int forced = [] {  // measurement knob: resident blocks in all
     const char* v = getenv("WT_LOGITS_BLOCKS");
-    const int n = v ? atoi(v) : 512;
-    return n >= 32 && n <= 1024 ? n : 512;
+    const int n = v ? atoi(v) : 0;
+    return n >= 32 && n <= 1024 ? n : 0;
   }();
+  // 512 = two per CU when the decoder has the chip; next to an encoder 256 measure 0.5 % more end to end
+  const int total = forced ? forced : (blocks >= 32 && blocks <= 1024 ? blocks : 512);
   const int per = total / m_tiles;
   const dim3 grid(n_tiles < per ? n_tiles : per, m_tiles);
   switch (g.K / 64) {
@@ -704,7 +706,7 @@ template <bool BF>
 static void dispatch_dec_gemm(const DecGemmArgs& a, const DecGemmDev& g, int pro, int epi, hipStream_t s) {
   if (pro == kProLn && epi == kDecLogits) {  // final LayerNorm inside the persistent logits kernel
     if (a.ids || !a.xin || !a.ln_g || !a.ln_b) throw Error(kErrInvalidArg, "logits GEMM: LayerNorm rows come from xin (+ xpart)");
-    const bool ok = a.xpart ? launch_logits_persistent<BF, 3>(g, s) : launch_logits_persistent<BF, 0>(g, s);
+    const bool ok = a.xpart ? launch_logits_persistent<BF, 3>(g, s, a.logits_blocks) : launch_logits_persistent<BF, 0>(g, s, a.logits_blocks);
     if (!ok) throw Error(kErrInvalidArg, "logits GEMM with the LayerNorm prologue: K must be a multiple of 64");
     return;
   }
@@ -725,7 +727,7 @@ static void dispatch_dec_gemm(const DecGemmArgs& a, const DecGemmDev& g, int pro
     case kProNone * 8 + kDecResid: launch_gt<kProNone, kDecResid, 0, 0, 8, 1, BF>(g, s); break;
     case kProNone * 8 + kDecBias: launch_gt<kProNone, kDecBias, 0, 0, 4, 1, BF>(g, s); break;
     case kProNone * 8 + kDecLogits:
-      if (!launch_logits_persistent<BF, -1>(g, s)) launch_gt<kProNone, kDecLogits, 0, 0, 4, 1, BF>(g, s);
+      if (!launch_logits_persistent<BF, -1>(g, s, a.logits_blocks)) launch_gt<kProNone, kDecLogits, 0, 0, 4, 1, BF>(g, s);
       break;
     case kProCombine * 8 + kDecResid:
       switch (a.chunks) {  // compile-time chunk count keeps the partial loads independent

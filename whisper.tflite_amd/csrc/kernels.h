@@ -148,6 +148,7 @@ enum DecEpi : int {
   kDecLogits = 3     // (optional Y = acc) + per-tile argmax records best[m][tile], reference tie rule
 };
 struct DecGemmArgs {
+  int logits_blocks = 0;  // resident blocks of the persistent logits kernel (0 = 512, two per CU; the pipeline asks for 256)
   const unsigned short* Wt = nullptr;
   float w_scale = 1.0f;  // power of two the planes were scaled by (tile_weights_f16)
   int N = 0, K = 0, B = 0;
