@@ -600,6 +600,11 @@ def main() -> None:
                     **{k: d[k] for k in ("peak_is", "executed_16bit_tflops", "vs_fp32_mfma_peak") if k in d},
                     "algorithmic_flops_per_launch": int(kstats[dom]["flops"] / max(1, kstats[dom]["launches"])),
                     "avg_launch_us": d["avg_launch_us"]}
+            if pipelined:
+                # the pipelined encoder stream is CU-masked: what the launches reach of the CUs they may use
+                cus = int(eng.get_option("pipelined_encoder_cus"))
+                roof["pipelined_stream_cus"] = cus
+                roof["frac_of_stream_cus"] = round(d["frac"] * 256.0 / cus, 4) if cus > 0 else None
         iso_det = rooflines(iso, 2) if iso else None
         # decoder phase against HBM: algorithmic bytes per step of this batch
         dm = eng.dims

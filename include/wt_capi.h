@@ -96,7 +96,7 @@ int wt_engine_dims(const wt_engine* h, wt_dims* out);
  * flight), "force_fallback" (test hook: bit mask of contractions sent to the full-range kernels, nothing in flight).
  * Read-only (wt_engine_get_option): "f16_fallbacks" = contractions that were given the full-range bf16
  * three-plane kernels at load time because an operand's weight-derived bound lies more than 2^12 above its
- * typical magnitude (csrc/engine.cpp, upload_weights) — only those leave the plane kernels, the others keep them; "in_flight" = submitted, uncollected batches.
+ * typical magnitude (csrc/engine.cpp, upload_weights) — only those leave the plane kernels, the others keep them; "in_flight" = submitted, uncollected batches; "pipelined_encoder_cus" = CUs the CU-masked encoder stream of the pipeline may use.
  * Environment, read at wt_engine_create: WT_ENC_CU_RESERVE (CUs per XCD the pipelined encoder
  * stream leaves to the decoders, default 8, 0 = none), WT_DEC_STREAMS (decoder streams, default 3),
  * WT_TRACE_PIPELINE (per-batch device timeline on stderr), WT_NO_STREAM_PROBE (skip the ~10 ms probe that picks decoder

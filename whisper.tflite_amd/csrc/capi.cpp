@@ -238,6 +238,7 @@ int wt_engine_get_option(const wt_engine* h, const char* key, long* value) {
   else if (k == "force_fallback") *value = e.force_fallback();
   else if (k == "f16_fallbacks") *value = e.f16_fallbacks();  // read-only
   else if (k == "in_flight") *value = e.in_flight();          // read-only
+  else if (k == "pipelined_encoder_cus") *value = e.pipelined_encoder_cus();  // read-only: CUs of the masked encoder stream
   else return WT_ERR_INVALID_ARG;
   return WT_OK;
 }

@@ -215,6 +215,9 @@ class Engine {
   void decode_collect(int slot, int64_t* ids, int32_t* n_ids);
 
   int enc_cus_masked_ = 0;  // CUs the pipelined encoder stream may use
+ public:
+  int pipelined_encoder_cus() const { return enc_cus_masked_ > 0 ? enc_cus_masked_ : n_cu_; }
+ private:
   int device_ = 0, n_cu_ = 0, reserve_ = 0;  // reserve_: CUs per XCD the pipelined encoder stream leaves free
   bool monolith_ = false, multilingual_ = true;
   hipStream_t stream_ = nullptr;   // encoder + front end: stream_full_ or stream_masked_ (select_stream)
