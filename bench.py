@@ -624,8 +624,8 @@ def main() -> None:
         emb_bytes = V * dstate * esz                                   # tied embedding (logits GEMM)
         # the prompt's positions share one pass: 27 passes over the weights and the cache, 27 logits GEMMs; a decoder
         # chain that takes two batches together (dec_pair) reads the weights once for both
-        n_pass = 30 if paired else 27                                  # 64 rows: the 4 prompt positions go one by one
-        dec_bytes = 27 * kv_bytes + n_pass * w_bytes // (2 if paired else 1) + 27 * emb_bytes // (2 if paired else 1)
+        n_pass = 28 if (paired or B > 32) else 27                      # 64 rows per pass: the 4 prompt positions go two and two
+        dec_bytes = n_pass * kv_bytes + n_pass * w_bytes // (2 if paired else 1) + 27 * emb_bytes // (2 if paired else 1)
         # decoder_ms is the chain's duration; a paired chain serves two steps
         dec_ms_per_step = stage["decoder_ms"] / (2 if paired else 1)
         dec_ach = dec_bytes / (dec_ms_per_step * 1e-3) / 1e9 if dec_ms_per_step > 0 else 0.0

@@ -1727,8 +1727,11 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
     // positions x clips <= 128, at most 4 positions: causal self-attention inside the pass, one sweep of the
     // cross-KV cache for all of them); the reference feeds the same prefix to its graph at once, whisper.cpp:367-375.
     // Every later position is one pass of `batch` rows.
-    const int first = (n_prompt <= 4 && n_prompt * batch <= kDecRowsMax) ? std::min(n_prompt, max_pos) : 1;
-    for (int pos0 = 0, np = first; pos0 < max_pos; pos0 += np, np = 1) {
+    // (a pair's 64 clips, or a 64-clip batch: the four prompt positions go two and two — 28 passes instead of 30)
+    const int np_max = std::max(1, std::min(4, kDecRowsMax / batch));
+    const int prompt_end = std::min(n_prompt, max_pos);
+    for (int pos0 = 0, np = 1; pos0 < max_pos; pos0 += np) {
+      np = pos0 < prompt_end ? std::min(np_max, prompt_end - pos0) : 1;
       const int M = np * batch, last = pos0 + np - 1;
       for (int l = 0; l < c.n_text_layer; ++l) {
         const DecBlockWeights& w = bf ? dec_blocks_bf_[l] : dec_blocks_[l];
