@@ -16,6 +16,10 @@ int wt_dbg_gemm(wt_engine* h, int M, int N, int K, const float* A, const float* 
 int wt_dbg_gemm_planes(wt_engine* h, int M, int N, int K, const float* A, const float* W, const float* bias,
                        const float* R, const float* pos, int pos_period, int epi, int planes_out, int iters, float* C,
                        float* avg_ms, int n_cu /* CUs the tile choice assumes; 0 = all */);
+/* schedule of the 384-column plane-GEMM tiles for subsequent launches of this process: 0 = gemm_planes_tile (both
+ * wavefronts of a SIMD in step), 1 = gemm_planes_pp (ping-pong groups), 2 = gemm_planes_pp16 (ping-pong groups on
+ * 16 x 16 x 32 MFMAs, default), 3 = + gemm_planes_v2 where it applies; A/B measurements in one process */
+int wt_dbg_set_plane_gemm_mode(int mode);
 /* the same GEMM (N = 384, fp32 output C, epi = bias | residual (5) or bias | gelu | pos (11)) with the LayerNorm of the
  * finished rows fused into its epilogue: ln_out [M][384] = LayerNorm(C row) * ln_g + ln_b reconstructed from the planes
  * the kernel wrote, ln_y32 (optional) its fp32 copy; *fused = 1 when a 384-column tile did it, 0 when the tile choice

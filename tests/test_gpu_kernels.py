@@ -529,11 +529,13 @@ def test_encoder_attention_bf16_storage(eng, B, T, H):
 
 
 @pytest.mark.parametrize("n_cu,expect", [(8, "256-row"), (11, "192-row"), (3, "256-row, three rounds")])
-def test_plane_gemm_every_tile_shape_gives_the_same_result(eng, n_cu, expect):
+def test_plane_gemm_every_tile_shape_gives_the_same_result(pkg, eng, n_cu, expect):
     """The plane GEMM picks its tile (192 x 128, 192 x 384, 256 x 384) from how the blocks fill the CUs the stream may
     use.  With M = 2000, N = 384: 11 row tiles of 192 or 8 of 256 — on 8 CUs the 256-row tile wins (one round instead of
-    two), on 11 CUs the 192-row one.  Whatever is picked, the result is the fp32-accurate product, and the tiles
-    agree with each other to accumulation-order rounding (same k order: bit-identical)."""
+    two), on 11 CUs the 192-row one.  Whatever is picked, the result is the fp32-accurate product.  The tiles agree
+    with each other to accumulation rounding: the 192 x 384 tile runs on 16 x 16 x 32 MFMAs since round 4 (a 32-deep
+    sum per instruction), the others on 32 x 32 x 16 (16-deep) — same k order, different partial sums, so the last
+    bits may differ; every schedule of ONE MFMA shape is bit-identical (wt_dbg_set_plane_gemm_mode 0 and 1)."""
     rng = np.random.default_rng(2000)
     M, N, K = 2000, 384, 384
     A = rng.standard_normal((M, K)).astype(np.float32)
@@ -544,7 +546,17 @@ def test_plane_gemm_every_tile_shape_gives_the_same_result(eng, n_cu, expect):
     base = eng.dbg_gemm_planes(A, W, bias, epi=1)
     got = eng.dbg_gemm_planes(A, W, bias, epi=1, n_cu=n_cu)
     assert rel_err(got, ref) < 2e-6, expect
-    assert np.array_equal(got, base), expect
+    assert rel_err(got, base) < 1e-6 and np.abs(got - base).max() < 4e-6, expect
+    L = pkg.lib()
+    try:  # the two schedules of the 32 x 32 x 16 form of the 192 x 384 tile: same arithmetic, bit for bit
+        outs = []
+        for mode in (0, 1):
+            assert L.wt_dbg_set_plane_gemm_mode(mode) == 0
+            outs.append(eng.dbg_gemm_planes(A, W, bias, epi=1, n_cu=11))
+        assert np.array_equal(outs[0], outs[1])
+        assert rel_err(outs[0], ref) < 2e-6
+    finally:
+        assert L.wt_dbg_set_plane_gemm_mode(2) == 0
     assert rel_err(eng.dbg_gemm_planes(A, W, bias, R=R, epi=5, n_cu=n_cu), ref + R) < 3e-6
     assert rel_err(eng.dbg_gemm_planes(A, W, bias, epi=3, planes_out=True, n_cu=n_cu), gelu(ref)) < 4e-6
 

@@ -319,6 +319,40 @@ def test_pipeline_pairs_two_batches_per_decoder_chain(tiny):
         d.free()
 
 
+def test_pipeline_follower_ids_survive_reuse_of_the_leaders_slot(tiny):
+    """A pair's second batch keeps its ids in its OWN slot: with all twelve slots in flight as six pairs, the first
+    collect frees the first leader's slot, and a batch that is decoded at once (announced last batch) with more clips
+    than the pair's halves re-initialises that slot's pinned buffers before the follower is collected.  (Round 3 read the
+    follower's ids out of the leader's buffers: the next collect returned prompt-only rows.)"""
+    from conftest import DevBuf
+    e, _ = tiny
+    rng = np.random.default_rng(4096)
+    mels = [rng.uniform(-1.0, 1.5, size=(4, 80, 3000)).astype(np.float32) for _ in range(12)]
+    big = rng.uniform(-1.0, 1.5, size=(8, 80, 3000)).astype(np.float32)
+    e.set_option("dec_pair", 0)
+    want = [e.encdec_tokens_batch(m) for m in mels]
+    want_big = e.encdec_tokens_batch(big)
+    e.set_option("dec_pair", 1)
+    dev = [DevBuf(m) for m in mels]
+    dev_big = DevBuf(big)
+    for graphs in (1, 0):
+        e.set_option("use_graphs", graphs)
+        for k in range(12):
+            e.pipeline_submit_dev(dev[k].data_ptr(), 4)
+        got = [e.pipeline_collect()]                      # the first leader: its slot is the next one submit() takes
+        e.set_option("last_batches", 1)                   # decoded at submit, alone
+        e.pipeline_submit_dev(dev_big.data_ptr(), 8)
+        got += [e.pipeline_collect() for _ in range(11)]
+        ids_b, n_b = e.pipeline_collect()
+        for k, (ids_g, n_g) in enumerate(got):
+            assert np.array_equal(want[k][1], n_g) and np.array_equal(want[k][0], ids_g), (graphs, k)
+        assert np.array_equal(want_big[0], ids_b) and np.array_equal(want_big[1], n_b)
+    e.set_option("use_graphs", 1)
+    for d in dev:
+        d.free()
+    dev_big.free()
+
+
 def test_pipeline_last_batches_drain_in_latency_form(pkg, tiny):
     """Option last_batches = N: the next N submits are announced as the last of a job and are decoded one chain per batch
     (the very last one on the encoder's own stream) instead of in pairs, so the pipeline drains sooner.  Same ids as the

@@ -49,7 +49,7 @@ CAPI_SYMBOLS = [
 DEBUG_SYMBOLS = [
     "wt_dbg_cross_absorbed", "wt_dbg_cross_absorbed_bf16", "wt_dbg_gemm_planes_ln", "wt_dbg_gemm", "wt_dbg_gemm_bench", "wt_dbg_dec_gemm_bench", "wt_dbg_dec_gemm", "wt_dbg_dec_ln_gemm", "wt_dbg_layernorm", "wt_dbg_encoder_attention",
     "wt_dbg_cross_attention", "wt_dbg_self_attention", "wt_dbg_interference", "wt_dbg_concurrency",
-    "wt_dbg_gemm_planes", "wt_dbg_encoder_attention_planes", "wt_dbg_gemm_bf16", "wt_dbg_encoder_attention_bf16",
+    "wt_dbg_gemm_planes", "wt_dbg_set_plane_gemm_mode", "wt_dbg_encoder_attention_planes", "wt_dbg_gemm_bf16", "wt_dbg_encoder_attention_bf16",
 ]
 
 

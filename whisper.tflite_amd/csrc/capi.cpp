@@ -762,6 +762,17 @@ struct DevPlanes {
     }
   }
 };
+// W [N][K] as the plane GEMM takes it: split_weight_planes()'s blocked layout on the device
+struct DevWeightPlanes {
+  void* p = nullptr;
+  DevWeightPlanes(const float* W, int N, int K, float scale) {
+    const std::vector<unsigned short> host = wt::split_weight_planes(W, N, K, K, scale);
+    hipchk(hipMalloc(&p, host.size() * 2 + 256), "hipMalloc");
+    hipchk(hipMemcpy(p, host.data(), host.size() * 2, hipMemcpyHostToDevice), "H2D");
+  }
+  ~DevWeightPlanes() { (void)hipFree(p); }
+  unsigned short* ptr() const { return static_cast<unsigned short*>(p); }
+};
 float max_abs(const float* x, size_t n) {
   float m = 0.0f;
   for (size_t i = 0; i < n; ++i) m = std::max(m, std::fabs(x[i]));
@@ -775,7 +786,8 @@ int wt_dbg_gemm_planes(wt_engine* h, int M, int N, int K, const float* A, const 
   if (!h || !A || !W || !C || N % 128 || K % 32 || M < 1 || n_cu < 0) return WT_ERR_INVALID_ARG;
   return guarded(h, [&] {
     const float sa = wt::f16_scale_for(max_abs(A, size_t(M) * K)), sw = wt::f16_scale_for(max_abs(W, size_t(N) * K));
-    const DevPlanes dA(A, size_t(M) * K, sa), dW(W, size_t(N) * K, sw);
+    const DevPlanes dA(A, size_t(M) * K, sa);
+    const DevWeightPlanes dW(W, N, K, sw);
     DevBuf dB(bias, N), dC(R ? R : nullptr, size_t(M) * N), dP(pos, pos ? size_t(pos_period) * N : 0);
     // plane output: scale from the fp64-free bound sum |a||w| is overkill for a test tap; 2^10 / max |bias| + ... is not
     // known here, so the caller's outputs are assumed O(max|A| max|W| K): use a conservative power of two
@@ -783,7 +795,7 @@ int wt_dbg_gemm_planes(wt_engine* h, int M, int N, int K, const float* A, const 
     const float so = wt::f16_scale_for(out_bound);
     DevPlanes dO(nullptr, size_t(M) * N, 1.0f);
     wt::PlaneGemmArgs g;
-    g.A = dA.ptr(); g.a_plane = dA.plane; g.lda = K; g.W = dW.ptr(); g.w_plane = dW.plane; g.bias = dB.p;
+    g.A = dA.ptr(); g.a_plane = dA.plane; g.lda = K; g.W = dW.ptr(); g.bias = dB.p;
     g.C = dC.p; g.R = dC.p; g.ldc = N; g.pos = dP.p; g.pos_period = pos_period > 0 ? pos_period : 1;
     g.M = M; g.N = N; g.K = K; g.a_scale = sa; g.w_scale = sw; g.n_cu = n_cu;
     if (planes_out) { g.P = dO.ptr(); g.p_plane = dO.plane; g.out_scale[0] = so; }
@@ -809,6 +821,12 @@ int wt_dbg_gemm_planes(wt_engine* h, int M, int N, int K, const float* A, const 
   });
 }
 
+int wt_dbg_set_plane_gemm_mode(int mode) {
+  if (mode < 0 || mode > 3) return WT_ERR_INVALID_ARG;
+  wt::set_plane_gemm_mode(mode);
+  return WT_OK;
+}
+
 int wt_dbg_gemm_planes_ln(wt_engine* h, int M, int K, const float* A, const float* W, const float* bias, const float* R,
                           const float* pos, int pos_period, int epi, const float* ln_g, const float* ln_b, int n_cu,
                           float* C, float* ln_out, float* ln_y32, int* fused) {
@@ -816,14 +834,15 @@ int wt_dbg_gemm_planes_ln(wt_engine* h, int M, int K, const float* A, const floa
   if (!h || !A || !W || !C || !ln_g || !ln_b || !ln_out || !fused || K % 32 || M < 1 || n_cu < 0) return WT_ERR_INVALID_ARG;
   return guarded(h, [&] {
     const float sa = wt::f16_scale_for(max_abs(A, size_t(M) * K)), sw = wt::f16_scale_for(max_abs(W, size_t(N) * K));
-    const DevPlanes dA(A, size_t(M) * K, sa), dW(W, size_t(N) * K, sw);
+    const DevPlanes dA(A, size_t(M) * K, sa);
+    const DevWeightPlanes dW(W, N, K, sw);
     DevBuf dB(bias, N), dC(R ? R : nullptr, size_t(M) * N), dP(pos, pos ? size_t(pos_period) * N : 0), dG(ln_g, N), dS(ln_b, N),
         dY(size_t(M) * N), dF(1);
     hipchk(hipMemset(dF.p, 0, 4), "memset");
     const float so = 64.0f;  // LayerNorm output is O(|g| sqrt(N))
     DevPlanes dO(nullptr, size_t(M) * N, 1.0f);
     wt::PlaneGemmArgs g;
-    g.A = dA.ptr(); g.a_plane = dA.plane; g.lda = K; g.W = dW.ptr(); g.w_plane = dW.plane; g.bias = dB.p;
+    g.A = dA.ptr(); g.a_plane = dA.plane; g.lda = K; g.W = dW.ptr(); g.bias = dB.p;
     g.C = dC.p; g.R = dC.p; g.ldc = N; g.pos = dP.p; g.pos_period = pos_period > 0 ? pos_period : 1;
     g.M = M; g.N = N; g.K = K; g.a_scale = sa; g.w_scale = sw; g.n_cu = n_cu;
     g.ln_g = dG.p; g.ln_b = dS.p; g.ln_P = dO.ptr(); g.ln_plane = dO.plane; g.ln_scale = so;

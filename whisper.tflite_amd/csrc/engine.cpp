@@ -107,29 +107,13 @@ std::vector<float> cross_q_layout(const float* Wq, int d) {
   return out;
 }
 
-// W [N][K] fp32 -> hi plane [N][Kpad], then lo plane [N][Kpad]: fp16(w * scale), fp16(w * scale - hi)
-std::vector<unsigned short> split_weight_planes(const float* W, int N, int K, int Kpad, float scale) {
-  std::vector<unsigned short> out(size_t(2) * N * Kpad, 0);
-  unsigned short* hi = out.data();
-  unsigned short* lo = out.data() + size_t(N) * Kpad;
-  for (int n = 0; n < N; ++n)
-    for (int k = 0; k < K; ++k) {
-      const float v = W[size_t(n) * K + k] * scale;
-      const _Float16 h = static_cast<_Float16>(v);
-      const _Float16 l = static_cast<_Float16>(v - static_cast<float>(h));
-      std::memcpy(hi + size_t(n) * Kpad + k, &h, 2);
-      std::memcpy(lo + size_t(n) * Kpad + k, &l, 2);
-    }
-  return out;
-}
-
 Engine::PlaneW Engine::upload_planes(const float* W, int N, int K, int Kpad, float scale) {
   const std::vector<unsigned short> planes = split_weight_planes(W, N, K, Kpad, scale);
   void* p = nullptr;
   HIPCHK(hipMalloc(&p, planes.size() * sizeof(unsigned short) + 256));
   allocations_.push_back(p);
   HIPCHK(hipMemcpy(p, planes.data(), planes.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
-  return PlaneW{static_cast<const unsigned short*>(p), long(N) * Kpad};
+  return PlaneW{static_cast<const unsigned short*>(p)};
 }
 
 TiledW Engine::upload_tiled(const float* W, int N, int K) {
@@ -1226,7 +1210,7 @@ void Engine::encode_enqueue(const float* d_mel, int batch) {
   if (c1p) {
     PlaneGemmArgs g;
     g.A = ws_.melTp; g.a_plane = melT_plane; g.a_rpb = T0; g.a_bs = long(T0 + 2) * nm; g.lda = nm;
-    g.W = conv1_p_.w; g.w_plane = conv1_p_.plane; g.bias = conv1_b;
+    g.W = conv1_p_.w; g.bias = conv1_b;
     if (c2p) {
       g.P = ws_.h1pp + d; g.p_plane = h1p_plane; g.out_scale[0] = sc_conv2_.a;
     } else {
@@ -1249,7 +1233,7 @@ void Engine::encode_enqueue(const float* d_mel, int batch) {
   if (c2p) {
     PlaneGemmArgs g;
     g.A = ws_.h1pp; g.a_plane = h1p_plane; g.a_rpb = T; g.a_bs = long(T0 + 2) * d; g.lda = 2 * d;
-    g.W = conv2_p_.w; g.w_plane = conv2_p_.plane; g.bias = conv2_b; g.pos = enc_pos; g.pos_period = T;
+    g.W = conv2_p_.w; g.bias = conv2_b; g.pos = enc_pos; g.pos_period = T;
     g.C = ws_.x; g.ldc = d; g.M = M; g.N = d; g.K = 3 * d;
     if (gemm_on_planes(sc_layers_[0].qkv)) fuse_ln(g, enc_blocks_[0].attn_ln_g, enc_blocks_[0].attn_ln_b, sc_layers_[0].qkv.a);
     ln_done = plane_gemm(g, sc_conv2_, kEpiBias | kEpiGelu | kEpiPos, 2.0 * g.M * g.N * g.K);
@@ -1289,7 +1273,7 @@ void Engine::encode_enqueue(const float* d_mel, int batch) {
     long qkv_src_plane = qkv_plane;
     if (qp) {
       PlaneGemmArgs q;  // q | k | v: the attention kernel's operand planes, or fp32 for the fall-back attention
-      q.A = lnp; q.a_plane = ln_plane; q.lda = d; q.W = wp.qkv.w; q.w_plane = wp.qkv.plane; q.bias = w.attn.bqkv;
+      q.A = lnp; q.a_plane = ln_plane; q.lda = d; q.W = wp.qkv.w; q.bias = w.attn.bqkv;
       if (ap) {
         q.P = qkvp; q.p_plane = qkv_plane; q.seg = d;
         q.out_scale[0] = qkv_scales[0]; q.out_scale[1] = qkv_scales[1]; q.out_scale[2] = qkv_scales[2];
@@ -1326,7 +1310,7 @@ void Engine::encode_enqueue(const float* d_mel, int batch) {
     }
     if (op) {
       PlaneGemmArgs o;
-      o.A = att_src; o.a_plane = att_src_plane; o.lda = d; o.W = wp.out.w; o.w_plane = wp.out.plane; o.bias = w.attn.bo;
+      o.A = att_src; o.a_plane = att_src_plane; o.lda = d; o.W = wp.out.w; o.bias = w.attn.bo;
       o.C = ws_.x; o.R = ws_.x; o.ldc = d; o.M = M; o.N = d; o.K = d;
       if (f1p) fuse_ln(o, w.mlp_ln_g, w.mlp_ln_b, sc.fc1.a);
       ln_done = plane_gemm(o, sc.out, kEpiBias | kEpiResidual, 2.0 * o.M * o.N * o.K);
@@ -1341,7 +1325,7 @@ void Engine::encode_enqueue(const float* d_mel, int batch) {
     long hid_src_plane = hid_plane;
     if (f1p) {
       PlaneGemmArgs f1;
-      f1.A = lnp; f1.a_plane = ln_plane; f1.lda = d; f1.W = wp.fc1.w; f1.w_plane = wp.fc1.plane; f1.bias = w.b1;
+      f1.A = lnp; f1.a_plane = ln_plane; f1.lda = d; f1.W = wp.fc1.w; f1.bias = w.b1;
       if (f2p) {
         f1.P = hidp; f1.p_plane = hid_plane; f1.out_scale[0] = sc.fc2.a;
       } else {
@@ -1361,7 +1345,7 @@ void Engine::encode_enqueue(const float* d_mel, int batch) {
     }
     if (f2p) {
       PlaneGemmArgs f2;
-      f2.A = hid_src; f2.a_plane = hid_src_plane; f2.lda = 4 * d; f2.W = wp.fc2.w; f2.w_plane = wp.fc2.plane; f2.bias = w.b2;
+      f2.A = hid_src; f2.a_plane = hid_src_plane; f2.lda = 4 * d; f2.W = wp.fc2.w; f2.bias = w.b2;
       f2.C = ws_.x; f2.R = ws_.x; f2.ldc = d; f2.M = M; f2.N = d; f2.K = 4 * d;
       if (l + 1 < c.n_audio_layer) {
         if (gemm_on_planes(sc_layers_[l + 1].qkv)) fuse_ln(f2, enc_blocks_[l + 1].attn_ln_g, enc_blocks_[l + 1].attn_ln_b, sc_layers_[l + 1].qkv.a);
@@ -1403,7 +1387,7 @@ void Engine::encode_enqueue(const float* d_mel, int batch) {
   if (absorb) {
   } else if (kp) {
     PlaneGemmArgs g;
-    g.A = lnp; g.a_plane = ln_plane; g.lda = d; g.W = cross_kv_p_.w; g.w_plane = cross_kv_p_.plane; g.bias = cross_kv_b;
+    g.A = lnp; g.a_plane = ln_plane; g.lda = d; g.W = cross_kv_p_.w; g.bias = cross_kv_b;
     g.C = slot.cross_kv; g.M = M; g.N = c.n_text_layer * 2 * d; g.K = d;
     g.c_rpb = T; g.kv_batch = batch; g.kv_heads = c.n_text_head; g.kv_dmodel = d;
     plane_gemm(g, sc_cross_kv_, kEpiBias | kEpiKvLayout, 2.0 * g.M * g.N * g.K);
@@ -1644,7 +1628,6 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
   auto dec_of = [&](int si) { return stream_override >= 0 ? stream_override : (paired ? si / 2 : si) % n_dec_streams_; };
   slot.dec = dec_of(slot_idx);
   slot.pair_leader = -1;
-  slot.pair_off = 0;
   DecWorkspace& dw = dws_[slot.dec];
   hipStream_t const stream_ = dec_stream_at(slot.dec);  // everything below runs on this decoder stream
   HIPCHK(hipStreamWaitEvent(stream_, slot.enc_done, 0));
@@ -1835,9 +1818,16 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
         ++steps;
       }
     }
-    HIPCHK(hipMemcpyAsync(h_ids_, dw.ids, size_t(batch) * stride * sizeof(long long),
-                          hipMemcpyDeviceToHost, stream_));
-    HIPCHK(hipMemcpyAsync(h_n_, dw.n_ids, size_t(batch) * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    // Every slot receives its OWN clips' ids in its own pinned buffers: a pair's second batch used to be read out of
+    // the leader's buffers, which the leader's next submit (collected first, reused first) could overwrite.
+    const int own = paired ? per : batch;
+    HIPCHK(hipMemcpyAsync(h_ids_, dw.ids, size_t(own) * stride * sizeof(long long), hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipMemcpyAsync(h_n_, dw.n_ids, size_t(own) * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    if (paired) {
+      HIPCHK(hipMemcpyAsync(slot2.h_ids, dw.ids + size_t(per) * stride, size_t(per) * stride * sizeof(long long),
+                            hipMemcpyDeviceToHost, stream_));
+      HIPCHK(hipMemcpyAsync(slot2.h_n, dw.n_ids + per, size_t(per) * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    }
   };
   // The ~1050 launches of a decode are identical from call to call for a given (slot, batch,
   // options). The first call with a signature runs them eagerly (which also performs the
@@ -1869,7 +1859,7 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
     if (paired) {
       Slot& sb = slots_[slot_b];
       HIPCHK(hipEventRecord(sb.dec_done, stream_));
-      sb.pair_leader = slot_idx, sb.pair_off = per, sb.steps = eager_steps, sb.dec = slot.dec;
+      sb.pair_leader = slot_idx, sb.steps = eager_steps, sb.dec = slot.dec;
     }
     if (use_graphs && !logits_host) {
       // A capture or instantiation failure is not fatal: the decoder keeps launching eagerly (same kernels, same
@@ -1910,7 +1900,7 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
   if (paired) {
     Slot& sb = slots_[slot_b];
     HIPCHK(hipEventRecord(sb.dec_done, stream_));
-    sb.pair_leader = slot_idx, sb.pair_off = per, sb.steps = steps, sb.dec = slot.dec;
+    sb.pair_leader = slot_idx, sb.steps = steps, sb.dec = slot.dec;
   }
 }
 
@@ -1953,13 +1943,12 @@ void Engine::decode_collect(int slot_idx, int64_t* ids, int32_t* n_ids) {
                    "attn_variant 1 (bf16 three-plane split) have the full fp32 range");
   }
   const int batch = slot.batch, stride = 32;
-  // a batch decoded by its pair leader's chain: the ids are in the leader's buffers behind the leader's own clips
+  // (a batch decoded by its pair leader's chain has its ids in its OWN buffers; the leader only times the chain)
   const Slot& src = slot.pair_leader >= 0 ? slots_[slot.pair_leader] : slot;
-  const size_t off = slot.pair_leader >= 0 ? size_t(slot.pair_off) : 0;
   for (int b = 0; b < batch; ++b) {
-    n_ids[b] = src.h_n[off + b];
+    n_ids[b] = slot.h_n[b];
     for (int i = 0; i < stride; ++i)
-      ids[size_t(b) * stride + i] = i < src.h_n[off + b] ? src.h_ids[(off + b) * stride + i] : 0;
+      ids[size_t(b) * stride + i] = i < slot.h_n[b] ? slot.h_ids[size_t(b) * stride + i] : 0;
   }
   resolve_kernel_stats(slot_idx);
   float ms = 0;

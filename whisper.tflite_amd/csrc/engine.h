@@ -242,7 +242,7 @@ class Engine {
     float* cross_kv = nullptr;  // [layer][k|v][clip][head][t][64]
     unsigned short* e_planes = nullptr;  // absorbed cross-attention: planes of the encoder output [clip][T][d]
     bool absorbed = false;               // which of the two this slot's encoder pass filled
-    int pair_leader = -1, pair_off = 0;  // decoded by another slot's chain: its ids sit in that slot's buffers at pair_off
+    int pair_leader = -1;  // decoded by another slot's chain (which copies this batch's ids into THIS slot's buffers)
     hipEvent_t enc_begin = nullptr, enc_mid = nullptr, enc_done = nullptr;
     hipEvent_t dec_begin = nullptr, dec_done = nullptr;
     long long* h_ids = nullptr;  // pinned [4096][32]
@@ -279,8 +279,7 @@ class Engine {
   int conv1_kpad = 0;
   // encoder weights as fp16 planes for the plane GEMM (hi plane, then lo plane at + N * K), scaled by GemmScale::w
   struct PlaneW {
-    const unsigned short* w = nullptr;
-    long plane = 0;
+    const unsigned short* w = nullptr;  // both fp16 planes, blocked (split_weight_planes)
   };
   PlaneW conv1_p_, conv2_p_, cross_kv_p_;
   struct EncLayerPlanes {

@@ -18,11 +18,26 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
+#include <type_traits>
 
 #include "bf16_split.h"
 #include "kernels.h"
 
 namespace wt {
+
+// schedule of the 384-column tiles: 0 = both wavefronts of a SIMD in step (gemm_planes_tile), 1 = ping-pong groups
+// (gemm_planes_pp), 2 = ping-pong groups on 16 x 16 x 32 MFMAs (gemm_planes_pp16).  WT_PLANE_GEMM_MODE / wt_dbg_set_plane_gemm_mode are measurement knobs (tools/gemm_planes_bench.py).
+static int g_plane_gemm_mode = -1;
+int plane_gemm_mode() {
+  if (g_plane_gemm_mode < 0) {
+    const char* v = getenv("WT_PLANE_GEMM_MODE");
+    g_plane_gemm_mode = v ? atoi(v) : 2;
+  }
+  return g_plane_gemm_mode;
+}
+void set_plane_gemm_mode(int m) { g_plane_gemm_mode = m; }
+
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -36,8 +51,7 @@ constexpr int BK = 32;
 struct PlaneGemmDev {
   const _Float16* A;   // hi plane; lo plane at A + a_plane
   long a_plane;
-  const _Float16* W;   // hi plane [N][K]; lo plane at W + w_plane
-  long w_plane;
+  const _Float16* W;   // both planes in the blocked LDS-image layout of split_weight_planes()
   float* C;            // fp32 output
   _Float16* P;         // plane output: hi at P, lo at P + p_plane
   long p_plane;
@@ -66,138 +80,109 @@ struct PlaneGemmDev {
   int* nonfinite;      // optional flag word: a row with a non-finite mean or variance sets it
 };
 
-// Block tile 192 x BN with BN = WN * NI * 32: 2 x WN wavefronts, each owning 3 x NI MFMA tiles.
-//   WN 2, NI 2: 192 x 128, 4 wavefronts, 40 KB per stage, two blocks per CU (round 2's first shape);
-//   WN 4, NI 3: 192 x 384, 8 wavefronts, 72 KB per stage, one block per CU.  What bounds this kernel is the LDS-DMA
-//   round trip (one k-tile of prefetch distance, ~2 us under load) against the bytes a CU can hold in flight (LDS):
-//   the wide tile contracts 197 FLOP per staged byte instead of 118 and needs 24 ds_read_b128 per 54 MFMAs instead of
-//   20 per 36.  Every N of the encoder (384, 1152, 1536, 3072) is a multiple of 384, and 250 row tiles x {1, 3, 4, 8}
-//   column tiles fill 0.98 / 2.93 / 3.9 / 7.8 rounds of the 256 CUs.
-//   MI = 32-row MFMA tiles per wavefront (two wavefront rows): 3 -> 192 block rows; 4 -> 256 rows x 384 columns, the
-//   whole register file (255 VGPRs) and all 160 KB of LDS, 230 FLOP per staged byte — used where 188 row tiles fill the
-//   available CUs in fewer rounds than 250 (the CU-masked stream of the pipeline on the N = d_model shapes).
-template <int EPI, bool PLANES_OUT, int WN, int NI, int MI, bool LN = false>
-__global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 2) void gemm_planes_tile(PlaneGemmDev g) {
-  static_assert(!LN || (!PLANES_OUT && WN == 4 && NI == 3), "LayerNorm fusion: fp32 output, 384-column tile");
-  constexpr int BN = WN * NI * 32, NW = 2 * WN, BM = 64 * MI;
-  constexpr int kAPlane = BM * BK * 2, kWPlane = BN * BK * 2;  // bytes of one plane of a stage
-  constexpr int kStage = 2 * kAPlane + 2 * kWPlane;
-  constexpr int QA = BM / 16, QW = BN / 16;                   // LDS-DMA instructions per A / W plane (16 rows each)
-  constexpr int QT = 2 * QA + 2 * QW, QPW = QT / NW;          // per stage, per wavefront
-  static_assert(QT % NW == 0, "whole instructions per wavefront");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// The four 16-byte chunks of a staged 64-byte row are XOR-swizzled by a function of the row: chunk c of row r sits in
+// slot c ^ chunk_swizzle(r).  (-(r >> 2)) & 3 = 0, 3, 2, 1 for rows 0-3, 4-7, 8-11, 12-15 (period 16) makes the
+// ds_read_b128 fragment reads conflict-free for the 32 x 32 x 16 pattern (lane = row l & 31, chunk pair l >> 5) AND for the
+// 16 x 16 x 32 pattern (lane = row l & 15, chunk l >> 4) under the 16-lane service groups of MI355X_MICROARCH.md; round
+// 3's (r >> 2) & 3 served the first pattern only.
+__host__ __device__ __forceinline__ constexpr int chunk_swizzle(int row) { return (0 - (row >> 2)) & 3; }
 
-  // XCD-aware bijective remap: blocks with equal blockIdx % 8 share an XCD (speed only).
-  const int nb = gridDim.x, bid = blockIdx.x;
-  const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7;
-  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int n_tiles = g.N / BN;
-  const int m0 = (logical / n_tiles) * BM;
-  const int n0 = (logical % n_tiles) * BN;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wid / WN, wn = wid % WN;
-  const int l31 = lane & 31, lh = lane >> 5;
-
-  // ---- LDS-DMA source addresses.  Instruction q of a stage copies 16 rows x 64 B: q in [0, QA) A hi, [QA, 2 QA) A lo,
-  // [2 QA, 2 QA + QW) W hi, then W lo; its LDS destination is the stage base + q * 1024 (lane-linear).  Wave w issues
-  // q = w, w + NW, ...  Lane i fills LDS slot (row i >> 2, chunk i & 3) of its instruction with the global chunk
-  // (i & 3) ^ ((row >> 2) & 3) of that row: the XOR swizzle lives on the SOURCE side.
+// ---- LDS-DMA source addresses of a stage, shared by the tile kernels.  Instruction q of a stage copies 16 rows x 64 B
+// (one plane of a 32-deep k-tile): q in [0, QA) A hi, [QA, 2 QA) A lo, [2 QA, 2 QA + QW) W hi, then W lo; its LDS
+// destination is the stage base + q * 1024 (lane-linear).  Wave w issues q = w, w + NW, ...  Lane i fills LDS slot
+// (row i >> 2, chunk i & 3) of its instruction with the chunk (i & 3) ^ chunk_swizzle(row) of that row: the XOR swizzle that
+// makes the fragment reads conflict-free lives on the SOURCE side.
+//   A (activations, row-major planes): 16 segments of 64 B per instruction, the swizzle in the per-lane offset.
+//   W (weights): stored by split_weight_planes() as the LDS image itself — [N / 16][K / 32][hi | lo][16 rows][32 k] with
+//   the chunks already swizzled — so an instruction reads 1 KiB CONTIGUOUS bytes (lane i its i-th 16).  Round 4, from
+//   tools/dma_probe.hip: the staging of a k-tile alone takes 2.05 us with 64-byte segments, 1.48 us with contiguous
+//   KiBs (36 against 50 GB/s per CU), and the 9 issues of a wave 1070 against 480 cycles; W is two thirds of a stage.
+// Addresses are (uniform base) + (32-bit per-lane byte offset): the LDS-DMA takes its base from SGPRs that SALU
+// instructions advance per k-tile (by kstep[j] bytes), and its issue needs NO vector instruction.
+template <int QA, int QW, int NW, int QPW>
+__device__ __forceinline__ void setup_stage_dma(const PlaneGemmDev& g, int m0, int n0, int wid, int lane, unsigned (&voff)[QPW],
+                                                const unsigned char* (&ubase)[QPW], unsigned (&kstep)[QPW]) {
   const int srow = lane >> 2;
-  // Addresses as (uniform base) + (32-bit per-lane byte offset): the LDS-DMA then takes its base from SGPRs that SALU
-  // instructions advance per k-tile, and its issue needs NO vector instruction.  With per-lane 64-bit pointers every
-  // issue was preceded by a v_lshl_add_u64 — and on this part a wavefront's VALU instruction does not slip into the
-  // other wavefront's MFMA burst (tools/mfma_valu_overlap.hip), so the loads of the next k-tile left a whole MFMA
-  // phase late: the main loop took MFMA time + DMA time (profiles/r03_gemm_mainloop_ablation.txt).
-  unsigned voff[QPW];
-  const unsigned char* ubase[QPW];
-  const unsigned lds_base = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)smem;
+  const int nkt = g.K / BK;
 #pragma unroll
   for (int j = 0; j < QPW; ++j) {
     const int q = wid + NW * j;
-    const bool is_a = q < 2 * QA;
-    const int qq = is_a ? (q < QA ? q : q - QA) : (q - 2 * QA < QW ? q - 2 * QA : q - 2 * QA - QW);
-    const bool lo = is_a ? q >= QA : q - 2 * QA >= QW;
-    const int row = 16 * qq + srow;
-    const int chunk = (lane & 3) ^ ((row >> 2) & 3);
-    if (is_a) {
+    if (q < 2 * QA) {
+      const bool lo = q >= QA;
+      const int row = 16 * (lo ? q - QA : q) + srow;
+      const int chunk = (lane & 3) ^ chunk_swizzle(row);
       int m = m0 + row;
       m = m < g.M ? m : g.M - 1;  // clamp: rows past M are computed and discarded
       voff[j] = (unsigned)(2 * ((lo ? g.a_plane : 0) + (long)(m / g.a_rpb) * g.a_bs + (long)(m % g.a_rpb) * g.lda + chunk * 8));
       ubase[j] = reinterpret_cast<const unsigned char*>(g.A);
+      kstep[j] = BK * 2;
     } else {
-      voff[j] = (unsigned)(2 * ((lo ? g.w_plane : 0) + (long)(n0 + row) * g.K + chunk * 8));
-      ubase[j] = reinterpret_cast<const unsigned char*>(g.W);
+      const int wq = q - 2 * QA;
+      const int rg = wq % QW, plane = wq / QW;
+      voff[j] = (unsigned)(lane * 16);
+      ubase[j] = reinterpret_cast<const unsigned char*>(g.W) + ((size_t)(n0 / 16 + rg) * nkt * 2 + plane) * 1024;
+      kstep[j] = 2048;
     }
   }
-  auto issue_stage = [&](int kt, int buf) {
-    unsigned char* base = smem + buf * kStage;
-    const size_t ko = (size_t)kt * (BK * 2);  // bytes
-#pragma unroll
-    for (int j = 0; j < QPW; ++j) {
-      // global_load_lds_dwordx4 in its SGPR-base form, written out: the builtin only selects the 64-bit per-lane address
-      // form (a v_lshl_add_u64 in front of every issue, even with the base held in SGPRs)
-      const unsigned long long sb = reinterpret_cast<unsigned long long>(ubase[j]) + ko;
-      const unsigned dst = lds_base + (unsigned)(buf * kStage + (wid + NW * j) * 1024);
-      lds_dma16_sgpr(voff[j], sb, dst);
-    }
-    (void)base;
-  };
+}
 
-  f32x16 acc[MI][NI];
+// ---- accumulators of a wave tile as the epilogue sees them: MI x NI blocks of 32 x 32 outputs, 16 floats per lane and
+// block.  stage_write() puts a block into the wave's private LDS stage (32 rows x 32 floats, columns XORed by 4 on rows
+// with bit 2 set); get / set address the 16 floats as plain storage (the LayerNorm fusion parks finished values there).
+template <int MI_, int NI_>
+struct Acc32 {  // v_mfma_f32_32x32x16: lane (l31, lh) holds column l31, rows (r & 3) + 8 (r >> 2) + 4 lh
+  static constexpr int MI = MI_, NI = NI_;
+  f32x16 t[MI_][NI_];
+  __device__ __forceinline__ void zero() {
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < MI_; ++i)
 #pragma unroll
-    for (int j = 0; j < NI; ++j)
+      for (int j = 0; j < NI_; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-  // fragment addresses: row = tile base (a multiple of 32) + l31, so the swizzle term depends on the lane only
-  const int swz = (l31 >> 2) & 3;
-  const int a_off = (wm * (32 * MI) + l31) * 64, b_off = 2 * kAPlane + (wn * NI * 32 + l31) * 64;
-  auto compute = [&](int buf) {
-    const unsigned char* base = smem + buf * kStage;
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      const int slot = ((ks * 2 + lh) ^ swz) * 16;
-      half8 ah[MI], al[MI], bh[NI], bl[NI];
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        ah[i] = *reinterpret_cast<const half8*>(base + a_off + i * 32 * 64 + slot);
-        al[i] = *reinterpret_cast<const half8*>(base + kAPlane + a_off + i * 32 * 64 + slot);
-      }
-#pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        bh[j] = *reinterpret_cast<const half8*>(base + b_off + j * 32 * 64 + slot);
-        bl[j] = *reinterpret_cast<const half8*>(base + kWPlane + b_off + j * 32 * 64 + slot);
-      }
-      // smallest products first
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-    }
-  };
-
-  const int nkt = g.K / BK;
-  issue_stage(0, 0);
-  for (int kt = 0; kt < nkt; ++kt) {
-    // k-tile kt has landed: every wave waits for its own LDS-DMA, the barrier for everybody else's; k-tile kt - 1 has
-    // been read by everyone, so its stage may be refilled
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (kt + 1 < nkt) issue_stage(kt + 1, (kt + 1) & 1);
-    compute(kt & 1);
+        for (int r = 0; r < 16; ++r) t[i][j][r] = 0.0f;
   }
+  __device__ __forceinline__ float get(int mi, int ni, int i) const { return t[mi][ni][i]; }
+  __device__ __forceinline__ void set(int mi, int ni, int i, float v) { t[mi][ni][i] = v; }
+  __device__ __forceinline__ void stage_write(int mi, int ni, float* stage, int lane, float scale) const {
+    const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + (l31 ^ (lh << 2))] = t[mi][ni][r] * scale;
+  }
+};
+template <int MI_, int NI_>
+struct Acc16 {  // v_mfma_f32_16x16x32: 2 x 2 tiles per block; lane (c = l & 15, q = l >> 4) holds column c, rows 4 q + r
+  static constexpr int MI = MI_, NI = NI_;
+  f32x4 t[2 * MI_][2 * NI_];
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int i = 0; i < 2 * MI_; ++i)
+#pragma unroll
+      for (int j = 0; j < 2 * NI_; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[i][j][r] = 0.0f;
+  }
+  __device__ __forceinline__ float get(int mi, int ni, int i) const { return t[2 * mi + (i >> 3)][2 * ni + ((i >> 2) & 1)][i & 3]; }
+  __device__ __forceinline__ void set(int mi, int ni, int i, float v) { t[2 * mi + (i >> 3)][2 * ni + ((i >> 2) & 1)][i & 3] = v; }
+  __device__ __forceinline__ void stage_write(int mi, int ni, float* stage, int lane, float scale) const {
+    const int c = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)  // row 16 a + 4 q + r: its bit 2 is q & 1
+          stage[(16 * a + 4 * q + r) * 32 + ((16 * b + c) ^ ((q & 1) << 2))] = t[2 * mi + a][2 * ni + b][r] * scale;
+  }
+};
+
+// ---- epilogue shared by the tile kernels: each wavefront transposes one 32 x 32 MFMA tile at a time through a
+// private LDS stage and moves 16 bytes per lane (128-byte row segments per 8 lanes, or two 64-byte plane segments
+// per 4).  `smem` is the block's dynamic LDS, dead as operand staging by the time this runs.
+template <int EPI, bool PLANES_OUT, int WN, bool LN, class Acc>
+__device__ __forceinline__ void planes_epilogue(const PlaneGemmDev& g, Acc& acc, unsigned char* smem, int m0, int n0, int wid, int wm,
+                                                int wn, int lane) {
+  constexpr int MI = Acc::MI, NI = Acc::NI;
+  constexpr int BN = WN * NI * 32, NW = 2 * WN, BM = 64 * MI;
   __syncthreads();  // the operand stages are dead: the epilogue reuses them
 
   // ---- epilogue: each wavefront transposes one 32 x 32 MFMA tile at a time through a private LDS stage and moves
@@ -224,8 +209,7 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 2) void gemm_planes_tile(Pl
     const int head = rem >> 6, dd = rem & 63;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * lh) * SLD + (l31 ^ (lh << 2))] = acc[mi][ni][r] * g.descale;
+      acc.stage_write(mi, ni, stage, lane, g.descale);
       // the stage is private to this wavefront and LDS executes a wave's operations in order.
       // One division per 32-row slab: rows advance by at most 31 < c_rpb, pos_period (host-checked).
       const int mbase = m0 + wm * (32 * MI) + mi * 32;
@@ -285,12 +269,12 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 2) void gemm_planes_tile(Pl
             *reinterpret_cast<f32x4*>(g.C + o) = out;
             if constexpr (LN) {  // the accumulator registers of this tile are dead: they keep the finished row-major values
 #pragma unroll
-              for (int e = 0; e < 4; ++e) acc[mi][ni][4 * p + e] = out[e];
+              for (int e = 0; e < 4; ++e) acc.set(mi, ni, 4 * p + e, out[e]);
             }
           }
         } else if constexpr (LN) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[mi][ni][4 * p + e] = 0.0f;  // rows past M: no part in anything
+          for (int e = 0; e < 4; ++e) acc.set(mi, ni, 4 * p + e, 0.0f);  // rows past M: no part in anything
         }
       }
     }
@@ -316,7 +300,7 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 2) void gemm_planes_tile(Pl
           for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const float x = acc[mi][ni][4 * p + e] - (pass ? mean[mi][p] : 0.0f);
+              const float x = acc.get(mi, ni, 4 * p + e) - (pass ? mean[mi][p] : 0.0f);
               t += pass ? x * x : x;
             }
           t += __shfl_xor(t, 1, 64);
@@ -351,7 +335,7 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 2) void gemm_planes_tile(Pl
           if (m >= g.M) continue;
           f32x4 y;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) y[e] = (acc[mi][ni][4 * p + e] - mean[mi][p]) * rstd[mi][p] * gg[e] + bb[e];
+          for (int e = 0; e < 4; ++e) y[e] = (acc.get(mi, ni, 4 * p + e) - mean[mi][p]) * rstd[mi][p] * gg[e] + bb[e];
           const long o = (long)m * BN + n;
           if (g.ln_y32 != nullptr) __builtin_nontemporal_store(y, reinterpret_cast<f32x4*>(g.ln_y32 + o));
           unsigned h0, l0, h1, l1;
@@ -365,6 +349,439 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 2) void gemm_planes_tile(Pl
   }
 }
 
+// Block tile 192 x BN with BN = WN * NI * 32: 2 x WN wavefronts, each owning 3 x NI MFMA tiles.
+//   WN 2, NI 2: 192 x 128, 4 wavefronts, 40 KB per stage, two blocks per CU (round 2's first shape);
+//   WN 4, NI 3: 192 x 384, 8 wavefronts, 72 KB per stage, one block per CU.  What bounds this kernel is the LDS-DMA
+//   round trip (one k-tile of prefetch distance, ~2 us under load) against the bytes a CU can hold in flight (LDS):
+//   the wide tile contracts 197 FLOP per staged byte instead of 118 and needs 24 ds_read_b128 per 54 MFMAs instead of
+//   20 per 36.  Every N of the encoder (384, 1152, 1536, 3072) is a multiple of 384, and 250 row tiles x {1, 3, 4, 8}
+//   column tiles fill 0.98 / 2.93 / 3.9 / 7.8 rounds of the 256 CUs.
+//   MI = 32-row MFMA tiles per wavefront (two wavefront rows): 3 -> 192 block rows; 4 -> 256 rows x 384 columns, the
+//   whole register file (255 VGPRs) and all 160 KB of LDS, 230 FLOP per staged byte — used where 188 row tiles fill the
+//   available CUs in fewer rounds than 250 (the CU-masked stream of the pipeline on the N = d_model shapes).
+template <int EPI, bool PLANES_OUT, int WN, int NI, int MI, bool LN = false>
+__global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 2) void gemm_planes_tile(PlaneGemmDev g) {
+  static_assert(!LN || (!PLANES_OUT && WN == 4 && NI == 3), "LayerNorm fusion: fp32 output, 384-column tile");
+  constexpr int BN = WN * NI * 32, NW = 2 * WN, BM = 64 * MI;
+  constexpr int kAPlane = BM * BK * 2, kWPlane = BN * BK * 2;  // bytes of one plane of a stage
+  constexpr int kStage = 2 * kAPlane + 2 * kWPlane;
+  constexpr int QA = BM / 16, QW = BN / 16;                   // LDS-DMA instructions per A / W plane (16 rows each)
+  constexpr int QT = 2 * QA + 2 * QW, QPW = QT / NW;          // per stage, per wavefront
+  static_assert(QT % NW == 0, "whole instructions per wavefront");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  // XCD-aware bijective remap: blocks with equal blockIdx % 8 share an XCD (speed only).
+  const int nb = gridDim.x, bid = blockIdx.x;
+  const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int n_tiles = g.N / BN;
+  const int m0 = (logical / n_tiles) * BM;
+  const int n0 = (logical % n_tiles) * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WN, wn = wid % WN;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  unsigned voff[QPW], kstep[QPW];
+  const unsigned char* ubase[QPW];
+  const unsigned lds_base = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)smem;
+  setup_stage_dma<QA, QW, NW, QPW>(g, m0, n0, wid, lane, voff, ubase, kstep);
+  auto issue_stage = [&](int kt, int buf) {
+#pragma unroll
+    for (int j = 0; j < QPW; ++j) {
+      // global_load_lds_dwordx4 in its SGPR-base form, written out: the builtin only selects the 64-bit per-lane address
+      // form (a v_lshl_add_u64 in front of every issue, even with the base held in SGPRs)
+      const unsigned long long sb = reinterpret_cast<unsigned long long>(ubase[j]) + (size_t)kt * kstep[j];
+      const unsigned dst = lds_base + (unsigned)(buf * kStage + (wid + NW * j) * 1024);
+      lds_dma16_sgpr(voff[j], sb, dst);
+    }
+  };
+
+  Acc32<MI, NI> accs;
+  accs.zero();
+  auto& acc = accs.t;
+
+  // fragment addresses: row = tile base (a multiple of 32) + l31, so the swizzle term depends on the lane only
+  const int swz = chunk_swizzle(l31);
+  const int a_off = (wm * (32 * MI) + l31) * 64, b_off = 2 * kAPlane + (wn * NI * 32 + l31) * 64;
+  auto compute = [&](int buf) {
+    const unsigned char* base = smem + buf * kStage;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      const int slot = ((ks * 2 + lh) ^ swz) * 16;
+      half8 ah[MI], al[MI], bh[NI], bl[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        ah[i] = *reinterpret_cast<const half8*>(base + a_off + i * 32 * 64 + slot);
+        al[i] = *reinterpret_cast<const half8*>(base + kAPlane + a_off + i * 32 * 64 + slot);
+      }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        bh[j] = *reinterpret_cast<const half8*>(base + b_off + j * 32 * 64 + slot);
+        bl[j] = *reinterpret_cast<const half8*>(base + kWPlane + b_off + j * 32 * 64 + slot);
+      }
+      // smallest products first
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  const int nkt = g.K / BK;
+  issue_stage(0, 0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    // k-tile kt has landed: every wave waits for its own LDS-DMA, the barrier for everybody else's; k-tile kt - 1 has
+    // been read by everyone, so its stage may be refilled
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 1 < nkt) issue_stage(kt + 1, (kt + 1) & 1);
+    compute(kt & 1);
+  }
+  planes_epilogue<EPI, PLANES_OUT, WN, LN>(g, accs, smem, m0, n0, wid, wm, wn, lane);
+}
+
+// Ping-pong form of the 384-column tiles (round 4).  Same tile, same staging image, same k order and product order
+// (bit-identical results), another schedule: the block's eight wavefronts are two GROUPS of four — waves w and w + 4
+// share a SIMD — that run the same program ONE PHASE apart.  A phase is either "read the fragments of a 16-deep k-step
+// (12 ds_read_b128) and issue the wave's share of the next-but-one k-tile's LDS-DMA" or "27 MFMAs"; a raw s_barrier
+// closes every phase, so while one wavefront of a SIMD streams its MFMAs the other one does its LDS reads and DMA
+// issues.  In gemm_planes_tile both wavefronts of a SIMD did the same thing at the same time: the matrix pipe idled
+// while both issued DMA (60-180 cycles per instruction, 9-10 per wave and k-tile) and fragment reads, then both
+// contended for it (profiles/r03_gemm_mainloop_ablation.txt: DMA + MFMA cost nearly their sum).
+//   phase p:     G0  L(0) C(0) L(1) C(1) L(2) ...        L(s) = fragment reads of k-step s (+ DMA issue on even s)
+//                G1       L(0) C(0) L(1) C(1) ...        C(s) = the 27 MFMAs of k-step s
+// Stage kt & 1 is read in L(2 kt) and L(2 kt + 1); its last reader is G1's L(2 kt + 1) in phase 4 kt + 3, so k-tile
+// kt + 2 is issued into it from phase 4 kt + 4 on: by every wave in its own L(2 kt + 2).  It is first read by G0's
+// L(2 kt + 4) in phase 4 kt + 8: G0 waves certify their DMA (vmcnt(0)) at the end of C(2 kt + 3), G1 waves at the end of
+// L(2 kt + 3), both phase 4 kt + 7.
+#ifdef WT_PP_STAMPS  // diagnostic build (tools/gemm_phase_probe.hip): where a wavefront's cycles of the main loop go
+__device__ long long g_pp_stamps[1024 * 8 * 9];  // per wave: 4 phase sums, loop, prologue, epilogue, kernel, realtime ticks
+#define PP_STAMP(i)                                  \
+  do {                                               \
+    const long long t_ = __builtin_readcyclecounter(); \
+    st_[i] += t_ - tl_;                              \
+    tl_ = t_;                                        \
+  } while (0)
+#else
+#define PP_STAMP(i) \
+  do {              \
+  } while (0)
+#endif
+
+template <int EPI, bool PLANES_OUT, int MI, bool LN = false>
+__global__ __launch_bounds__(512, 2) void gemm_planes_pp(PlaneGemmDev g) {
+  constexpr int WN = 4, NI = 3;
+  static_assert(!LN || !PLANES_OUT, "LayerNorm fusion: fp32 output");
+  constexpr int BN = WN * NI * 32, NW = 2 * WN, BM = 64 * MI;
+  constexpr int kAPlane = BM * BK * 2, kWPlane = BN * BK * 2;
+  constexpr int kStage = 2 * kAPlane + 2 * kWPlane;
+  constexpr int QA = BM / 16, QW = BN / 16;
+  constexpr int QT = 2 * QA + 2 * QW, QPW = QT / NW;
+  static_assert(QT % NW == 0, "whole instructions per wavefront");
+#ifdef WT_PP_STAMPS
+  const long long t_kernel_ = __builtin_readcyclecounter();
+  const long long r_kernel_ = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int nb = gridDim.x, bid = blockIdx.x;
+  const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int n_tiles = g.N / BN;
+  const int m0 = (logical / n_tiles) * BM;
+  const int n0 = (logical % n_tiles) * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WN, wn = wid % WN;  // wm = the wave's group
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  unsigned voff[QPW], kstep[QPW];
+  const unsigned char* ubase[QPW];
+  const unsigned lds_base = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)smem;
+  setup_stage_dma<QA, QW, NW, QPW>(g, m0, n0, wid, lane, voff, ubase, kstep);
+  auto issue_stage = [&](int kt, int buf) {
+#pragma unroll
+    for (int j = 0; j < QPW; ++j) {
+      const unsigned long long sb = reinterpret_cast<unsigned long long>(ubase[j]) + (size_t)kt * kstep[j];
+      const unsigned dst = lds_base + (unsigned)(buf * kStage + (wid + NW * j) * 1024);
+      lds_dma16_sgpr(voff[j], sb, dst);
+    }
+  };
+
+  Acc32<MI, NI> accs;
+  accs.zero();
+  auto& acc = accs.t;
+
+  const int swz = chunk_swizzle(l31);
+  const int a_off = (wm * (32 * MI) + l31) * 64, b_off = 2 * kAPlane + (wn * NI * 32 + l31) * 64;
+  half8 ah[MI], al[MI], bh[NI], bl[NI];
+  auto load_frags = [&](int buf, int ks) {
+    const unsigned char* base = smem + buf * kStage;
+    const int slot = ((ks * 2 + lh) ^ swz) * 16;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      ah[i] = *reinterpret_cast<const half8*>(base + a_off + i * 32 * 64 + slot);
+      al[i] = *reinterpret_cast<const half8*>(base + kAPlane + a_off + i * 32 * 64 + slot);
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      bh[j] = *reinterpret_cast<const half8*>(base + b_off + j * 32 * 64 + slot);
+      bl[j] = *reinterpret_cast<const half8*>(base + kWPlane + b_off + j * 32 * 64 + slot);
+    }
+  };
+  auto compute = [&]() {  // smallest products first, as gemm_planes_tile
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+  };
+  // a phase boundary: nothing (the register-only MFMAs included) is scheduled across it
+  auto phase_end = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto reads_done = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+  auto dma_done = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+
+  const int nkt = g.K / BK;
+  issue_stage(0, 0);
+  if (nkt > 1) {
+    issue_stage(1, 1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QPW) : "memory");  // k-tile 0 has landed, k-tile 1 stays in flight
+  } else {
+    dma_done();
+  }
+  phase_end();
+  if (wm == 1) phase_end();  // G1 runs one phase behind
+  load_frags(0, 0);
+  reads_done();
+  phase_end();
+#ifdef WT_PP_STAMPS
+  long long st_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long tl_ = __builtin_readcyclecounter();
+  const long long t_begin_ = tl_;
+  st_[5] = tl_ - t_kernel_;
+#endif
+  for (int kt = 0; kt < nkt; ++kt) {
+    compute();  // C(2 kt)
+    phase_end();
+    PP_STAMP(0);
+    load_frags(kt & 1, 1);  // L(2 kt + 1)
+    reads_done();
+    if (wm == 1) dma_done();
+    phase_end();
+    PP_STAMP(1);
+    compute();  // C(2 kt + 1)
+    if (wm == 0) dma_done();
+    phase_end();
+    PP_STAMP(2);
+    if (kt + 1 < nkt) {  // L(2 kt + 2)
+      if (kt + 2 < nkt) issue_stage(kt + 2, kt & 1);
+      load_frags((kt + 1) & 1, 0);
+      reads_done();
+    }
+    phase_end();
+    PP_STAMP(3);
+  }
+  if (wm == 0) phase_end();
+#ifdef WT_PP_STAMPS
+  const long long t_loop_end_ = __builtin_readcyclecounter();
+  st_[4] = t_loop_end_ - t_begin_;
+#endif
+  planes_epilogue<EPI, PLANES_OUT, WN, LN>(g, accs, smem, m0, n0, wid, wm, wn, lane);
+#ifdef WT_PP_STAMPS
+  {
+    const long long t_end_ = __builtin_readcyclecounter();
+    st_[6] = t_end_ - t_loop_end_;
+    st_[7] = t_end_ - t_kernel_;
+    st_[8] = (long long)__builtin_amdgcn_s_memrealtime() - r_kernel_;
+    if (lane == 0 && blockIdx.x < 1024)
+      for (int i = 0; i < 9; ++i) g_pp_stamps[(blockIdx.x * 8 + wid) * 9 + i] = st_[i];
+  }
+#endif
+}
+
+// The same ping-pong schedule on v_mfma_f32_16x16x32_f16 (round 4; tile 192 x 384, wave tile 96 x 96 = 6 x 6 MFMA tiles).
+// Why another MFMA shape: this kernel is POWER-bound — the chip holds 1.25-1.4 GHz under it (s_memtime over s_memrealtime,
+// tools/gemm_phase_probe.hip) while the loop is within 15 % of its MFMA cycle count — and the 16 x 16 x 32 form does the
+// same arithmetic on less energy: a register-only loop of the three plane products on random planes sustains 1855 TF/s
+// at 1.79 GHz against 1590 TF/s at 1.53 GHz for 32 x 32 x 16 (tools/mfma_shape_probe.hip, profiles/r04_mfma_shape.txt).
+// A k-tile is two half-tiles of 54 MFMAs (864 cycles, as before): rows 0-47 of the wave tile, then rows 48-95.
+//   L_A(kt): 12 reads of the W fragments (kept for both halves) + 6 of the first three A tiles (+ the DMA issue of k-tile
+//   kt + 1's successor);  C_A: 54 MFMAs;  L_B: 6 reads of the other three A tiles;  C_B: 54 MFMAs.  Stage lifetimes and
+//   the vmcnt certification are those of gemm_planes_pp with L_A / L_B in the place of L(2 kt) / L(2 kt + 1).
+// A 16 x 16 x 32 fragment is (row l & 15, chunk l >> 4): one ds_read_b128 covers a whole 16-row x 64-byte block, and
+// chunk_swizzle() keeps its 16-lane service groups on distinct banks.  A 32-deep sum per MFMA instead of 16: results
+// differ from the 32 x 32 x 16 kernels in the last bits (both within the fp32 error budget of tests/test_gpu_kernels.py).
+template <int EPI, bool PLANES_OUT, bool LN = false>
+__global__ __launch_bounds__(512, 2) void gemm_planes_pp16(PlaneGemmDev g) {
+  constexpr int WN = 4, NI = 3, MI = 3;
+  static_assert(!LN || !PLANES_OUT, "LayerNorm fusion: fp32 output");
+  constexpr int BN = WN * NI * 32, NW = 2 * WN, BM = 64 * MI;
+  constexpr int kAPlane = BM * BK * 2, kWPlane = BN * BK * 2;
+  constexpr int kStage = 2 * kAPlane + 2 * kWPlane;
+  constexpr int QA = BM / 16, QW = BN / 16;
+  constexpr int QT = 2 * QA + 2 * QW, QPW = QT / NW;
+  static_assert(QT % NW == 0, "whole instructions per wavefront");
+#ifdef WT_PP_STAMPS
+  const long long t_kernel_ = __builtin_readcyclecounter();
+  const long long r_kernel_ = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int nb = gridDim.x, bid = blockIdx.x;
+  const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int n_tiles = g.N / BN;
+  const int m0 = (logical / n_tiles) * BM;
+  const int n0 = (logical % n_tiles) * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WN, wn = wid % WN;  // wm = the wave's group
+
+  unsigned voff[QPW], kstep[QPW];
+  const unsigned char* ubase[QPW];
+  const unsigned lds_base = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)smem;
+  setup_stage_dma<QA, QW, NW, QPW>(g, m0, n0, wid, lane, voff, ubase, kstep);
+  auto issue_stage = [&](int kt, int buf) {
+#pragma unroll
+    for (int j = 0; j < QPW; ++j) {
+      const unsigned long long sb = reinterpret_cast<unsigned long long>(ubase[j]) + (size_t)kt * kstep[j];
+      const unsigned dst = lds_base + (unsigned)(buf * kStage + (wid + NW * j) * 1024);
+      lds_dma16_sgpr(voff[j], sb, dst);
+    }
+  };
+
+  Acc16<MI, NI> accs;
+  accs.zero();
+  auto& acc = accs.t;
+
+  const int fc = lane & 15, fq = lane >> 4;
+  const int frag = fc * 64 + ((fq ^ chunk_swizzle(fc)) * 16);  // byte offset of the lane's 16 bytes inside a 16-row block
+  const int a_off = wm * (32 * MI) * 64 + frag, b_off = 2 * kAPlane + wn * (NI * 32) * 64 + frag;
+  half8 ah[3], al[3], bh[6], bl[6];
+  auto load_b = [&](int buf) {
+    const unsigned char* base = smem + buf * kStage + b_off;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      bh[j] = *reinterpret_cast<const half8*>(base + j * 1024);
+      bl[j] = *reinterpret_cast<const half8*>(base + kWPlane + j * 1024);
+    }
+  };
+  auto load_a = [&](int buf, int half) {
+    const unsigned char* base = smem + buf * kStage + a_off + half * 3 * 1024;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      ah[i] = *reinterpret_cast<const half8*>(base + i * 1024);
+      al[i] = *reinterpret_cast<const half8*>(base + kAPlane + i * 1024);
+    }
+  };
+  auto compute = [&](auto half_c) {  // smallest products first
+    constexpr int H = decltype(half_c)::value;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) acc[3 * H + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[3 * H + i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) acc[3 * H + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[3 * H + i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) acc[3 * H + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[3 * H + i][j], 0, 0, 0);
+  };
+  using H0 = std::integral_constant<int, 0>;
+  using H1 = std::integral_constant<int, 1>;
+  auto phase_end = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto reads_done = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+  auto dma_done = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+
+  const int nkt = g.K / BK;
+  issue_stage(0, 0);
+  if (nkt > 1) {
+    issue_stage(1, 1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QPW) : "memory");
+  } else {
+    dma_done();
+  }
+  phase_end();
+  if (wm == 1) phase_end();  // G1 runs one phase behind
+  load_b(0);
+  load_a(0, 0);
+  reads_done();
+  phase_end();
+#ifdef WT_PP_STAMPS
+  long long st_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long tl_ = __builtin_readcyclecounter();
+  const long long t_begin_ = tl_;
+  st_[5] = tl_ - t_kernel_;
+#endif
+  for (int kt = 0; kt < nkt; ++kt) {
+    compute(H0{});  // C_A(kt)
+    phase_end();
+    PP_STAMP(0);
+    load_a(kt & 1, 1);  // L_B(kt)
+    reads_done();
+    if (wm == 1) dma_done();
+    phase_end();
+    PP_STAMP(1);
+    compute(H1{});  // C_B(kt)
+    if (wm == 0) dma_done();
+    phase_end();
+    PP_STAMP(2);
+    if (kt + 1 < nkt) {  // L_A(kt + 1)
+      if (kt + 2 < nkt) issue_stage(kt + 2, kt & 1);
+      load_b((kt + 1) & 1);
+      load_a((kt + 1) & 1, 0);
+      reads_done();
+    }
+    phase_end();
+    PP_STAMP(3);
+  }
+  if (wm == 0) phase_end();
+#ifdef WT_PP_STAMPS
+  const long long t_loop_end_ = __builtin_readcyclecounter();
+  st_[4] = t_loop_end_ - t_begin_;
+#endif
+  planes_epilogue<EPI, PLANES_OUT, WN, LN>(g, accs, smem, m0, n0, wid, wm, wn, lane);
+#ifdef WT_PP_STAMPS
+  {
+    const long long t_end_ = __builtin_readcyclecounter();
+    st_[6] = t_end_ - t_loop_end_;
+    st_[7] = t_end_ - t_kernel_;
+    st_[8] = (long long)__builtin_amdgcn_s_memrealtime() - r_kernel_;
+    if (lane == 0 && blockIdx.x < 1024)
+      for (int i = 0; i < 9; ++i) g_pp_stamps[(blockIdx.x * 8 + wid) * 9 + i] = st_[i];
+  }
+#endif
+}
+
 template <int EPI, bool PLANES_OUT, int WN, int NI, int MI = 3, bool LN = false>
 void launch_planes_shape(const PlaneGemmDev& g, hipStream_t s) {
   constexpr int BN = WN * NI * 32, BM = 64 * MI;
@@ -376,6 +793,28 @@ void launch_planes_shape(const PlaneGemmDev& g, hipStream_t s) {
     return true;
   }();
   (void)raised;
+  if constexpr (WN == 4 && NI == 3 && MI == 3) {  // (the 256-row tile's fragments do not fit beside its accumulators)
+    if (plane_gemm_mode() == 2) {
+      static const bool raised_pp16 = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_planes_pp16<EPI, PLANES_OUT, LN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        return true;
+      }();
+      (void)raised_pp16;
+      WT_LAUNCH_TIMED((gemm_planes_pp16<EPI, PLANES_OUT, LN>), dim3(blocks), dim3(512), smem, s, g);
+      return;
+    }
+    if (plane_gemm_mode() == 1) {
+      static const bool raised_pp = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_planes_pp<EPI, PLANES_OUT, MI, LN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        return true;
+      }();
+      (void)raised_pp;
+      WT_LAUNCH_TIMED((gemm_planes_pp<EPI, PLANES_OUT, MI, LN>), dim3(blocks), dim3(512), smem, s, g);
+      return;
+    }
+  }
   WT_LAUNCH_TIMED((gemm_planes_tile<EPI, PLANES_OUT, WN, NI, MI, LN>), dim3(blocks), dim3(128 * WN), smem, s, g);
 }
 
@@ -424,10 +863,34 @@ bool launch_planes(const PlaneGemmDev& g, int n_cu, hipStream_t s) {
 
 }  // namespace
 
+// W [N][K] fp32 -> two fp16 planes (hi = fp16(w * scale), lo = fp16(w * scale - hi)) in the layout the plane GEMM's
+// LDS-DMA stages without rearranging (k_gemm_planes.hip, setup_stage_dma): [N / 16][Kpad / 32][hi | lo][16 rows][32 k],
+// 1 KiB per (row group, k-tile, plane) — exactly the LDS image of one global_load_lds_dwordx4, the four 16-byte chunks of
+// a row XOR-swizzled by (row >> 2) & 3 as the fragment reads expect.  N a multiple of 16, Kpad of 32, zero filled.
+std::vector<unsigned short> split_weight_planes(const float* W, int N, int K, int Kpad, float scale) {
+  if (N % 16 != 0 || Kpad % 32 != 0 || K > Kpad) throw Error(kErrInvalidArg, "split_weight_planes: N % 16, Kpad % 32");
+  std::vector<unsigned short> out(size_t(2) * N * Kpad, 0);
+  const int nkt = Kpad / 32;
+  for (int n = 0; n < N; ++n) {
+    const int rg = n / 16, r = n % 16;
+    for (int k = 0; k < K; ++k) {
+      const float v = W[size_t(n) * K + k] * scale;
+      const _Float16 h = static_cast<_Float16>(v);
+      const _Float16 l = static_cast<_Float16>(v - static_cast<float>(h));
+      const int kt = k / 32, c = (k % 32) / 8, e = k % 8;
+      const size_t blk = (size_t(rg) * nkt + kt) * 2 * 512;  // halfs
+      const size_t at = size_t(r * 4 + (c ^ chunk_swizzle(r))) * 8 + e;
+      std::memcpy(out.data() + blk + at, &h, 2);
+      std::memcpy(out.data() + blk + 512 + at, &l, 2);
+    }
+  }
+  return out;
+}
+
 bool launch_gemm_planes(const PlaneGemmArgs& a, int epi, hipStream_t s) {
   PlaneGemmDev g{};
   g.A = reinterpret_cast<const _Float16*>(a.A); g.a_plane = a.a_plane;
-  g.W = reinterpret_cast<const _Float16*>(a.W); g.w_plane = a.w_plane;
+  g.W = reinterpret_cast<const _Float16*>(a.W);
   g.C = a.C; g.P = reinterpret_cast<_Float16*>(a.P); g.p_plane = a.p_plane;
   g.bias = a.bias; g.R = a.R; g.pos = a.pos;
   g.M = a.M; g.N = a.N; g.K = a.K;
@@ -454,8 +917,7 @@ bool launch_gemm_planes(const PlaneGemmArgs& a, int epi, hipStream_t s) {
   // the kernel addresses both operands as a uniform base + 32-bit per-lane byte offset (see gemm_planes_tile)
   {
     const long a_span = a.a_plane + (long)((a.M - 1) / a.a_rpb) * a.a_bs + (long)std::min(a.a_rpb, a.M) * a.lda + a.K + 64;
-    const long w_span = a.w_plane + (long)a.N * a.K + 64;
-    if (a.a_plane < 0 || a.w_plane < 0 || a.a_bs < 0 || 2 * a_span >= (1L << 32) || 2 * w_span >= (1L << 32)) {
+    if (a.a_plane < 0 || a.a_bs < 0 || 2 * a_span >= (1L << 32)) {
       throw Error(kErrInvalidArg, "plane GEMM operand spans more than the 4 GiB its 32-bit offsets reach");
     }
   }

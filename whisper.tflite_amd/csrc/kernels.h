@@ -82,7 +82,7 @@ bool gemm_variant_supported(int variant);
 // ------------------------------------------------------- GEMM on fp16 planes ---
 // The default encoder GEMM (k_gemm_planes.hip): both operands are pairs of fp16 planes (hi = fp16(x * scale), lo =
 // fp16(x * scale - hi); 4 bytes per element like fp32).  A planes: hi at A, lo at A + a_plane (element offsets, same
-// row addressing as GemmArgs); W planes [N][K]: hi at W, lo at W + w_plane (split_weight_planes).  Output: fp32 C
+// row addressing as GemmArgs); W: both planes in the blocked layout of split_weight_planes().  Output: fp32 C
 // (epilogues kEpiBias, | kEpiResidual, | kEpiGelu | kEpiPos, | kEpiKvLayout) or, when P != nullptr, planes of the
 // result for the next contraction (kEpiBias, | kEpiGelu): column n multiplied by out_scale[n / seg] before the split.
 // Requires N % 128 == 0, K % 32 == 0, lda / a_bs / ldc / c_bs multiples of 8 elements.
@@ -90,7 +90,6 @@ struct PlaneGemmArgs {
   const unsigned short* A = nullptr;
   long a_plane = 0;
   const unsigned short* W = nullptr;
-  long w_plane = 0;
   float* C = nullptr;
   unsigned short* P = nullptr;
   long p_plane = 0;
@@ -123,13 +122,17 @@ struct PlaneGemmArgs {
   int* nonfinite = nullptr;
 };
 bool launch_gemm_planes(const PlaneGemmArgs& a, int epi, hipStream_t s);
+// schedule of the 384-column plane tiles (0 in step, 1 ping-pong groups; k_gemm_planes.hip) — measurement knob
+int plane_gemm_mode();
+void set_plane_gemm_mode(int m);
 // bf16 storage mode (k_gemm_bf16.hip): A, W single bf16 matrices (the plane offsets and scales of the struct are
 // unused), K a multiple of 64; P set = bf16 output (row-major, or the cross-KV cache layout with kEpiKvLayout),
 // else fp32 output C
 void launch_gemm_bf16_planes(const PlaneGemmArgs& a, int epi, hipStream_t s);
 // W [N][K] fp32 -> bf16 [N][Kpad] (round to nearest even, zero filled)
 std::vector<unsigned short> round_weights_bf16(const float* W, int N, int K, int Kpad);
-// W [N][K] fp32 -> hi plane [N][Kpad] followed by lo plane [N][Kpad] (Kpad >= K, zero filled), scaled by `scale`
+// W [N][K] fp32 -> both fp16 planes, scaled by `scale`, as [N / 16][Kpad / 32][hi | lo][16 rows][32 k] with swizzled
+// 16-byte chunks: the LDS image of the plane GEMM's staging instructions, 1 KiB contiguous each (Kpad >= K, zero filled)
 std::vector<unsigned short> split_weight_planes(const float* W, int N, int K, int Kpad, float scale);
 
 // Decoder-step GEMM: out[M][N] = epi(pro(x)[M][K] . W[N][K]^T), M = positions x B clips <= 128 rows (row =
