@@ -16,6 +16,11 @@ int wt_dbg_gemm(wt_engine* h, int M, int N, int K, const float* A, const float* 
 int wt_dbg_gemm_planes(wt_engine* h, int M, int N, int K, const float* A, const float* W, const float* bias,
                        const float* R, const float* pos, int pos_period, int epi, int planes_out, int iters, float* C,
                        float* avg_ms, int n_cu /* CUs the tile choice assumes; 0 = all */);
+/* Teacher forcing for step-by-step comparisons: ids [clips][32] (prompt first) that every following decode of exactly
+ * `clips` clips (for a pair of pipelined batches: both, in chain order) feeds to the decoder instead of its own argmax
+ * choices; logits, id counts and the EOT rule are computed as always, the returned ids are the given ones.  clips = 0
+ * switches it off.  Ids outside the vocabulary are refused by the decode (WT_ERR_INVALID_ARG). */
+int wt_dbg_set_forced_ids(wt_engine* h, const int64_t* ids, int clips);
 /* schedule of the 384-column plane-GEMM tiles for subsequent launches of this process: 0 = gemm_planes_tile (both
  * wavefronts of a SIMD in step), 1 = gemm_planes_pp (ping-pong groups), 2 = gemm_planes_pp16 (ping-pong groups on
  * 16 x 16 x 32 MFMAs, default), 3 = + gemm_planes_v2 where it applies; A/B measurements in one process */
@@ -85,6 +90,20 @@ int wt_dbg_gemm_bf16(wt_engine* h, int M, int N, int K, const float* A, const fl
                      float* avg_ms);
 int wt_dbg_encoder_attention_bf16(wt_engine* h, int batch, int T, int heads, const float* qkv, int iters, float* out,
                                   float* avg_ms);
+/* the decoder's kernels in the bf16 storage mode (k_decoder.hip instantiations with BF = true): weights as one bf16 plane in
+ * fragment order, activations rounded to bf16 in registers, fp32 accumulation; self-attention and cross-attention on
+ * bf16 caches (the host passes fp32 arrays, the taps store them as bf16 and return the updated caches widened).  Same
+ * arguments as the taps without the suffix. */
+int wt_dbg_dec_gemm_bf16(wt_engine* h, int mode, int B, int N, int K, const float* X, const float* W, const float* bias,
+                         const float* R, float* Y, int64_t* argmax_out);
+int wt_dbg_dec_ln_gemm_bf16(wt_engine* h, int B, int N, int K, const float* xin, const int64_t* ids, int pos,
+                            const float* tok_emb, const float* pos_emb, int n_vocab, int n_pos, const float* ln_g,
+                            const float* ln_b, const float* W, const float* bias, int gelu, float* Y, float* xout);
+int wt_dbg_self_attention_bf16(wt_engine* h, int batch, int heads, int cap, int pos, int npos, const float* qkv,
+                               float* kcache, float* vcache, float* out);
+int wt_dbg_cross_attention_bf16(wt_engine* h, int batch, int heads, int T, int chunks, int nq, const float* x,
+                                const float* ln_g, const float* ln_b, const float* wq, const float* bq, const float* kc,
+                                const float* vc, float* out);
 #ifdef __cplusplus
 }
 #endif

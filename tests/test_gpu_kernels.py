@@ -618,3 +618,135 @@ def test_cross_attention_absorbed_bf16_storage(eng, B, H, T, chunks, nq):
             ref = wv[h * 64:(h + 1) * 64].astype(np.float64) @ c + bv[h * 64:(h + 1) * 64]
             worst = max(worst, np.abs(out[r, h * 64:(h + 1) * 64] - ref).max())
     assert worst < 4e-3, worst
+
+
+# ------------------------------------------------ the DECODER's kernels in the bf16 storage mode (round 4) ---
+# dec_gemm<..., BF = true>, dec_logits_persistent<..., true, ...>, self_attention_step<true>, cross_attention_step<..., true>:
+# weights are one bf16 plane in fragment order, activations are rounded to bf16 in registers (round to nearest even),
+# products are exact in fp32 and accumulated in fp32 — so against fp64 on the bf16-ROUNDED operands only fp32
+# accumulation error remains, the bar of the fp32-accurate kernels.
+
+@pytest.mark.parametrize("B,N,K", [(32, 512, 512), (64, 1536, 512), (7, 2048, 512), (64, 512, 2048), (33, 1000, 128), (32, 51865, 384),
+                                   (64, 51865, 512), (128, 1536, 512), (100, 384, 384), (128, 96, 128)])
+def test_decoder_gemm_bf16_storage(eng, B, N, K):
+    """Every epilogue of dec_gemm<BF = true> and the persistent logits kernel (N = 51865: whisper's vocabulary, base and
+    tiny widths; 64 rows = a pair of batches) with the fused argmax and its tie rule."""
+    rng = np.random.default_rng(B + N + K + 1)
+    X = rng.standard_normal((B, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / 16).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    ref = _bf16_round(X).astype(np.float64) @ _bf16_round(W).astype(np.float64).T
+    assert rel_err(eng.dbg_dec_gemm(X, W, bias, mode=0, bf16=True), ref + bias) < 3e-6
+    assert rel_err(eng.dbg_dec_gemm(X, W, bias, mode=1, bf16=True), gelu(ref + bias)) < 3e-6
+    if B <= 64 or N * K <= 1536 * 2048:
+        R = rng.standard_normal((B, N)).astype(np.float32)
+        Y = eng.dbg_dec_gemm(X, W, bias, mode=2, R=R, bf16=True)
+        assert rel_err(Y, R + bias + ref) < 3e-6
+        assert np.array_equal(Y, eng.dbg_dec_gemm(X, W, bias, mode=2, R=R, bf16=True))  # fixed reduction order
+    Y, am = eng.dbg_dec_gemm(X, W, mode=3, bf16=True)
+    assert rel_err(Y, ref) < 3e-6
+    assert list(am) == [int(N - 1 - np.argmax(Y[b][::-1])) for b in range(B)]
+    # it IS the bf16 instantiation: the fp32-accurate kernel on the same operands differs by bf16 rounding
+    assert rel_err(eng.dbg_dec_gemm(X, W, bias, mode=0), ref + bias) > 1e-4
+
+
+def test_decoder_argmax_tie_rule_bf16_storage(eng):
+    rng = np.random.default_rng(6)
+    B, N, K = 4, 512, 128
+    X = _bf16_round(rng.standard_normal((B, K)).astype(np.float32))
+    W = (rng.standard_normal((N, K)) / 64).astype(np.float32)
+    W[100] = W[7] = W[400] = X[0] / 4
+    W[33] = W[300] = X[1] / 4
+    Y, am = eng.dbg_dec_gemm(X, W, mode=3, bf16=True)
+    assert Y[0, 7] == Y[0, 100] == Y[0, 400] and am[0] == 400
+    assert am[1] == 300
+
+
+@pytest.mark.parametrize("B,K,N,gelu_on", [(32, 512, 1536, False), (9, 128, 512, True), (64, 512, 2048, True), (64, 384, 1152, False)])
+def test_decoder_ln_fused_gemm_bf16_storage(eng, B, K, N, gelu_on):
+    """LayerNorm prologue in fp32, its rows rounded to bf16 for the matrix cores.  The reference rounds an fp64
+    LayerNorm: an element within 1e-7 of a bf16 rounding boundary may round the other way (2^-8 of one product) —
+    hence an absolute bar of 1e-3 on O(1) outputs beside the fp32-accumulation bar on the median error."""
+    rng = np.random.default_rng(B + K + N + 2)
+    xin = (rng.standard_normal((B, K)) * 2 + 0.5).astype(np.float32)
+    g_, b_ = rng.standard_normal(K).astype(np.float32), rng.standard_normal(K).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / 16).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    Y, _ = eng.dbg_dec_ln_gemm(W, bias, g_, b_, xin=xin, gelu=gelu_on, bf16=True)
+    x = xin.astype(np.float64)
+    ln = (x - x.mean(1, keepdims=True)) / np.sqrt(x.var(1, keepdims=True) + 1e-5) * g_ + b_
+    ref = _bf16_round(ln.astype(np.float32)).astype(np.float64) @ _bf16_round(W).astype(np.float64).T + bias
+    if gelu_on:
+        ref = gelu(ref)
+    err = np.abs(Y - ref)
+    assert err.max() < 1e-3 and np.median(err) < 2e-6, (err.max(), np.median(err))
+
+
+def test_decoder_ln_fused_embedding_bf16_storage(eng):
+    rng = np.random.default_rng(9)
+    B, K, N, V = 6, 128, 384, 50
+    tok = rng.standard_normal((V, K)).astype(np.float32)
+    pos = rng.standard_normal((10, K)).astype(np.float32)
+    ids = np.array([3, 49, 0, 7, 7, 12], np.int64)
+    g_, b_ = np.ones(K, np.float32), np.zeros(K, np.float32)
+    W = (rng.standard_normal((N, K)) / 16).astype(np.float32)
+    Y, xout = eng.dbg_dec_ln_gemm(W, np.zeros(N, np.float32), g_, b_, ids=ids, pos=4, tok_emb=tok, pos_emb=pos, bf16=True)
+    assert np.array_equal(xout, tok[ids] + pos[4])  # the residual stream stays fp32 in the bf16 mode
+    x = (tok[ids] + pos[4]).astype(np.float64)
+    ln = (x - x.mean(1, keepdims=True)) / np.sqrt(x.var(1, keepdims=True) + 1e-5)
+    ref = _bf16_round(ln.astype(np.float32)).astype(np.float64) @ _bf16_round(W).astype(np.float64).T
+    assert np.abs(Y - ref).max() < 1e-3
+
+
+@pytest.mark.parametrize("H", [2, 6, 8])
+def test_self_attention_bf16_cache_appends_and_attends(eng, H):
+    """self_attention_step<true>: the prompt pass (four positions at once, causal among themselves), then one position
+    at a time up to the decoder's last (30), on a bf16 cache: the appended rows ARE the bf16 roundings, every position
+    reads back exactly what was appended (a wrong cache read at any position >= 5 shows here), and the new position's
+    own k / v enter rounded like the cached ones."""
+    rng = np.random.default_rng(30 + H)
+    B, cap = 3, 32
+    d = 64 * H
+    kc = np.zeros((B, cap, d), np.float32)
+    vc = np.zeros((B, cap, d), np.float32)
+    pos = 0
+    for npos in [4] + [1] * 27:
+        qkv = rng.standard_normal((npos * B, 3 * d)).astype(np.float32)
+        out, kc2, vc2 = eng.dbg_self_attention(qkv, kc, vc, pos, npos, bf16=True)
+        for p in range(npos):
+            kc[:, pos + p] = _bf16_round(qkv[p * B:(p + 1) * B, d:2 * d])
+            vc[:, pos + p] = _bf16_round(qkv[p * B:(p + 1) * B, 2 * d:])
+        assert np.array_equal(kc2, kc) and np.array_equal(vc2, vc), pos
+        for p in range(npos):
+            n = pos + p + 1
+            for b in range(B):
+                for h in range(H):
+                    sl = slice(h * 64, (h + 1) * 64)
+                    ref = attn_ref(qkv[p * B + b, sl].astype(np.float64)[None], kc[b, :n, sl].astype(np.float64),
+                                   vc[b, :n, sl].astype(np.float64))[0]
+                    assert np.abs(out[p * B + b, sl] - ref).max() < 1e-5, (pos, p, b, h)
+        pos += npos
+    assert pos == 31
+
+
+@pytest.mark.parametrize("B,H,T,chunks,nq", [(2, 8, 1500, 4, 1), (3, 6, 1500, 2, 1), (2, 2, 37, 8, 1), (64, 8, 1500, 1, 2), (5, 8, 200, 2, 3),
+                                             (3, 2, 64, 4, 4)])
+def test_cross_attention_bf16_cache(eng, B, H, T, chunks, nq):
+    """cross_attention_step<NQ, DM, true>: K / V cache rows of 64 bf16, eight lanes per key; the query projection stays
+    fp32.  Against fp64 on the bf16-rounded cache: the fp32-accurate kernel's bar."""
+    rng = np.random.default_rng(B + H + T + chunks + nq + 5)
+    d = H * 64
+    x = (rng.standard_normal((nq * B, d)) * 2 + 0.3).astype(np.float32)
+    g_, b_ = (1 + 0.2 * rng.standard_normal(d)).astype(np.float32), (0.1 * rng.standard_normal(d)).astype(np.float32)
+    wq = (rng.standard_normal((d, d)) / np.sqrt(d)).astype(np.float32)
+    bq = (0.1 * rng.standard_normal(d)).astype(np.float32)
+    kc = _bf16_round(rng.standard_normal((B, H, T, 64)).astype(np.float32))
+    vc = _bf16_round(rng.standard_normal((B, H, T, 64)).astype(np.float32))
+    out = eng.dbg_cross_attention(x, g_, b_, wq, bq, kc, vc, chunks, nq, bf16=True)
+    q = _ln64(x, g_, b_) @ wq.astype(np.float64).T + bq
+    for p in range(nq):
+        for b in (range(B) if B <= 5 else (0, B // 2, B - 1)):
+            for h in range(H):
+                sl = slice(h * 64, (h + 1) * 64)
+                ref = attn_ref(q[p * B + b, sl][None], kc[b, h].astype(np.float64), vc[b, h].astype(np.float64))[0]
+                assert np.abs(out[p * B + b, sl] - ref).max() < 2e-5, (p, b, h)

@@ -626,7 +626,36 @@ def _bf16_vs_fp32(e, mel, enc_ref=None):
     for b in range(mel.shape[0]):
         if top2[b, 1] - top2[b, 0] > 2 * dl:
             assert ids16[b, 4] == ids32[b, 4]
+    _bf16_every_step_behind_the_fp32_prefix(e, mel, ids32, lg32)
     return ids16, n16, ids32, n32
+
+
+def _bf16_every_step_behind_the_fp32_prefix(e, mel, ids32, lg32, pipelined_pair=False):
+    """All 27 logit rows of the bf16 mode, not only the first: the decoder is fed the fp32 run's ids (teacher forcing,
+    wt_dbg_set_forced_ids), so step i of both runs sits behind the same prefix and the self-attention cache, the
+    cross-attention and the logits GEMM of EVERY position are compared with the fp32 engine (itself within 1e-4 of the
+    oracle): per step |logit difference| < 0.15 — the first step's bar — and the bf16 argmax may only differ from the
+    fp32 one inside twice that step's error."""
+    B = mel.shape[0]
+    assert e.get_option("bf16") == 1
+    e.set_forced_ids(ids32)
+    try:
+        ids_f, n_f, _, lg_f = e.encdec_debug_batch(mel)
+    finally:
+        e.set_forced_ids(None)
+    assert np.array_equal(ids_f, ids32) and (n_f == 31).all()
+    steps = lg32.shape[1]
+    assert steps == 27
+    worst = 0.0
+    for i in range(steps):
+        dl = np.abs(lg_f[:, i] - lg32[:, i]).max()
+        worst = max(worst, dl)
+        assert dl < 1.5e-1, (i, dl)
+        top2 = np.sort(lg32[:, i], axis=1)[:, -2:]
+        for b in range(B):
+            if top2[b, 1] - top2[b, 0] > 2 * dl:
+                assert int(np.argmax(lg_f[b, i])) == int(ids32[b, 4 + i]), (b, i)
+    assert worst > 1e-4  # bf16 arithmetic, not a replay of the fp32 run
 
 
 def test_bf16_storage_mode_micro_and_tiny(micro, tiny, orc):
@@ -686,4 +715,41 @@ def test_config4_base_batch64_bf16_storage(pkg, assets, orc):
     ids16, n16, _, _ = _bf16_vs_fp32(e, mel[:2], enc_ref)
     ids64, n64 = e.encdec_tokens_batch(mel)
     assert np.array_equal(ids64[:2], ids16) and (n64 == 31).all()
+    # all 64 rows of the chain (the 64-row instantiations of the decoder's kernels), every one of the 27 steps
+    e.set_option("bf16", 0)
+    ids32, _, _, lg32 = e.encdec_debug_batch(mel)
+    e.set_option("bf16", 1)
+    _bf16_every_step_behind_the_fp32_prefix(e, mel, ids32, lg32)
     e.close()
+
+
+def test_forced_ids_tap(micro):
+    """wt_dbg_set_forced_ids: fed its own greedy ids the decoder reproduces its logits bit for bit; fed another
+    sequence, the logits agree up to the first changed position and differ behind it; a clip count other than the
+    decode's, or an id outside the vocabulary, is refused."""
+    e, _ = micro
+    e.set_prompt([3, 5, 7, 11])
+    e.set_option("stop_at_eot", 0)
+    mel = np.random.default_rng(5).uniform(-1.0, 1.5, size=(3,) + e.mel_shape).astype(np.float32)
+    ids, n, _, lg = e.encdec_debug_batch(mel)
+    e.set_forced_ids(ids)
+    try:
+        ids_f, n_f, _, lg_f = e.encdec_debug_batch(mel)
+        assert np.array_equal(ids_f, ids) and np.array_equal(n_f, n) and np.array_equal(lg_f, lg)
+        other = ids.copy()
+        other[:, 10] = (other[:, 10] + 1) % 1000  # position 10 is the input of step 7 (row index 7 = position 10's successor)
+        e.set_forced_ids(other)
+        ids_o, _, _, lg_o = e.encdec_debug_batch(mel)
+        assert np.array_equal(ids_o, other)
+        assert np.array_equal(lg_o[:, :7], lg[:, :7]) and not np.array_equal(lg_o[:, 7], lg[:, 7])
+        with pytest.raises(Exception):
+            e.encdec_debug_batch(mel[:2])
+        bad = ids.copy()
+        bad[0, 6] = 10 ** 6
+        e.set_forced_ids(bad)
+        with pytest.raises(Exception):
+            e.encdec_debug_batch(mel)
+    finally:
+        e.set_forced_ids(None)
+    ids2, _, _, lg2 = e.encdec_debug_batch(mel)
+    assert np.array_equal(ids2, ids) and np.array_equal(lg2, lg)

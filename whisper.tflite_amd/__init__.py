@@ -49,7 +49,8 @@ CAPI_SYMBOLS = [
 DEBUG_SYMBOLS = [
     "wt_dbg_cross_absorbed", "wt_dbg_cross_absorbed_bf16", "wt_dbg_gemm_planes_ln", "wt_dbg_gemm", "wt_dbg_gemm_bench", "wt_dbg_dec_gemm_bench", "wt_dbg_dec_gemm", "wt_dbg_dec_ln_gemm", "wt_dbg_layernorm", "wt_dbg_encoder_attention",
     "wt_dbg_cross_attention", "wt_dbg_self_attention", "wt_dbg_interference", "wt_dbg_concurrency",
-    "wt_dbg_gemm_planes", "wt_dbg_set_plane_gemm_mode", "wt_dbg_encoder_attention_planes", "wt_dbg_gemm_bf16", "wt_dbg_encoder_attention_bf16",
+    "wt_dbg_gemm_planes", "wt_dbg_set_plane_gemm_mode", "wt_dbg_set_forced_ids", "wt_dbg_dec_gemm_bf16", "wt_dbg_dec_ln_gemm_bf16",
+    "wt_dbg_self_attention_bf16", "wt_dbg_cross_attention_bf16", "wt_dbg_encoder_attention_planes", "wt_dbg_gemm_bf16", "wt_dbg_encoder_attention_bf16",
 ]
 
 
@@ -153,9 +154,14 @@ def lib() -> ctypes.CDLL:
         L.wt_dbg_dec_ln_gemm.argtypes = [c_void_p, c_int, c_int, c_int, fp, ip64, c_int, fp, fp,
                                          c_int, c_int, fp, fp, fp, fp, c_int, fp, fp]
         L.wt_dbg_layernorm.argtypes = [c_void_p, c_int, c_int, fp, fp, fp, fp]
+        L.wt_dbg_set_forced_ids.argtypes = [c_void_p, POINTER(c_int64), c_int]
+        L.wt_dbg_dec_gemm_bf16.argtypes = L.wt_dbg_dec_gemm.argtypes
+        L.wt_dbg_dec_ln_gemm_bf16.argtypes = L.wt_dbg_dec_ln_gemm.argtypes
         L.wt_dbg_encoder_attention.argtypes = [c_void_p, c_int, c_int, c_int, fp, fp]
         L.wt_dbg_cross_attention.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, fp, fp, fp, fp, fp, fp, fp, fp]
         L.wt_dbg_self_attention.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, fp, fp, fp, fp]
+        L.wt_dbg_self_attention_bf16.argtypes = L.wt_dbg_self_attention.argtypes
+        L.wt_dbg_cross_attention_bf16.argtypes = L.wt_dbg_cross_attention.argtypes
         _lib = L
     return _lib
 
@@ -542,13 +548,24 @@ class Engine:
         self._check(lib().wt_dbg_gemm_bench(self._h, M, N, K, epi, variant, iters, byref(ms)))
         return ms.value
 
+    def set_forced_ids(self, ids=None):
+        """Teacher forcing (test tap): ids [clips][32] every following decode of that many clips follows instead of its
+        own argmax; None switches it off."""
+        if ids is None:
+            self._check(lib().wt_dbg_set_forced_ids(self._h, None, 0))
+            return
+        a = np.ascontiguousarray(ids, dtype=np.int64)
+        assert a.ndim == 2 and a.shape[1] == 32
+        self._check(lib().wt_dbg_set_forced_ids(self._h, a.ctypes.data_as(POINTER(c_int64)), a.shape[0]))
+
     def dbg_dec_gemm_bench(self, kind, B, N, K, rows=None, iters=200) -> float:
         us = c_float(0)
         self._check(lib().wt_dbg_dec_gemm_bench(self._h, kind, B, N, K, rows or B, iters, byref(us)))
         return us.value
 
-    def dbg_dec_gemm(self, X, W, bias=None, mode=0, R=None):
-        """mode 0 bias, 1 bias+gelu, 2 residual (Y = R + bias + X.W^T), 3 logits + argmax."""
+    def dbg_dec_gemm(self, X, W, bias=None, mode=0, R=None, bf16=False):
+        """mode 0 bias, 1 bias+gelu, 2 residual (Y = R + bias + X.W^T), 3 logits + argmax.  bf16: the bf16 storage
+        mode's instantiation (weights one bf16 plane, activations rounded to bf16 in registers)."""
         X, W = _f32(X), _f32(W)
         B, K = X.shape
         N = W.shape[0]
@@ -556,12 +573,12 @@ class Engine:
         R = _f32(R) if R is not None else None
         Y = np.zeros((B, N), np.float32)
         am = np.zeros(B, np.int64)
-        self._check(lib().wt_dbg_dec_gemm(self._h, mode, B, N, K, _fp(X), _fp(W), _fp(bias), _fp(R), _fp(Y),
-                                          am.ctypes.data_as(POINTER(c_int64))))
+        fn = lib().wt_dbg_dec_gemm_bf16 if bf16 else lib().wt_dbg_dec_gemm
+        self._check(fn(self._h, mode, B, N, K, _fp(X), _fp(W), _fp(bias), _fp(R), _fp(Y), am.ctypes.data_as(POINTER(c_int64))))
         return (Y, am) if mode == 3 else Y
 
     def dbg_dec_ln_gemm(self, W, bias, ln_g, ln_b, xin=None, ids=None, pos=0, tok_emb=None, pos_emb=None,
-                        gelu=False):
+                        gelu=False, bf16=False):
         W, bias, ln_g, ln_b = _f32(W), _f32(bias), _f32(ln_g), _f32(ln_b)
         N, K = W.shape
         xin = _f32(xin) if xin is not None else None
@@ -571,7 +588,8 @@ class Engine:
         B = xin.shape[0] if xin is not None else ids_a.shape[0]
         Y = np.zeros((B, N), np.float32)
         xout = np.zeros((B, K), np.float32)
-        self._check(lib().wt_dbg_dec_ln_gemm(
+        fn = lib().wt_dbg_dec_ln_gemm_bf16 if bf16 else lib().wt_dbg_dec_ln_gemm
+        self._check(fn(
             self._h, B, N, K, _fp(xin),
             ids_a.ctypes.data_as(POINTER(c_int64)) if ids_a is not None else None, pos, _fp(tok_emb), _fp(pos_emb),
             tok_emb.shape[0] if tok_emb is not None else 0, pos_emb.shape[0] if pos_emb is not None else 0,
@@ -590,22 +608,22 @@ class Engine:
         self._check(lib().wt_dbg_encoder_attention(self._h, batch, T, heads, _fp(qkv), _fp(out)))
         return out
 
-    def dbg_cross_attention(self, x, ln_g, ln_b, wq, bq, kc, vc, chunks=2, nq=1):
+    def dbg_cross_attention(self, x, ln_g, ln_b, wq, bq, kc, vc, chunks=2, nq=1, bf16=False):
         """x [nq*B][d] residual rows (row = p * B + b) -> attention output [nq*B][d]; the query projection
         q = LayerNorm(x) . wq^T + bq runs inside the kernel."""
         x, ln_g, ln_b, wq, bq, kc, vc = (_f32(a) for a in (x, ln_g, ln_b, wq, bq, kc, vc))
         B, H, T, _ = kc.shape
         out = np.zeros((nq * B, H * 64), np.float32)
-        self._check(lib().wt_dbg_cross_attention(self._h, B, H, T, chunks, nq, _fp(x), _fp(ln_g), _fp(ln_b), _fp(wq),
-                                                 _fp(bq), _fp(kc), _fp(vc), _fp(out)))
+        fn = lib().wt_dbg_cross_attention_bf16 if bf16 else lib().wt_dbg_cross_attention
+        self._check(fn(self._h, B, H, T, chunks, nq, _fp(x), _fp(ln_g), _fp(ln_b), _fp(wq), _fp(bq), _fp(kc), _fp(vc), _fp(out)))
         return out
 
-    def dbg_self_attention(self, qkv, kcache, vcache, pos, npos=1):
+    def dbg_self_attention(self, qkv, kcache, vcache, pos, npos=1, bf16=False):
         qkv, kcache, vcache = _f32(qkv), _f32(kcache).copy(), _f32(vcache).copy()
         B, cap, d = kcache.shape
         out = np.zeros((npos * B, d), np.float32)
-        self._check(lib().wt_dbg_self_attention(self._h, B, d // 64, cap, pos, npos, _fp(qkv), _fp(kcache),
-                                                _fp(vcache), _fp(out)))
+        fn = lib().wt_dbg_self_attention_bf16 if bf16 else lib().wt_dbg_self_attention
+        self._check(fn(self._h, B, d // 64, cap, pos, npos, _fp(qkv), _fp(kcache), _fp(vcache), _fp(out)))
         return out, kcache, vcache
 
 

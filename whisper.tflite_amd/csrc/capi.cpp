@@ -706,8 +706,8 @@ namespace {
 struct DevTiled {
   void* p = nullptr;
   float scale = 1.0f;
-  DevTiled(const float* W, int N, int K) {
-    const std::vector<unsigned short> planes = wt::tile_weights_f16(W, N, K, &scale);
+  DevTiled(const float* W, int N, int K, bool bf16 = false) {
+    const std::vector<unsigned short> planes = bf16 ? wt::tile_weights_bf16(W, N, K) : wt::tile_weights_f16(W, N, K, &scale);
     hipchk(hipMalloc(&p, std::max<size_t>(planes.size(), 1) * 2), "hipMalloc");
     hipchk(hipMemcpy(p, planes.data(), planes.size() * 2, hipMemcpyHostToDevice), "H2D");
   }
@@ -818,6 +818,15 @@ int wt_dbg_gemm_planes(wt_engine* h, int M, int N, int K, const float* A, const 
       (void)hipEventDestroy(e0);
       (void)hipEventDestroy(e1);
     }
+  });
+}
+
+int wt_dbg_set_forced_ids(wt_engine* h, const int64_t* ids, int clips) {
+  if (!h || clips < 0 || clips > 4096 || (clips && !ids)) return WT_ERR_INVALID_ARG;
+  return guarded(h, [&] {
+    h->impl->forced_ids.assign(ids, ids + size_t(clips) * 32);
+    for (long long v : h->impl->forced_ids)
+      if (v < 0) throw wt::Error(wt::kErrInvalidArg, "forced ids must be token ids");
   });
 }
 
@@ -1095,8 +1104,8 @@ int wt_dbg_dec_gemm_bench(wt_engine* h, int kind, int B, int N, int K, int rows,
   });
 }
 
-int wt_dbg_dec_gemm(wt_engine* h, int mode, int B, int N, int K, const float* X, const float* W,
-                    const float* bias, const float* R, float* Y, int64_t* argmax_out) {
+static int dbg_dec_gemm_impl(wt_engine* h, int mode, int B, int N, int K, const float* X, const float* W, const float* bias,
+                             const float* R, float* Y, int64_t* argmax_out, bool bf) {
   if (!h || mode < 0 || mode > 3 || B < 1 || B > 128 || (mode == 2 && !R)) {
     return WT_ERR_INVALID_ARG;
   }
@@ -1104,7 +1113,7 @@ int wt_dbg_dec_gemm(wt_engine* h, int mode, int B, int N, int K, const float* X,
   const int rows_per = B > 64 ? (B % 4 == 0 ? B / 4 : (B % 2 == 0 ? B / 2 : 0)) : B;
   if (rows_per == 0) return WT_ERR_INVALID_ARG;
   return guarded(h, [&] {
-    const DevTiled dW(W, N, K);
+    const DevTiled dW(W, N, K, bf);
     const int n_tiles = (N + 31) / 32;
     DevBuf dX(X, size_t(B) * K), dB(bias, N);
     DevBuf dY(mode == 2 ? R : nullptr, size_t(B) * N);
@@ -1112,6 +1121,7 @@ int wt_dbg_dec_gemm(wt_engine* h, int mode, int B, int N, int K, const float* X,
     hipchk(hipMemset(dBest.p, 0, size_t(B) * 8 * n_tiles), "memset");
     wt::DecGemmArgs g;
     g.Wt = dW.w(); g.w_scale = dW.scale; g.N = N; g.K = K; g.B = rows_per > 0 ? rows_per : B; g.M = B; g.X = dX.p; g.ldx = K;
+    g.bf16 = bf;
     g.bias = dB.p; g.R = dY.p; g.Y = dY.p; g.ldy = N;  // residual in place, as the engine does
     g.best = reinterpret_cast<unsigned long long*>(dBest.p);
     const int epi = mode == 0 ? wt::kDecBias : mode == 1 ? wt::kDecBiasGelu : mode == 2 ? wt::kDecResid : wt::kDecLogits;
@@ -1131,13 +1141,21 @@ int wt_dbg_dec_gemm(wt_engine* h, int mode, int B, int N, int K, const float* X,
   });
 }
 
-int wt_dbg_dec_ln_gemm(wt_engine* h, int B, int N, int K, const float* xin, const int64_t* ids, int pos,
-                       const float* tok_emb, const float* pos_emb, int n_vocab, int n_pos,
-                       const float* ln_g, const float* ln_b, const float* W, const float* bias,
-                       int gelu, float* Y, float* xout) {
+int wt_dbg_dec_gemm(wt_engine* h, int mode, int B, int N, int K, const float* X, const float* W,
+                    const float* bias, const float* R, float* Y, int64_t* argmax_out) {
+  return dbg_dec_gemm_impl(h, mode, B, N, K, X, W, bias, R, Y, argmax_out, false);
+}
+int wt_dbg_dec_gemm_bf16(wt_engine* h, int mode, int B, int N, int K, const float* X, const float* W,
+                         const float* bias, const float* R, float* Y, int64_t* argmax_out) {
+  return dbg_dec_gemm_impl(h, mode, B, N, K, X, W, bias, R, Y, argmax_out, true);
+}
+
+static int dbg_dec_ln_gemm_impl(wt_engine* h, int B, int N, int K, const float* xin, const int64_t* ids, int pos,
+                                const float* tok_emb, const float* pos_emb, int n_vocab, int n_pos, const float* ln_g,
+                                const float* ln_b, const float* W, const float* bias, int gelu, float* Y, float* xout, bool bf) {
   if (!h || B < 1 || B > 64 || (K != 128 && K != 384 && K != 512) || (!xin && !ids) || pos < 0 || (ids && pos >= n_pos)) return WT_ERR_INVALID_ARG;
   return guarded(h, [&] {
-    const DevTiled dW(W, N, K);
+    const DevTiled dW(W, N, K, bf);
     DevBuf dxin(xin, xin ? size_t(B) * K : 0);
     DevBuf dtok(tok_emb, ids ? size_t(n_vocab) * K : 0), dpos(pos_emb, ids ? size_t(n_pos) * K : 0);
     DevBuf dg(ln_g, K), db(ln_b, K), dB(bias, N), dY(size_t(B) * N), dxo(size_t(B) * K);
@@ -1149,7 +1167,7 @@ int wt_dbg_dec_ln_gemm(wt_engine* h, int B, int N, int K, const float* xin, cons
     hipchk(hipMemcpy(dids.p, idrows.data(), idrows.size() * 8, hipMemcpyHostToDevice), "H2D ids");
     hipchk(hipMemset(dxo.p, 0, size_t(B) * K * 4), "memset");
     wt::DecGemmArgs g;
-    g.Wt = dW.w(); g.w_scale = dW.scale; g.N = N; g.K = K; g.B = B;
+    g.Wt = dW.w(); g.w_scale = dW.scale; g.N = N; g.K = K; g.B = B; g.bf16 = bf;
     g.xin = dxin.p; g.xout = dxo.p; g.ln_g = dg.p; g.ln_b = db.p;
     if (ids) {
       g.ids = reinterpret_cast<const long long*>(dids.p); g.ids_stride = pos + 1; g.pos = pos;
@@ -1161,6 +1179,19 @@ int wt_dbg_dec_ln_gemm(wt_engine* h, int B, int N, int K, const float* xin, cons
     dY.to_host(Y, size_t(B) * N);
     if (xout) dxo.to_host(xout, size_t(B) * K);
   });
+}
+
+int wt_dbg_dec_ln_gemm(wt_engine* h, int B, int N, int K, const float* xin, const int64_t* ids, int pos,
+                       const float* tok_emb, const float* pos_emb, int n_vocab, int n_pos,
+                       const float* ln_g, const float* ln_b, const float* W, const float* bias,
+                       int gelu, float* Y, float* xout) {
+  return dbg_dec_ln_gemm_impl(h, B, N, K, xin, ids, pos, tok_emb, pos_emb, n_vocab, n_pos, ln_g, ln_b, W, bias, gelu, Y, xout, false);
+}
+int wt_dbg_dec_ln_gemm_bf16(wt_engine* h, int B, int N, int K, const float* xin, const int64_t* ids, int pos,
+                            const float* tok_emb, const float* pos_emb, int n_vocab, int n_pos,
+                            const float* ln_g, const float* ln_b, const float* W, const float* bias,
+                            int gelu, float* Y, float* xout) {
+  return dbg_dec_ln_gemm_impl(h, B, N, K, xin, ids, pos, tok_emb, pos_emb, n_vocab, n_pos, ln_g, ln_b, W, bias, gelu, Y, xout, true);
 }
 
 int wt_dbg_layernorm(wt_engine* h, int M, int d, const float* x, const float* g, const float* b, float* y) {
@@ -1196,15 +1227,17 @@ int wt_dbg_encoder_attention(wt_engine* h, int batch, int T, int heads, const fl
   });
 }
 
-int wt_dbg_cross_attention(wt_engine* h, int batch, int heads, int T, int chunks, int nq, const float* x,
-                           const float* ln_g, const float* ln_b, const float* wq, const float* bq, const float* kc,
-                           const float* vc, float* out) {
+static int dbg_cross_attention_impl(wt_engine* h, int batch, int heads, int T, int chunks, int nq, const float* x,
+                                    const float* ln_g, const float* ln_b, const float* wq, const float* bq, const float* kc,
+                                    const float* vc, float* out, bool bf) {
   if (!h || (chunks != 1 && chunks != 2 && chunks != 4 && chunks != 8) || batch < 1 || nq < 1 || nq * batch > 128 ||
       !x || !ln_g || !ln_b || !wq || !bq || !kc || !vc || !out)
     return WT_ERR_INVALID_ARG;
   return guarded(h, [&] {
     const size_t d = size_t(heads) * 64, rows = size_t(nq) * batch;
-    DevBuf dx(x, rows * d), dg(ln_g, d), db(ln_b, d), dbq(bq, d), dk(kc, size_t(batch) * T * d), dv(vc, size_t(batch) * T * d);
+    DevBuf dx(x, rows * d), dg(ln_g, d), db(ln_b, d), dbq(bq, d), dk(bf ? nullptr : kc, bf ? 0 : size_t(batch) * T * d),
+        dv(bf ? nullptr : vc, bf ? 0 : size_t(batch) * T * d);
+    const DevBf16 dkb(bf ? kc : nullptr, bf ? size_t(batch) * T * d : 0), dvb(bf ? vc : nullptr, bf ? size_t(batch) * T * d : 0);
     const std::vector<float> wqt = wt::cross_q_layout(wq, int(d));
     DevBuf dwq(wqt.data(), wqt.size());
     DevBuf dws(rows * heads * chunks * 68), dout(rows * d), dzero(d);
@@ -1216,7 +1249,8 @@ int wt_dbg_cross_attention(wt_engine* h, int batch, int heads, int T, int chunks
     for (size_t i = 0; i < d; ++i) eye[i * d + i] = 1.0f;
     const DevTiled dW(eye.data(), int(d), int(d));
     wt::CrossAttnArgs ca;
-    ca.x = dx.p; ca.ln_g = dg.p; ca.ln_b = db.p; ca.wq_t = dwq.p; ca.bq = dbq.p; ca.kc = dk.p; ca.vc = dv.p;
+    ca.x = dx.p; ca.ln_g = dg.p; ca.ln_b = db.p; ca.wq_t = dwq.p; ca.bq = dbq.p;
+    ca.kc = bf ? static_cast<const void*>(dkb.ptr()) : dk.p; ca.vc = bf ? static_cast<const void*>(dvb.ptr()) : dv.p; ca.bf16 = bf;
     ca.ws = dws.p; ca.batch = batch; ca.heads = heads; ca.T = T; ca.chunks = chunks; ca.nq = nq;
     wt::launch_cross_attention(ca, h->impl->stream());
     wt::DecGemmArgs g;
@@ -1227,6 +1261,17 @@ int wt_dbg_cross_attention(wt_engine* h, int batch, int heads, int T, int chunks
     h->impl->sync();
     dout.to_host(out, rows * d);
   });
+}
+
+int wt_dbg_cross_attention(wt_engine* h, int batch, int heads, int T, int chunks, int nq, const float* x,
+                           const float* ln_g, const float* ln_b, const float* wq, const float* bq, const float* kc,
+                           const float* vc, float* out) {
+  return dbg_cross_attention_impl(h, batch, heads, T, chunks, nq, x, ln_g, ln_b, wq, bq, kc, vc, out, false);
+}
+int wt_dbg_cross_attention_bf16(wt_engine* h, int batch, int heads, int T, int chunks, int nq, const float* x,
+                                const float* ln_g, const float* ln_b, const float* wq, const float* bq, const float* kc,
+                                const float* vc, float* out) {
+  return dbg_cross_attention_impl(h, batch, heads, T, chunks, nq, x, ln_g, ln_b, wq, bq, kc, vc, out, true);
 }
 
 static int dbg_cross_absorbed_impl(wt_engine* h, int batch, int heads, int T, int chunks, int nq, const float* qp, const float* E,
@@ -1282,19 +1327,33 @@ int wt_dbg_cross_absorbed_bf16(wt_engine* h, int batch, int heads, int T, int ch
   return dbg_cross_absorbed_impl(h, batch, heads, T, chunks, nq, qp, E, wv, bv, out, iters, avg_us, true);
 }
 
-int wt_dbg_self_attention(wt_engine* h, int batch, int heads, int cap, int pos, int npos, const float* qkv,
-                          float* kcache, float* vcache, float* out) {
+static int dbg_self_attention_impl(wt_engine* h, int batch, int heads, int cap, int pos, int npos, const float* qkv,
+                                   float* kcache, float* vcache, float* out, bool bf) {
   if (!h || npos < 1 || pos < 0 || pos + npos > cap || cap > 64) return WT_ERR_INVALID_ARG;
   return guarded(h, [&] {
-    const size_t d = size_t(heads) * 64, rows = size_t(npos) * batch;
-    DevBuf dq(qkv, rows * 3 * d), dk(kcache, size_t(batch) * cap * d), dv(vcache, size_t(batch) * cap * d),
-        dout(rows * d);
-    wt::launch_self_attention(dq.p, dk.p, dv.p, cap, pos, npos, dout.p, batch, heads, h->impl->stream());
+    const size_t d = size_t(heads) * 64, rows = size_t(npos) * batch, nc = size_t(batch) * cap * d;
+    DevBuf dq(qkv, rows * 3 * d), dk(bf ? nullptr : kcache, bf ? 0 : nc), dv(bf ? nullptr : vcache, bf ? 0 : nc), dout(rows * d);
+    const DevBf16 dkb(bf ? kcache : nullptr, bf ? nc : 0), dvb(bf ? vcache : nullptr, bf ? nc : 0);  // bf16 caches (storage mode)
+    wt::launch_self_attention(dq.p, bf ? static_cast<void*>(dkb.ptr()) : dk.p, bf ? static_cast<void*>(dvb.ptr()) : dv.p, cap, pos,
+                              npos, dout.p, batch, heads, h->impl->stream(), bf);
     h->impl->sync();
     dout.to_host(out, rows * d);
-    dk.to_host(kcache, size_t(batch) * cap * d);
-    dv.to_host(vcache, size_t(batch) * cap * d);
+    if (bf) {
+      dkb.to_host(kcache, nc);
+      dvb.to_host(vcache, nc);
+    } else {
+      dk.to_host(kcache, nc);
+      dv.to_host(vcache, nc);
+    }
   });
+}
+int wt_dbg_self_attention(wt_engine* h, int batch, int heads, int cap, int pos, int npos, const float* qkv,
+                          float* kcache, float* vcache, float* out) {
+  return dbg_self_attention_impl(h, batch, heads, cap, pos, npos, qkv, kcache, vcache, out, false);
+}
+int wt_dbg_self_attention_bf16(wt_engine* h, int batch, int heads, int cap, int pos, int npos, const float* qkv,
+                               float* kcache, float* vcache, float* out) {
+  return dbg_self_attention_impl(h, batch, heads, cap, pos, npos, qkv, kcache, vcache, out, true);
 }
 
 }  // extern "C"

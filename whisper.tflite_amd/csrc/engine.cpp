@@ -1643,8 +1643,17 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
     if (id < 0 || id >= V) throw Error(1, "prompt token id outside the model's vocabulary");
   }
   const int max_pos = int(std::min<long>(std::max<long>(max_tokens, n_prompt), 31));
+  const bool forced = !forced_ids.empty();
+  if (forced && forced_ids.size() != size_t(batch) * stride) {
+    throw Error(kErrInvalidArg, "forced ids are set for another number of clips than this decode has");
+  }
+  for (long long id : forced_ids) {
+    if (id < 0 || id >= V) throw Error(kErrInvalidArg, "forced token id outside the model's vocabulary");
+  }
   for (int b = 0; b < batch; ++b) {
-    for (int i = 0; i < stride; ++i) h_ids_[size_t(b) * stride + i] = i < n_prompt ? prompt[i] : 0;
+    for (int i = 0; i < stride; ++i) {
+      h_ids_[size_t(b) * stride + i] = forced ? forced_ids[size_t(b) * stride + i] : (i < n_prompt ? prompt[i] : 0);
+    }
     h_n_[b] = n_prompt;
   }
   int chunks = int(cross_chunks);  // 1, 2, 4 or 8 (wt_engine_set_option), 0 = by batch size
@@ -1814,7 +1823,7 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
                                   hipMemcpyDeviceToHost, stream_));
         }
         DT(10, launch_select_token(dw.best, (V + 31) / 32, dw.ids, stride, last, dw.n_ids, dw.finished,
-                            vocab_.token_eot, int(stop_at_eot), batch, stream_));
+                            vocab_.token_eot, int(stop_at_eot), batch, stream_, forced));
         ++steps;
       }
     }
@@ -1834,7 +1843,7 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
   // kernels' one-time attribute set-up) and then captures one hipGraph per slot; later calls
   // replay the slot's graph: one host call instead of ~1100. The logits tap stays eager.
   auto key_of = [&](int si) {
-    return std::vector<long long>{si, batch, max_pos, n_prompt, chunks, long(stop_at_eot), fc2_ksplit, bf16, absorbed ? 1 : 0, n_abs, paired ? 1 : 0, stream_override};
+    return std::vector<long long>{si, batch, max_pos, n_prompt, chunks, long(stop_at_eot), fc2_ksplit, bf16, absorbed ? 1 : 0, n_abs, paired ? 1 : 0, stream_override, forced ? 1 : 0};
   };
   hipGraphExec_t exec = nullptr;
   if (use_graphs && !logits_host) {

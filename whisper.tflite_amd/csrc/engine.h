@@ -129,6 +129,9 @@ class Engine {
   long kernel_timers = 1;
   // non-empty: replaces the reference's hard-coded prompt (test-sized vocabularies)
   std::vector<long long> prompt_override;
+  // test tap (wt_dbg_set_forced_ids): id rows [clips][32] every decode of exactly that many clips follows instead of its
+  // own argmax (the argmax still runs: logits, counts and the EOT rule are unchanged); empty = off
+  std::vector<long long> forced_ids;
   // ids the decoder starts from (prompt_override, or the reference's rule for the engine type)
   std::vector<long long> prompt() const;
 

@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void mel_normalize(float* __restrict__ logmel,
 __global__ __launch_bounds__(256) void select_token(const unsigned long long* __restrict__ best,
                                                     int n_tiles, long long* ids, int ids_stride,
                                                     int pos, int* n_ids, int* finished, long long eot,
-                                                    int stop_at_eot) {
+                                                    int stop_at_eot, int keep_ids) {
   __shared__ unsigned long long wmax[4];
   const int b = blockIdx.x;
   unsigned long long p = 0ull;
@@ -302,7 +302,9 @@ __global__ __launch_bounds__(256) void select_token(const unsigned long long* __
   const long long tok = (long long)(unsigned)(p & 0xffffffffull);
   // ids always receives the token so the next position has a defined input; n_ids stops
   // growing once the clip has emitted EOT (reference loop break, whisper.cpp:397-399)
-  ids[(long)b * ids_stride + pos + 1] = tok;
+  // keep_ids (test tap wt_dbg_set_forced_ids): the id rows were filled by the host and stay as they are, so every
+  // position is decoded behind a GIVEN prefix (the logits of two engine modes become comparable step by step)
+  if (!keep_ids) ids[(long)b * ids_stride + pos + 1] = tok;
   if (!finished[b]) {
     n_ids[b] = pos + 2;
     if (stop_at_eot && tok == eot) finished[b] = 1;
@@ -407,9 +409,9 @@ void launch_mel_normalize(float* logmel, const unsigned* clip_max, int batch, in
 
 void launch_select_token(const unsigned long long* best, int n_tiles, long long* ids, int ids_stride,
                          int pos, int* n_ids, int* finished, long long eot, int stop_at_eot, int batch,
-                         hipStream_t s) {
+                         hipStream_t s, bool keep_ids) {
   hipLaunchKernelGGL(select_token, dim3(batch), dim3(256), 0, s, best, n_tiles, ids, ids_stride, pos,
-                     n_ids, finished, eot, stop_at_eot);
+                     n_ids, finished, eot, stop_at_eot, keep_ids ? 1 : 0);
 }
 
 

@@ -292,9 +292,10 @@ void launch_cross_absorbed_combine(const float* ws, const float* wv_t, const flo
                                    int chunks, int d_model, hipStream_t s);
 // Greedy selection after the logits GEMM: reduces the per-tile (value, column) records
 // best[B][n_tiles], appends to ids and applies the EOT stop (reference whisper.cpp:397-399).
+// keep_ids: the id rows are given (test tap): the token is selected, counted and checked for EOT but not written.
 void launch_select_token(const unsigned long long* best, int n_tiles, long long* ids, int ids_stride,
                          int pos, int* n_ids, int* finished, long long eot, int stop_at_eot, int batch,
-                         hipStream_t s);
+                         hipStream_t s, bool keep_ids = false);
 
 // ---- load-time re-layouts of decoder weights (host) ----
 // bf16 storage mode: W [N][K] fp32 -> ONE bf16 plane (round to nearest even) in the same fragment order,
