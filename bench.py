@@ -226,7 +226,7 @@ def traffic_from_profile(dom, bf16, known_names):
     """HBM-side bytes per launch of kernel class `dom` from the committed rocprofv3 --pmc summary (separate
     FETCH_SIZE / WRITE_SIZE passes, tools/pmc_traffic.py).  A summary that was recorded for kernels this library no
     longer launches is refused (traffic null) instead of being quoted stale."""
-    for tf in (("r03_c4_pmc_traffic.json", "r02_c4_pmc_traffic.json") if bf16 else ("r03_pmc_traffic.json", "r02_pmc_traffic.json")):
+    for tf in (("r04_c4_pmc_traffic.json", "r03_c4_pmc_traffic.json") if bf16 else ("r04_pmc_traffic.json", "r03_pmc_traffic.json")):
         try:
             with open(os.path.join(ROOT, "profiles", tf)) as f:
                 t = json.load(f)
@@ -275,6 +275,7 @@ def main() -> None:
     ap.add_argument("--kernel-timers", type=int, default=None,
                     help="event pairs around every encoder launch on every N-th pass (0 = off; engine default 1)")
     ap.add_argument("--emit-ids", action="store_true", help="add a CRC of every step's ids and the gathered record count to the line")
+    ap.add_argument("--report-maps", action="store_true", help="add the libamdhip64 files this process has mapped to the line")
     ap.add_argument("--rehearse-nccl", action="store_true",
                     help="single rank: create the RCCL communicator and run the N > 1 collectives anyway")
     args = ap.parse_args()
@@ -282,8 +283,6 @@ def main() -> None:
         dry_run_gloo(args)
         return
 
-    import torch
-    import torch.distributed as dist
     import __graft_entry__ as ge
 
     rank = int(os.environ.get("RANK", 0))
@@ -291,18 +290,26 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the engine")
     if args.single_device:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
     global FORCE_COLLECTIVES
     FORCE_COLLECTIVES = bool(args.rehearse_nccl) and world == 1
     if FORCE_COLLECTIVES:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+    # One HIP runtime in the measured path: every device buffer the engine touches is allocated by the ENGINE
+    # (wt_device_alloc: the ROCm libamdhip64 the product links), never by torch, whose wheel bundles a HIP runtime of its
+    # own.  torch is imported only where a collective is needed (N > 1, --rehearse-nccl); its tensors — the id records of
+    # the all_gather — never meet an engine pointer: ids leave the engine as host arrays.  At N = 1 the process maps one
+    # libamdhip64.
+    torch = dist = None
     if world > 1 or FORCE_COLLECTIVES:
+        import torch
+        import torch.distributed as dist
         if args.backend == "nccl":
+            if not torch.cuda.is_available():
+                raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the engine")
+            torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -310,7 +317,7 @@ def main() -> None:
     pkg = ge.load_package()
     tmp = tempfile.mkdtemp(prefix=f"wt_bench_r{rank}_")
     prefix, vocab = ge._assets(tmp, args.arch, 0)
-    eng = pkg.Engine(prefix, vocab, True, device_id=local_rank)
+    eng = pkg.Engine(prefix, vocab, True, device_id=local_rank)  # fails loudly (WT_ERR_DEVICE) without a gfx950 GPU
     if args.attn_variant is not None:
         eng.set_option("attn_variant", args.attn_variant)
     if args.cross_chunks:
@@ -334,8 +341,8 @@ def main() -> None:
     B = args.batch
     lo, hi = shard_range(rank, world, world * B)
     mel_host = synthetic_mel(lo, hi, eng.mel_shape)
-    d_mel = torch.from_numpy(mel_host).cuda()  # resident in HBM before the timed region
-    torch.cuda.synchronize()
+    d_mel = eng.device_array(mel_host)  # resident in HBM before the timed region
+    eng.device_synchronize()
 
     pipelined = not args.no_pipeline
     host = {"submit_s": 0.0, "submits": 0}  # host time spent enqueueing (launch-bound check)
@@ -344,21 +351,26 @@ def main() -> None:
     # collectives: an RCCL kernel per batch would sit in a hardware queue next to a decoder chain and
     # couple the ranks batch by batch).  Every record is gathered inside the timed region.
     pending = []
-    gathered = {"rec": None, "collectives": 0, "records": 0, "crc": 0}
+    gathered = {"rec": None, "collectives": 0, "records": 0, "crc": 0, "digest": 0}
 
     def flush_gather():
         if not pending:
             return
-        rec = torch.from_numpy(np.concatenate(pending, axis=0))
+        rec = np.concatenate(pending, axis=0)
         pending.clear()
         if world > 1 or FORCE_COLLECTIVES:
-            rec = gather_records(rec.cuda() if args.backend == "nccl" else rec, world)
+            t = torch.from_numpy(rec)
+            rec = gather_records(t.cuda() if args.backend == "nccl" else t, world).cpu().numpy()
             gathered["collectives"] += 1
         gathered["rec"] = rec
         gathered["records"] += int(rec.shape[0])
         if args.emit_ids:
             import zlib
-            gathered["crc"] = zlib.crc32(np.ascontiguousarray(rec.cpu().numpy()).tobytes(), gathered["crc"])
+            rec = np.ascontiguousarray(rec)
+            gathered["crc"] = zlib.crc32(rec.tobytes(), gathered["crc"])
+            # order-independent digest of the records (a sum of per-record CRCs): equal for any split of the same global
+            # clips over ranks and batches
+            gathered["digest"] = (gathered["digest"] + sum(zlib.crc32(r.tobytes()) for r in rec)) & 0xFFFFFFFFFFFF
 
     def finish(ids, n):
         pending.append(pack_records(ids, n))
@@ -413,7 +425,15 @@ def main() -> None:
     def fence():
         if world > 1 or FORCE_COLLECTIVES:
             dist.barrier()
-        torch.cuda.synchronize()
+            if args.backend == "nccl":
+                torch.cuda.synchronize()
+        eng_now.device_synchronize()  # hipDeviceSynchronize() in the engine's runtime: the device is idle
+
+    class _Live:  # the engine fence() synchronises (the extra-engine legs swap it)
+        def device_synchronize(self):
+            (self.e or eng).device_synchronize()
+        e = None
+    eng_now = _Live()
 
     stage = {"encoder_ms": 0.0, "cross_kv_ms": 0.0, "decoder_ms": 0.0}
     kstats = {}
@@ -430,7 +450,7 @@ def main() -> None:
             for k in acc:
                 acc[k] += v[k]
 
-    gathered.update(collectives=0, records=0, crc=0)  # count the timed region only
+    gathered.update(collectives=0, records=0, crc=0, digest=0)  # count the timed region only
     fence()
     t0 = time.perf_counter()
     ids, n, rec = run_steps(args.steps, accumulate)
@@ -481,8 +501,8 @@ def main() -> None:
     with_frontend = None
     if pipelined and not args.no_fp32_leg and not args.bf16:
         pcm_host = np.clip(np.random.default_rng([MEL_SEED, 7]).normal(0.0, 0.1, size=(B, eng.pcm_len)), -1, 1).astype(np.float32)
-        d_pcm = torch.from_numpy(pcm_host).cuda()
-        torch.cuda.synchronize()
+        d_pcm = eng.device_array(pcm_host)
+        eng.device_synchronize()
 
         def run_pcm(k):
             in_flight = 0
@@ -496,13 +516,13 @@ def main() -> None:
                 eng.pipeline_collect()
                 in_flight -= 1
 
-        d_mel2 = torch.empty_like(d_mel)
+        d_mel2 = eng.device_array(np.zeros_like(mel_host))
         eng.logmel_batch_dev(d_pcm.data_ptr(), B, d_mel2.data_ptr())
         t1 = time.perf_counter()
         for _ in range(5):
             eng.logmel_batch_dev(d_pcm.data_ptr(), B, d_mel2.data_ptr())
         logmel_ms = 1e3 * (time.perf_counter() - t1) / 5
-        del d_mel2
+        d_mel2.free()
         run_pcm(5)
         fence()
         t1 = time.perf_counter()
@@ -512,7 +532,7 @@ def main() -> None:
         with_frontend = {"value": round(world * B * 40 * CLIP_SECONDS / dt, 1), "unit": "audio-sec/s", "steps": 40,
                          "ms_per_step": round(1e3 * dt / 40, 3), "logmel_ms_per_batch_alone": round(logmel_ms, 3),
                          "input": "PCM [32][480000] resident in HBM, N(0, 0.1^2) clipped"}
-        del d_pcm
+        d_pcm.free()
 
     legs_ok = pipelined and world == 1 and not args.no_fp32_leg and not args.bf16 and args.arch == "tiny" \
         and args.gemm_variant is None and args.attn_variant is None
@@ -531,6 +551,7 @@ def main() -> None:
         e2 = pkg.Engine(adv, vocab, True, device_id=local_rank)
         e2.set_option("stop_at_eot", 0)
         e2.set_option("kernel_timers", 4)
+        eng_now.e = e2
         dt, _, n2, det2 = timed_leg(e2, d_mel.data_ptr(), B, 40, 12, args.depth, fence)
         outlier_leg = {"value": round(B * 40 * CLIP_SECONDS / dt, 1), "unit": "audio-sec/s", "steps": 40,
                        "ms_per_step": round(1e3 * dt / 40, 3), "f16_fallbacks": int(e2.get_option("f16_fallbacks")),
@@ -542,6 +563,38 @@ def main() -> None:
         e2.close()
         return outlier_leg
 
+    # The same on weights with trained-checkpoint statistics in EVERY layer (tools/wtw.py trained_like_weights: log-normal
+    # LayerNorm gains with outlier channels, heavy-tailed rows, two massive residual channels): how many of the 23
+    # contractions the load-time check takes off the fp16-plane kernels, and what that costs.
+    def run_trained_like_leg():
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from wtw import trained_like_weights
+
+        def one(tag, what, **kw):
+            tl = os.path.join(tmp, "tiny-" + tag)
+            trained_like_weights(prefix + ".wtw", tl + ".wtw", **kw)
+            e4 = pkg.Engine(tl, vocab, True, device_id=local_rank)
+            e4.set_option("stop_at_eot", 0)
+            e4.set_option("kernel_timers", 4)
+            eng_now.e = e4
+            dt, _, n4, det4 = timed_leg(e4, d_mel.data_ptr(), B, 40, 12, args.depth, fence)
+            leg = {"value": round(B * 40 * CLIP_SECONDS / dt, 1), "unit": "audio-sec/s", "steps": 40,
+                   "ms_per_step": round(1e3 * dt / 40, 3), "f16_fallbacks": int(e4.get_option("f16_fallbacks")),
+                   "f16_contractions": int(e4.get_option("f16_contractions")),
+                   "min_slack_bits": round(e4.get_option("f16_min_slack_millibits") / 1000.0, 2),
+                   "launches_per_step": {k: v["launches_per_step"] for k, v in det4.items()},
+                   "all_clips_decoded": bool((n4 == 31).all()), "weights": what}
+            e4.close()
+            return leg
+
+        leg = one("trained-like", "tools/wtw.py trained_like_weights(seed 4321): LayerNorm gains log-normal sigma 0.35 with 2 % of the "
+                                  "channels 6..20 x, weight rows Student-t(4) entries with log-normal norms (sigma 0.5), residual "
+                                  "channels 23 and 187 forty times the others, in every encoder layer")
+        # far beyond published checkpoint statistics: row norms spread over e^+-4 (sigma 2) — where the check starts to act
+        leg["extreme_row_spread"] = one("trained-like-x", "the same with row_sigma = 2.0 (row norms of every weight matrix spread "
+                                                          "over a factor ~3000)", row_sigma=2.0)
+        return leg
+
     # BASELINE.json configs[3] in the driver's line: whisper-base, batch 64, bf16 storage + bf16 MFMA
     def run_c3_leg():
         prefix3, vocab3 = ge._assets(tmp, "base", 0)
@@ -550,8 +603,9 @@ def main() -> None:
         e3.set_option("stop_at_eot", 0)
         e3.set_option("kernel_timers", 4)
         B3 = 64
-        d_mel3 = torch.from_numpy(synthetic_mel(0, B3, e3.mel_shape)).cuda()
-        torch.cuda.synchronize()
+        eng_now.e = e3
+        d_mel3 = e3.device_array(synthetic_mel(0, B3, e3.mel_shape))
+        e3.device_synchronize()
         dt, _, n3, det3 = timed_leg(e3, d_mel3.data_ptr(), B3, 40, 6, 5, fence)
         dom3 = max(det3, key=lambda k: det3[k]["ms_per_step"]) if det3 else None
         tr3, tr3_src = traffic_from_profile(dom3, True, set(e3.kernel_stats())) if dom3 else (None, None)
@@ -564,8 +618,8 @@ def main() -> None:
                                 "traffic": tr3, "traffic_source": tr3_src,
                                 "note": "HIP events inside the pipelined region of this leg"} if dom3 else None),
                   "roofline_detail": det3}
+        d_mel3.free()
         e3.close()
-        del d_mel3
         return c3_leg
 
     iso = None
@@ -676,17 +730,32 @@ def main() -> None:
                                           "query / value sides)" if absorbed else "cross-KV cache") +
                                          (", two batches per decoder chain" if paired else ""),
                                  "chain_ms": round(stage["decoder_ms"], 3)},
+            # what the headline assumes about the weights: every contraction whose weight-derived bound stays within 2^12
+            # of its typical magnitude runs on two fp16 planes; the others (none here) on the full-range kernels
+            "weights_assumption": {"weights": "random-init seed 0: Linear N(0, 1/fan_in), LayerNorm gain 1 / shift 0, embeddings "
+                                              "N(0, 0.02^2) (there is no checkpoint in this environment)",
+                                   "f16_contractions": int(eng.get_option("f16_contractions")),
+                                   "f16_fallbacks": int(eng.get_option("f16_fallbacks")),
+                                   "min_slack_bits": round(eng.get_option("f16_min_slack_millibits") / 1000.0, 2),
+                                   "note": "slack = log2(4096 * typical / bound) of the tightest operand; a contraction with "
+                                           "negative slack leaves the fp16-plane kernels (legs outlier_weights, "
+                                           "trained_like_weights: count and cost)"},
             "encoder_fp32_mfma": fp32_leg,
             "outlier_weights": None,
+            "trained_like_weights": None,
             "configs3_bf16_base": None,
             "with_frontend": with_frontend,
             "stage_ms_per_step": stage,
             "host_enqueue_ms_per_step": round(1e3 * host["submit_s"] / max(1, host["submits"]), 3) if pipelined else None,
         }
         out["collectives"] = timed["collectives"]
+        if args.report_maps:
+            with open("/proc/self/maps") as f:
+                out["hip_runtimes_mapped"] = sorted({ln.split()[-1] for ln in f if "libamdhip64" in ln})
         if args.emit_ids:
             out["gathered_records"] = timed["records"]
             out["ids_crc"] = timed["crc"]
+            out["ids_digest"] = timed["digest"]
         if not args.no_cpu_baseline:
             info = eng.vocab_info()
             prompt = [info["sot"], 50259 + eng.get_option("language"), info["transcribe"], info["not"]]
@@ -698,6 +767,7 @@ def main() -> None:
         if legs_ok:
             eng.close()
             out["outlier_weights"] = run_outlier_leg()
+            out["trained_like_weights"] = run_trained_like_leg()
             out["configs3_bf16_base"] = run_c3_leg()
         print(json.dumps(out))
     eng.close()

@@ -133,6 +133,14 @@ int wt_transcribe_long_pcm(wt_engine* h, const float* pcm, size_t n_samples, cha
  *   layout, whisper.cpp:184: [mel][frame])     ids [B][WT_MAX_IDS] int64, n_ids [B] int32.
  * ids rows hold prompt + generated ids exactly as Decoder::forward returns them
  * (whisper.cpp:402), zero-padded. */
+/* Device buffers for the *_dev forms, allocated on the engine's GPU by the engine's own HIP runtime: a host program
+ * (bench.py, the tests, a binding) needs no HIP of its own to keep its inputs resident in HBM.  upload / download are
+ * synchronous copies (offset in bytes into the buffer); wt_device_synchronize returns once the device is idle. */
+int wt_device_alloc(wt_engine* h, size_t bytes, void** d_ptr);
+int wt_device_free(wt_engine* h, void* d_ptr);
+int wt_device_upload(wt_engine* h, void* d_dst, size_t offset, const void* src, size_t bytes);
+int wt_device_download(wt_engine* h, void* dst, const void* d_src, size_t offset, size_t bytes);
+int wt_device_synchronize(wt_engine* h);
 int wt_logmel_batch(wt_engine* h, const float* pcm, int batch, float* mel);
 int wt_logmel_batch_dev(wt_engine* h, const float* d_pcm, int batch, float* d_mel);
 int wt_encdec_tokens_batch(wt_engine* h, const float* mel, int batch, int64_t* ids, int32_t* n_ids);

@@ -79,3 +79,46 @@ def adversarial_weights(src_wtw, dst_wtw, ln_gain=30.0, heavy=True, v_row_scale=
         out["encoder.blocks.0.attn.value.bias"][77] *= v_row_scale
         out["encoder.blocks.0.attn.out.weight"][:, 77] /= v_row_scale
     write_wtw(dst_wtw, dims, out)
+
+
+def trained_like_weights(src_wtw, dst_wtw, seed=4321, massive=(23, 187), massive_gain=40.0, ln_outliers=0.02,
+                         ln_outlier_range=(6.0, 20.0), row_sigma=0.5):
+    """Random-init weights re-shaped towards the statistics published for trained transformer checkpoints, in EVERY
+    encoder layer (adversarial_weights above perturbs single places):
+      * LayerNorm gains log-normal (sigma 0.35) with `ln_outliers` of the channels `ln_outlier_range` (6..20) x larger,
+        shifts N(0, 0.15^2);
+      * every Linear / Conv weight with log-normal row norms (sigma `row_sigma` = 0.5) and heavy-tailed entries (a Student-t with 4
+        degrees of freedom, rescaled to the row's former norm): a few entries per row 5..10 sigma out;
+      * "massive activations": the residual-stream channels `massive` carry values `massive_gain` x the others in all
+        layers — the rows of conv2 / attention-out / fc2 that write them and their biases are scaled up, so every
+        LayerNorm sees them and every consumer's bound / typical ratio grows with them.
+    The decoder keeps its weights (its kernels scale per row from the data).  Used by bench.py's trained_like_weights leg
+    and tests/test_gpu_boundary.py."""
+    dims, t = read_wtw(src_wtw)
+    rng = np.random.default_rng(seed)
+    d = int(dims["n_audio_state"])
+    massive = [c % d for c in massive]
+    out = {}
+    for k, v in t.items():
+        a = np.array(v, dtype=np.float32)
+        enc = k.startswith("encoder.")
+        if enc and (k.endswith("_ln.weight") or k == "encoder.ln_post.weight"):
+            a *= np.exp(rng.normal(0.0, 0.35, a.size)).astype(np.float32)
+            hot = rng.random(a.size) < ln_outliers
+            a[hot] *= rng.uniform(ln_outlier_range[0], ln_outlier_range[1], int(hot.sum())).astype(np.float32)
+        elif enc and (k.endswith("_ln.bias") or k == "encoder.ln_post.bias"):
+            a += rng.normal(0.0, 0.15, a.size).astype(np.float32)
+        elif enc and k.endswith(".weight") and a.ndim >= 2:
+            rows = a.reshape(a.shape[0], -1)
+            norm = np.linalg.norm(rows, axis=1, keepdims=True)
+            heavy = rng.standard_t(4, size=rows.shape).astype(np.float32)
+            heavy *= norm / np.maximum(np.linalg.norm(heavy, axis=1, keepdims=True), 1e-30)
+            heavy *= np.exp(rng.normal(0.0, row_sigma, (rows.shape[0], 1))).astype(np.float32)
+            a = heavy.reshape(a.shape)
+        out[k] = a
+    writers = ["encoder.conv2"] + [f"encoder.blocks.{l}.{m}" for l in range(int(dims["n_audio_layer"])) for m in ("attn.out", "mlp.2")]
+    for w in writers:
+        for c in massive:
+            out[w + ".weight"][c] *= massive_gain
+            out[w + ".bias"][c] = out[w + ".bias"][c] * massive_gain + (3.0 if w == "encoder.conv2" else 0.0)
+    write_wtw(dst_wtw, dims, out)

@@ -36,6 +36,7 @@ STATUS_NAMES = {0: "WT_OK", 1: "WT_ERR_INVALID_ARG", 2: "WT_ERR_IO", 3: "WT_ERR_
 
 # Every symbol include/wt_capi.h and include/wt_debug.h declare.
 CAPI_SYMBOLS = [
+    "wt_device_alloc", "wt_device_free", "wt_device_upload", "wt_device_download", "wt_device_synchronize",
     "wt_engine_create", "wt_engine_destroy", "wt_last_error", "wt_engine_dims",
     "wt_engine_set_option", "wt_engine_get_option", "wt_engine_set_prompt", "wt_transcribe_pcm", "wt_transcribe_long_pcm", "wt_transcribe_file",
     "wt_logmel_batch", "wt_logmel_batch_dev", "wt_encdec_tokens_batch",
@@ -154,6 +155,11 @@ def lib() -> ctypes.CDLL:
         L.wt_dbg_dec_ln_gemm.argtypes = [c_void_p, c_int, c_int, c_int, fp, ip64, c_int, fp, fp,
                                          c_int, c_int, fp, fp, fp, fp, c_int, fp, fp]
         L.wt_dbg_layernorm.argtypes = [c_void_p, c_int, c_int, fp, fp, fp, fp]
+        L.wt_device_alloc.argtypes = [c_void_p, ctypes.c_size_t, POINTER(c_void_p)]
+        L.wt_device_free.argtypes = [c_void_p, c_void_p]
+        L.wt_device_upload.argtypes = [c_void_p, c_void_p, ctypes.c_size_t, c_void_p, ctypes.c_size_t]
+        L.wt_device_download.argtypes = [c_void_p, c_void_p, c_void_p, ctypes.c_size_t, ctypes.c_size_t]
+        L.wt_device_synchronize.argtypes = [c_void_p]
         L.wt_dbg_set_forced_ids.argtypes = [c_void_p, POINTER(c_int64), c_int]
         L.wt_dbg_dec_gemm_bf16.argtypes = L.wt_dbg_dec_gemm.argtypes
         L.wt_dbg_dec_ln_gemm_bf16.argtypes = L.wt_dbg_dec_ln_gemm.argtypes
@@ -548,6 +554,14 @@ class Engine:
         self._check(lib().wt_dbg_gemm_bench(self._h, M, N, K, epi, variant, iters, byref(ms)))
         return ms.value
 
+    def device_array(self, a):
+        """A copy of the numpy array `a` resident in this engine's HBM (wt_device_alloc + upload): the caller-owned input
+        of the *_dev entry points.  Returns a DeviceArray (data_ptr(), download(), free())."""
+        return DeviceArray(self, a)
+
+    def device_synchronize(self):
+        self._check(lib().wt_device_synchronize(self._h))
+
     def set_forced_ids(self, ids=None):
         """Teacher forcing (test tap): ids [clips][32] every following decode of that many clips follows instead of its
         own argmax; None switches it off."""
@@ -625,6 +639,31 @@ class Engine:
         fn = lib().wt_dbg_self_attention_bf16 if bf16 else lib().wt_dbg_self_attention
         self._check(fn(self._h, B, d // 64, cap, pos, npos, _fp(qkv), _fp(kcache), _fp(vcache), _fp(out)))
         return out, kcache, vcache
+
+
+class DeviceArray:
+    """Device buffer owned by the caller, allocated through the engine's C ABI (no HIP runtime on the Python side)."""
+
+    def __init__(self, eng, a):
+        a = np.ascontiguousarray(a)
+        self._eng, self.shape, self.dtype, self.nbytes = eng, a.shape, a.dtype, a.nbytes
+        p = c_void_p()
+        eng._check(lib().wt_device_alloc(eng._h, a.nbytes, byref(p)))
+        self._p = p
+        eng._check(lib().wt_device_upload(eng._h, p, 0, a.ctypes.data_as(c_void_p), a.nbytes))
+
+    def data_ptr(self) -> int:
+        return self._p.value
+
+    def download(self):
+        out = np.empty(self.shape, self.dtype)
+        self._eng._check(lib().wt_device_download(self._eng._h, out.ctypes.data_as(c_void_p), self._p, 0, self.nbytes))
+        return out
+
+    def free(self):
+        if self._p:
+            self._eng._check(lib().wt_device_free(self._eng._h, self._p))
+            self._p = None
 
 
 def create_engine(engine_type, model_prefix: str, vocab_path: str, multilingual: bool):

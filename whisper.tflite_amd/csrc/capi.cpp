@@ -7,6 +7,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -237,6 +238,8 @@ int wt_engine_get_option(const wt_engine* h, const char* key, long* value) {
   else if (k == "attn_variant") *value = e.attn_variant;
   else if (k == "force_fallback") *value = e.force_fallback();
   else if (k == "f16_fallbacks") *value = e.f16_fallbacks();  // read-only
+  else if (k == "f16_contractions") *value = e.f16_contractions();  // read-only: contractions the load-time check looked at
+  else if (k == "f16_min_slack_millibits") *value = long(std::lround(1000.0 * e.f16_min_slack_bits()));  // read-only
   else if (k == "in_flight") *value = e.in_flight();          // read-only
   else if (k == "pipelined_encoder_cus") *value = e.pipelined_encoder_cus();  // read-only: CUs of the masked encoder stream
   else return WT_ERR_INVALID_ARG;
@@ -244,6 +247,47 @@ int wt_engine_get_option(const wt_engine* h, const char* key, long* value) {
 }
 
 // ------------------------------------------------------------- batches ---
+
+int wt_device_alloc(wt_engine* h, size_t bytes, void** d_ptr) {
+  if (!h || !d_ptr) return WT_ERR_INVALID_ARG;
+  *d_ptr = nullptr;
+  return guarded(h, [&] {
+    h->impl->bind_device();
+    hipchk(hipMalloc(d_ptr, bytes > 0 ? bytes : 4), "hipMalloc");
+  });
+}
+
+int wt_device_free(wt_engine* h, void* d_ptr) {
+  if (!h) return WT_ERR_INVALID_ARG;
+  return guarded(h, [&] {
+    h->impl->bind_device();
+    if (d_ptr) hipchk(hipFree(d_ptr), "hipFree");
+  });
+}
+
+int wt_device_upload(wt_engine* h, void* d_dst, size_t offset, const void* src, size_t bytes) {
+  if (!h || !d_dst || (!src && bytes)) return WT_ERR_INVALID_ARG;
+  return guarded(h, [&] {
+    h->impl->bind_device();
+    if (bytes) hipchk(hipMemcpy(static_cast<char*>(d_dst) + offset, src, bytes, hipMemcpyHostToDevice), "H2D");
+  });
+}
+
+int wt_device_download(wt_engine* h, void* dst, const void* d_src, size_t offset, size_t bytes) {
+  if (!h || !d_src || (!dst && bytes)) return WT_ERR_INVALID_ARG;
+  return guarded(h, [&] {
+    h->impl->bind_device();
+    if (bytes) hipchk(hipMemcpy(dst, static_cast<const char*>(d_src) + offset, bytes, hipMemcpyDeviceToHost), "D2H");
+  });
+}
+
+int wt_device_synchronize(wt_engine* h) {
+  if (!h) return WT_ERR_INVALID_ARG;
+  return guarded(h, [&] {
+    h->impl->bind_device();
+    hipchk(hipDeviceSynchronize(), "hipDeviceSynchronize");
+  });
+}
 
 int wt_logmel_batch_dev(wt_engine* h, const float* d_pcm, int batch, float* d_mel) {
   if (!h || !d_pcm || !d_mel) return WT_ERR_INVALID_ARG;

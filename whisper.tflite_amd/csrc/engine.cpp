@@ -438,7 +438,13 @@ void Engine::upload_weights(const std::string& path) {
       return o;
     };
     n_f16_fallbacks_ = 0;
-    auto slack_ok = [&](const Op& o) { return !(vmax(o.bound) > kF16Slack * o.typ); };
+    // slack of an operand in bits: log2(kF16Slack * typical / bound) — negative: the contraction leaves the plane kernels
+    f16_min_slack_bits_ = 1.0e9f;
+    auto slack_ok = [&](const Op& o) {
+      const float b = vmax(o.bound);
+      if (b > 0.0f && o.typ > 0.0f) f16_min_slack_bits_ = std::min(f16_min_slack_bits_, std::log2(kF16Slack * o.typ / b));
+      return !(b > kF16Slack * o.typ);
+    };
     auto scale_of = [&](const Op& in, const float* w, size_t n) {
       GemmScale g{f16_scale_for(vmax(in.bound)), f16_scale_for(maxabs(w, n)), slack_ok(in)};
       if (!g.f16_ok) ++n_f16_fallbacks_;
@@ -1095,7 +1101,7 @@ void Engine::resolve_kernel_stats(int slot) {
   Slot& sl = slots_[slot];
   // class names = the kernels the current options select (what rocprofv3 lists)
   const long gv = gemm_variant;
-  kstats_[kKcGemm].name = bf16 ? "gemm_bf16_planes" : "gemm_planes_tile";
+  kstats_[kKcGemm].name = bf16 ? "gemm_bf16_planes" : "gemm_planes";  // the class: gemm_planes_pp16 / _tile instantiations
   kstats_[kKcEncAttn].name = bf16 ? "encoder_attention_bf16" : "encoder_attention_planes";
   kstats_[kKcGemmAlt].name = gv == 0 ? "gemm_f32_tile" : "gemm_split16_tile";
   kstats_[kKcEncAttnAlt].name = attn_variant == 0 ? "encoder_attention_f32" : "encoder_attention_split";

@@ -160,6 +160,8 @@ class Engine {
   int in_flight() const { return int(inflight_.size()); }
   // contractions that were given the full-range bf16 three-plane kernels at load time (bound slack, engine.cpp)
   int f16_fallbacks() const { return n_f16_fallbacks_; }
+  float f16_min_slack_bits() const { return f16_min_slack_bits_; }
+  int f16_contractions() const { return int(load_ok_.size()); }
   // Test hook (option "force_fallback"): bit i treats contraction i — launch order: conv1, conv2, then per layer
   // qkv, attention, out, fc1, fc2, and last the cross-KV projection — as flagged by the load-time slack check, on top
   // of the contractions that check flagged itself.  Exercises every plane <-> fall-back hand-over on any weights.
@@ -315,6 +317,7 @@ class Engine {
   static constexpr float kMelBound = 8.0f;
   static constexpr float kF16Slack = 4096.0f;  // largest bound / typical ratio the two-plane fp16 form is used for
   int n_f16_fallbacks_ = 0;
+  float f16_min_slack_bits_ = 0.0f;  // smallest log2(kF16Slack * typical / bound) over the checked operands (load time)
   long force_fallback_ = 0;
   std::vector<bool> load_ok_;  // the slack check's own verdicts, in contraction order (set_force_fallback)
   std::vector<bool*> ok_flags();  // the f16_ok / attn_f16_ok members in contraction order
