@@ -192,6 +192,31 @@ __device__ __forceinline__ unsigned round2_bf16(float lo, float hi) {
 // in front of every issue — and on this part a wavefront's vector instruction waits for the SIMD's other wavefronts'
 // MFMA bursts (tools/mfma_valu_overlap.hip), so prefetches left late.  M0 is not used by
 // anything else in the kernels that call this (gfx9+ LDS instructions do not need it).
+// Reductions over the lanes l, l ^ 16 (, l ^ 32, l ^ 48) without LDS: gfx950's v_permlane32_swap / v_permlane16_swap
+// exchange 32- / 16-lane rows between two registers in the vector ALU.  __shfl_xor compiles to ds_bpermute_b32, an LDS
+// round trip (~100+ cycles) in the middle of a softmax's dependency chain.  swap(x, x) leaves [lo, lo] and [hi, hi]
+// (32: halves; 16: the even and the odd 16-lane row of each half), so op(a, b) holds the pair's result in every lane.
+__device__ __forceinline__ float xor32_max(float x) {
+  using u32x2_ = __attribute__((ext_vector_type(2))) unsigned;
+  const u32x2_ r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor16_max(float x) {
+  using u32x2_ = __attribute__((ext_vector_type(2))) unsigned;
+  const u32x2_ r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor32_sum(float x) {
+  using u32x2_ = __attribute__((ext_vector_type(2))) unsigned;
+  const u32x2_ r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor16_sum(float x) {
+  using u32x2_ = __attribute__((ext_vector_type(2))) unsigned;
+  const u32x2_ r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ void lds_dma16_sgpr(unsigned voff, unsigned long long sbase, unsigned lds_dst) {

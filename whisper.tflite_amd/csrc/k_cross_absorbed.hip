@@ -107,6 +107,24 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // BF: bf16 storage mode (BASELINE configs[3]) — E is ONE bf16 plane, Q' and P are rounded to bf16 in registers, one
 // v_mfma_f32_16x16x32_bf16 per product instead of three f16 ones, no operand scales (bf16 has the fp32 range).
+#ifdef WT_ABS_STAMPS  // diagnostic build (tools/cross_abs_phase_probe.hip): where a block's cycles go
+__device__ long long g_abs_stamps[4096 * 16];
+#define ABS_ACC(i)                                    \
+  do {                                                \
+    const long long t__ = __builtin_readcyclecounter(); \
+    ph_[i] += t__ - tl_;                              \
+    tl_ = t__;                                        \
+  } while (0)
+#define ABS_STAMP(i) st_[i] = __builtin_readcyclecounter()
+#else
+#define ABS_STAMP(i) \
+  do {               \
+  } while (0)
+#define ABS_ACC(i) \
+  do {             \
+  } while (0)
+#endif
+
 template <int DM, int NST, bool BF>
 __global__ __launch_bounds__(256) void cross_absorbed_attention(CrossAbsDev a) {
   using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
@@ -119,6 +137,12 @@ __global__ __launch_bounds__(256) void cross_absorbed_attention(CrossAbsDev a) {
   constexpr int IPW = 2 * NP * P;              // LDS-DMA instructions per wavefront and tile
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   float* const xch = reinterpret_cast<float*>(lds + NST * kStage);  // [2][4 waves][64 lanes][4]
+#ifdef WT_ABS_STAMPS
+  long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long ph_[6] = {0, 0, 0, 0, 0, 0}, tl_ = 0;
+  const long long rt0_ = (long long)__builtin_amdgcn_s_memrealtime();
+  ABS_STAMP(0);
+#endif
 
   const int b = blockIdx.x / a.chunks, ck = blockIdx.x % a.chunks;
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -155,9 +179,36 @@ __global__ __launch_bounds__(256) void cross_absorbed_attention(CrossAbsDev a) {
     }
   };
 
-  // the stream starts before anything else: the first NST - 1 tiles are in flight while the queries are prepared
+  // The same instructions in the SGPR-base form of the LDS-DMA (round 4): the per-lane part of the address — key row
+  // lq inside the instruction's four keys and the swizzled chunk, whose key & 7 = 4 (wid & 1) + lq is the same for all
+  // of a wave's instructions — is ONE constant 32-bit offset, everything else (plane, panel, key group, tile) a scalar
+  // base the SALU advances: no vector instruction in front of a load (the builtin's per-lane 64-bit form costs ~10 VALU
+  // instructions per issue, twelve issues per tile and wave).  A tile that reaches past the clip's last key row keeps
+  // the clamping per-lane form above.
+  const unsigned fast_voff = (unsigned)(lq * DM * 2 + (((lane & 15) ^ (((4 * (wid & 1) + lq) & 7) << 1)) << 4));
+  const unsigned long long ebytes = reinterpret_cast<unsigned long long>(ebase);
+  const unsigned lds_ring = lds_addr(lds);
+  auto dma_tile_fast = [&](int t, int stage) {
+    const unsigned long long tb = ebytes + (unsigned long long)(key_lo + t * 32) * (DM * 2);
 #pragma unroll
-  for (int st0 = 0; st0 < NST - 1; ++st0) dma_tile(st0, st0);
+    for (int j = 0; j < IPW; ++j) {
+      const int i = wid + 4 * j;
+      const int plane = i / (8 * P), rem = i % (8 * P), panel = rem / 8, kg = rem % 8;
+      const unsigned long long sb = tb + (unsigned long long)plane * (unsigned long long)a.e_plane * 2 + (unsigned)((4 * kg * DM + panel * 128) * 2);
+      lds_dma16_sgpr(fast_voff, sb, lds_ring + (unsigned)(stage * kStage + plane * kPlane + panel * 8192 + kg * 1024));
+    }
+  };
+  // tiles whose 32 key rows all exist take the fast form; tiles past the chunk's end are NOT loaded (round 3 re-loaded
+  // the last tile NST - 1 times to keep the counted waits uniform: a third more bytes for a six-tile chunk, and a full DMA
+  // round trip before the block could give its LDS back)
+  auto dma = [&](int t, int stage) {
+    if (t >= n_tiles) return;
+    if (key_lo + t * 32 + 32 <= a.T) {
+      dma_tile_fast(t, stage);
+    } else {
+      dma_tile(t, stage);
+    }
+  };
 
   // ---- Q' planes of this lane's query column: dynamic power-of-two scale from the column's largest element
   u32x4 qh[KS], ql[KS];
@@ -166,20 +217,48 @@ __global__ __launch_bounds__(256) void cross_absorbed_attention(CrossAbsDev a) {
     const float* src = a.qp + row * (long)(a.H * DM) + qh_i * DM + 8 * lq;
     float mx = 0.0f;
     float own[KS][8];
+    // all 4 KS loads of the column are issued back to back, then consumed: written as a loop with the khalf test inside,
+    // hipcc made the test a branch and waited for the loads two at a time — five L2 round trips, 11-13 k cycles per block
+    // ... and they are issued from inline asm, IN FRONT of the stream's first tiles, with the wait written by hand: vmcnt
+    // retires in issue order, so rows loaded behind the 96 KB of the first two tiles would come back behind them, and a
+    // load hipcc knows of is waited for with vmcnt(0) while LDS-DMA it does not know of is in flight.  vmcnt(first-tile
+    // instructions) = "everything older than the tiles has arrived" (cdna_hip_programming.md 5.7, form (ii)).
+    f32x4 qv[2 * KS][2];
 #pragma unroll
     for (int c = 0; c < 2 * KS; ++c) {
-      f32x4 v0 = *reinterpret_cast<const f32x4*>(src + 32 * c), v1 = *reinterpret_cast<const f32x4*>(src + 32 * c + 4);
-      if (!q_ok) v0 = v1 = f32x4{0, 0, 0, 0};
+      asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(qv[c][0]) : "v"(src), "i"(128 * c) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(qv[c][1]) : "v"(src), "i"(128 * c + 16) : "memory");
+    }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) mx = fmaxf(mx, fmaxf(fabsf(v0[e]), fabsf(v1[e])));
-      // khalf is wave-uniform: the compare below selects registers at compile time after unrolling
-      if ((c / KS) == khalf) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) own[c % KS][e] = v0[e], own[c % KS][4 + e] = v1[e];
+    for (int st0 = 0; st0 < NST - 1; ++st0) dma(st0, st0);
+    static_assert(KS == 2 || KS == 6 || KS == 8, "d_model 128 / 384 / 512");
+    {
+      const int first = n_tiles < NST - 1 ? n_tiles : NST - 1;  // tiles the prologue really issued (uniform)
+      if (first == 2) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPW) : "memory");
+      } else if (first == 1) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPW) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+#pragma unroll
+    for (int c = 0; c < 2 * KS; c += 2)  // the destinations are defined from here on (two groups of operands per statement)
+      asm volatile("" : "+v"(qv[c][0]), "+v"(qv[c][1]), "+v"(qv[c + 1][0]), "+v"(qv[c + 1][1]));
+    const float keep = q_ok ? 1.0f : 0.0f;  // columns past nq * heads contribute zeros
+#pragma unroll
+    for (int c = 0; c < 2 * KS; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) mx = fmaxf(mx, fmaxf(fabsf(qv[c][0][e]), fabsf(qv[c][1][e])));
+    mx *= keep;
+#pragma unroll
+    for (int c = 0; c < KS; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {  // khalf is wave-uniform: two scalar-predicated selects per element, no branch
+        own[c][e] = (khalf ? qv[c + KS][0][e] : qv[c][0][e]) * keep;
+        own[c][4 + e] = (khalf ? qv[c + KS][1][e] : qv[c][1][e]) * keep;
+      }
+    mx = xor32_max(xor16_max(mx));
     const unsigned ex = (__float_as_uint(mx) >> 23) & 0xFFu;
     const float sc = ex < 32u ? 1.0f : __uint_as_float((268u - ex) << 23);  // largest element -> [2^14, 2^15)
     const float inv = ex < 32u ? 1.0f : __uint_as_float((ex - 14u) << 23);
@@ -203,6 +282,9 @@ __global__ __launch_bounds__(256) void cross_absorbed_attention(CrossAbsDev a) {
     }
   }
 
+  // (round 3 issued the first NST - 1 tiles in front of the query loads and spent 11-17 k cycles — 5-7 us of a block's
+  // 18-25 us — before its first tile: tools/cross_abs_phase_probe.hip)
+  ABS_STAMP(1);  // queries prepared
   f32x4 cacc[DT];
 #pragma unroll
   for (int t = 0; t < DT; ++t) cacc[t] = f32x4{0, 0, 0, 0};
@@ -214,13 +296,26 @@ __global__ __launch_bounds__(256) void cross_absorbed_attention(CrossAbsDev a) {
   const int tq = (lane >> 2) & 3, tp = lane & 3;          // transposed read: lane 4 q + p of its 16-lane group
   const unsigned lds0 = lds_addr(lds);
 
+#ifdef WT_ABS_STAMPS
+  tl_ = __builtin_readcyclecounter();
+#endif
   for (int t = 0; t < n_tiles; ++t) {
     // tile t has landed (this wave's pieces: the counted wait, which leaves the NST - 2 younger tiles in flight;
     // everybody's: the barrier), and every wave has finished tile t - 1, whose stage is refilled now
-    wait_vmcnt<(NST - 2) * IPW>();
+    // (the NST - 2 younger tiles exist only while t + NST - 2 < n_tiles: the chunk's last tiles wait for everything)
+    if (t + NST - 2 < n_tiles) {
+      wait_vmcnt<(NST - 2) * IPW>();
+    } else {
+      wait_vmcnt<0>();
+    }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    dma_tile(t + NST - 1, (t + NST - 1) % NST);
+#ifdef WT_ABS_STAMPS
+    if (t == 0) ABS_STAMP(2);  // first tile landed
+#endif
+    ABS_ACC(0);  // wait + barrier
+    dma(t + NST - 1, (t + NST - 1) % NST);
+    ABS_ACC(1);  // DMA issue
     const unsigned char* const st = lds + (t % NST) * kStage;
 
     // -- partial scores of sub-tile `sub` over d-half `khalf`
@@ -239,6 +334,7 @@ __global__ __launch_bounds__(256) void cross_absorbed_attention(CrossAbsDev a) {
         sp = __builtin_amdgcn_mfma_f32_16x16x32_f16(eh, __builtin_bit_cast(half8, qh[c]), sp, 0, 0, 0);
       }
     }
+    ABS_ACC(2);  // partial scores
     float* const xb = xch + (t & 1) * 1024;
     *reinterpret_cast<f32x4*>(xb + (wid * 64 + lane) * 4) = sp;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // raw barrier: __syncthreads() would also drain the ring's DMAs
@@ -246,6 +342,7 @@ __global__ __launch_bounds__(256) void cross_absorbed_attention(CrossAbsDev a) {
     __builtin_amdgcn_sched_barrier(0);
     f32x4 s0 = *reinterpret_cast<const f32x4*>(xb + (0 * 64 + lane) * 4) + *reinterpret_cast<const f32x4*>(xb + (2 * 64 + lane) * 4);
     f32x4 s1 = *reinterpret_cast<const f32x4*>(xb + (1 * 64 + lane) * 4) + *reinterpret_cast<const f32x4*>(xb + (3 * 64 + lane) * 4);
+    ABS_ACC(3);  // exchange + barrier
     // accumulator register r of this lane: key 4 lq + r of its sub-tile, query column qc
     const int kbase = key_lo + t * 32 + 4 * lq;
     if (kbase + 32 > key_hi) {  // the chunk's last tile: keys past its end do not exist
@@ -257,8 +354,7 @@ __global__ __launch_bounds__(256) void cross_absorbed_attention(CrossAbsDev a) {
     }
     // -- online softmax per query column (a column lives on lanes qc, qc + 16, qc + 32, qc + 48), deferred maximum
     float tmax = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    tmax = xor32_max(xor16_max(tmax));  // lanes qc, qc + 16, qc + 32, qc + 48: no LDS round trip (bf16_split.h)
     tmax *= s_inv;
     if (__any(tmax > m_run + kDeferA)) {
       const float m_new = fmaxf(m_run, tmax);
@@ -276,8 +372,7 @@ __global__ __launch_bounds__(256) void cross_absorbed_attention(CrossAbsDev a) {
       s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], s_inv, shift));
       psum += s0[r] + s1[r];
     }
-    psum += __shfl_xor(psum, 16, 64);
-    psum += __shfl_xor(psum, 32, 64);
+    psum = xor32_sum(xor16_sum(psum));
     l_run += psum;
     // P^T B fragment: element j of this lane = key 4 lq + j (j < 4, sub-tile 0) / 16 + 4 lq + j - 4 (sub-tile 1)
     unsigned ph[4], pl[4] = {0, 0, 0, 0};
@@ -294,6 +389,7 @@ __global__ __launch_bounds__(256) void cross_absorbed_attention(CrossAbsDev a) {
     }
     const half8 pH = __builtin_bit_cast(half8, u32x4{ph[0], ph[1], ph[2], ph[3]});
     const half8 pL = __builtin_bit_cast(half8, u32x4{pl[0], pl[1], pl[2], pl[3]});
+    ABS_ACC(4);  // softmax + split
     // -- context: this wave's DT d tiles; E^T fragments by transposed reads, keys in the same order as P^T
     const unsigned sa = lds0 + (unsigned)((t % NST) * kStage);
     const int k0 = 4 * lq + tq, k1 = 16 + 4 * lq + tq;  // rows this lane addresses for the two 4-key blocks
@@ -328,9 +424,10 @@ __global__ __launch_bounds__(256) void cross_absorbed_attention(CrossAbsDev a) {
         }
       }
     }
+    ABS_ACC(5);  // context
   }
-  wait_vmcnt<0>();  // the ring's trailing (dummy) pieces must have landed before the block gives its LDS back
 
+  ABS_STAMP(3);  // tiles done
   // ---- record of this (row, head, chunk): c = sum p e (relative to the chunk's maximum), m, l
   if (q_ok) {
     const float cs = 1.0f / (a.e_scale * 4096.0f);  // planes of E carry e_scale, probabilities 2^12
@@ -342,6 +439,16 @@ __global__ __launch_bounds__(256) void cross_absorbed_attention(CrossAbsDev a) {
       rec[DM + 1] = l_run * (1.0f / 4096.0f);
     }
   }
+#ifdef WT_ABS_STAMPS
+  ABS_STAMP(4);
+  if (tid == 0 && blockIdx.x < 4096) {
+    long long* o = g_abs_stamps + blockIdx.x * 16;
+    o[0] = st_[1] - st_[0], o[1] = st_[2] - st_[1], o[2] = st_[3] - st_[2], o[3] = st_[4] - st_[3], o[4] = st_[4] - st_[0];
+    o[5] = (long long)__builtin_amdgcn_s_memrealtime() - rt0_;
+    o[6] = n_tiles;
+    for (int i = 0; i < 6; ++i) o[8 + i] = ph_[i];
+  }
+#endif
 }
 
 // One block per (row, head): c[d] = sum_k w_k c_k[d] / sum_k w_k l_k with w_k = exp(m_k - max m) (the key chunks'
