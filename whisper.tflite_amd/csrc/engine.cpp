@@ -727,7 +727,9 @@ void Engine::create_streams() {
   // to an encoder that owns every CU stretch it by 2.5 ms per batch, next to one that owns
   // 224 of 256 CUs by 0.9 ms; with the faster encoder kernels 4..8 CUs per XCD measure
   // within 2 % of each other. Synchronous calls keep the whole chip.
-  int reserve = 8;  // 192 CUs for the pipelined encoder: 188 row tiles of 256 and 2304 / 3 attention blocks fill whole rounds
+  // (round 4: the absorbed cross-attention needs a third less CU time — 4 per XCD = 224 CUs for the encoder measured
+  // 148.6 k against 146.8 k audio-sec/s with 8, 5 / 6 in between, 3: 139.5 k; tools/ab_r4_pipeline.sh)
+  int reserve = 4;  // 224 CUs for the pipelined encoder: 188 row tiles of 256 fill one round
   if (const char* v = getenv("WT_ENC_CU_RESERVE")) reserve = std::min(std::max(atoi(v), 0), 16);
   reserve_ = reserve;
   const int n_cu = n_cu_;

@@ -94,17 +94,6 @@ __device__ __forceinline__ void ds_read_tr16_x2_one_plane(unsigned a0, unsigned 
       : "memory");
 }
 
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  static_assert(N == 0 || N == 2 || N == 4 || N == 6 || N == 8 || N == 12, "ring depths in use");
-  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-}
-
 // BF: bf16 storage mode (BASELINE configs[3]) — E is ONE bf16 plane, Q' and P are rounded to bf16 in registers, one
 // v_mfma_f32_16x16x32_bf16 per product instead of three f16 ones, no operand scales (bf16 has the fp32 range).
 #ifdef WT_ABS_STAMPS  // diagnostic build (tools/cross_abs_phase_probe.hip): where a block's cycles go
@@ -126,7 +115,7 @@ __device__ long long g_abs_stamps[4096 * 16];
 #endif
 
 template <int DM, int NST, bool BF>
-__global__ __launch_bounds__(256) void cross_absorbed_attention(CrossAbsDev a) {
+__global__ __launch_bounds__(320) void cross_absorbed_attention(CrossAbsDev a) {
   using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
   constexpr int P = DM / 128;                  // column panels of 128 halfs (256-byte LDS rows)
   constexpr int kPlane = P * 8192;             // bytes of one plane of a 32-key tile
@@ -134,7 +123,7 @@ __global__ __launch_bounds__(256) void cross_absorbed_attention(CrossAbsDev a) {
   constexpr int kStage = NP * kPlane;
   constexpr int KS = DM / 64;                  // 32-deep k-steps of one d-half (score product)
   constexpr int DT = DM / 64;                  // 16-wide d tiles per wavefront (context product)
-  constexpr int IPW = 2 * NP * P;              // LDS-DMA instructions per wavefront and tile
+  constexpr int IPT = 8 * NP * P;              // LDS-DMA instructions per tile (1 KiB each), all issued by the loader wave
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   float* const xch = reinterpret_cast<float*>(lds + NST * kStage);  // [2][4 waves][64 lanes][4]
 #ifdef WT_ABS_STAMPS
@@ -159,56 +148,69 @@ __global__ __launch_bounds__(256) void cross_absorbed_attention(CrossAbsDev a) {
   key_hi = key_hi < a.T ? key_hi : a.T;
   const int n_tiles = key_hi > key_lo ? (key_hi - key_lo + 31) / 32 : 0;
 
-  // ---- LDS-DMA: instruction i of a tile (i = wid + 4 j) copies 4 keys x 256 B of (plane, panel): LDS slot
-  // (key lane >> 4, chunk lane & 15) takes the global chunk (lane & 15) ^ ((key & 7) << 1) of that key row
+  // ---- LDS-DMA, issued by the LOADER wave (wavefront 4, round 4).  Instruction i of a tile copies 4 keys x 256 B of
+  // (plane, panel, key group kg): LDS slot (key lane >> 4, chunk lane & 15) takes the global chunk (lane & 15) ^ ((key & 7)
+  // << 1) of that key row.  In rounds 3 the four computing waves issued twelve instructions each at the head of every
+  // tile and stood 850-1260 cycles in the issue (the CU's vector memory path takes ~16 cycles per KiB: 48 KiB per tile),
+  // a quarter of a tile's 3700 cycles (tools/cross_abs_phase_probe.hip); a fifth wave does nothing else, beside them.
+  // SGPR-base form: the per-lane part of an address is the key row lq inside the instruction's four keys and the swizzled
+  // chunk, whose key & 7 = 4 (kg & 1) + lq takes two values — two constant 32-bit offsets; plane, panel, key group and
+  // tile are a scalar base.  A tile that reaches past the clip's last key row takes the clamping per-lane form.
   const _Float16* const ebase = b < a.split ? a.e + (long)b * a.T * DM : a.e2 + (long)(b - a.split) * a.T * DM;
-  auto dma_tile = [&](int t, int stage) {
-    const int tt = t < n_tiles ? t : (n_tiles > 0 ? n_tiles - 1 : 0);  // past the end: a harmless re-load (uniform vmcnt)
-    unsigned char* const sbase = lds + stage * kStage;
+  const unsigned long long ebytes = reinterpret_cast<unsigned long long>(ebase);
+  const unsigned lds_ring = lds_addr(lds);
+  const unsigned voff_even = (unsigned)(lq * DM * 2 + (((lane & 15) ^ ((lq & 7) << 1)) << 4));
+  const unsigned voff_odd = (unsigned)(lq * DM * 2 + (((lane & 15) ^ (((4 + lq) & 7) << 1)) << 4));
+  auto dma_part = [&](int t, int i0, int i1) {  // instructions [i0, i1) of tile t
+    if (t >= n_tiles) return;
+    const int stage = t % NST;
+    if (key_lo + t * 32 + 32 <= a.T) {
+      const unsigned long long tb = ebytes + (unsigned long long)(key_lo + t * 32) * (DM * 2);
 #pragma unroll
-    for (int j = 0; j < IPW; ++j) {
-      const int i = wid + 4 * j;
-      const int plane = i / (8 * P), rem = i % (8 * P), panel = rem / 8, kg = rem % 8;
-      const int key = 4 * kg + lq;
-      int gk = key_lo + tt * 32 + key;
-      gk = gk < a.T ? gk : a.T - 1;  // keys past T re-read the last row; their scores are masked
-      const int chunk = (lane & 15) ^ ((key & 7) << 1);
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(ebase + plane * a.e_plane + (long)gk * DM + panel * 128 + chunk * 8),
-          (__attribute__((address_space(3))) void*)(sbase + plane * kPlane + panel * 8192 + kg * 1024), 16, 0, 0);
+      for (int i = i0; i < i1; ++i) {
+        const int plane = i / (8 * P), rem = i % (8 * P), panel = rem / 8, kg = rem % 8;
+        const unsigned long long sb = tb + (unsigned long long)plane * (unsigned long long)a.e_plane * 2 + (unsigned)((4 * kg * DM + panel * 128) * 2);
+        lds_dma16_sgpr((kg & 1) ? voff_odd : voff_even, sb, lds_ring + (unsigned)(stage * kStage + plane * kPlane + panel * 8192 + kg * 1024));
+      }
+    } else {
+      unsigned char* const sbase = lds + stage * kStage;
+#pragma unroll
+      for (int i = i0; i < i1; ++i) {
+        const int plane = i / (8 * P), rem = i % (8 * P), panel = rem / 8, kg = rem % 8;
+        const int key = 4 * kg + lq;
+        int gk = key_lo + t * 32 + key;
+        gk = gk < a.T ? gk : a.T - 1;  // keys past T re-read the last row; their scores are masked
+        const int chunk = (lane & 15) ^ ((key & 7) << 1);
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(ebase + plane * a.e_plane + (long)gk * DM + panel * 128 + chunk * 8),
+            (__attribute__((address_space(3))) void*)(sbase + plane * kPlane + panel * 8192 + kg * 1024), 16, 0, 0);
+      }
     }
   };
 
-  // The same instructions in the SGPR-base form of the LDS-DMA (round 4): the per-lane part of the address — key row
-  // lq inside the instruction's four keys and the swizzled chunk, whose key & 7 = 4 (wid & 1) + lq is the same for all
-  // of a wave's instructions — is ONE constant 32-bit offset, everything else (plane, panel, key group, tile) a scalar
-  // base the SALU advances: no vector instruction in front of a load (the builtin's per-lane 64-bit form costs ~10 VALU
-  // instructions per issue, twelve issues per tile and wave).  A tile that reaches past the clip's last key row keeps
-  // the clamping per-lane form above.
-  const unsigned fast_voff = (unsigned)(lq * DM * 2 + (((lane & 15) ^ (((4 * (wid & 1) + lq) & 7) << 1)) << 4));
-  const unsigned long long ebytes = reinterpret_cast<unsigned long long>(ebase);
-  const unsigned lds_ring = lds_addr(lds);
-  auto dma_tile_fast = [&](int t, int stage) {
-    const unsigned long long tb = ebytes + (unsigned long long)(key_lo + t * 32) * (DM * 2);
+  if (wid == 4) {
+    // ---- the loader: the ring's first NST - 1 tiles, then per tile "tile t has landed" (its own counted wait: the younger
+    // tile stays in flight; at most 63 of the IPT = 48 + 48 outstanding instructions are counted — the issue simply blocks
+    // on the 64th), the two block-wide barriers of a tile, and the next free stage's refill split around the second one
+    // so that it arrives there with the computing waves.
+    constexpr int kHead = IPT / 3;
+    static_assert(NST <= 2 || IPT <= 63, "the counted wait leaves one whole tile in flight: it must fit the 6-bit counter");
 #pragma unroll
-    for (int j = 0; j < IPW; ++j) {
-      const int i = wid + 4 * j;
-      const int plane = i / (8 * P), rem = i % (8 * P), panel = rem / 8, kg = rem % 8;
-      const unsigned long long sb = tb + (unsigned long long)plane * (unsigned long long)a.e_plane * 2 + (unsigned)((4 * kg * DM + panel * 128) * 2);
-      lds_dma16_sgpr(fast_voff, sb, lds_ring + (unsigned)(stage * kStage + plane * kPlane + panel * 8192 + kg * 1024));
+    for (int st0 = 0; st0 < NST - 1; ++st0) dma_part(st0, 0, IPT);
+    for (int t = 0; t < n_tiles; ++t) {
+      if (NST > 2 && t + 1 < n_tiles) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPT < 63 ? IPT : 63) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      dma_part(t + NST - 1, 0, kHead);
+      __builtin_amdgcn_s_barrier();
+      dma_part(t + NST - 1, kHead, IPT);
     }
-  };
-  // tiles whose 32 key rows all exist take the fast form; tiles past the chunk's end are NOT loaded (round 3 re-loaded
-  // the last tile NST - 1 times to keep the counted waits uniform: a third more bytes for a six-tile chunk, and a full DMA
-  // round trip before the block could give its LDS back)
-  auto dma = [&](int t, int stage) {
-    if (t >= n_tiles) return;
-    if (key_lo + t * 32 + 32 <= a.T) {
-      dma_tile_fast(t, stage);
-    } else {
-      dma_tile(t, stage);
-    }
-  };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
 
   // ---- Q' planes of this lane's query column: dynamic power-of-two scale from the column's largest element
   u32x4 qh[KS], ql[KS];
@@ -219,32 +221,12 @@ __global__ __launch_bounds__(256) void cross_absorbed_attention(CrossAbsDev a) {
     float own[KS][8];
     // all 4 KS loads of the column are issued back to back, then consumed: written as a loop with the khalf test inside,
     // hipcc made the test a branch and waited for the loads two at a time — five L2 round trips, 11-13 k cycles per block
-    // ... and they are issued from inline asm, IN FRONT of the stream's first tiles, with the wait written by hand: vmcnt
-    // retires in issue order, so rows loaded behind the 96 KB of the first two tiles would come back behind them, and a
-    // load hipcc knows of is waited for with vmcnt(0) while LDS-DMA it does not know of is in flight.  vmcnt(first-tile
-    // instructions) = "everything older than the tiles has arrived" (cdna_hip_programming.md 5.7, form (ii)).
     f32x4 qv[2 * KS][2];
 #pragma unroll
     for (int c = 0; c < 2 * KS; ++c) {
-      asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(qv[c][0]) : "v"(src), "i"(128 * c) : "memory");
-      asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(qv[c][1]) : "v"(src), "i"(128 * c + 16) : "memory");
+      qv[c][0] = *reinterpret_cast<const f32x4*>(src + 32 * c);
+      qv[c][1] = *reinterpret_cast<const f32x4*>(src + 32 * c + 4);
     }
-#pragma unroll
-    for (int st0 = 0; st0 < NST - 1; ++st0) dma(st0, st0);
-    static_assert(KS == 2 || KS == 6 || KS == 8, "d_model 128 / 384 / 512");
-    {
-      const int first = n_tiles < NST - 1 ? n_tiles : NST - 1;  // tiles the prologue really issued (uniform)
-      if (first == 2) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPW) : "memory");
-      } else if (first == 1) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPW) : "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < 2 * KS; c += 2)  // the destinations are defined from here on (two groups of operands per statement)
-      asm volatile("" : "+v"(qv[c][0]), "+v"(qv[c][1]), "+v"(qv[c + 1][0]), "+v"(qv[c + 1][1]));
     const float keep = q_ok ? 1.0f : 0.0f;  // columns past nq * heads contribute zeros
 #pragma unroll
     for (int c = 0; c < 2 * KS; ++c)
@@ -282,8 +264,9 @@ __global__ __launch_bounds__(256) void cross_absorbed_attention(CrossAbsDev a) {
     }
   }
 
-  // (round 3 issued the first NST - 1 tiles in front of the query loads and spent 11-17 k cycles — 5-7 us of a block's
-  // 18-25 us — before its first tile: tools/cross_abs_phase_probe.hip)
+  // (round 3's computing waves issued the first NST - 1 tiles in front of these loads — which then came back behind
+  // 96 KB of HBM traffic, vmcnt retiring in issue order — and spent 11-17 k cycles, 5-7 us of a block's 18-25 us, before
+  // their first tile: tools/cross_abs_phase_probe.hip; now the loader wave streams while the queries are prepared)
   ABS_STAMP(1);  // queries prepared
   f32x4 cacc[DT];
 #pragma unroll
@@ -300,22 +283,15 @@ __global__ __launch_bounds__(256) void cross_absorbed_attention(CrossAbsDev a) {
   tl_ = __builtin_readcyclecounter();
 #endif
   for (int t = 0; t < n_tiles; ++t) {
-    // tile t has landed (this wave's pieces: the counted wait, which leaves the NST - 2 younger tiles in flight;
-    // everybody's: the barrier), and every wave has finished tile t - 1, whose stage is refilled now
-    // (the NST - 2 younger tiles exist only while t + NST - 2 < n_tiles: the chunk's last tiles wait for everything)
-    if (t + NST - 2 < n_tiles) {
-      wait_vmcnt<(NST - 2) * IPW>();
-    } else {
-      wait_vmcnt<0>();
-    }
-    __builtin_amdgcn_s_barrier();
+    // tile t has landed (the loader's counted wait, then this barrier), and every wave has finished tile t - 1, whose
+    // stage the loader refills now
+    __builtin_amdgcn_s_barrier();  // (the loader wave waited for tile t's DMA before it)
     __builtin_amdgcn_sched_barrier(0);
 #ifdef WT_ABS_STAMPS
     if (t == 0) ABS_STAMP(2);  // first tile landed
 #endif
-    ABS_ACC(0);  // wait + barrier
-    dma(t + NST - 1, (t + NST - 1) % NST);
-    ABS_ACC(1);  // DMA issue
+    ABS_ACC(0);  // barrier
+    ABS_ACC(1);
     const unsigned char* const st = lds + (t % NST) * kStage;
 
     // -- partial scores of sub-tile `sub` over d-half `khalf`
@@ -501,7 +477,7 @@ void launch_abs(const CrossAbsDev& g, hipStream_t s) {
     return true;
   }();
   (void)raised;
-  hipLaunchKernelGGL((cross_absorbed_attention<DM, NST, BF>), dim3(g.B * g.chunks), dim3(256), smem, s, g);
+  hipLaunchKernelGGL((cross_absorbed_attention<DM, NST, BF>), dim3(g.B * g.chunks), dim3(320), smem, s, g);
 }
 
 }  // namespace
