@@ -675,23 +675,39 @@ void Engine::build_frontend_tables() {
     have_logmel_ = false;  // front end needs the 80x201 bank; encoder/decoder still work
     return;
   }
+  // Round 4: the STFT runs on the fp16-plane GEMM (PCM is bounded, the windowed basis is bounded: the two-plane form is
+  // admissible) and writes the POWER spectrum from its epilogue (kEpiPower).  Rows (2 k, 2 k + 1) of the basis are the
+  // real and imaginary parts of bin k for k = 0 .. 200 only: the input is real, so the mirror bin the reference adds
+  // (P[j] += P[400 - j], whisper.cpp:164-166) is folded into the row of bin j (below).  402 rows, padded to 512;
+  // round 3 contracted all 800 rows (896 padded) on six bf16 products and squared / folded in a kernel of its own.
   dft_k = int(round_up(n_fft, 32));  // 416: samples 400..415 meet zero basis entries
-  dft_im_off = n_fft;                // rows [0,400) real parts, [400,800) imaginary parts
-  dft_n = int(round_up(2 * n_fft, 128));  // 896
+  dft_n = int(round_up(2 * n_bins, 128));  // 512
   std::vector<float> basis(size_t(dft_n) * dft_k, 0.0f);
   std::vector<cd> impulse(n_fft), col;
+  const double r2 = std::sqrt(2.0);
+  float bmax = 0.0f;
   for (int n = 0; n < n_fft; ++n) {
     const float hann = static_cast<float>(0.5 * (1.0 - std::cos((2.0 * M_PI * n) / n_fft)));
     std::fill(impulse.begin(), impulse.end(), cd(0, 0));
     impulse[n] = cd(double(hann), 0);
     effective_fft(impulse, col);
-    for (int k = 0; k < n_fft; ++k) {
-      basis[size_t(k) * dft_k + n] = static_cast<float>(col[k].real());
-      basis[size_t(dft_im_off + k) * dft_k + n] = static_cast<float>(col[k].imag());
+    for (int k = 0; k < n_bins; ++k) {
+      // bins 1 .. 199: sqrt(2) * (X_k + conj(X_{400-k})) / 2 — twice its squared magnitude is |X_k|^2 + |X_{400-k}|^2 up to
+      // the SQUARE of the two bins' difference (the reference's inexact twiddles make them differ by ~1e-7 of the
+      // largest amplitude, which shows at the 2e-4 level in bins eight decades below the maximum: a sweep's far bins)
+      const bool folded = k >= 1 && k < n_fft / 2;
+      const cd y = folded ? r2 * 0.5 * (col[k] + std::conj(col[n_fft - k])) : col[k];
+      const float re = static_cast<float>(y.real()), im = static_cast<float>(y.imag());
+      basis[size_t(2 * k) * dft_k + n] = re;
+      basis[size_t(2 * k + 1) * dft_k + n] = im;
+      bmax = std::max(bmax, std::max(std::fabs(re), std::fabs(im)));
     }
   }
-  dft_basis = upload(basis);
-  mel_k = int(round_up(n_bins, 32));  // 224
+  dft_w_scale_ = f16_scale_for(bmax);
+  dft_basis_p_ = upload_planes(basis.data(), dft_n, dft_k, dft_k, dft_w_scale_);
+  dft_zero_bias_ = upload(std::vector<float>(size_t(dft_n), 0.0f));
+  pw_ld_ = dft_n / 2;  // 256 powers per frame row (201 used)
+  mel_k = int(round_up(n_bins, 32));  // 224 (the mel GEMM reads rows of pw_ld_ = 256 powers)
   mel_n = int(round_up(size_t(dims_.n_mels), 128));
   std::vector<float> mw(size_t(mel_n) * mel_k, 0.0f);
   for (int j = 0; j < dims_.n_mels; ++j)
@@ -1012,7 +1028,7 @@ void Engine::logmel(const float* d_pcm, int batch, float* d_mel, int valid_frame
   if (!have_logmel_) throw Error(3, "vocab file carries no 80x201 mel filter bank");
   ensure_batch(batch);
   const size_t T0 = mel_frames(), n_samples = pcm_elems(), pad = n_samples + 512;
-  if (!ws_.pcm_pad) {
+  if (!ws_.pcm_planes) {
     const size_t Bc = ws_.batch;
     auto alloc = [&](size_t n_floats) -> float* {
       void* p = nullptr;
@@ -1021,40 +1037,47 @@ void Engine::logmel(const float* d_pcm, int batch, float* d_mel, int valid_frame
       HIPCHK(hipMemsetAsync(p, 0, n_floats * sizeof(float), stream_));
       return static_cast<float*>(p);
     };
-    ws_.pcm_pad = alloc(Bc * pad + 1024);
-    ws_.spec = alloc(Bc * T0 * dft_n);
-    ws_.pw = alloc(Bc * T0 * mel_k);
+    // PCM as two fp16 planes, [clip][480000 + 512] each, the tail of every clip zero for good (the reference's zero fill
+    // past the last sample, whisper.cpp:149-153: only the first 480000 columns are ever written)
+    pcm_plane_ = long(Bc * pad + 1024);
+    ws_.pcm_planes = reinterpret_cast<unsigned short*>(alloc((size_t(pcm_plane_) * 2 * sizeof(unsigned short) + 3) / 4 + 64));
+    ws_.pw = alloc(Bc * T0 * size_t(pw_ld_));
     ws_.melacc = alloc(Bc * T0 * mel_n);
     ws_.clip_max = reinterpret_cast<unsigned*>(alloc(Bc));
   }
   HIPCHK(hipEventRecord(ev_[0], stream_));
-  // zero tail per clip = the reference's zero fill past n_samples (whisper.cpp:149-153)
-  HIPCHK(hipMemcpy2DAsync(ws_.pcm_pad, pad * sizeof(float), d_pcm, n_samples * sizeof(float),
-                          n_samples * sizeof(float), batch, hipMemcpyDeviceToDevice, stream_));
   const long M = long(batch) * long(T0);
-  GemmArgs g;
-  g.A = ws_.pcm_pad;
+  // STFT as a plane GEMM: frame i of a clip is the 416 samples from 160 i (hop-strided rows read in place), PCM within
+  // +-kPcmBound (beyond: clamped), power spectrum out of the epilogue
+  launch_pcm_to_planes(d_pcm, ws_.pcm_planes, pcm_plane_, f16_scale_for(kPcmBound), kPcmBound, batch, long(n_samples), long(pad),
+                       stream_);
+  PlaneGemmArgs g;
+  g.A = ws_.pcm_planes;
+  g.a_plane = pcm_plane_;
   g.a_rpb = int(T0);
   g.a_bs = long(pad);
   g.lda = 160;  // hop: frame i starts at sample 160 * i
-  g.W = dft_basis;
-  g.C = ws_.spec;
+  g.W = dft_basis_p_.w;
+  g.bias = dft_zero_bias_;
+  g.C = ws_.pw;
   g.M = int(M);
   g.N = dft_n;
   g.K = dft_k;
-  g.ldc = dft_n;
-  g.variant = gemm_variant >= 0 ? int(gemm_variant) : 13;  // full fp32 range: the power spectrum exceeds fp16's
-  launch_gemm(g, 0, stream_);
-  launch_power_fold(ws_.spec, dft_n, dft_im_off, ws_.pw, mel_k, 400, M, stream_);
+  g.ldc = pw_ld_;
+  g.a_scale = f16_scale_for(kPcmBound);
+  g.w_scale = dft_w_scale_;
+  g.n_cu = stream_ == stream_masked_ && enc_cus_masked_ > 0 ? enc_cus_masked_ : n_cu_;
+  launch_gemm_planes(g, kEpiBias | kEpiPower, stream_);
   GemmArgs m;
   m.A = ws_.pw;
-  m.lda = mel_k;
+  m.lda = pw_ld_;
   m.W = mel_w;
   m.C = ws_.melacc;
   m.M = int(M);
   m.N = mel_n;
   m.K = mel_k;
   m.ldc = mel_n;
+  // the mel GEMM stays on the full-range three-plane kernel: power values span more decades than two fp16 planes keep
   m.variant = gemm_variant >= 0 ? int(gemm_variant) : 13;
   launch_gemm(m, 0, stream_);
   HIPCHK(hipMemsetAsync(ws_.clip_max, 0, sizeof(unsigned) * batch, stream_));

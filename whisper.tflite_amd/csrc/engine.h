@@ -334,9 +334,14 @@ class Engine {
   const float *tok_emb = nullptr, *dec_pos = nullptr, *dec_ln_g = nullptr, *dec_ln_b = nullptr;
   TiledW tok_emb_tiled;  // logits GEMM against the tied embedding
   // front end
-  const float* dft_basis = nullptr;  // [dft_n][dft_k]  windowed cos | sin rows
+  PlaneW dft_basis_p_;               // [dft_n][dft_k] windowed basis, rows (2 k, 2 k + 1) = (re, im) of bin k, as fp16 planes
+  const float* dft_zero_bias_ = nullptr;
+  float dft_w_scale_ = 1.0f;
+  int pw_ld_ = 0;                    // row stride of the power spectrum (dft_n / 2)
+  long pcm_plane_ = 0;               // elements between the hi and the lo plane of the PCM workspace
+  static constexpr float kPcmBound = 32.0f;  // PCM is clamped to +-32 for the fp16 planes (audio lives in +-1)
   const float* mel_w = nullptr;      // [mel_n][mel_k]
-  int dft_n = 0, dft_k = 0, dft_im_off = 0, mel_n = 0, mel_k = 0;
+  int dft_n = 0, dft_k = 0, mel_n = 0, mel_k = 0;
 
   struct DecWorkspace {  // one per decoder stream
     float *xb = nullptr, *xpart = nullptr;  // fc2's K-split: first-half result / second-half partial
@@ -357,7 +362,8 @@ class Engine {
     // planes made by launch_f32_to_planes from the fp32 output of a fall-back contraction ([B T][4 d] elements)
     unsigned short* cvt = nullptr;
     // front end
-    float *pcm_pad = nullptr, *spec = nullptr, *pw = nullptr, *melacc = nullptr;
+    unsigned short* pcm_planes = nullptr;
+    float *pw = nullptr, *melacc = nullptr;
     unsigned* clip_max = nullptr;
     float *mel_stage = nullptr, *pcm_stage = nullptr;
     std::vector<void*> owned;

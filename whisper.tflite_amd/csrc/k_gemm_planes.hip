@@ -262,6 +262,11 @@ __device__ __forceinline__ void planes_epilogue(const PlaneGemmDev& g, Acc& acc,
             const long o = (((long)slab * g.kv_batch + mb) * g.kv_heads + head) * (long)g.c_rpb * 64 + (long)mt * 64 + dd;
             // the cache is next read by the decoder, long after L2 / Infinity Cache have turned over: streaming store
             __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4*>(g.C + o));
+          } else if constexpr ((EPI & kEpiPower) != 0) {
+            // columns (2 k, 2 k + 1) = (re, im) of bin k: the power spectrum, two bins per lane, row stride ldc
+            using f32x2 = __attribute__((ext_vector_type(2))) float;
+            const long o = (long)mb * g.c_bs + (long)mt * g.ldc + (n >> 1);
+            *reinterpret_cast<f32x2*>(g.C + o) = f32x2{v[0] * v[0] + v[1] * v[1], v[2] * v[2] + v[3] * v[3]};
           } else {
             const long o = (long)mb * g.c_bs + (long)mt * g.ldc + n;
             f32x4 out = {v[0], v[1], v[2], v[3]};
@@ -927,6 +932,7 @@ bool launch_gemm_planes(const PlaneGemmArgs& a, int epi, hipStream_t s) {
     case kEpiBias | kEpiResidual: return launch_planes<kEpiBias | kEpiResidual, false>(g, a.n_cu, s);
     case kEpiBias | kEpiGelu | kEpiPos: return launch_planes<kEpiBias | kEpiGelu | kEpiPos, false>(g, a.n_cu, s);
     case kEpiBias | kEpiKvLayout: return launch_planes<kEpiBias | kEpiKvLayout, false>(g, a.n_cu, s);
+    case kEpiBias | kEpiPower: return launch_planes<kEpiBias | kEpiPower, false>(g, a.n_cu, s);
     case kEpiBias | 256: return launch_planes<kEpiBias, true>(g, a.n_cu, s);
     case kEpiBias | kEpiGelu | 256: return launch_planes<kEpiBias | kEpiGelu, true>(g, a.n_cu, s);
     default: throw Error(kErrInvalidArg, "unsupported plane GEMM epilogue combination");

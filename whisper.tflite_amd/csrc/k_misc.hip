@@ -146,6 +146,28 @@ __global__ __launch_bounds__(256) void f32_to_planes(const float* __restrict__ x
   }
 }
 
+// PCM -> planes for the STFT-as-GEMM (Engine::logmel): the clip's samples, clamped to the bound the scale was chosen for
+__global__ __launch_bounds__(256) void pcm_to_planes(const float* __restrict__ x, _Float16* __restrict__ yp, long plane, float scale,
+                                                     float limit, long n4_per_clip, long out_stride, long total4) {
+  using f32x4 = __attribute__((ext_vector_type(4))) float;
+  using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+    const long b = i / n4_per_clip, j = i - b * n4_per_clip;
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {  // a NaN sample stays NaN (it poisons its frames, as in the reference); fmin / fmax would drop it
+      const float c = fminf(fmaxf(v[e], -limit), limit);
+      v[e] = (v[e] != v[e] ? v[e] : c) * scale;
+    }
+    unsigned h0, l0, h1, l1;
+    split_f16x2(v[0], v[1], &h0, &l0);
+    split_f16x2(v[2], v[3], &h1, &l1);
+    const long o = b * out_stride + 4 * j;
+    *reinterpret_cast<u32x2*>(yp + o) = u32x2{h0, h1};
+    *reinterpret_cast<u32x2*>(yp + plane + o) = u32x2{l0, l1};
+  }
+}
+
 // mel [B][C][T] -> fp16 planes of melT * scale, [B][T + 2][ld] (rows 1..T, columns < C).  32x32 LDS tile transpose.
 template <bool BF>
 __global__ __launch_bounds__(256) void mel_transpose_planes(const float* __restrict__ mel, _Float16* __restrict__ out,
@@ -197,28 +219,6 @@ __global__ __launch_bounds__(256) void mel_transpose(const float* __restrict__ m
     const int t = t0 + ty + 8 * i, c = c0 + tx;
     if (c < C && t < T) dst[(long)(t + 1) * C + c] = tile[tx][ty + 8 * i];
   }
-}
-
-__global__ __launch_bounds__(256) void power_fold(const float* __restrict__ spec, int ld,
-                                                  int im_off, float* __restrict__ pw, int ldp,
-                                                  int n_fft, long M) {
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  const long m = idx / ldp;
-  const int k = (int)(idx % ldp);
-  if (m >= M) return;
-  const float* row = spec + m * ld;
-  float p = 0.0f;
-  if (k <= n_fft / 2) {
-    // whisper.cpp:159-166: |X[k]|^2 for all bins, then bins 1..N/2-1 gain the mirror bin's
-    // power; same operation order, no fused multiply-add
-    const float re = row[k], im = row[im_off + k];
-    p = __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
-    if (k >= 1 && k < n_fft / 2) {
-      const float rm = row[n_fft - k], jm = row[im_off + n_fft - k];
-      p = __fadd_rn(p, __fadd_rn(__fmul_rn(rm, rm), __fmul_rn(jm, jm)));
-    }
-  }
-  pw[m * ldp + k] = p;
 }
 
 __device__ __forceinline__ unsigned ordered_bits(float v) {
@@ -362,6 +362,17 @@ void launch_f32_to_planes(const float* x, unsigned short* yp, long plane, long M
   hipLaunchKernelGGL(f32_to_planes, dim3(blocks), dim3(256), 0, s, x, reinterpret_cast<_Float16*>(yp), plane, sc, seg, ld, n4);
 }
 
+void launch_pcm_to_planes(const float* pcm, unsigned short* yp, long plane, float scale, float limit, int batch, long n,
+                          long out_stride, hipStream_t s) {
+  if (batch < 1 || n < 4 || n % 4 != 0 || out_stride % 8 != 0 || out_stride < n || !(scale > 0.0f) || !(limit > 0.0f)) {
+    throw Error(kErrInvalidArg, "pcm_to_planes: bad shape");
+  }
+  const long total4 = (long)batch * (n / 4);
+  const unsigned blocks = (unsigned)std::min<long>((total4 + 255) / 256, 256 * 32);
+  hipLaunchKernelGGL(pcm_to_planes, dim3(blocks), dim3(256), 0, s, pcm, reinterpret_cast<_Float16*>(yp), plane, scale, limit, n / 4,
+                     out_stride, total4);
+}
+
 void launch_mel_transpose_planes(const float* mel, unsigned short* out, long plane, float scale, int batch, int n_mels,
                                  int T, int ld, hipStream_t s, bool bf16) {
   const dim3 grid((T + 31) / 32, (n_mels + 31) / 32, batch);
@@ -386,13 +397,6 @@ void launch_mel_transpose(const float* mel, float* melT, int batch, int n_mels, 
                           hipStream_t s) {
   hipLaunchKernelGGL(mel_transpose, dim3((T + 31) / 32, (n_mels + 31) / 32, batch), dim3(256), 0, s,
                      mel, melT, n_mels, T);
-}
-
-void launch_power_fold(const float* spec, int ld, int im_off, float* pw, int ldp, int n_fft,
-                       long M, hipStream_t s) {
-  const long total = M * ldp;
-  hipLaunchKernelGGL(power_fold, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, spec, ld,
-                     im_off, pw, ldp, n_fft, M);
 }
 
 void launch_log_clipmax(const float* melacc, int ld, float* logmel, unsigned* clip_max, int batch,

@@ -44,7 +44,10 @@ enum GemmEpi : int {
   kEpiGelu = 2,      // exact erf GELU
   kEpiResidual = 4,  // + R[row m][n]  (R addressed like C; R may alias C)
   kEpiPos = 8,       // + pos[(m % pos_period)][n]   (encoder positional embedding)
-  kEpiKvLayout = 16  // scatter into the cross-attention KV cache layout (see below)
+  kEpiKvLayout = 16,  // scatter into the cross-attention KV cache layout (see below)
+  // plane GEMM only: columns (2 k, 2 k + 1) hold the real and imaginary part of bin k; the output is |.|^2 per pair,
+  // fp32 [M][N / 2] (row stride ldc): the front end's STFT-as-GEMM writes the power spectrum directly
+  kEpiPower = 32
 };
 
 struct GemmArgs {
@@ -207,6 +210,11 @@ void launch_spin(int microseconds, hipStream_t s);
 
 void launch_f32_to_planes(const float* x, unsigned short* yp, long plane, long M, int ld, const float* scales, int seg,
                           hipStream_t s);
+// PCM [batch][n] fp32 -> fp16 planes of clamp(x, -limit, limit) * scale, [batch][out_stride] (columns >= n untouched:
+// the caller zeroes them once — the reference's zero fill past the last sample, whisper.cpp:149-153): hi at yp, lo at
+// yp + plane.  n % 4 == 0, out_stride % 8 == 0.
+void launch_pcm_to_planes(const float* pcm, unsigned short* yp, long plane, float scale, float limit, int batch, long n,
+                          long out_stride, hipStream_t s);
 
 // ------------------------------------------------------ encoder attention ---
 // qkv [B*T][3*d] (q | k | v, heads of 64 inside each third) -> out [B*T][d].
@@ -235,11 +243,6 @@ void launch_mel_transpose(const float* mel, float* melT, int batch, int n_mels, 
 // rows 0, T + 1 stay zero): hi at out, lo at out + plane
 void launch_mel_transpose_planes(const float* mel, unsigned short* out, long plane, float scale, int batch, int n_mels,
                                  int T, int ld, hipStream_t s, bool bf16 = false);
-// spec [M][ld] holding re parts of all n_fft bins at columns [0,n_fft) and im parts at
-// [im_off, im_off+n_fft) -> pw [M][ldp]: |X[k]|^2 (+ |X[n_fft-k]|^2 for 0 < k < n_fft/2, the
-// reference's mirror fold) for k <= n_fft/2; columns above zeroed up to ldp.
-void launch_power_fold(const float* spec, int ld, int im_off, float* pw, int ldp, int n_fft,
-                       long M, hipStream_t s);
 // melacc [B*T][ld] (first n_mel columns) -> logmel [B][n_mel][T] = log10(max(x,1e-10)),
 // and per-clip maximum over frames [0, t_valid) (t_valid < 0: all T) into clip_max[b] (ordered-uint
 // encoding, pre-zeroed).
