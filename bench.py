@@ -256,7 +256,7 @@ def main() -> None:
     ap.add_argument("--tail", type=int, default=2, choices=(0, 1, 2, 3, 4),
                     help="announce the last N batches of every run of steps to the engine (option last_batches: one decoder "
                          "chain per batch while the pipeline drains); 0 = never")
-    ap.add_argument("--attn-variant", type=int, default=None, choices=(0, 1, 2, 3, 4))
+    ap.add_argument("--attn-variant", type=int, default=None, choices=(0, 1, 4))
     ap.add_argument("--cross-chunks", type=int, default=None, choices=(1, 2, 4, 8))
     ap.add_argument("--cross-absorb", type=int, default=None, choices=(0, 1),
                     help="0 = round 2's cross-KV cache instead of the absorbed cross-attention (default 1)")

@@ -88,8 +88,9 @@ int wt_engine_dims(const wt_engine* h, wt_dims* out);
  * consumer; 1 = one block per column tile), "use_graphs" (1 = default: the decoder's launch sequence is replayed from a hipGraph).
  * Decoder form: "cross_absorb" (1 = default: cross-attention scores the decoder's queries, pre-multiplied by Wk, directly
  * against the encoder output planes and applies Wv after the softmax, so no cross K/V cache is projected or streamed;
- * 0 = the cross-KV cache of whisper.cpp's graph; fp32-accurate mode only, "cross_absorb_active" reads what is in
- * effect), "abs_chunks" (key chunks per clip of that form, 0 = by batch size), "dec_pair" (1 = default: two consecutive
+ * 0 = the cross-KV cache of whisper.cpp's graph; both the fp32-accurate and the bf16 storage mode run either form —
+ * pipelined batches and synchronous calls of 32 clips or more the absorbed one, smaller synchronous calls the cached
+ * one; "cross_absorb_active" reads what is in effect), "abs_chunks" (key chunks per clip of that form, 0 = by batch size), "dec_pair" (1 = default: two consecutive
  * pipelined batches of equal size <= 32 share one decoder chain; change only with nothing in flight),
  * "last_batches" (N = the next N pipelined submits are the last of a job: they are decoded one chain per batch, the very
  * last on the encoder's stream, so the pipeline drains sooner; counts down to 0 by itself, may be set with batches in

@@ -217,3 +217,58 @@ def test_converted_file_appears_atomically_and_a_broken_one_is_rebuilt(pkg, tmp_
     except pkg.WtError as e:
         assert e.code in (3, 5)
     assert len(open(lone + ".wtw", "rb").read()) == len(good) // 2
+
+
+def test_read_only_model_directory_converts_once_into_a_private_cache(pkg, tmp_path, monkeypatch):
+    """A model directory that cannot be written: the converted weights go to a per-user cache directory
+    ($XDG_CACHE_HOME/whisper-tflite-amd, created 0700), the second engine start REUSES the cached file instead of
+    converting again, a symlink planted under the temporary file's name is not followed, and a cache directory other users
+    could write is refused.  (No GPU needed: creation ends with WT_ERR_DEVICE after the host-side work.)"""
+    # (as root directory permissions do not bind: the test then only checks that the ordinary path still works)
+    model_dir = tmp_path / "ro-model"
+    model_dir.mkdir()
+    prefix, dims, expected = make_pair(pkg, model_dir, "micro", named=True, tag="-ro")
+    vocab = str(tmp_path / "v.bin")
+    pkg.write_synthetic_vocab(vocab, 1000)
+    cache = tmp_path / "xdg"
+    cache.mkdir()
+    monkeypatch.setenv("XDG_CACHE_HOME", str(cache))
+
+    def create():
+        try:
+            pkg.Engine(prefix, vocab, True).close()
+            return 0
+        except pkg.WtError as e:
+            return e.code
+
+    os.chmod(model_dir, 0o555)
+    try:
+        writable = os.access(str(model_dir), os.W_OK)  # root: permissions do not bind
+        rc = create()
+        assert rc in (0, 5)
+        if writable:
+            assert os.path.exists(prefix + ".wtw")
+            return
+        assert not os.path.exists(prefix + ".wtw")
+        cdir = cache / "whisper-tflite-amd"
+        files = [f for f in os.listdir(cdir) if f.endswith(".wtw")]
+        assert len(files) == 1 and (os.stat(cdir).st_mode & 0o777) == 0o700
+        cached = cdir / files[0]
+        assert _same(read_wtw(str(cached))[1], expected)
+        stamp = os.stat(cached).st_mtime_ns
+        assert create() == rc and os.stat(cached).st_mtime_ns == stamp  # reused, not converted again
+        # a broken cached file is replaced; a symlink planted as the temporary's name is not followed
+        open(cached, "wb").write(b"junk")
+        victim = tmp_path / "victim.txt"
+        victim.write_text("mine")
+        os.symlink(str(victim), str(cached) + ".tmp." + str(os.getpid()))  # the writer's temporary name, pre-planted
+        assert create() == rc and _same(read_wtw(str(cached))[1], expected) and victim.read_text() == "mine"
+        assert not [f for f in os.listdir(cdir) if ".tmp." in f]
+        # a cache directory that others may write is not trusted
+        os.chmod(cdir, 0o777)
+        os.remove(cached)
+        assert create() == 2  # WT_ERR_IO
+    finally:
+        os.chmod(model_dir, 0o755)
+        if (cache / "whisper-tflite-amd").exists():
+            os.chmod(cache / "whisper-tflite-amd", 0o700)

@@ -7,6 +7,8 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <cmath>
 #include <cstring>
 #include <memory>
@@ -73,6 +75,32 @@ void hipchk(hipError_t e, const char* what) {
 }
 }  // namespace
 
+namespace {
+// Where a converted model goes when its own directory is read-only: $XDG_CACHE_HOME/whisper-tflite-amd (or
+// ~/.cache/..., or a per-uid directory under $TMPDIR), created 0700 and accepted only if it IS a directory owned by this
+// user that nobody else may write (a predictable name in a shared /tmp could be pre-planted, also as a symlink).
+std::string cache_path_for(const std::string& prefix, bool create = true) {
+  std::string dir;
+  const char* x = getenv("XDG_CACHE_HOME");
+  const char* home = getenv("HOME");
+  const char* t = getenv("TMPDIR");
+  if (x && *x) dir = std::string(x) + "/whisper-tflite-amd";
+  else if (home && *home) dir = std::string(home) + "/.cache/whisper-tflite-amd";
+  else dir = std::string(t && *t ? t : "/tmp") + "/whisper-tflite-amd-" + std::to_string(static_cast<long>(::getuid()));
+  struct stat st;
+  if (create) {
+    const size_t slash = dir.rfind('/');
+    if (slash != std::string::npos && slash > 0) (void)::mkdir(dir.substr(0, slash).c_str(), 0700);  // ~/.cache itself
+    (void)::mkdir(dir.c_str(), 0700);
+  }
+  if (::lstat(dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode) || st.st_uid != ::getuid() || (st.st_mode & 022) != 0) {
+    if (!create) return std::string();
+    throw wt::Error(wt::kErrIo, "no private cache directory for the converted model: " + dir);
+  }
+  return dir + "/wt-" + std::to_string(std::hash<std::string>{}(prefix)) + ".wtw";
+}
+}  // namespace
+
 extern "C" {
 
 int wt_engine_create(int engine_type, const char* model_prefix, const char* vocab_path,
@@ -99,12 +127,23 @@ int wt_engine_create(int engine_type, const char* model_prefix, const char* voca
         wt::convert_tflite(prefix, wpath);
       } catch (const wt::Error& e) {
         if (e.code != wt::kErrIo) throw;
-        const char* t = getenv("TMPDIR");
-        wpath = std::string(t && *t ? t : "/tmp") + "/wt-" + std::to_string(std::hash<std::string>{}(prefix)) + ".wtw";
+        wpath = cache_path_for(prefix);  // a per-user 0700 directory: nobody else can plant or swap the file
         wt::convert_tflite(prefix, wpath);
       }
       converted = true;
     };
+    // a model directory that cannot be written: an earlier run's conversion in the user's cache is taken as it is when it
+    // passes the header check (a read-only directory no longer means converting the model at every start)
+    if (!wt::file_exists(wpath) && have_pair) {
+      const std::string cached = cache_path_for(prefix, false);
+      if (!cached.empty() && wt::file_exists(cached)) {
+        try {
+          wt::check_wtw_file(cached);
+          wpath = cached;
+        } catch (const wt::Error&) {
+        }
+      }
+    }
     if (!wt::file_exists(wpath) && have_pair) convert();
     if (have_pair && !converted) {
       try {

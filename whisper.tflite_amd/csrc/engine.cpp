@@ -901,8 +901,11 @@ void Engine::pick_decoder_streams() {
   launch_spin(50, enc);  // first launch of the kernel (code object load) outside the timed pairs
   double alone = chain_us(enc, nullptr);  // the reference is the fastest of three (a slow first run would hide clashes)
   for (int i = 0; i < 2; ++i) alone = std::min(alone, chain_us(enc, nullptr));
+  // a pair shares a hardware queue when it is slow in BOTH of two runs: the timing is host wall-clock over ~0.5 ms, and a
+  // single run disturbed by the host (a page fault, another rank starting) would otherwise reject a good stream — or the
+  // choice, and with it the throughput, would differ between two runs of the same program
   auto serialised = [&](hipStream_t a, hipStream_t b) {
-    const double us = chain_us(a, b);
+    const double us = std::min(chain_us(a, b), chain_us(a, b));
     if (trace) std::fprintf(stderr, "[wt] stream probe: pair %p %p %.0f us (one chain alone %.0f us)\n", (void*)a, (void*)b, us, alone);
     return us > 1.5 * alone;
   };
@@ -916,7 +919,11 @@ void Engine::pick_decoder_streams() {
     ++chosen;
   }
   n_spare_streams_ = std::max(0, chosen - n_dec_streams_);
-  if (trace) std::fprintf(stderr, "[wt] stream probe: %d decoder streams (%d wanted + spares) run beside the encoder stream\n", chosen, n_dec_streams_);
+  if (trace || verbose) {
+    std::fprintf(stderr, "[wt] stream probe: %d decoder streams (%d wanted + spares) run beside the encoder stream:", chosen, n_dec_streams_);
+    for (int i = 0; i < chosen; ++i) std::fprintf(stderr, " %p", (void*)dstream_[i]);
+    std::fprintf(stderr, "\n");
+  }
 }
 
 void Engine::select_stream(bool pipelined) {
@@ -935,6 +942,19 @@ void Engine::sync() {
   HIPCHK(hipStreamSynchronize(stream_full_));
   if (stream_masked_) HIPCHK(hipStreamSynchronize(stream_masked_));
   for (auto& ds : dstream_) HIPCHK(hipStreamSynchronize(ds));
+}
+
+// The cross K/V cache (layers x 2 x clips x 1500 x d fp32: 590 MB per slot for tiny at 32 clips, 1.2 GB for base at 64)
+// belongs to the cached decoder form only — cross_absorb = 0, synchronous calls below 32 clips, a flagged cross
+// operand — so it is allocated per slot the first time a batch of that form is encoded into the slot, not for all
+// twelve slots up front (the default absorbed form never touches it).
+void Engine::need_cross_kv(Slot& slot) {
+  if (slot.cross_kv) return;
+  const wtw::Dims& c = dims_;
+  void* p = nullptr;
+  HIPCHK(hipMalloc(&p, size_t(c.n_text_layer) * 2 * size_t(ws_.batch) * c.n_audio_ctx * c.n_audio_state * sizeof(float)));
+  ws_.owned.push_back(p);
+  slot.cross_kv = static_cast<float*>(p);
 }
 
 void Engine::ensure_batch(int batch) {
@@ -977,7 +997,7 @@ void Engine::ensure_batch(int batch) {
   ws_.enc_out = alloc(B * T * d, false);
   ws_.cvt = reinterpret_cast<unsigned short*>(alloc(B * T * 4 * d, false));
   for (Slot& sl : slots_) {
-    sl.cross_kv = alloc(size_t(c.n_text_layer) * 2 * B * T * d, false);
+    sl.cross_kv = nullptr;  // the cross K/V cache of the CACHED decoder form: allocated when a batch first takes that form (need_cross_kv)
     sl.e_planes = reinterpret_cast<unsigned short*>(alloc(B * T * d, false));  // two planes of halfs
     sl.used = false;
   }
@@ -1091,6 +1111,14 @@ void Engine::logmel(const float* d_pcm, int batch, float* d_mel, int valid_frame
 
 thread_local LaunchTimer g_launch_timer;
 
+namespace {
+// The dispatch-attached event pair must not outlive the encoder pass that armed it: a launcher that throws (shape or span
+// error) between kt_begin and kt_end would leave it armed for the thread's next timed launch — possibly another engine's.
+struct TimerDisarm {
+  ~TimerDisarm() { g_launch_timer = LaunchTimer{}; }
+};
+}  // namespace
+
 void Engine::kt_begin(int cls, double flops, double bytes) {
   if (!kt_on_) return;
   Slot& sl = slots_[enc_slot_];
@@ -1159,6 +1187,7 @@ void Engine::encode(const float* d_mel, int batch) {
 void Engine::encode_enqueue(const float* d_mel, int batch) {
   if (dims_.n_audio_state == 0) throw Error(kErrUnsupported, "front-end-only engine: no model weights loaded");
   ensure_batch(batch);
+  TimerDisarm disarm_on_exit;  // (covers the bf16 pass too: it is called from here)
   // per-launch event pairs (bench.py's live roofline figures) on every kernel_timers-th encoder pass: an event pair
   // costs the stream a few microseconds per launch, which 41 launches per pass make visible in the pipeline period
   kt_on_ = kernel_timers > 0 && (enc_count_++ % kernel_timers) == 0;
@@ -1418,12 +1447,14 @@ void Engine::encode_enqueue(const float* d_mel, int batch) {
   if (absorb) {
   } else if (kp) {
     PlaneGemmArgs g;
+    need_cross_kv(slot);
     g.A = lnp; g.a_plane = ln_plane; g.lda = d; g.W = cross_kv_p_.w; g.bias = cross_kv_b;
     g.C = slot.cross_kv; g.M = M; g.N = c.n_text_layer * 2 * d; g.K = d;
     g.c_rpb = T; g.kv_batch = batch; g.kv_heads = c.n_text_head; g.kv_dmodel = d;
     plane_gemm(g, sc_cross_kv_, kEpiBias | kEpiKvLayout, 2.0 * g.M * g.N * g.K);
   } else {
     GemmArgs g;
+    need_cross_kv(slot);
     g.A = ws_.enc_out; g.lda = d; g.W = cross_kv_w; g.bias = cross_kv_b; g.C = slot.cross_kv;
     g.M = M; g.N = c.n_text_layer * 2 * d; g.K = d;
     g.c_rpb = T; g.kv_batch = batch; g.kv_heads = c.n_text_head; g.kv_dmodel = d;
@@ -1525,6 +1556,7 @@ void Engine::encode_enqueue_bf16(const float* d_mel, int batch) {
   slot.absorbed = absorb;
   if (!absorb) {
     PlaneGemmArgs g;  // cross-attention K/V of every decoder layer into the slot's cache, as bf16
+    need_cross_kv(slot);
     g.A = lnp; g.lda = d; g.W = bf_.cross_kv; g.bias = cross_kv_b;
     g.P = reinterpret_cast<unsigned short*>(slot.cross_kv); g.M = M; g.N = c.n_text_layer * 2 * d; g.K = d;
     g.c_rpb = T; g.kv_batch = batch; g.kv_heads = c.n_text_head; g.kv_dmodel = d;
@@ -1874,7 +1906,7 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
   // kernels' one-time attribute set-up) and then captures one hipGraph per slot; later calls
   // replay the slot's graph: one host call instead of ~1100. The logits tap stays eager.
   auto key_of = [&](int si) {
-    return std::vector<long long>{si, batch, max_pos, n_prompt, chunks, long(stop_at_eot), fc2_ksplit, bf16, absorbed ? 1 : 0, n_abs, paired ? 1 : 0, stream_override, forced ? 1 : 0};
+    return std::vector<long long>{si, batch, max_pos, n_prompt, chunks, long(stop_at_eot), fc2_ksplit, bf16, absorbed ? 1 : 0, n_abs, paired ? 1 : 0, stream_override, forced ? 1 : 0, pipelined ? 1 : 0};
   };
   hipGraphExec_t exec = nullptr;
   if (use_graphs && !logits_host) {

@@ -102,7 +102,8 @@ class Engine {
   long use_graphs = 1;  // replay the decoder's launch sequence from a captured hipGraph
   // 1 = decoder cross-attention against the encoder output itself, K / V projections absorbed into the query and
   // output sides (k_cross_absorbed.hip: half the bytes per decoder position, no cross-KV GEMM in the encoder);
-  // 0 = round 2's cross-KV cache.  The bf16 storage mode and a flagged ln_post operand always take the cache.
+  // 0 = round 2's cross-KV cache.  Both storage modes run either form (absorb_active()); a flagged ln_post operand
+  // (its planes are what the absorbed form streams) always takes the cache.
   long cross_absorb = 1;
   long abs_chunks = 0;  // key chunks per clip of the absorbed form: 1..16, 0 = by batch size and mode (decode_enqueue)
   // 1 = the pipeline decodes TWO consecutive submitted batches of equal size (<= 32 clips each, absorbed form) with
@@ -265,6 +266,7 @@ class Engine {
     hipGraphExec_t exec;
     int steps;
   };
+  void need_cross_kv(Slot& slot);  // the cached decoder form's cross K/V cache of a slot, on first use
   std::map<std::vector<long long>, GraphEntry> graphs_;
   hipEvent_t trace_base_ = nullptr;  // WT_TRACE_PIPELINE=1: origin of the per-batch device timeline
   int enc_slot_ = 0;        // slot the next encode() fills

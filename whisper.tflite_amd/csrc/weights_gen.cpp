@@ -8,6 +8,7 @@
 // element are used, so the bytes do not depend on libm or the host CPU.
 #include "weights_gen.h"
 
+#include <fcntl.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -191,9 +192,14 @@ int write_tensors(const char* path, const Dims& dims, const std::vector<NamedTen
 
   // Written next to the target under a name of its own and renamed into place: a reader (another rank converting
   // the same .tflite pair, a later wt_engine_create) sees either no file or a complete one, never a short write.
+  // The temporary is created exclusively and without following links (O_EXCL | O_NOFOLLOW, mode 0600): in a shared
+  // directory nobody can pre-plant the name — as a file or as a symlink to one of the user's own files.
   const std::string tmp = std::string(path) + ".tmp." + std::to_string(static_cast<long>(::getpid()));
-  FILE* f = std::fopen(tmp.c_str(), "wb");
+  ::unlink(tmp.c_str());  // a leftover of a killed run of this very pid
+  const int fd = ::open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+  FILE* f = fd >= 0 ? ::fdopen(fd, "wb") : nullptr;
   if (!f) {
+    if (fd >= 0) ::close(fd);
     if (err) *err = std::string("cannot open for writing: ") + tmp;
     return 2;
   }
