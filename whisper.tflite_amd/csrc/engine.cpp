@@ -1908,6 +1908,11 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
   auto key_of = [&](int si) {
     return std::vector<long long>{si, batch, max_pos, n_prompt, chunks, long(stop_at_eot), fc2_ksplit, bf16, absorbed ? 1 : 0, n_abs, paired ? 1 : 0, stream_override, forced ? 1 : 0, pipelined ? 1 : 0};
   };
+  // the cached form's graphs are captured for EVERY slot at once (below) and hold each slot's cache pointer: all of
+  // them must exist before the capture (need_cross_kv allocates; nothing may be allocated inside a capture)
+  if (!absorbed && use_graphs && !logits_host) {
+    for (Slot& s : slots_) need_cross_kv(s);
+  }
   hipGraphExec_t exec = nullptr;
   if (use_graphs && !logits_host) {
     auto it = graphs_.find(key_of(slot_idx));
