@@ -22,8 +22,9 @@ int wt_dbg_gemm_planes(wt_engine* h, int M, int N, int K, const float* A, const 
  * switches it off.  Ids outside the vocabulary are refused by the decode (WT_ERR_INVALID_ARG). */
 int wt_dbg_set_forced_ids(wt_engine* h, const int64_t* ids, int clips);
 /* schedule of the 384-column plane-GEMM tiles for subsequent launches of this process: 0 = gemm_planes_tile (both
- * wavefronts of a SIMD in step), 1 = gemm_planes_pp (ping-pong groups), 2 = gemm_planes_pp16 (ping-pong groups on
- * 16 x 16 x 32 MFMAs, default), 3 = + gemm_planes_v2 where it applies; A/B measurements in one process */
+ * wavefronts of a SIMD in step), 1 = gemm_planes_pp (ping-pong groups, 32 x 32 x 16), 2 = gemm_planes_pp16 (ping-pong groups on
+ * 16 x 16 x 32 MFMAs; its persistent form where a CU runs several plane-output tiles: the default), 4 = the same without the
+ * persistent form; A/B measurements in one process */
 int wt_dbg_set_plane_gemm_mode(int mode);
 /* the same GEMM (N = 384, fp32 output C, epi = bias | residual (5) or bias | gelu | pos (11)) with the LayerNorm of the
  * finished rows fused into its epilogue: ln_out [M][384] = LayerNorm(C row) * ln_g + ln_b reconstructed from the planes

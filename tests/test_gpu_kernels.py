@@ -557,6 +557,22 @@ def test_plane_gemm_every_tile_shape_gives_the_same_result(pkg, eng, n_cu, expec
         assert rel_err(outs[0], ref) < 2e-6
     finally:
         assert L.wt_dbg_set_plane_gemm_mode(2) == 0
+    # several tiles per CU with plane output: the PERSISTENT form of the ping-pong kernel (a block walks its tiles and
+    # prefetches the next one's first k-tile from its epilogue) — bit for bit the one-tile-per-block kernel (mode 4),
+    # whole tiles and a ragged last row tile, both epilogues it serves
+    for Mp, Np, Kp, epi in ((3000, 1152, 384, 1), (2900, 1536, 384, 3), (5000, 768, 256, 1)):
+        Ap = rng.standard_normal((Mp, Kp)).astype(np.float32)
+        Wp = (rng.standard_normal((Np, Kp)) / np.sqrt(Kp)).astype(np.float32)
+        bp = rng.standard_normal(Np).astype(np.float32)
+        try:
+            assert L.wt_dbg_set_plane_gemm_mode(4) == 0
+            one = eng.dbg_gemm_planes(Ap, Wp, bp, epi=epi, planes_out=True, n_cu=8)
+        finally:
+            assert L.wt_dbg_set_plane_gemm_mode(2) == 0
+        per = eng.dbg_gemm_planes(Ap, Wp, bp, epi=epi, planes_out=True, n_cu=8)
+        refp = Ap.astype(np.float64) @ Wp.astype(np.float64).T + bp
+        assert np.array_equal(one, per), (Mp, Np, Kp)
+        assert rel_err(per, gelu(refp) if epi & 2 else refp) < 4e-6
     assert rel_err(eng.dbg_gemm_planes(A, W, bias, R=R, epi=5, n_cu=n_cu), ref + R) < 3e-6
     assert rel_err(eng.dbg_gemm_planes(A, W, bias, epi=3, planes_out=True, n_cu=n_cu), gelu(ref)) < 4e-6
 

@@ -1,15 +1,15 @@
 #!/bin/bash
 # Round-N profile collection on the GPU box (run through gpurun from the repo root):
-#   bash tools/collect_profiles.sh r03                                   (default workload: BASELINE configs[1])
-#   bash tools/collect_profiles.sh r03_c4 "--arch base --batch 64 --bf16" gemm_bf16_planes   (configs[3])
+#   bash tools/collect_profiles.sh r04                                   (default workload: BASELINE configs[1])
+#   bash tools/collect_profiles.sh r04_c4 "--arch base --batch 64 --bf16" gemm_bf16_planes   (configs[3])
 # 1. rocprofv3 --kernel-trace --stats over the default bench command (per-kernel averages)
 # 2. separate --pmc passes (never combined with other trace domains) over a serial 2-step run
 # Raw output goes to gpurun_out/prof_<tag>_*; the summaries are written to gpurun_out/<tag>_*.{csv,json}
 # and copied into profiles/ by hand afterwards.
 set -o pipefail
-tag=${1:-r03}
+tag=${1:-r04}
 extra=${2:-}
-dominant=${3:-gemm_planes_tile}
+dominant=${3:-gemm_planes}
 root=$PWD
 out=$root/gpurun_out
 mkdir -p $out

@@ -914,7 +914,7 @@ int wt_dbg_set_forced_ids(wt_engine* h, const int64_t* ids, int clips) {
 }
 
 int wt_dbg_set_plane_gemm_mode(int mode) {
-  if (mode < 0 || mode > 3) return WT_ERR_INVALID_ARG;
+  if (mode < 0 || mode > 4) return WT_ERR_INVALID_ARG;
   wt::set_plane_gemm_mode(mode);
   return WT_OK;
 }

@@ -27,7 +27,8 @@
 namespace wt {
 
 // schedule of the 384-column tiles: 0 = both wavefronts of a SIMD in step (gemm_planes_tile), 1 = ping-pong groups
-// (gemm_planes_pp), 2 = ping-pong groups on 16 x 16 x 32 MFMAs (gemm_planes_pp16).  WT_PLANE_GEMM_MODE / wt_dbg_set_plane_gemm_mode are measurement knobs (tools/gemm_planes_bench.py).
+// (gemm_planes_pp), 2 = ping-pong groups on 16 x 16 x 32 MFMAs (gemm_planes_pp16, persistent where a CU runs several
+// plane-output tiles), 4 = the same, one tile per block everywhere.  WT_PLANE_GEMM_MODE / wt_dbg_set_plane_gemm_mode are measurement knobs (tools/gemm_planes_bench.py).
 static int g_plane_gemm_mode = -1;
 int plane_gemm_mode() {
   if (g_plane_gemm_mode < 0) {
@@ -127,8 +128,9 @@ __device__ __forceinline__ void setup_stage_dma(const PlaneGemmDev& g, int m0, i
 }
 
 // ---- accumulators of a wave tile as the epilogue sees them: MI x NI blocks of 32 x 32 outputs, 16 floats per lane and
-// block.  stage_write() puts a block into the wave's private LDS stage (32 rows x 32 floats, columns XORed by 4 on rows
-// with bit 2 set); get / set address the 16 floats as plain storage (the LayerNorm fusion parks finished values there).
+// block.  stage_write() puts a block into the wave's private LDS stage (32 rows x 32 floats, columns XORed by 20 — bits 2
+// and 4 — on rows with bit 2 set: conflict-free for the ds_write_b32 of BOTH accumulator layouts and for the row reads of 4
+// and 8 columns per lane; round 3's XOR by 4 served the 32 x 32 layout only, the 16 x 16 one wrote 2-way); get / set address the 16 floats as plain storage (the LayerNorm fusion parks finished values there).
 template <int MI_, int NI_>
 struct Acc32 {  // v_mfma_f32_32x32x16: lane (l31, lh) holds column l31, rows (r & 3) + 8 (r >> 2) + 4 lh
   static constexpr int MI = MI_, NI = NI_;
@@ -146,7 +148,7 @@ struct Acc32 {  // v_mfma_f32_32x32x16: lane (l31, lh) holds column l31, rows (r
   __device__ __forceinline__ void stage_write(int mi, int ni, float* stage, int lane, float scale) const {
     const int l31 = lane & 31, lh = lane >> 5;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + (l31 ^ (lh << 2))] = t[mi][ni][r] * scale;
+    for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + (l31 ^ (lh * 20))] = t[mi][ni][r] * scale;  // row bit 2 = lh
   }
 };
 template <int MI_, int NI_>
@@ -171,23 +173,35 @@ struct Acc16 {  // v_mfma_f32_16x16x32: 2 x 2 tiles per block; lane (c = l & 15,
       for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int r = 0; r < 4; ++r)  // row 16 a + 4 q + r: its bit 2 is q & 1
-          stage[(16 * a + 4 * q + r) * 32 + ((16 * b + c) ^ ((q & 1) << 2))] = t[2 * mi + a][2 * ni + b][r] * scale;
+          stage[(16 * a + 4 * q + r) * 32 + ((16 * b + c) ^ ((q & 1) * 20))] = t[2 * mi + a][2 * ni + b][r] * scale;
   }
 };
 
 // ---- epilogue shared by the tile kernels: each wavefront transposes one 32 x 32 MFMA tile at a time through a
 // private LDS stage and moves 16 bytes per lane (128-byte row segments per 8 lanes, or two 64-byte plane segments
 // per 4).  `smem` is the block's dynamic LDS, dead as operand staging by the time this runs.
-template <int EPI, bool PLANES_OUT, int WN, bool LN, class Acc>
+struct NoEpilogueHook {
+  static constexpr bool active = false;
+  __device__ __forceinline__ void operator()() const {}
+};
+template <class F>
+struct ActiveEpilogueHook {
+  static constexpr bool active = true;
+  F& f;
+  __device__ __forceinline__ void operator()() const { f(); }
+};
+// `hook` (persistent kernel): called once after the tile's bias values are IN registers and before anything else touches
+// memory — the point where the next tile's first LDS-DMA may be issued without an epilogue load queueing behind it.
+template <int EPI, bool PLANES_OUT, int WN, bool LN, class Acc, class Hook = NoEpilogueHook>
 __device__ __forceinline__ void planes_epilogue(const PlaneGemmDev& g, Acc& acc, unsigned char* smem, int m0, int n0, int wid, int wm,
-                                                int wn, int lane) {
+                                                int wn, int lane, Hook hook = Hook{}) {
   constexpr int MI = Acc::MI, NI = Acc::NI;
   constexpr int BN = WN * NI * 32, NW = 2 * WN, BM = 64 * MI;
   __syncthreads();  // the operand stages are dead: the epilogue reuses them
 
   // ---- epilogue: each wavefront transposes one 32 x 32 MFMA tile at a time through a private LDS stage and moves
   // 16 bytes per lane (128-byte row segments per 8 lanes, or two 64-byte plane segments per 4)
-  // Staging image: 32 rows x 32 floats, unpadded, columns XORed by 4 on rows with bit 2 set.  With that the
+  // Staging image: 32 rows x 32 floats, unpadded, columns XORed by 20 on rows with bit 2 set.  With that the
   // ds_write_b32 of the accumulator registers (32 consecutive lanes = one row) and the ds_read_b128 of the row
   // segments (served in the non-contiguous 16-lane groups of MI355X_MICROARCH.md, LDS table) are both conflict-free
   // for 4 and for 8 columns per lane; 36-float rows made every read 2-way.
@@ -197,12 +211,28 @@ __device__ __forceinline__ void planes_epilogue(const PlaneGemmDev& g, Acc& acc,
   constexpr int LPR = 32 / CPL;              // lanes per staged row
   constexpr int RPS = 64 / LPR;              // rows per pass
   const int prow = lane / LPR, c0 = (lane % LPR) * CPL;
+  float bias_all[NI][CPL];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+    for (int e = 0; e < CPL; ++e) bias_all[ni][e] = (EPI & kEpiBias) ? g.bias[n0 + (wn * NI + ni) * 32 + c0 + e] : 0.0f;
+  if constexpr (Hook::active) {
+    // the values are "used" here, so hipcc's wait for the loads sits here too — in front of the hook's LDS-DMA, which
+    // the same wait would otherwise have to sit out (vmcnt retires in issue order, and the DMA is inline asm hipcc
+    // does not count)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int e = 0; e < CPL; e += 4)
+        asm volatile("" : "+v"(bias_all[ni][e]), "+v"(bias_all[ni][e + 1]), "+v"(bias_all[ni][e + 2]), "+v"(bias_all[ni][e + 3]));
+    hook();
+  }
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
     const int n = n0 + (wn * NI + ni) * 32 + c0;
     float bias_v[CPL];
 #pragma unroll
-    for (int e = 0; e < CPL; ++e) bias_v[e] = (EPI & kEpiBias) ? g.bias[n + e] : 0.0f;
+    for (int e = 0; e < CPL; ++e) bias_v[e] = bias_all[ni][e];
     const float oscale = PLANES_OUT ? g.out_scale[n / g.seg] : 1.0f;  // CPL consecutive columns never straddle a segment
     // kEpiKvLayout: the column decomposition does not depend on the row
     const int slab = (EPI & kEpiKvLayout) ? n / g.kv_dmodel : 0, rem = (EPI & kEpiKvLayout) ? n % g.kv_dmodel : 0;
@@ -221,7 +251,7 @@ __device__ __forceinline__ void planes_epilogue(const PlaneGemmDev& g, Acc& acc,
         float v[CPL];
 #pragma unroll
         for (int e = 0; e < CPL; e += 4) {
-          const f32x4 t = *reinterpret_cast<const f32x4*>(&stage[row * SLD + ((c0 + e) ^ (((row >> 2) & 1) << 2))]);
+          const f32x4 t = *reinterpret_cast<const f32x4*>(&stage[row * SLD + ((c0 + e) ^ (((row >> 2) & 1) * 20))]);
           v[e] = t[0], v[e + 1] = t[1], v[e + 2] = t[2], v[e + 3] = t[3];
         }
         if (mbase + row < g.M) {
@@ -787,8 +817,160 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_pp16(PlaneGemmDev g) {
 #endif
 }
 
+// gemm_planes_pp16 as a PERSISTENT launch for the shapes a CU runs several tiles of (qkv, fc1: plane output, bias / GELU):
+// one block per CU walks tiles bid, bid + grid, ... and issues the NEXT tile's first k-tile from the head of the current
+// tile's epilogue (into the stage the epilogue's LDS staging does not touch), the second right behind the epilogue.  A
+// tile of these shapes spent 9 k of its 75 k cycles waiting for its first k-tile (tools/gemm_phase_probe.hip).
+// Stages: k-tile kt lives in stage (kt + 1) & 1, so that a tile's first k-tile is in stage 1 — the epilogue stages its
+// 32 x 32 blocks at the bottom of stage 0.  The next tile's first k-tile is certified behind the epilogue with a counted
+// vmcnt: the epilogue's 36 plane stores per wave are younger (a tile with rows past M may skip stores: it waits for all).
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_planes_pp16_persist(PlaneGemmDev g, int total_tiles) {
+  constexpr int WN = 4, NI = 3, MI = 3;
+  constexpr bool PLANES_OUT = true;
+  static_assert((EPI & ~(kEpiBias | kEpiGelu)) == 0, "bias / GELU epilogues with plane output");
+  constexpr int BN = WN * NI * 32, NW = 2 * WN, BM = 64 * MI;
+  constexpr int kAPlane = BM * BK * 2, kWPlane = BN * BK * 2;
+  constexpr int kStage = 2 * kAPlane + 2 * kWPlane;
+  constexpr int QA = BM / 16, QW = BN / 16;
+  constexpr int QT = 2 * QA + 2 * QW, QPW = QT / NW;
+  constexpr int kEpiStores = MI * NI * 4;  // per wave: 9 blocks x 2 passes x (hi, lo)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int grid = gridDim.x, bid = blockIdx.x;
+  const int q8 = total_tiles >> 3, r8 = total_tiles & 7;
+  const int n_tiles = g.N / BN;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WN, wn = wid % WN;
+
+  unsigned voff[QPW], kstep[QPW];
+  const unsigned char* ubase[QPW];
+  const unsigned lds_base = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)smem;
+  int m0 = 0, n0 = 0;
+  // virtual block id -> tile: the XCD-aware bijective remap of the one-tile-per-block kernels over all tiles (grid is a
+  // multiple of 8, so a block's tiles keep its XCD)
+  auto set_tile = [&](int vid) {
+    const int xcd = vid & 7;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (vid >> 3);
+    m0 = (logical / n_tiles) * BM;
+    n0 = (logical % n_tiles) * BN;
+    setup_stage_dma<QA, QW, NW, QPW>(g, m0, n0, wid, lane, voff, ubase, kstep);
+  };
+  auto issue_stage = [&](int kt) {
+    const int buf = (kt + 1) & 1;
+#pragma unroll
+    for (int j = 0; j < QPW; ++j) {
+      const unsigned long long sb = reinterpret_cast<unsigned long long>(ubase[j]) + (size_t)kt * kstep[j];
+      lds_dma16_sgpr(voff[j], sb, lds_base + (unsigned)(buf * kStage + (wid + NW * j) * 1024));
+    }
+  };
+
+  Acc16<MI, NI> accs;
+  auto& acc = accs.t;
+  const int fc = lane & 15, fq = lane >> 4;
+  const int frag = fc * 64 + ((fq ^ chunk_swizzle(fc)) * 16);
+  const int a_off = wm * (32 * MI) * 64 + frag, b_off = 2 * kAPlane + wn * (NI * 32) * 64 + frag;
+  half8 ah[3], al[3], bh[6], bl[6];
+  auto load_b = [&](int kt) {
+    const unsigned char* base = smem + ((kt + 1) & 1) * kStage + b_off;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      bh[j] = *reinterpret_cast<const half8*>(base + j * 1024);
+      bl[j] = *reinterpret_cast<const half8*>(base + kWPlane + j * 1024);
+    }
+  };
+  auto load_a = [&](int kt, int half) {
+    const unsigned char* base = smem + ((kt + 1) & 1) * kStage + a_off + half * 3 * 1024;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      ah[i] = *reinterpret_cast<const half8*>(base + i * 1024);
+      al[i] = *reinterpret_cast<const half8*>(base + kAPlane + i * 1024);
+    }
+  };
+  auto compute = [&](auto half_c) {
+    constexpr int H = decltype(half_c)::value;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) acc[3 * H + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[3 * H + i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) acc[3 * H + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[3 * H + i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) acc[3 * H + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[3 * H + i][j], 0, 0, 0);
+  };
+  using H0 = std::integral_constant<int, 0>;
+  using H1 = std::integral_constant<int, 1>;
+  auto phase_end = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto reads_done = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+  auto dma_done = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+
+  const int nkt = g.K / BK;  // even and >= 4 (launcher)
+  int vid = bid;
+  set_tile(vid);
+  issue_stage(0);
+  issue_stage(1);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QPW) : "memory");
+  phase_end();
+  for (;;) {
+    if (wm == 1) phase_end();  // G1 runs one phase behind
+    accs.zero();
+    load_b(0);
+    load_a(0, 0);
+    reads_done();
+    phase_end();
+    for (int kt = 0; kt < nkt; ++kt) {
+      compute(H0{});
+      phase_end();
+      load_a(kt, 1);
+      reads_done();
+      if (wm == 1) dma_done();
+      phase_end();
+      compute(H1{});
+      if (wm == 0) dma_done();
+      phase_end();
+      if (kt + 1 < nkt) {
+        if (kt + 2 < nkt) issue_stage(kt + 2);
+        load_b(kt + 1);
+        load_a(kt + 1, 0);
+        reads_done();
+      }
+      phase_end();
+    }
+    if (wm == 0) phase_end();
+    const int m_cur = m0, n_cur = n0;
+    const int next = vid + grid;
+    const bool has_next = next < total_tiles;
+    const bool whole = m_cur + BM <= g.M;
+    auto prefetch = [&]() {
+      if (has_next) {
+        set_tile(next);
+        issue_stage(0);
+      }
+    };
+    planes_epilogue<EPI, PLANES_OUT, WN, false>(g, accs, smem, m_cur, n_cur, wid, wm, wn, lane, ActiveEpilogueHook<decltype(prefetch)>{prefetch});
+    if (!has_next) break;
+    if (whole) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kEpiStores) : "memory");
+    } else {
+      dma_done();
+    }
+    phase_end();  // every wave is done with the epilogue's LDS; the next tile's first k-tile is visible
+    issue_stage(1);
+    vid = next;
+  }
+}
+
 template <int EPI, bool PLANES_OUT, int WN, int NI, int MI = 3, bool LN = false>
-void launch_planes_shape(const PlaneGemmDev& g, hipStream_t s) {
+void launch_planes_shape(const PlaneGemmDev& g, hipStream_t s, int n_cu = 0) {
   constexpr int BN = WN * NI * 32, BM = 64 * MI;
   const int blocks = ((g.M + BM - 1) / BM) * (g.N / BN);
   constexpr size_t smem = 2 * (2 * BM * BK * 2 + 2 * BN * BK * 2);  // two stages; the epilogue stages fit inside
@@ -799,7 +981,21 @@ void launch_planes_shape(const PlaneGemmDev& g, hipStream_t s) {
   }();
   (void)raised;
   if constexpr (WN == 4 && NI == 3 && MI == 3) {  // (the 256-row tile's fragments do not fit beside its accumulators)
-    if (plane_gemm_mode() == 2) {
+    if constexpr (PLANES_OUT && !LN && (EPI & ~(kEpiBias | kEpiGelu)) == 0) {
+      // several tiles per CU: one persistent block per CU that prefetches across tiles (WT_PLANE_GEMM_MODE=4 switches it off)
+      const int cu = n_cu > 0 ? n_cu : 256;
+      if (plane_gemm_mode() == 2 && cu % 8 == 0 && blocks >= 2 * cu && (g.K / BK) % 2 == 0 && g.K / BK >= 4) {
+        static const bool raised_p = [] {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_planes_pp16_persist<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024);
+          return true;
+        }();
+        (void)raised_p;
+        WT_LAUNCH_TIMED((gemm_planes_pp16_persist<EPI>), dim3(cu), dim3(512), smem, s, g, blocks);
+        return;
+      }
+    }
+    if (plane_gemm_mode() == 2 || plane_gemm_mode() == 4) {
       static const bool raised_pp16 = [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_planes_pp16<EPI, PLANES_OUT, LN>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -833,14 +1029,15 @@ bool launch_planes(const PlaneGemmDev& g, int n_cu, hipStream_t s) {
   // Tile choice by how the blocks fill the CUs this stream may use (the pipelined encoder stream leaves some CUs
   // to the decoders): 250 wide row tiles are one round on 256 CUs but two on 224, 188 tall ones one round on either.
   // Cost of a candidate = rows x 128-column units x rounds of the CUs; the narrow kernel (two co-resident blocks per
-  // CU, which share the CU's throughput) costs ~10 % more per unit, the 256-row tile ~5 % less (fewer staged bytes
-  // per FLOP).
+  // CU, which share the CU's throughput) costs ~10 % more per unit.
   const int cu = n_cu > 0 ? n_cu : 256;
   auto rounds = [&](long tiles) { return (tiles + cu - 1) / cu; };
   const long rt192 = (g.M + 191) / 192, rt256 = (g.M + 255) / 256;
   const bool can_wide = g.N % 384 == 0;
   const double c_wide = can_wide ? 192.0 * 3 * rounds(rt192 * (g.N / 384)) : 1e30;
-  const double c_tall = can_wide ? 256.0 * 3 * 0.95 * rounds(rt256 * (g.N / 384)) : 1e30;
+  // (round 4: the 192-row tile runs the ping-pong 16 x 16 x 32 kernel, the 256-row one the older in-step kernel — 8 % more per
+  // unit of work instead of 5 % less: fc1 236 us on 4 rounds of 192-row tiles against 260 us on 3 rounds of 256-row tiles)
+  const double c_tall = can_wide ? 256.0 * 3 * 1.08 * rounds(rt256 * (g.N / 384)) : 1e30;
   const double c_narrow = 192.0 * 1.1 * rounds(rt192 * (g.N / 128));
   int pick = c_wide <= c_narrow ? (c_tall < c_wide ? 2 : 1) : (c_tall < c_narrow ? 2 : 0);
   if (forced == 128) pick = 0;
@@ -859,7 +1056,7 @@ bool launch_planes(const PlaneGemmDev& g, int n_cu, hipStream_t s) {
   if (pick == 2) {
     launch_planes_shape<EPI, PLANES_OUT, 4, 3, 4>(g, s);
   } else if (pick == 1) {
-    launch_planes_shape<EPI, PLANES_OUT, 4, 3, 3>(g, s);
+    launch_planes_shape<EPI, PLANES_OUT, 4, 3, 3>(g, s, n_cu);
   } else {
     launch_planes_shape<EPI, PLANES_OUT, 2, 2, 3>(g, s);
   }
