@@ -1063,7 +1063,7 @@ void Engine::logmel(const float* d_pcm, int batch, float* d_mel, int valid_frame
     ws_.pcm_planes = reinterpret_cast<unsigned short*>(alloc((size_t(pcm_plane_) * 2 * sizeof(unsigned short) + 3) / 4 + 64));
     ws_.pw = alloc(Bc * T0 * size_t(pw_ld_));
     ws_.melacc = alloc(Bc * T0 * mel_n);
-    ws_.clip_max = reinterpret_cast<unsigned*>(alloc(Bc));
+    ws_.clip_max = reinterpret_cast<unsigned*>(alloc(Bc * kClipMaxStride * kClipMaxWays));
   }
   HIPCHK(hipEventRecord(ev_[0], stream_));
   const long M = long(batch) * long(T0);
@@ -1100,7 +1100,7 @@ void Engine::logmel(const float* d_pcm, int batch, float* d_mel, int valid_frame
   // the mel GEMM stays on the full-range three-plane kernel: power values span more decades than two fp16 planes keep
   m.variant = gemm_variant >= 0 ? int(gemm_variant) : 13;
   launch_gemm(m, 0, stream_);
-  HIPCHK(hipMemsetAsync(ws_.clip_max, 0, sizeof(unsigned) * batch, stream_));
+  HIPCHK(hipMemsetAsync(ws_.clip_max, 0, sizeof(unsigned) * batch * kClipMaxStride * kClipMaxWays, stream_));
   launch_log_clipmax(ws_.melacc, mel_n, d_mel, ws_.clip_max, batch, dims_.n_mels, int(T0), stream_, valid_frames);
   launch_mel_normalize(d_mel, ws_.clip_max, batch, dims_.n_mels, int(T0), stream_);
   HIPCHK(hipEventRecord(ev_[1], stream_));

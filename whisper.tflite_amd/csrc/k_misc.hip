@@ -241,19 +241,38 @@ __global__ __launch_bounds__(256) void log_clipmax(const float* __restrict__ mel
   if (threadIdx.x == 0) smax = 0u;
   __syncthreads();
   unsigned lmax = 0u;
+  // the four loads of a thread are issued together from clamped (always valid) addresses and masked afterwards: under
+  // their bounds tests hipcc waited for each in turn — four dependent memory round trips, 98 us per batch for 80 MB
+  float e4[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int t = t0 + ty + 8 * i, c = c0 + tx;
+    e4[i] = melacc[((long)b * T + (t < T ? t : T - 1)) * ld + (c < ld ? c : ld - 1)];
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int t = t0 + ty + 8 * i, c = c0 + tx;
     float v = 0.0f;
     if (t < T && c < n_mel) {
-      float e = melacc[((long)b * T + t) * ld + c];
+      float e = e4[i];
       e = e < 1e-10f ? 1e-10f : e;         // whisper.cpp:176-180 (a float epsilon)
-      v = (float)log10((double)e);          // :182 log10 in double, stored as float
+      // :182 takes log10 in double and stores a float; v_log_f32 (1 ulp of log2) times log10(2) as a two-term product is
+      // within 2e-6 of it in absolute terms on [-10, 6] — the bar on the normalised log-mel is 1e-4
+      const float l2 = __builtin_amdgcn_logf(e);
+      v = fmaf(l2, 0.30102999566f, l2 * -1.4320989e-8f);  // log10(2) = float(0.30102999566) - 1.4320989e-8
+      if (e <= 1e-10f) v = -10.0f;  // the floor itself is exact: silence normalises to exactly -1.5, as in the reference
       const unsigned o = ordered_bits(v);
       if (t < t_valid) lmax = o > lmax ? o : lmax;  // the reference's maximum runs over n_len frames only
     }
     tile[ty + 8 * i][tx] = v;
   }
+  // one LDS atomic per wavefront
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const unsigned o = __shfl_xor(lmax, off, 64);
+    lmax = o > lmax ? o : lmax;
+  }
+  if ((threadIdx.x & 63) != 0) lmax = 0u;
   atomicMax(&smax, lmax);
   __syncthreads();
 #pragma unroll
@@ -261,14 +280,21 @@ __global__ __launch_bounds__(256) void log_clipmax(const float* __restrict__ mel
     const int c = c0 + ty + 8 * i, t = t0 + tx;
     if (c < n_mel && t < T) logmel[((long)b * n_mel + c) * T + t] = tile[tx][ty + 8 * i];
   }
-  if (threadIdx.x == 0 && smax != 0u) atomicMax(&clip_max[b], smax);
+  // a clip's maximum in kClipMaxWays words on 128-byte lines of their own (kClipMaxStride): with the 32 clips' words in ONE
+  // line all 9024 blocks' atomics serialised on it at the memory side — 98 of this kernel's 100 us
+  if (threadIdx.x == 0 && smax != 0u) atomicMax(&clip_max[((long)b * kClipMaxWays + (blockIdx.x % kClipMaxWays)) * kClipMaxStride], smax);
 }
 
 __global__ __launch_bounds__(256) void mel_normalize(float* __restrict__ logmel,
                                                      const unsigned* __restrict__ clip_max,
                                                      long per_clip) {
   const int b = blockIdx.y;
-  const double floor_v = (double)from_ordered(clip_max[b]) - 8.0;  // whisper.cpp:198-205, double
+  unsigned mx = 0u;
+  for (int w = 0; w < kClipMaxWays; ++w) {
+    const unsigned o = clip_max[((long)b * kClipMaxWays + w) * kClipMaxStride];
+    mx = o > mx ? o : mx;
+  }
+  const double floor_v = (double)from_ordered(mx) - 8.0;  // whisper.cpp:198-205, double
   float* p = logmel + (long)b * per_clip;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per_clip; i += (long)gridDim.x * 256) {
     float v = p[i];

@@ -244,8 +244,9 @@ void launch_mel_transpose(const float* mel, float* melT, int batch, int n_mels, 
 void launch_mel_transpose_planes(const float* mel, unsigned short* out, long plane, float scale, int batch, int n_mels,
                                  int T, int ld, hipStream_t s, bool bf16 = false);
 // melacc [B*T][ld] (first n_mel columns) -> logmel [B][n_mel][T] = log10(max(x,1e-10)),
-// and per-clip maximum over frames [0, t_valid) (t_valid < 0: all T) into clip_max[b] (ordered-uint
+// and per-clip maximum over frames [0, t_valid) (t_valid < 0: all T) into clip_max[(b * kClipMaxWays + w) * kClipMaxStride], w < kClipMaxWays (ordered-uint
 // encoding, pre-zeroed).
+constexpr int kClipMaxStride = 32, kClipMaxWays = 4;  // a clip's maximum: kClipMaxWays partial maxima, one 128-byte line each
 void launch_log_clipmax(const float* melacc, int ld, float* logmel, unsigned* clip_max, int batch,
                         int n_mel, int T, hipStream_t s, int t_valid = -1);
 // in place: x = (max(x, clipmax[b] - 8) + 4) / 4
