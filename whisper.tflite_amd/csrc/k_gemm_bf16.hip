@@ -27,6 +27,20 @@ using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 constexpr int BM = 192, BK = 64;
 constexpr int MI = 3;
 
+// diagnostic build (tools/gemm_bf16_probe.hip): WT_BF16_ABL 1 = no LDS-DMA after the first k-tile, 2 = no MFMAs,
+// 3 = no epilogue; s_memtime per phase of wave 0 into g_bf16_stamps.  The product build compiles none of it.
+#ifndef WT_BF16_ABL
+#define WT_BF16_ABL 0
+#endif
+#ifdef WT_BF16_STAMPS
+__device__ long long g_bf16_stamps[4096 * 8];
+#define BF_STAMP(i) do { if (tid == 0 && blockIdx.x < 4096) g_bf16_stamps[blockIdx.x * 8 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define BF_STAMP_RT(i) do { if (tid == 0 && blockIdx.x < 4096) g_bf16_stamps[blockIdx.x * 8 + (i)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define BF_STAMP(i) do {} while (0)
+#define BF_STAMP_RT(i) do {} while (0)
+#endif
+
 struct Bf16GemmDev {
   const unsigned short* A;
   const unsigned short* W;
@@ -133,14 +147,19 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_bf16_planes(Bf16GemmDev g) {
   };
 
   const int nkt = g.K / BK;
+  BF_STAMP(0);
+  BF_STAMP_RT(4);
   issue_stage(0, 0);
   for (int kt = 0; kt < nkt; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (kt + 1 < nkt) issue_stage(kt + 1, (kt + 1) & 1);
-    compute(kt & 1);
+    if (kt == 0) BF_STAMP(1);
+    if (kt + 1 < nkt && WT_BF16_ABL != 1) issue_stage(kt + 1, (kt + 1) & 1);
+    if (WT_BF16_ABL != 2) compute(kt & 1);
   }
   __syncthreads();
+  BF_STAMP(2);
+  if (WT_BF16_ABL == 3 && acc[0][0][0] != 12345.678f) return;
 
   // epilogue: per-wave 32 x 32 transposing stage, conflict-free image of k_gemm_planes.hip
   constexpr int SLD = 32;
@@ -217,6 +236,8 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_bf16_planes(Bf16GemmDev g) {
       }
     }
   }
+  BF_STAMP(3);
+  BF_STAMP_RT(5);
 }
 
 template <int EPI, bool BF_OUT, int WN, int NI>
