@@ -184,6 +184,10 @@ __global__ __launch_bounds__(256, BF ? 4 : 3) void encoder_attention_planes(cons
     for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, fmaxf(s0[r], s1[r]));
     // (the LDS shuffle stays here: with three blocks per CU its latency is hidden, and v_permlane32_swap — a vector
     // instruction in a VALU-bound softmax — measured 1.5 % slower, round 4)
+    // (also round 4: scaling the scores first with packed multiplies — no canonicalising v_max x, x, x per raw MFMA
+    // result, v_max3 chains, packed adds for the shift and the row sum: 135 instead of 180 vector instructions per
+    // tile — measured 0-4 % SLOWER in three alternating runs on one box (tools/ab_attn.sh): the loop is not bound by
+    // the count of vector instructions)
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * s_inv;
     // deferred maximum: raise m_run (and rescale O, l) only when some row's tile maximum exceeds it by more than
     // kDefer; otherwise the probabilities of this tile are at most 2^kDefer, which the planes hold
