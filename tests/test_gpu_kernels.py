@@ -444,7 +444,8 @@ def bf16_round(x):
     return u.astype(np.uint32).view(np.float32)
 
 
-@pytest.mark.parametrize("M,N,K", [(192, 128, 64), (300, 256, 128), (1, 128, 64), (257, 384, 448), (1500, 512, 1536), (3000, 1536, 512)])
+@pytest.mark.parametrize("M,N,K", [(192, 128, 64), (300, 256, 128), (1, 128, 64), (257, 384, 448), (1500, 512, 1536), (3000, 1536, 512),
+                                   (129, 256, 64), (193, 128, 64), (500, 640, 192), (1000, 2048, 512), (77, 768, 64)])
 def test_bf16_gemm_matches_bf16_rounded_operands(eng, M, N, K):
     """gemm_bf16_planes contracts bf16 operands EXACTLY (bf16 x bf16 products are exact in fp32) with fp32
     accumulation: against fp64 on the rounded operands the error is the fp32 accumulation error, not a bf16 one.
@@ -491,6 +492,11 @@ def test_bf16_gemm_is_exact_on_integers(eng):
     A[K:, :] = (np.arange(70)[:, None] % 5 - 2 + (np.arange(K)[None, :] % 3)).astype(np.float32)
     C = eng.dbg_gemm_bf16(A, W, epi=1)
     assert np.array_equal(C, (A.astype(np.float64) @ W.astype(np.float64).T).astype(np.float32))
+    # the other two tile shapes (192 x 384 and 192 x 128; 192 x 256 above)
+    for N2 in (384, 128):
+        W2 = ((np.arange(N2)[:, None] * 5 + np.arange(K)[None, :] * 11) % 113).astype(np.float32)
+        C2 = eng.dbg_gemm_bf16(A, W2, epi=1)
+        assert np.array_equal(C2, (A.astype(np.float64) @ W2.astype(np.float64).T).astype(np.float32))
 
 
 @pytest.mark.parametrize("growth", [0.5, 2.9, 3.1, 9.0])

@@ -56,8 +56,8 @@ int main(int argc, char** argv) {
     hipEventElapsedTime(&ms, e0, e1);
     std::vector<long long> st(4096 * 8);
     hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(wt::g_bf16_stamps), st.size() * 8);
-    const int bn = sh.N % 384 == 0 ? 384 : 256;
-    const int blocks = ((sh.M + 191) / 192) * (sh.N / bn), nb = std::min(4096, blocks);
+    const int bn = sh.N % 384 == 0 ? 384 : 256, bm = 192;
+    const int blocks = ((sh.M + bm - 1) / bm) * (sh.N / bn), nb = std::min(4096, blocks);
     double fill = 0, loop = 0, epi = 0, tot = 0, rt = 0;
     for (int b = 0; b < nb; ++b) {
       const long long* s = &st[b * 8];
@@ -65,10 +65,12 @@ int main(int argc, char** argv) {
     }
     fill /= nb; loop /= nb; epi /= nb; tot /= nb; rt /= nb;
     const double ghz = tot / rt * 0.1;
-    const double mfma_cycles = 2.0 * (sh.K / 16) * 3 * (bn / 128) * 32;  // per SIMD: two waves of 3 x NI MFMAs of 8 passes per k-step
-    printf("ABL %d %-8s %dx%dx%d tile 192x%d: %7.1f us per launch = %6.1f TF/s | per tile (%d blocks, %.2f per CU): fill %6.0f loop %7.0f "
-           "(MFMA issue alone %6.0f) epilogue %6.0f total %7.0f cycles = %5.1f us at %.2f GHz\n",
-           WT_BF16_ABL, sh.name, sh.M, sh.N, sh.K, bn, 1e3 * ms / 10, 2.0 * sh.M * sh.N * sh.K / (ms / 10) / 1e9, blocks, blocks / 256.0,
+    // MFMA issue per wavefront: its share of the tile's 32 x 32 x 16 products, 8 passes of 4 cycles each (two wavefronts
+    // share a SIMD); WT_BF16_RING=0 runs round 3's two-stage kernel
+    const double mfma_cycles = (double)(sh.K / 16) * (bm / 32) * (bn / 32) / 8 * 32;
+    printf("ABL %d %-8s %dx%dx%d tile %dx%d: %7.1f us per launch = %6.1f TF/s | per tile (%d blocks, %.2f per CU): fill %6.0f loop %7.0f "
+           "(own MFMA issue %6.0f) epilogue %6.0f total %7.0f cycles = %5.1f us at %.2f GHz\n",
+           WT_BF16_ABL, sh.name, sh.M, sh.N, sh.K, bm, bn, 1e3 * ms / 10, 2.0 * sh.M * sh.N * sh.K / (ms / 10) / 1e9, blocks, blocks / 256.0,
            fill, loop, mfma_cycles, epi, tot, tot / ghz * 1e-3, ghz);
     hipFree(dA); hipFree(dW); hipFree(dP); hipFree(dC); hipFree(dB);
   }

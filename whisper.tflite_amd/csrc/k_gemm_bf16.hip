@@ -60,6 +60,89 @@ struct Bf16GemmDev {
   int kv_batch, kv_heads, kv_dmodel;
 };
 
+// Epilogue shared by the two tile kernels: each wavefront transposes one 32 x 32 MFMA tile at a time through a private
+// 4 KB LDS stage (conflict-free image of k_gemm_planes.hip) and moves 16 bytes per lane.  `smem` is the block's dynamic
+// LDS, dead as operand staging by the time this runs; (mw0, nw0) is the wave tile's origin.
+template <int EPI, bool BF_OUT, int MI_, int NI>
+__device__ __forceinline__ void bf16_epilogue(const Bf16GemmDev& g, f32x16 (&acc)[MI_][NI], unsigned char* smem, int wid, int lane,
+                                              int mw0, int nw0) {
+  const int l31 = lane & 31, lh = lane >> 5;
+  constexpr int SLD = 32;
+  float* const stage = reinterpret_cast<float*>(smem) + wid * (32 * SLD);
+  constexpr int CPL = BF_OUT ? 8 : 4;
+  constexpr int LPR = 32 / CPL;
+  constexpr int RPS = 64 / LPR;
+  const int prow = lane / LPR, c0 = (lane % LPR) * CPL;
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int n = nw0 + ni * 32 + c0;
+    float bias_v[CPL];
+#pragma unroll
+    for (int e = 0; e < CPL; ++e) bias_v[e] = (EPI & kEpiBias) ? g.bias[n + e] : 0.0f;
+    const int slab = (EPI & kEpiKvLayout) ? n / g.kv_dmodel : 0, rem = (EPI & kEpiKvLayout) ? n % g.kv_dmodel : 0;
+    const int head = rem >> 6, dd = rem & 63;
+#pragma unroll
+    for (int mi = 0; mi < MI_; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * lh) * SLD + (l31 ^ (lh << 2))] = acc[mi][ni][r];
+      const int mbase = mw0 + mi * 32;
+      const int mb0 = mbase / g.c_rpb, mt0 = mbase % g.c_rpb;
+      const int mp0 = (EPI & kEpiPos) ? mbase % g.pos_period : 0;
+#pragma unroll
+      for (int p = 0; p < 32 / RPS; ++p) {
+        const int row = p * RPS + prow;
+        float v[CPL];
+#pragma unroll
+        for (int e = 0; e < CPL; e += 4) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(&stage[row * SLD + ((c0 + e) ^ (((row >> 2) & 1) << 2))]);
+          v[e] = t[0], v[e + 1] = t[1], v[e + 2] = t[2], v[e + 3] = t[3];
+        }
+        if (mbase + row < g.M) {
+          int mb = mb0, mt = mt0 + row;
+          if (mt >= g.c_rpb) mt -= g.c_rpb, mb += 1;
+#pragma unroll
+          for (int e = 0; e < CPL; e += 2) {
+            v[e] += bias_v[e];
+            v[e + 1] += bias_v[e + 1];
+            if (EPI & kEpiGelu) {
+              const f32x2_t gl = gelu_erf2(f32x2_t{v[e], v[e + 1]});
+              v[e] = gl[0];
+              v[e + 1] = gl[1];
+            }
+          }
+          if (EPI & kEpiPos) {
+            int mp = mp0 + row;
+            if (mp >= g.pos_period) mp -= g.pos_period;
+#pragma unroll
+            for (int e = 0; e < CPL; e += 4) {
+              const f32x4 t = *reinterpret_cast<const f32x4*>(g.pos + (long)mp * g.N + n + e);
+              v[e] += t[0], v[e + 1] += t[1], v[e + 2] += t[2], v[e + 3] += t[3];
+            }
+          }
+          if (BF_OUT) {
+            const long o = (EPI & kEpiKvLayout)
+                               ? (((long)slab * g.kv_batch + mb) * g.kv_heads + head) * (long)g.c_rpb * 64 + (long)mt * 64 + dd
+                               : (long)mb * g.c_bs + (long)mt * g.ldc + n;
+            u32x4 pk;
+#pragma unroll
+            for (int e = 0; e < CPL; e += 2) pk[e / 2] = pack_bf16x2(v[e], v[e + 1]);
+            if (EPI & kEpiKvLayout) {  // read next by the decoder, after the caches have turned over: streaming store
+              __builtin_nontemporal_store(pk, reinterpret_cast<u32x4*>(g.P + o));
+            } else {
+              *reinterpret_cast<u32x4*>(g.P + o) = pk;
+            }
+          } else {
+            const long o = (long)mb * g.c_bs + (long)mt * g.ldc + n;
+            f32x4 out = {v[0], v[1], v[2], v[3]};
+            if (EPI & kEpiResidual) out += *reinterpret_cast<const f32x4*>(g.R + o);
+            *reinterpret_cast<f32x4*>(g.C + o) = out;
+          }
+        }
+      }
+    }
+  }
+}
+
 // Block tile 192 x BN, BN = WN * NI * 32, 2 x WN wavefronts of 3 x NI MFMA tiles:
 //   (2, 2) 192 x 128, 4 wavefronts, 40 KB per stage, two blocks per CU;  (4, 2) 192 x 256 and (4, 3) 192 x 384,
 //   8 wavefronts, 56 / 72 KB per stage, one block per CU.
@@ -161,81 +244,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_bf16_planes(Bf16GemmDev g) {
   BF_STAMP(2);
   if (WT_BF16_ABL == 3 && acc[0][0][0] != 12345.678f) return;
 
-  // epilogue: per-wave 32 x 32 transposing stage, conflict-free image of k_gemm_planes.hip
-  constexpr int SLD = 32;
-  float* const stage = reinterpret_cast<float*>(smem) + wid * (32 * SLD);
-  constexpr int CPL = BF_OUT ? 8 : 4;
-  constexpr int LPR = 32 / CPL;
-  constexpr int RPS = 64 / LPR;
-  const int prow = lane / LPR, c0 = (lane % LPR) * CPL;
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-    const int n = n0 + (wn * NI + ni) * 32 + c0;
-    float bias_v[CPL];
-#pragma unroll
-    for (int e = 0; e < CPL; ++e) bias_v[e] = (EPI & kEpiBias) ? g.bias[n + e] : 0.0f;
-    const int slab = (EPI & kEpiKvLayout) ? n / g.kv_dmodel : 0, rem = (EPI & kEpiKvLayout) ? n % g.kv_dmodel : 0;
-    const int head = rem >> 6, dd = rem & 63;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * lh) * SLD + (l31 ^ (lh << 2))] = acc[mi][ni][r];
-      const int mbase = m0 + wm * 96 + mi * 32;
-      const int mb0 = mbase / g.c_rpb, mt0 = mbase % g.c_rpb;
-      const int mp0 = (EPI & kEpiPos) ? mbase % g.pos_period : 0;
-#pragma unroll
-      for (int p = 0; p < 32 / RPS; ++p) {
-        const int row = p * RPS + prow;
-        float v[CPL];
-#pragma unroll
-        for (int e = 0; e < CPL; e += 4) {
-          const f32x4 t = *reinterpret_cast<const f32x4*>(&stage[row * SLD + ((c0 + e) ^ (((row >> 2) & 1) << 2))]);
-          v[e] = t[0], v[e + 1] = t[1], v[e + 2] = t[2], v[e + 3] = t[3];
-        }
-        if (mbase + row < g.M) {
-          int mb = mb0, mt = mt0 + row;
-          if (mt >= g.c_rpb) mt -= g.c_rpb, mb += 1;
-#pragma unroll
-          for (int e = 0; e < CPL; e += 2) {
-            v[e] += bias_v[e];
-            v[e + 1] += bias_v[e + 1];
-            if (EPI & kEpiGelu) {
-              const f32x2_t gl = gelu_erf2(f32x2_t{v[e], v[e + 1]});
-              v[e] = gl[0];
-              v[e + 1] = gl[1];
-            }
-          }
-          if (EPI & kEpiPos) {
-            int mp = mp0 + row;
-            if (mp >= g.pos_period) mp -= g.pos_period;
-#pragma unroll
-            for (int e = 0; e < CPL; e += 4) {
-              const f32x4 t = *reinterpret_cast<const f32x4*>(g.pos + (long)mp * g.N + n + e);
-              v[e] += t[0], v[e + 1] += t[1], v[e + 2] += t[2], v[e + 3] += t[3];
-            }
-          }
-          if (BF_OUT) {
-            const long o = (EPI & kEpiKvLayout)
-                               ? (((long)slab * g.kv_batch + mb) * g.kv_heads + head) * (long)g.c_rpb * 64 + (long)mt * 64 + dd
-                               : (long)mb * g.c_bs + (long)mt * g.ldc + n;
-            u32x4 pk;
-#pragma unroll
-            for (int e = 0; e < CPL; e += 2) pk[e / 2] = pack_bf16x2(v[e], v[e + 1]);
-            if (EPI & kEpiKvLayout) {  // read next by the decoder, after the caches have turned over: streaming store
-              __builtin_nontemporal_store(pk, reinterpret_cast<u32x4*>(g.P + o));
-            } else {
-              *reinterpret_cast<u32x4*>(g.P + o) = pk;
-            }
-          } else {
-            const long o = (long)mb * g.c_bs + (long)mt * g.ldc + n;
-            f32x4 out = {v[0], v[1], v[2], v[3]};
-            if (EPI & kEpiResidual) out += *reinterpret_cast<const f32x4*>(g.R + o);
-            *reinterpret_cast<f32x4*>(g.C + o) = out;
-          }
-        }
-      }
-    }
-  }
+  bf16_epilogue<EPI, BF_OUT, MI, NI>(g, acc, smem, wid, lane, m0 + wm * (MI * 32), n0 + wn * (NI * 32));
   BF_STAMP(3);
   BF_STAMP_RT(5);
 }
