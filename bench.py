@@ -252,7 +252,10 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="synchronous steps (encoder then decoder) instead of the two-deep pipeline")
-    ap.add_argument("--depth", type=int, default=10, choices=tuple(range(1, 13)), help="batches in flight (pipelined mode)")
+    ap.add_argument("--depth", type=int, default=None, choices=tuple(range(1, 25)),
+                    help="batches in flight (pipelined mode); default 10, or 3 x --dec-group + 4 from three batches per chain on")
+    ap.add_argument("--dec-group", type=int, default=None, choices=(1, 2, 3, 4),
+                    help="consecutive steps' batches that share one decoder chain (engine default 2; 1 = a chain per batch)")
     ap.add_argument("--tail", type=int, default=2, choices=(0, 1, 2, 3, 4),
                     help="announce the last N batches of every run of steps to the engine (option last_batches: one decoder "
                          "chain per batch while the pipeline drains); 0 = never")
@@ -326,8 +329,12 @@ def main() -> None:
         eng.set_option("cross_absorb", args.cross_absorb)
     if args.abs_chunks is not None:
         eng.set_option("abs_chunks", args.abs_chunks)
-    if os.environ.get("WT_NO_PAIR"):
+    if os.environ.get("WT_NO_PAIR") or args.dec_group == 1:
         eng.set_option("dec_pair", 0)
+    elif args.dec_group:
+        eng.set_option("dec_group", args.dec_group)
+    if args.depth is None:
+        args.depth = 10 if (args.dec_group or 2) <= 2 else 3 * args.dec_group + 4
     if args.no_graphs:
         eng.set_option("use_graphs", 0)
     if args.gemm_variant is not None:
@@ -667,6 +674,7 @@ def main() -> None:
         Hh = dm.n_text_head
         absorbed = bool(eng.get_option("cross_absorb_active"))
         paired = pipelined and absorbed and bool(eng.get_option("dec_pair")) and B <= 32
+        group = max(1, min(int(eng.get_option("dec_group")), 128 // B)) if paired else 1
         if absorbed:
             # cross-attention against the encoder output itself: one [T][d] matrix of planes per clip and (layer, position)
             kv_bytes = L * T * dstate * 4 * B
@@ -678,10 +686,11 @@ def main() -> None:
         emb_bytes = V * dstate * esz                                   # tied embedding (logits GEMM)
         # the prompt's positions share one pass: 27 passes over the weights and the cache, 27 logits GEMMs; a decoder
         # chain that takes two batches together (dec_pair) reads the weights once for both
-        n_pass = 28 if (paired or B > 32) else 27                      # 64 rows per pass: the 4 prompt positions go two and two
-        dec_bytes = n_pass * kv_bytes + n_pass * w_bytes // (2 if paired else 1) + 27 * emb_bytes // (2 if paired else 1)
-        # decoder_ms is the chain's duration; a paired chain serves two steps
-        dec_ms_per_step = stage["decoder_ms"] / (2 if paired else 1)
+        rows = group * B                                               # 64 rows per pass: the 4 prompt positions go two and two; more: one by one
+        n_pass = 27 if rows <= 32 else 28 if rows <= 64 else 30
+        dec_bytes = n_pass * kv_bytes + n_pass * w_bytes // group + 27 * emb_bytes // group
+        # decoder_ms is the chain's duration; a shared chain serves `group` steps
+        dec_ms_per_step = stage["decoder_ms"] / group
         dec_ach = dec_bytes / (dec_ms_per_step * 1e-3) / 1e9 if dec_ms_per_step > 0 else 0.0
         out = {
             "metric": f"audio-sec/s (RTF) whisper-{args.arch} 30s clips batch={B} at 1/2/4/8 MI355X",
@@ -704,7 +713,7 @@ def main() -> None:
                        "clips_per_gpu": B, "global_batch": world * B, "decoder_positions": 30,
                        "argmax_steps": 27, "parallelism": f"clip-parallel dp{world}, one RCCL all_gather of id records per {GATHER_EVERY} batches",
                        "pipelined": pipelined, "batches_in_flight": args.depth if pipelined else 1,
-                       "decoder": "two consecutive steps' batches share one decoder chain (dec_pair)" if (pipelined and eng.get_option("dec_pair") and eng.get_option("cross_absorb_active") and B <= 32) else "one decoder chain per step",
+                       "decoder": f"{group} consecutive steps' batches share one decoder chain (dec_pair, dec_group)" if group > 1 else "one decoder chain per step",
                        "last_batches_announced": args.tail if pipelined else 0,
                        "priming_batches": 1,
                        "compute": "bf16 storage mode: weights, activations, the encoder output the decoder's cross-attention streams and the "
@@ -728,7 +737,7 @@ def main() -> None:
                                  "algorithmic_bytes_per_step": int(dec_bytes),
                                  "form": ("absorbed cross-attention (encoder output planes, K / V projections folded into the "
                                           "query / value sides)" if absorbed else "cross-KV cache") +
-                                         (", two batches per decoder chain" if paired else ""),
+                                         (f", {group} batches per decoder chain" if group > 1 else ""),
                                  "chain_ms": round(stage["decoder_ms"], 3)},
             # what the headline assumes about the weights: every contraction whose weight-derived bound stays within 2^12
             # of its typical magnitude runs on two fp16 planes; the others (none here) on the full-range kernels

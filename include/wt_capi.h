@@ -91,7 +91,9 @@ int wt_engine_dims(const wt_engine* h, wt_dims* out);
  * 0 = the cross-KV cache of whisper.cpp's graph; both the fp32-accurate and the bf16 storage mode run either form —
  * pipelined batches and synchronous calls of 32 clips or more the absorbed one, smaller synchronous calls the cached
  * one; "cross_absorb_active" reads what is in effect), "abs_chunks" (key chunks per clip of that form, 0 = by batch size), "dec_pair" (1 = default: two consecutive
- * pipelined batches of equal size <= 32 share one decoder chain; change only with nothing in flight),
+ * pipelined batches of equal size <= 32 share one decoder chain; change only with nothing in flight), "dec_group" (2 =
+ * default, 3 or 4: that many consecutive batches per chain, rows = group x batch <= 128; three or four want 3 x group + 4
+ * or more batches in flight and pay off on long jobs only: +1 % at four),
  * "last_batches" (N = the next N pipelined submits are the last of a job: they are decoded one chain per batch, the very
  * last on the encoder's stream, so the pipeline drains sooner; counts down to 0 by itself, may be set with batches in
  * flight), "force_fallback" (test hook: bit mask of contractions sent to the full-range kernels, nothing in flight).
@@ -156,8 +158,8 @@ int wt_transcribe_tokens_batch_dev(wt_engine* h, const float* d_pcm, int batch, 
  * collect blocks until the OLDEST submitted batch has its ids on the host.  In steady state
  * the MFMA-bound encoder of the newest batch shares the chip with the latency/HBM-bound
  * decoder chains of the previous ones.  d_mel must stay valid until that batch is collected.
- * At most WT_PIPELINE_DEPTH uncollected submits; batch <= 64. */
-#define WT_PIPELINE_DEPTH 12
+ * At most WT_PIPELINE_DEPTH uncollected submits (ten keep the default pipeline full); batch <= 64. */
+#define WT_PIPELINE_DEPTH 24
 int wt_pipeline_submit_dev(wt_engine* h, const float* d_mel, int batch);
 /* Same from device-resident PCM [batch][480000]: the log-mel front end (whisper.cpp:109-216) runs
  * on the pipeline's encoder stream ahead of the encoder; d_pcm may be reused once the call returns

@@ -239,7 +239,7 @@ def test_sync_call_with_batches_in_flight_is_refused_before_any_work(pkg, assets
     e.set_option("stop_at_eot", 0)
     e.set_prompt([3, 5, 7, 11])
     rng = np.random.default_rng(21)
-    D = 12  # WT_PIPELINE_DEPTH
+    D = pkg.WT_PIPELINE_DEPTH
     mels = [rng.uniform(-1.0, 1.5, size=(3,) + e.mel_shape).astype(np.float32) for _ in range(D)]
     big = rng.uniform(-1.0, 1.5, size=(9,) + e.mel_shape).astype(np.float32)
     want = [e.encdec_tokens_batch(m) for m in mels]

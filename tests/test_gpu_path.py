@@ -262,7 +262,8 @@ def test_pipeline_submit_collect_matches_sync(tiny):
         ids_g, n_g = e.pipeline_collect()
         assert np.array_equal(want_pcm[k][0], ids_g) and np.array_equal(want_pcm[k][1], n_g)
     # one uncollected submit more than WT_PIPELINE_DEPTH is refused, and so is a sync call with batches in flight
-    D = 12
+    D = 24
+    assert D == __import__("__graft_entry__").load_package().WT_PIPELINE_DEPTH
     for k in range(D):
         e.pipeline_submit_dev(dev[k % 4].data_ptr(), mels[k % 4].shape[0])
     with pytest.raises(Exception):
@@ -303,31 +304,36 @@ def test_pipeline_pairs_two_batches_per_decoder_chain(tiny):
         for k, (ids_g, n_g) in zip(order, got):
             assert np.array_equal(want[k][0], ids_g) and np.array_equal(want[k][1], n_g), (order, depth, k)
 
-    for pair in (1, 0, 1):
+    for pair, group in ((1, 2), (0, 2), (1, 3), (1, 4), (1, 2)):
         e.set_option("dec_pair", pair)
+        e.set_option("dec_group", group)  # (round 4) three or four batches per chain: 12 / 16 rows here, 96 / 128 at 32 clips
         for graphs in (1, 0):
             e.set_option("use_graphs", graphs)
-            run([0, 1, 2, 3], 4)          # two full pairs
-            run([0, 1, 2, 3, 4], 2)       # pairs, then a single at the end
+            run([0, 1, 2, 3], 4)          # two full pairs (a triple and a single; one chain of four)
+            run([0, 1, 2, 3, 4], 2)       # pairs, then a single at the end (groups cut short by the collects)
             run([0], 1)                   # partner never comes
             run([0, 1, 2], 1)             # every batch collected before the next is submitted: all decoded alone
-            run([0, 5, 6, 1, 2, 5], 3)    # unequal sizes are not paired; equal neighbours are
-            run([4, 3, 2, 1, 0, 1], 6)    # pipeline full
+            run([0, 5, 6, 1, 2, 5], 3)    # unequal sizes are not grouped; equal neighbours are
+            run([4, 3, 2, 1, 0, 1], 6)    # full groups of every size
+            run([0, 1, 2, 3, 4, 0, 1, 2, 3, 4, 0, 1, 2], 13)
         e.set_option("use_graphs", 1)
     e.set_option("dec_pair", 1)
+    e.set_option("dec_group", 2)
     for d in dev:
         d.free()
 
 
 def test_pipeline_follower_ids_survive_reuse_of_the_leaders_slot(tiny):
-    """A pair's second batch keeps its ids in its OWN slot: with all twelve slots in flight as six pairs, the first
-    collect frees the first leader's slot, and a batch that is decoded at once (announced last batch) with more clips
-    than the pair's halves re-initialises that slot's pinned buffers before the follower is collected.  (Round 3 read the
-    follower's ids out of the leader's buffers: the next collect returned prompt-only rows.)"""
+    """A group's later batches keep their ids in their OWN slots: with all 24 slots in flight as twelve pairs (eight
+    triples), the first collect frees the first leader's slot, and a batch that is decoded at once (announced last batch)
+    with more clips than the group's members re-initialises that slot's pinned buffers before the followers are
+    collected.  (Round 3 read the follower's ids out of the leader's buffers: the next collect returned prompt-only
+    rows.)"""
     from conftest import DevBuf
     e, _ = tiny
+    D = 24
     rng = np.random.default_rng(4096)
-    mels = [rng.uniform(-1.0, 1.5, size=(4, 80, 3000)).astype(np.float32) for _ in range(12)]
+    mels = [rng.uniform(-1.0, 1.5, size=(4, 80, 3000)).astype(np.float32) for _ in range(D)]
     big = rng.uniform(-1.0, 1.5, size=(8, 80, 3000)).astype(np.float32)
     e.set_option("dec_pair", 0)
     want = [e.encdec_tokens_batch(m) for m in mels]
@@ -335,19 +341,21 @@ def test_pipeline_follower_ids_survive_reuse_of_the_leaders_slot(tiny):
     e.set_option("dec_pair", 1)
     dev = [DevBuf(m) for m in mels]
     dev_big = DevBuf(big)
-    for graphs in (1, 0):
+    for graphs, group in ((1, 2), (0, 2), (1, 3)):
         e.set_option("use_graphs", graphs)
-        for k in range(12):
+        e.set_option("dec_group", group)
+        for k in range(D):
             e.pipeline_submit_dev(dev[k].data_ptr(), 4)
         got = [e.pipeline_collect()]                      # the first leader: its slot is the next one submit() takes
         e.set_option("last_batches", 1)                   # decoded at submit, alone
         e.pipeline_submit_dev(dev_big.data_ptr(), 8)
-        got += [e.pipeline_collect() for _ in range(11)]
+        got += [e.pipeline_collect() for _ in range(D - 1)]
         ids_b, n_b = e.pipeline_collect()
         for k, (ids_g, n_g) in enumerate(got):
-            assert np.array_equal(want[k][1], n_g) and np.array_equal(want[k][0], ids_g), (graphs, k)
+            assert np.array_equal(want[k][1], n_g) and np.array_equal(want[k][0], ids_g), (graphs, group, k)
         assert np.array_equal(want_big[0], ids_b) and np.array_equal(want_big[1], n_b)
     e.set_option("use_graphs", 1)
+    e.set_option("dec_group", 2)
     for d in dev:
         d.free()
     dev_big.free()
@@ -365,7 +373,7 @@ def test_pipeline_last_batches_drain_in_latency_form(pkg, tiny):
     want = [e.encdec_tokens_batch(m) for m in mels]
     dev = [DevBuf(m) for m in mels]
     with pytest.raises(pkg.WtError):
-        e.set_option("last_batches", 13)
+        e.set_option("last_batches", 25)
     for graphs in (1, 0, 1):
         e.set_option("use_graphs", graphs)
         for tail in (1, 2, 3):

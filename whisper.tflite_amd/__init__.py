@@ -29,7 +29,7 @@ LIB_PATH = os.environ.get("WT_LIB_PATH") or os.path.join(_HERE, "lib", "libwhisp
 
 WT_OK = 0
 WT_MAX_IDS = 32
-WT_PIPELINE_DEPTH = 12  # include/wt_capi.h
+WT_PIPELINE_DEPTH = 24  # include/wt_capi.h
 CHUNK_SAMPLES = 480000
 STATUS_NAMES = {0: "WT_OK", 1: "WT_ERR_INVALID_ARG", 2: "WT_ERR_IO", 3: "WT_ERR_FORMAT",
                 4: "WT_ERR_UNSUPPORTED", 5: "WT_ERR_DEVICE", 6: "WT_ERR_BUFFER"}

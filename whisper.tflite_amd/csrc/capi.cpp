@@ -210,11 +210,15 @@ int wt_engine_set_option(wt_engine* h, const char* key, long value) {
   } else if (k == "cross_absorb") {
     e.cross_absorb = value != 0;
   } else if (k == "last_batches") {
-    if (value < 0 || value > 12) return fail(h, WT_ERR_INVALID_ARG, "last_batches: 0..12");
+    if (value < 0 || value > WT_PIPELINE_DEPTH) return fail(h, WT_ERR_INVALID_ARG, "last_batches: 0..24");
     e.last_batches = value;
   } else if (k == "dec_pair") {
     if (h->impl->in_flight() > 0) return fail(h, WT_ERR_INVALID_ARG, "collect the submitted batches before changing dec_pair");
     e.dec_pair = value != 0;
+  } else if (k == "dec_group") {
+    if (h->impl->in_flight() > 0) return fail(h, WT_ERR_INVALID_ARG, "collect the submitted batches before changing dec_group");
+    if (value < 2 || value > 4) return fail(h, WT_ERR_INVALID_ARG, "dec_group: 2, 3 or 4 batches per decoder chain (dec_pair = 0 turns grouping off)");
+    e.dec_group = value;
   } else if (k == "abs_chunks") {
     if (value < 0 || value > 16) return fail(h, WT_ERR_INVALID_ARG, "abs_chunks must be 0 (automatic) or 1..16");
     e.abs_chunks = value;
@@ -269,6 +273,7 @@ int wt_engine_get_option(const wt_engine* h, const char* key, long* value) {
   else if (k == "cross_absorb") *value = e.cross_absorb;
   else if (k == "abs_chunks") *value = e.abs_chunks;
   else if (k == "dec_pair") *value = e.dec_pair;
+  else if (k == "dec_group") *value = e.dec_group;
   else if (k == "last_batches") *value = e.last_batches;
   else if (k == "cross_absorb_active") *value = e.absorb_active() ? 1 : 0;  // read-only
   else if (k == "bf16") *value = e.bf16;
@@ -374,7 +379,7 @@ int wt_encdec_tokens_batch_dev(wt_engine* h, const float* d_mel, int batch, int6
       const int b0 = submitted * 32, nb = std::min(32, batch - b0);
       e.submit(d_mel + size_t(b0) * e.mel_elems(), nb);
       ++submitted;
-      if (submitted - collected == WT_PIPELINE_DEPTH) collect_one();
+      if (submitted - collected == 12) collect_one();  // (twelve in flight keep the pipeline full; WT_PIPELINE_DEPTH is the limit)
     }
     while (collected < submitted) collect_one();
   });

@@ -772,6 +772,8 @@ void Engine::create_streams() {
   } else {
     const char* dp = getenv("WT_DEC_PRIO");  // measurement knob: "lo" = decoder streams at the encoder's priority
     const int prio = dp && dp[0] == 'l' ? prio_lo : prio_hi;
+    // (round 4: candidates on a second priority level, or GPU_MAX_HW_QUEUES=8, give the probe no further stream that
+    // overlaps with the four in use — the process has four hardware queues, the encoder's and three decoders')
     for (auto& ds : dstream_) HIPCHK(hipStreamCreateWithPriority(&ds, hipStreamNonBlocking, prio));
   }
   pick_decoder_streams();
@@ -1596,30 +1598,34 @@ void Engine::decode(int batch, int64_t* ids, int32_t* n_ids, float* logits_host,
 }
 
 void Engine::flush_pending() {
-  if (pending_slot_ < 0) return;
-  const int p = pending_slot_;
-  pending_slot_ = -1;
-  decode_enqueue(slots_[p].batch, p, nullptr, 0, -1, true);
+  if (pending_.empty()) return;
+  const int p = pending_.front(), n = int(pending_.size());
+  pending_.clear();
+  decode_enqueue(slots_[p].batch, p, nullptr, 0, n, true);  // the rest of the group never came: a shorter chain
 }
 
-// decoder side of a pipelined submit: alone, or together with the previous submit's batch (dec_pair)
-static bool can_pair(const Engine& e, int batch) { return e.dec_pair != 0 && e.absorb_active() && batch <= 32; }
+// decoder side of a pipelined submit: alone, or together with the neighbouring submits' batches (dec_pair, dec_group)
+int Engine::group_of(int batch) const {
+  if (dec_pair == 0 || !absorb_active() || batch > 32) return 1;
+  const int g = int(std::min<long>(std::max<long>(dec_group, 2), 4));
+  return std::max(1, std::min(g, kDecRowsMax / batch));
+}
 
-// Throughput form: two consecutive batches share one decoder chain.  Latency form — the last `last_batches` submits of
-// a job (option, counted down here): a chain per batch, on spare decoder streams when the probe found any, so that the
-// pipeline drains in one short chain instead of a long paired one behind two others (measured on the driver's 20-step
+// Throughput form: `group` consecutive batches share one decoder chain.  Latency form — the last `last_batches` submits
+// of a job (option, counted down here): a chain per batch, on spare decoder streams when the probe found any, so that the
+// pipeline drains in one short chain instead of a long shared one behind two others (measured on the driver's 20-step
 // command: 16.7 ms from the last encoder pass to the last token with the paired form).
 void Engine::submit_decoder(int batch, int s) {
   const bool tail = last_batches > 0;
   if (tail) --last_batches;
-  if (!tail && can_pair(*this, batch) && ws_.batch >= 2 * batch) {
-    if (pending_slot_ >= 0 && slots_[pending_slot_].batch == batch) {
-      const int a = pending_slot_;
-      pending_slot_ = -1;
-      decode_enqueue(batch, a, nullptr, 0, s, true);
-    } else {
-      flush_pending();
-      pending_slot_ = s;
+  const int group = group_of(batch);
+  if (!tail && group > 1 && ws_.batch >= group * batch) {
+    if (!pending_.empty() && (slots_[pending_.front()].batch != batch || (pending_.back() + 1) % kSlots != s)) flush_pending();
+    pending_.push_back(s);
+    if (int(pending_.size()) == group) {
+      const int a = pending_.front();
+      pending_.clear();
+      decode_enqueue(batch, a, nullptr, 0, group, true);
     }
   } else {
     flush_pending();
@@ -1630,25 +1636,25 @@ void Engine::submit_decoder(int batch, int s) {
     // The batches before it use a spare decoder stream when the probe found one.
     if (tail && last_batches == 0) spare = kEncAsDec;
     else if (tail && n_spare_streams_ > 0) spare = n_dec_streams_ + int(last_batches % n_spare_streams_);
-    decode_enqueue(batch, s, nullptr, 0, -1, true, spare);
+    decode_enqueue(batch, s, nullptr, 0, 1, true, spare);
   }
   inflight_.push_back(s);
 }
 
 void Engine::submit(const float* d_mel, int batch) {
-  if (int(inflight_.size()) >= kSlots) throw Error(1, "pipeline is full (12 batches in flight): collect() first");
+  if (int(inflight_.size()) >= kSlots) throw Error(1, "pipeline is full (24 batches in flight): collect() first");
   if (batch > 64) throw Error(1, "decoder batches are limited to 64 clips per call");
   select_stream(true);
-  if (can_pair(*this, batch) && inflight_.empty()) ensure_batch(2 * batch);  // the pair's decoder rows; never grown in flight
+  if (inflight_.empty()) ensure_batch(group_of(batch) * batch);  // the group's decoder rows; never grown in flight
   encode_enqueue(d_mel, batch);
   submit_decoder(batch, last_enc_slot_);
 }
 
 void Engine::submit_pcm(const float* d_pcm, int batch) {
-  if (int(inflight_.size()) >= kSlots) throw Error(1, "pipeline is full (12 batches in flight): collect() first");
+  if (int(inflight_.size()) >= kSlots) throw Error(1, "pipeline is full (24 batches in flight): collect() first");
   if (batch > 64) throw Error(1, "decoder batches are limited to 64 clips per call");
   select_stream(true);
-  if (can_pair(*this, batch) && inflight_.empty()) ensure_batch(2 * batch);
+  if (inflight_.empty()) ensure_batch(group_of(batch) * batch);
   // one staging mel buffer: the front end of batch k+1 follows the encoder of batch k on the same stream
   float* d_mel = staging_mel(batch);
   logmel(d_pcm, batch, d_mel);
@@ -1659,7 +1665,7 @@ void Engine::submit_pcm(const float* d_pcm, int batch) {
 void Engine::collect(int64_t* ids, int32_t* n_ids) {
   if (inflight_.empty()) throw Error(1, "collect() without a submitted batch");
   const int slot = inflight_.front();
-  if (slot == pending_slot_) flush_pending();  // its partner never came: decode it alone now
+  if (std::find(pending_.begin(), pending_.end(), slot) != pending_.end()) flush_pending();  // its group never filled: decode now
   inflight_.erase(inflight_.begin());
   decode_collect(slot, ids, n_ids);
 }
@@ -1675,26 +1681,27 @@ std::vector<long long> Engine::prompt() const {
   return {vocab_.token_sot, 50259 + language, vocab_.token_transcribe, vocab_.token_not};
 }
 
-void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int logits_steps_cap, int slot_b, bool pipelined,
+void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int logits_steps_cap, int group, bool pipelined,
                             int stream_override) {
-  const bool paired = slot_b >= 0;
-  const int per = batch;          // clips per encoder batch
-  if (paired) batch = 2 * per;    // the chain decodes both: rows / clips below count the pair
-  if (batch > 64) throw Error(1, "decoder batches are limited to 64 clips per call");  // before any stream operation
-  if (paired && (slot_b != (slot_idx + 1) % kSlots || !slots_[slot_idx].absorbed || !slots_[slot_b].absorbed || logits_host)) {
-    throw Error(kErrInvalidArg, "decoder pairing: consecutive slots of the absorbed form only");
+  const bool paired = group > 1;
+  const int per = batch;            // clips per encoder batch
+  if (group < 1 || group > 4) throw Error(kErrInvalidArg, "decoder chains take one to four batches");
+  batch = group * per;              // the chain decodes them all: rows / clips below count the group
+  if (batch > (paired ? kDecRowsMax : 64)) throw Error(1, "decoder batches are limited to 64 clips per call");  // before any stream operation
+  for (int j = 0; paired && j < group; ++j) {
+    if (!slots_[(slot_idx + j) % kSlots].absorbed || logits_host) throw Error(kErrInvalidArg, "decoder groups: the absorbed form only");
   }
   ensure_batch(batch);
   Slot& slot = slots_[slot_idx];
   // fixed slot -> stream map (few captured graphs); pair leaders are the even slots, so a pair counts as one
   // (stream_override: a spare stream + workspace for a batch decoded in the latency form, submit_decoder)
-  auto dec_of = [&](int si) { return stream_override >= 0 ? stream_override : (paired ? si / 2 : si) % n_dec_streams_; };
+  auto dec_of = [&](int si) { return stream_override >= 0 ? stream_override : (si / group) % n_dec_streams_; };
   slot.dec = dec_of(slot_idx);
   slot.pair_leader = -1;
   DecWorkspace& dw = dws_[slot.dec];
   hipStream_t const stream_ = dec_stream_at(slot.dec);  // everything below runs on this decoder stream
   HIPCHK(hipStreamWaitEvent(stream_, slot.enc_done, 0));
-  if (paired) HIPCHK(hipStreamWaitEvent(stream_, slots_[slot_b].enc_done, 0));
+  for (int j = 1; j < group; ++j) HIPCHK(hipStreamWaitEvent(stream_, slots_[(slot_idx + j) % kSlots].enc_done, 0));
   HIPCHK(hipEventRecord(slot.dec_begin, stream_));
   long long* const h_ids_ = slot.h_ids;
   int* const h_n_ = slot.h_n;
@@ -1759,7 +1766,7 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
   (void)dw;
   auto enqueue_all = [&](int si) {
     Slot& slot = slots_[si];
-    const Slot& slot2 = slots_[(si + 1) % kSlots];  // the pair's second batch (paired only)
+    const Slot* const member[4] = {&slot, &slots_[(si + 1) % kSlots], &slots_[(si + 2) % kSlots], &slots_[(si + 3) % kSlots]};  // the group's batches
     DecWorkspace& dw = dws_[dec_of(si)];
     hipStream_t const stream_ = dec_stream_at(dec_of(si));
     long long* const h_ids_ = slot.h_ids;
@@ -1828,7 +1835,12 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
             CrossAbsorbedArgs ca;
             ca.qp = dw.qp; ca.e = slot.e_planes; ca.e_plane = long(ws_.batch) * T * d; ca.e_scale = sc_cross_kv_.a;
             ca.bf16 = bf;
-            if (paired) ca.e2 = slot2.e_planes, ca.split = per;
+            if (paired) {
+              ca.split = per;
+              ca.e2 = member[1]->e_planes;
+              if (group > 2) ca.e3 = member[2]->e_planes;
+              if (group > 3) ca.e4 = member[3]->e_planes;
+            }
             ca.ws = dw.abs_ws; ca.batch = batch; ca.heads = H; ca.d_model = d; ca.T = T; ca.chunks = n_abs;
             ca.nq = std::min(nq_max, np - p0); ca.p0 = p0;
             DT(4, launch_cross_absorbed(ca, stream_));
@@ -1892,13 +1904,10 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
     }
     // Every slot receives its OWN clips' ids in its own pinned buffers: a pair's second batch used to be read out of
     // the leader's buffers, which the leader's next submit (collected first, reused first) could overwrite.
-    const int own = paired ? per : batch;
-    HIPCHK(hipMemcpyAsync(h_ids_, dw.ids, size_t(own) * stride * sizeof(long long), hipMemcpyDeviceToHost, stream_));
-    HIPCHK(hipMemcpyAsync(h_n_, dw.n_ids, size_t(own) * sizeof(int), hipMemcpyDeviceToHost, stream_));
-    if (paired) {
-      HIPCHK(hipMemcpyAsync(slot2.h_ids, dw.ids + size_t(per) * stride, size_t(per) * stride * sizeof(long long),
+    for (int j = 0; j < group; ++j) {
+      HIPCHK(hipMemcpyAsync(member[j]->h_ids, dw.ids + size_t(j) * per * stride, size_t(per) * stride * sizeof(long long),
                             hipMemcpyDeviceToHost, stream_));
-      HIPCHK(hipMemcpyAsync(slot2.h_n, dw.n_ids + per, size_t(per) * sizeof(int), hipMemcpyDeviceToHost, stream_));
+      HIPCHK(hipMemcpyAsync(member[j]->h_n, dw.n_ids + size_t(j) * per, size_t(per) * sizeof(int), hipMemcpyDeviceToHost, stream_));
     }
   };
   // The ~1050 launches of a decode are identical from call to call for a given (slot, batch,
@@ -1906,7 +1915,7 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
   // kernels' one-time attribute set-up) and then captures one hipGraph per slot; later calls
   // replay the slot's graph: one host call instead of ~1100. The logits tap stays eager.
   auto key_of = [&](int si) {
-    return std::vector<long long>{si, batch, max_pos, n_prompt, chunks, long(stop_at_eot), fc2_ksplit, bf16, absorbed ? 1 : 0, n_abs, paired ? 1 : 0, stream_override, forced ? 1 : 0, pipelined ? 1 : 0};
+    return std::vector<long long>{si, batch, max_pos, n_prompt, chunks, long(stop_at_eot), fc2_ksplit, bf16, absorbed ? 1 : 0, n_abs, group, stream_override, forced ? 1 : 0, pipelined ? 1 : 0};
   };
   // the cached form's graphs are captured for EVERY slot at once (below) and hold each slot's cache pointer: all of
   // them must exist before the capture (need_cross_kv allocates; nothing may be allocated inside a capture)
@@ -1933,8 +1942,8 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
     // fail, so that submit() / collect() stay consistent whatever happens to the captures below
     HIPCHK(hipEventRecord(slot.dec_done, stream_));
     slot.steps = eager_steps;
-    if (paired) {
-      Slot& sb = slots_[slot_b];
+    for (int j = 1; j < group; ++j) {
+      Slot& sb = slots_[(slot_idx + j) % kSlots];
       HIPCHK(hipEventRecord(sb.dec_done, stream_));
       sb.pair_leader = slot_idx, sb.steps = eager_steps, sb.dec = slot.dec;
     }
@@ -1974,8 +1983,8 @@ void Engine::decode_enqueue(int batch, int slot_idx, float* logits_host, int log
   }
   HIPCHK(hipEventRecord(slot.dec_done, stream_));
   slot.steps = steps;
-  if (paired) {
-    Slot& sb = slots_[slot_b];
+  for (int j = 1; j < group; ++j) {
+    Slot& sb = slots_[(slot_idx + j) % kSlots];
     HIPCHK(hipEventRecord(sb.dec_done, stream_));
     sb.pair_leader = slot_idx, sb.steps = steps, sb.dec = slot.dec;
   }

@@ -111,6 +111,9 @@ class Engine {
   // what the pipeline waits for.  Results and their order are unchanged; a batch whose partner has
   // not been submitted yet is decoded alone as soon as it is collected.
   long dec_pair = 1;
+  // batches per decoder chain when dec_pair is on: 2 (default), 3 or 4 — rows of a chain = group x batch <= 128 (the
+  // decoder GEMMs' row contract); the pipeline needs about 3 x group + 3 batches in flight to keep three chains fed
+  long dec_group = 2;
   long last_batches = 0;  // the next N submits are the last of a job: decoded one chain per batch (latency form); counts down
   // absorbed cross-attention in effect: the default mode needs E as fp16 planes (no fall-back on that operand); bf16
   // storage mode streams E as one bf16 plane
@@ -210,13 +213,14 @@ class Engine {
   TiledW upload_tiled(const float* W, int N, int K);
   void build_frontend_tables();
 
-  // slot_b >= 0: the decoder chain takes the batches of slot and slot_b (same size) together
-  void decode_enqueue(int batch, int slot, float* logits_host, int logits_steps_cap, int slot_b = -1, bool pipelined = false,
+  // group > 1: the decoder chain takes the batches (same size) of `group` consecutive slots from `slot` together
+  void decode_enqueue(int batch, int slot, float* logits_host, int logits_steps_cap, int group = 1, bool pipelined = false,
                       int stream_override = -1);
-  void submit_decoder(int batch, int slot);  // decoder side of submit / submit_pcm: paired, alone, or latency form
+  void submit_decoder(int batch, int slot);  // decoder side of submit / submit_pcm: grouped, alone, or latency form
+  int group_of(int batch) const;             // batches per decoder chain for pipelined batches of this size
   int n_spare_streams_ = 0;  // probe-selected decoder streams beyond n_dec_streams_ (latency form of the last batches)
   bool pipelined_call_ = false;  // set by select_stream: the batch being enqueued belongs to submit(), not to a synchronous call
-  int pending_slot_ = -1;  // submitted, encoder enqueued, decoder waiting for a partner batch
+  std::vector<int> pending_;  // consecutive slots submitted, encoder enqueued, decoder waiting for the rest of their group
   void flush_pending();
   void decode_collect(int slot, int64_t* ids, int32_t* n_ids);
 
@@ -234,10 +238,10 @@ class Engine {
   // default encoder GEMM: the k16 split kernel in its two-plane fp16 form, at 2 blocks per CU when decoders
   // share the chip (pipelined), at 3 blocks per CU otherwise
   void encode_enqueue(const float* d_mel, int batch);
-  // slots (WT_PIPELINE_DEPTH): a multiple of twice the 3 decoder streams in use, so single batches AND pair leaders
-  // (every second slot) rotate evenly over them; a pair's chain holds two slots for ~4 pipeline periods, so the
-  // encoder needs that many slots ahead of it to keep running
-  static constexpr int kDecStreams = 8, kSlots = 12;
+  // slots (WT_PIPELINE_DEPTH): a multiple of 1, 2, 3 and 4 times the 3 decoder streams in use, so single batches AND
+  // group leaders (every second / third / fourth slot) rotate evenly over them; a group's chain holds its slots for
+  // several pipeline periods, so the encoder needs that many slots ahead of it to keep running
+  static constexpr int kDecStreams = 8, kSlots = 24;
   int n_dec_streams_ = 3;  // decoder streams in use: one hardware queue each (the runtime multiplexes
                            // streams onto 4 queues per priority; two decoders sharing one serialise)
   hipStream_t dstream_[kDecStreams] = {};  // decoders (batches rotate over them)

@@ -44,7 +44,7 @@ using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
 struct CrossAbsDev {
   const float* qp;       // [rows][heads * DM] absorbed queries (log2 domain: d_head^-1/2 * log2 e folded in)
   const _Float16* e;     // E planes: hi [clips * T][DM], lo at e + e_plane (bf16 storage mode: ONE bf16 plane)
-  const _Float16* e2;    // clips >= split: a second encoder batch (two batches decoded by one chain), indexed from 0
+  const _Float16* eg[4]; // clip b reads eg[b / split] at clip b % split: up to four encoder batches decoded by one chain
   int split;
   long e_plane;
   float e_scale;         // power of two baked into the planes
@@ -156,7 +156,8 @@ __global__ __launch_bounds__(320) void cross_absorbed_attention(CrossAbsDev a) {
   // SGPR-base form: the per-lane part of an address is the key row lq inside the instruction's four keys and the swizzled
   // chunk, whose key & 7 = 4 (kg & 1) + lq takes two values — two constant 32-bit offsets; plane, panel, key group and
   // tile are a scalar base.  A tile that reaches past the clip's last key row takes the clamping per-lane form.
-  const _Float16* const ebase = b < a.split ? a.e + (long)b * a.T * DM : a.e2 + (long)(b - a.split) * a.T * DM;
+  const int eb = b / a.split;  // (block-uniform)
+  const _Float16* const ebase = (eb == 0 ? a.e : eb == 1 ? a.eg[1] : eb == 2 ? a.eg[2] : a.eg[3]) + (long)(b - eb * a.split) * a.T * DM;
   const unsigned long long ebytes = reinterpret_cast<unsigned long long>(ebase);
   const unsigned lds_ring = lds_addr(lds);
   const unsigned voff_even = (unsigned)(lq * DM * 2 + (((lane & 15) ^ ((lq & 7) << 1)) << 4));
@@ -488,14 +489,22 @@ void launch_cross_absorbed(const CrossAbsorbedArgs& a, hipStream_t s) {
   const int dm = a.d_model;
   if (!a.qp || !a.e || !a.ws || a.batch < 1 || a.heads < 1 || a.heads * 64 != dm || a.T < 1 || a.chunks < 1 || a.chunks > 16 ||
       a.nq < 1 || a.nq * a.heads > 16 || a.p0 < 0 || !(a.e_scale > 0.0f) ||
-      (!a.bf16 && a.e_plane < (long)(a.e2 ? std::max(a.split, a.batch - a.split) : a.batch) * a.T * dm)) {
+      (!a.bf16 && a.e_plane < (long)(a.e2 ? std::min(a.split, a.batch) : a.batch) * a.T * dm)) {
     throw Error(kErrInvalidArg, "absorbed cross-attention: shape outside the kernel contract");
   }
   const int tiles = (a.T + 31) / 32;
   const int split = a.e2 ? a.split : a.batch;
   if (split < 1 || split > a.batch) throw Error(kErrInvalidArg, "absorbed cross-attention: bad batch split");
-  CrossAbsDev g{a.qp, reinterpret_cast<const _Float16*>(a.e), reinterpret_cast<const _Float16*>(a.e2 ? a.e2 : a.e), split, a.e_plane,
-                a.bf16 ? 1.0f : a.e_scale, a.ws, a.batch, a.heads, a.T, a.chunks, a.nq, a.p0, (tiles + a.chunks - 1) / a.chunks};
+  const int groups = (a.batch + split - 1) / split;
+  const unsigned short* src[4] = {a.e, a.e2, a.e3, a.e4};
+  if (groups > 4) throw Error(kErrInvalidArg, "absorbed cross-attention: at most four encoder batches per chain");
+  for (int i = 0; i < groups; ++i)
+    if (!src[i]) throw Error(kErrInvalidArg, "absorbed cross-attention: an encoder batch of the chain has no planes");
+  CrossAbsDev g{a.qp, reinterpret_cast<const _Float16*>(a.e),
+                {reinterpret_cast<const _Float16*>(a.e), reinterpret_cast<const _Float16*>(src[1] ? src[1] : a.e),
+                 reinterpret_cast<const _Float16*>(src[2] ? src[2] : a.e), reinterpret_cast<const _Float16*>(src[3] ? src[3] : a.e)},
+                split, a.e_plane, a.bf16 ? 1.0f : a.e_scale, a.ws, a.batch, a.heads, a.T, a.chunks, a.nq, a.p0,
+                (tiles + a.chunks - 1) / a.chunks};
   switch (dm) {
     case 128: a.bf16 ? launch_abs<128, 3, true>(g, s) : launch_abs<128, 3>(g, s); break;
     case 384: a.bf16 ? launch_abs<384, 3, true>(g, s) : launch_abs<384, 3>(g, s); break;

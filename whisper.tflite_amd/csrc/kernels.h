@@ -280,13 +280,17 @@ void launch_cross_attention(const CrossAttnArgs& a, hipStream_t s);
 struct CrossAbsorbedArgs {
   const float* qp = nullptr;
   const unsigned short* e = nullptr;
-  const unsigned short* e2 = nullptr;  // set: clips [split, batch) belong to a second encoder batch whose planes start here
+  // set: the chain decodes several encoder batches of `split` clips each (the last may be shorter): clips
+  // [split, 2 split) read e2, [2 split, 3 split) e3, [3 split, batch) e4 — every one indexed from 0
+  const unsigned short* e2 = nullptr;
+  const unsigned short* e3 = nullptr;
+  const unsigned short* e4 = nullptr;
   int split = 0;
   long e_plane = 0;
   float e_scale = 1.0f;
   float* ws = nullptr;
   int batch = 0, heads = 0, d_model = 0, T = 0, chunks = 1, nq = 1, p0 = 0;
-  bool bf16 = false;  // bf16 storage mode: e (and e2) are ONE bf16 plane [clips * T][d_model]; e_plane and e_scale unused
+  bool bf16 = false;  // bf16 storage mode: e (and e2 .. e4) are ONE bf16 plane [clips * T][d_model]; e_plane and e_scale unused
 };
 void launch_cross_absorbed(const CrossAbsorbedArgs& a, hipStream_t s);
 int cross_absorbed_max_nq(int heads);  // positions one launch can take
