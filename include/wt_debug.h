@@ -40,7 +40,7 @@ int wt_dbg_encoder_attention_planes(wt_engine* h, int batch, int T, int heads, c
 /* times `iters` back-to-back launches of the encoder GEMM on random operands (HIP events on the
  * engine's stream); variant selects the tile shape (k_gemm.hip) */
 int wt_dbg_gemm_bench(wt_engine* h, int M, int N, int K, int epi, int variant, int iters, float* avg_ms);
-/* (wt_dbg_dec_gemm_bench, below) times back-to-back launches of a decoder GEMM: kind 0 residual, 1 LayerNorm-fused,
+/* (wt_dbg_dec_gemm_bench, below) times back-to-back launches of a decoder GEMM: kind 0 residual, 1 LayerNorm-fused (3: + logits and argmax records),
  * 2 combine + residual; rows = B x positions in the pass (<= 128) */
 /* Interference probe: enqueues `n_enc` encoder passes over d_mel [batch][80][3000] on the encoder
  * stream and, concurrently, a chain of `chain_len` dependent trivial launches (`blocks` x 64

@@ -1154,7 +1154,7 @@ int wt_dbg_concurrency(wt_engine* h, const float* d_mel, int batch, int n_dec, i
 int wt_dbg_dec_gemm_bench(wt_engine* h, int kind, int B, int N, int K, int rows, int iters, float* avg_us) {
   if (!h || !avg_us || B < 1 || B > 64 || iters < 1 || rows < B || rows % B != 0) return WT_ERR_INVALID_ARG;
   return guarded(h, [&] {
-    // kind 0: residual GEMM, 1: LayerNorm-fused GEMM (+bias), 2: combine + residual GEMM
+    // kind 0: residual GEMM, 1: LayerNorm-fused GEMM (+bias), 2: combine + residual GEMM, 3: LayerNorm + logits + argmax records
     std::vector<float> hostW(size_t(N) * K), hostX(size_t(rows) * std::max(K, N));
     uint64_t x = 88172645463325252ull;
     auto rnd = [&x] { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return float(int64_t(x % 2000001) - 1000000) * 1e-6f; };
@@ -1175,6 +1175,11 @@ int wt_dbg_dec_gemm_bench(wt_engine* h, int kind, int B, int N, int K, int rows,
     if (kind == 0 && K > 1024) { g.ksplit = 2; g.part = dPart.p; g.R = dR.p; }  // fc2: K split over twice the blocks
     if (kind == 1) { pro = wt::kProLn; epi = wt::kDecBias; g.xin = dX.p; g.ln_g = dG.p; g.ln_b = dG.p; }
     if (kind == 2) { pro = wt::kProCombine; g.cross_ws = dWs.p; g.heads = heads; g.chunks = chunks; g.R = dY.p; }
+    DevBuf dBest(kind == 3 ? size_t(rows) * 2 * size_t((N + 31) / 32) : 1);
+    if (kind == 3) {  // final LayerNorm + logits + argmax records (the persistent kernel; no logits written)
+      pro = wt::kProLn; epi = wt::kDecLogits; g.xin = dX.p; g.ln_g = dG.p; g.ln_b = dG.p; g.Y = nullptr; g.bias = nullptr;
+      g.best = reinterpret_cast<unsigned long long*>(dBest.p);
+    }
     hipStream_t st = h->impl->stream();
     hipEvent_t e0, e1;
     hipchk(hipEventCreate(&e0), "event");
