@@ -179,19 +179,20 @@ __global__ __launch_bounds__(256, BF ? 4 : 3) void encoder_attention_planes(cons
     // the planes (s_inv > 0 takes them out): the maximum is taken on the raw values, and s_inv, the running maximum
     // and the 2^12 that puts the probabilities into fp16's normal range all go into ONE fma per score in front of
     // the exp2.  l_run and O then both carry the 2^12, which cancels in O / l.
-    float tmax = fmaxf(s0[0], s1[0]);
+    // (round 4) No cross-lane traffic in the common tile: the lane compares the maximum of ITS 32 scores with the running
+    // maximum (kept equal in both lanes of a row) — only when some lane of the wave exceeds it by more than kDefer is
+    // the row maximum formed (one LDS shuffle) and O, l rescaled; the row sum stays a per-lane partial until the end.
+    // (tried and not kept: v_permlane32_swap instead of the LDS shuffle, 1.5 % slower; scaling the scores first with
+    // packed multiplies, v_max3 chains and packed adds — 135 instead of 180 vector instructions per tile — 0-4 % slower,
+    // tools/ab_attn.sh: the loop is not bound by the count of vector instructions)
+    float lmax = fmaxf(s0[0], s1[0]);
 #pragma unroll
-    for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, fmaxf(s0[r], s1[r]));
-    // (the LDS shuffle stays here: with three blocks per CU its latency is hidden, and v_permlane32_swap — a vector
-    // instruction in a VALU-bound softmax — measured 1.5 % slower, round 4)
-    // (also round 4: scaling the scores first with packed multiplies — no canonicalising v_max x, x, x per raw MFMA
-    // result, v_max3 chains, packed adds for the shift and the row sum: 135 instead of 180 vector instructions per
-    // tile — measured 0-4 % SLOWER in three alternating runs on one box (tools/ab_attn.sh): the loop is not bound by
-    // the count of vector instructions)
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * s_inv;
+    for (int r = 1; r < 16; ++r) lmax = fmaxf(lmax, fmaxf(s0[r], s1[r]));
+    lmax *= s_inv;
     // deferred maximum: raise m_run (and rescale O, l) only when some row's tile maximum exceeds it by more than
     // kDefer; otherwise the probabilities of this tile are at most 2^kDefer, which the planes hold
-    if (__any(tmax > m_run + kDefer)) {
+    if (__any(lmax > m_run + kDefer)) {
+      const float tmax = fmaxf(lmax, __shfl_xor(lmax, 32, 64));
       const float m_new = fmaxf(m_run, tmax);
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       l_run *= alpha;
@@ -210,8 +211,7 @@ __global__ __launch_bounds__(256, BF ? 4 : 3) void encoder_attention_planes(cons
       s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], s_inv, shift));
       psum += s0[r] + s1[r];
     }
-    psum += __shfl_xor(psum, 32, 64);
-    l_run += psum;
+    l_run += psum;  // this lane's keys only: the two halves of a row are added once, after the last tile
     // V_t and K_t+1 have landed (this wave's parts: vmcnt; everybody's: the barrier), and every wave is done with K_t
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -289,6 +289,7 @@ __global__ __launch_bounds__(256, BF ? 4 : 3) void encoder_attention_planes(cons
     if (kt + 2 < n_tiles) dma_tile(false, kt + 2, lds + (kt & 1) * NP * kPlaneBytes);
   }
 
+  l_run += __shfl_xor(l_run, 32, 64);
   if (q_row < T) {
     const float inv = o_scale / l_run;  // o_scale = out_scale / v_scale (the 2^12 of the probabilities is in l_run too)
     _Float16* orow = out + ((long)b * T + q_row) * d_model + h * 64;
