@@ -1,4 +1,5 @@
-# attention A/B of two library builds on ONE box: bash tools/ab_attn.sh tools/bin/lib_a.so tools/bin/lib_b.so
+# encoder attention A/B of two library builds on ONE box: bash tools/ab_attn.sh tools/bin/lib_a.so tools/bin/lib_b.so
+# (fp32-accurate form in bursts, bf16 form in bursts; three alternating rounds)
 set -o pipefail
 for i in 1 2 3; do
   for l in "$@"; do
