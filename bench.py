@@ -673,7 +673,7 @@ def main() -> None:
         esz = 2 if args.bf16 else 4                                    # bytes per stored element
         Hh = dm.n_text_head
         absorbed = bool(eng.get_option("cross_absorb_active"))
-        paired = pipelined and absorbed and bool(eng.get_option("dec_pair")) and B <= 32
+        paired = pipelined and absorbed and bool(eng.get_option("dec_pair")) and B <= int(os.environ.get("WT_PAIR_MAX_BATCH", "32")) and 2 * B <= 128
         group = max(1, min(int(eng.get_option("dec_group")), 128 // B)) if paired else 1
         if absorbed:
             # cross-attention against the encoder output itself: one [T][d] matrix of planes per clip and (layer, position)

@@ -1606,7 +1606,12 @@ void Engine::flush_pending() {
 
 // decoder side of a pipelined submit: alone, or together with the neighbouring submits' batches (dec_pair, dec_group)
 int Engine::group_of(int batch) const {
-  if (dec_pair == 0 || !absorb_active() || batch > 32) return 1;
+  // (WT_PAIR_MAX_BATCH: largest batch that is grouped — 32 until round 4, when a chain's rows were limited to 64)
+  static const int pair_max = [] {
+    const char* v = getenv("WT_PAIR_MAX_BATCH");
+    return v ? atoi(v) : 32;
+  }();
+  if (dec_pair == 0 || !absorb_active() || batch > pair_max) return 1;
   const int g = int(std::min<long>(std::max<long>(dec_group, 2), 4));
   return std::max(1, std::min(g, kDecRowsMax / batch));
 }
