@@ -1,7 +1,7 @@
 // Encoder GEMM of the bf16 STORAGE mode (BASELINE configs[3]: whisper-base, bf16 weights / activations / KV with
 // fp32 accumulation; option "bf16").  C = epilogue(A . W^T): A [M][K] and W [N][K] are bf16 in HBM — weights rounded
 // once at load time, activations written as bf16 by the kernel that produces them (LayerNorm, this kernel's GELU /
-// plain epilogues, encoder attention) — one v_mfma_f32_32x32x16_bf16 product per k-step, fp32 accumulators, fp32
+// plain epilogues, encoder attention) — one v_mfma_f32_16x16x32_bf16 product per k-step, fp32 accumulators, fp32
 // bias / GELU / positional add / residual in the epilogue.  The residual stream itself stays fp32 (it is only ever an
 // epilogue operand); everything a matrix unit reads is bf16.
 //
@@ -64,9 +64,9 @@ struct Bf16GemmDev {
 // 4 KB LDS stage (conflict-free image of k_gemm_planes.hip) and moves 16 bytes per lane.  `smem` is the block's dynamic
 // LDS, dead as operand staging by the time this runs; (mw0, nw0) is the wave tile's origin.
 template <int EPI, bool BF_OUT, int MI_, int NI>
-__device__ __forceinline__ void bf16_epilogue(const Bf16GemmDev& g, f32x16 (&acc)[MI_][NI], unsigned char* smem, int wid, int lane,
+__device__ __forceinline__ void bf16_epilogue(const Bf16GemmDev& g, f32x4 (&acc)[2 * MI_][2 * NI], unsigned char* smem, int wid, int lane,
                                               int mw0, int nw0) {
-  const int l31 = lane & 31, lh = lane >> 5;
+  const int lc = lane & 15, lq = lane >> 4;  // accumulator tile (16 x 16): column lc, rows 4 lq + r
   constexpr int SLD = 32;
   float* const stage = reinterpret_cast<float*>(smem) + wid * (32 * SLD);
   constexpr int CPL = BF_OUT ? 8 : 4;
@@ -84,7 +84,12 @@ __device__ __forceinline__ void bf16_epilogue(const Bf16GemmDev& g, f32x16 (&acc
 #pragma unroll
     for (int mi = 0; mi < MI_; ++mi) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * lh) * SLD + (l31 ^ (lh << 2))] = acc[mi][ni][r];
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)  // row 16 a + 4 lq + r (its bit 2 is lq & 1), columns XORed by 20 on rows with bit 2 set
+            stage[(16 * a + 4 * lq + r) * SLD + ((16 * b + lc) ^ ((lq & 1) * 20))] = acc[2 * mi + a][2 * ni + b][r];
       const int mbase = mw0 + mi * 32;
       const int mb0 = mbase / g.c_rpb, mt0 = mbase % g.c_rpb;
       const int mp0 = (EPI & kEpiPos) ? mbase % g.pos_period : 0;
@@ -94,7 +99,7 @@ __device__ __forceinline__ void bf16_epilogue(const Bf16GemmDev& g, f32x16 (&acc
         float v[CPL];
 #pragma unroll
         for (int e = 0; e < CPL; e += 4) {
-          const f32x4 t = *reinterpret_cast<const f32x4*>(&stage[row * SLD + ((c0 + e) ^ (((row >> 2) & 1) << 2))]);
+          const f32x4 t = *reinterpret_cast<const f32x4*>(&stage[row * SLD + ((c0 + e) ^ (((row >> 2) & 1) * 20))]);
           v[e] = t[0], v[e + 1] = t[1], v[e + 2] = t[2], v[e + 3] = t[3];
         }
         if (mbase + row < g.M) {
@@ -166,7 +171,6 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_bf16_planes(Bf16GemmDev g) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid / WN, wn = wid % WN;
-  const int l31 = lane & 31, lh = lane >> 5;
 
   // LDS-DMA: instruction q copies rows 8 q .. 8 q + 7 of the A tile (q < QA) or of the W tile; lane i fills slot
   // (row i >> 3, chunk i & 7) with the global chunk (i & 7) ^ ((row >> 1) & 7) of that row
@@ -202,30 +206,31 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_bf16_planes(Bf16GemmDev g) {
     }
   };
 
-  f32x16 acc[MI][NI];
+  // (round 4) v_mfma_f32_16x16x32_bf16: the matrix pipe is power-bound and this shape does the same arithmetic on less
+  // energy; lane (row lc of a 16-row fragment, 16-byte chunk lq of the 32-deep k-step)
+  f32x4 acc[2 * MI][2 * NI];
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
+  for (int i = 0; i < 2 * MI; ++i)
 #pragma unroll
-    for (int j = 0; j < NI; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    for (int j = 0; j < 2 * NI; ++j) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
-  const int swz = (l31 >> 1) & 7;  // tile bases are multiples of 32 rows: the swizzle term depends on the lane only
-  const int a_off = (wm * 96 + l31) * 128, b_off = kABytes + (wn * NI * 32 + l31) * 128;
+  const int lc = lane & 15, lq = lane >> 4;
+  const int swz = (lc >> 1) & 7;  // fragment bases are multiples of 16 rows: the swizzle term depends on the lane only
+  const int a_off = (wm * 96 + lc) * 128, b_off = kABytes + (wn * NI * 32 + lc) * 128;
   auto compute = [&](int buf) {
     const unsigned char* base = smem + buf * kStage;
 #pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      const int slot = ((ks * 2 + lh) ^ swz) * 16;
-      bf16x8 af[MI], bf[NI];
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      const int slot = ((ks * 4 + lq) ^ swz) * 16;
+      bf16x8 af[2 * MI], bf[2 * NI];
 #pragma unroll
-      for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(base + a_off + i * 32 * 128 + slot);
+      for (int i = 0; i < 2 * MI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(base + a_off + i * 16 * 128 + slot);
 #pragma unroll
-      for (int j = 0; j < NI; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(base + b_off + j * 32 * 128 + slot);
+      for (int j = 0; j < 2 * NI; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(base + b_off + j * 16 * 128 + slot);
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
+      for (int i = 0; i < 2 * MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2 * NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
   };
 
