@@ -9,7 +9,7 @@ PKG   := whisper.tflite_amd
 SRC   := $(PKG)/csrc
 OBJ   := $(PKG)/build
 CXXFLAGS := -std=c++17 -O3 -fPIC -Iinclude -I$(SRC) -Wall -Wno-unused-result
-HIPFLAGS := $(CXXFLAGS) --offload-arch=$(ARCH) -ffp-contract=fast
+HIPFLAGS := $(CXXFLAGS) --offload-arch=$(ARCH) -ffp-contract=fast $(HIPFLAGS_EXTRA)
 
 KERNELS := k_gemm k_gemm_planes k_gemm_bf16 k_misc k_attention k_attention_planes k_decoder k_cross_absorbed
 HOSTSRC := engine capi host_util weights_gen whisper_api tflite_extract
