@@ -4,6 +4,7 @@
 //   hipcc --offload-arch=gfx950 -O3 tools/cu_stream_probe.hip -o tools/bin/cu_stream_probe && tools/bin/cu_stream_probe
 // N blocks (one per CU: N <= 256), each streams its own contiguous 16 MB slice of a 4 GB buffer once per launch:
 //   regs W x U   W wavefronts, U global_load_dwordx4 in flight per lane (1 KiB contiguous per wave-instruction), summed
+//   stores W x U  W wavefronts, U global_store_dwordx4 per lane and loop step, the same slices written
 //   dma L: S x KB  L loader wavefronts (a wavefront holds at most 63 memory instructions in flight: vmcnt is 6 bits),
 //                LDS-DMA (global_load_lds_dwordx4, 1 KiB contiguous per instruction) into a ring of S stages of KB KiB;
 //                four consumer wavefronts read every stage from LDS (ds_read_b128) and sum
@@ -31,6 +32,18 @@ __global__ __launch_bounds__(64 * W) void stream_regs(const u32x4* __restrict__ 
     for (int u = 0; u < U; ++u) acc += v[u];
   }
   if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) out[blockIdx.x] = acc[0];
+}
+
+// stores: W wavefronts, U dwordx4 stores per lane and loop step (1 KiB contiguous per wave-instruction)
+template <int W, int U>
+__global__ __launch_bounds__(64 * W) void stream_stores(u32x4* __restrict__ dst, unsigned seed) {
+  u32x4* p = dst + (size_t)blockIdx.x * (kSlice / 16) + threadIdx.x;
+  constexpr int kStep = 64 * W;
+  const u32x4 v = {seed, seed + threadIdx.x, seed ^ blockIdx.x, 7u};
+  for (size_t i = 0; i < kSlice / 16 / kStep; i += U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) p[(i + u) * kStep] = v;
+  }
 }
 
 __device__ __forceinline__ void lds_dma16_sgpr(unsigned voff, unsigned long long sbase, unsigned lds_dst) {
@@ -116,6 +129,10 @@ int main() {
   run("regs 16 x 4", [&](int n) { stream_regs<16, 4><<<n, 1024>>>(b4, out); });
   run("regs 16 x 8", [&](int n) { stream_regs<16, 8><<<n, 1024>>>(b4, out); });
   run("regs 16 x 16", [&](int n) { stream_regs<16, 16><<<n, 1024>>>(b4, out); });
+  u32x4* w4 = reinterpret_cast<u32x4*>(buf);
+  run("stores 4 x 4", [&](int n) { stream_stores<4, 4><<<n, 256>>>(w4, 1u); });
+  run("stores 8 x 8", [&](int n) { stream_stores<8, 8><<<n, 512>>>(w4, 2u); });
+  run("stores 16 x 8", [&](int n) { stream_stores<16, 8><<<n, 1024>>>(w4, 3u); });
 #define DMA(S, KB, L)                                                                                                   \
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stream_dma<S, KB, L>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
   run("dma " #L ": " #S " x " #KB, [&](int n) { stream_dma<S, KB, L><<<n, 256 + 64 * L, S * KB * 1024>>>(buf, out); });
@@ -125,6 +142,5 @@ int main() {
   DMA(5, 32, 2)
   DMA(9, 16, 2)
   DMA(5, 32, 4)
-  DMA(4, 48, 4)
   return 0;
 }
