@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256, BF ? 4 : 3) void encoder_attention_planes(cons
   for (int dg = 0; dg < 4; ++dg)
 #pragma unroll
     for (int qa = 0; qa < 2; ++qa) o[dg][qa] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-  float m_run[2] = {-1e30f, -1e30f}, l_run[2] = {0.0f, 0.0f};
+  float m_run[2] = {0.0f, 0.0f}, l_run[2] = {0.0f, 0.0f};  // m_run: set from the first tile
 
   // LDS-DMA of a K or V tile: one wave-instruction copies 8 rows x 128 B (1 KiB) of one plane; wave w issues row groups
   // w and w + 4 of every plane.  (uniform base) + (32-bit per-lane byte offset that never changes): row drow (+ 32) of
@@ -186,37 +186,61 @@ __global__ __launch_bounds__(256, BF ? 4 : 3) void encoder_attention_planes(cons
     // out); the probabilities carry 2^12 (fp16's normal range for their low plane), l_run and O carry it too, and it
     // cancels in O / l.  Deferred maximum: raise m_run (and rescale O, l) only when some lane's scores exceed it by more
     // than kDefer; otherwise the probabilities of this tile are at most 2^kDefer, which the planes hold.
+    // The exponent t = s * s_inv + (2^12 shift) - m_run is formed FIRST, against the running maximum as it stands (one fma
+    // per score; the maximum of fma results needs no canonicalising v_max x, x, x per score, which the maximum of raw
+    // MFMA results did): t <= shift + kDefer in every lane is the common tile, and exp2(t) follows at once.
+    const float t_cap = (BF ? 0.0f : kPShift) + kDefer;
+    if (kt == 0) {  // the running maximum starts as the first tile's row maximum (an exponent formed against "minus infinity" would lose the score)
+#pragma unroll
+      for (int qa = 0; qa < 2; ++qa) {
+        float m = fmaxf(fmaxf(sacc[0][qa][0], sacc[0][qa][1]), fmaxf(sacc[0][qa][2], sacc[0][qa][3]));
+#pragma unroll
+        for (int kg = 1; kg < 4; ++kg)
+          m = fmaxf(m, fmaxf(fmaxf(sacc[kg][qa][0], sacc[kg][qa][1]), fmaxf(sacc[kg][qa][2], sacc[kg][qa][3])));
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        m_run[qa] = m * s_inv;
+      }
+    }
     float lmax[2];
 #pragma unroll
     for (int qa = 0; qa < 2; ++qa) {
+      const float sh0 = (BF ? 0.0f : kPShift) - m_run[qa];
+#pragma unroll
+      for (int kg = 0; kg < 4; ++kg)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sacc[kg][qa][r] = fmaf(sacc[kg][qa][r], s_inv, sh0);
       lmax[qa] = fmaxf(fmaxf(sacc[0][qa][0], sacc[0][qa][1]), fmaxf(sacc[0][qa][2], sacc[0][qa][3]));
 #pragma unroll
       for (int kg = 1; kg < 4; ++kg)
         lmax[qa] = fmaxf(lmax[qa], fmaxf(fmaxf(sacc[kg][qa][0], sacc[kg][qa][1]), fmaxf(sacc[kg][qa][2], sacc[kg][qa][3])));
-      lmax[qa] *= s_inv;
     }
-    if (__any(lmax[0] > m_run[0] + kDefer || lmax[1] > m_run[1] + kDefer)) {
+    if (__any(lmax[0] > t_cap || lmax[1] > t_cap)) {
 #pragma unroll
       for (int qa = 0; qa < 2; ++qa) {
         float tmax = fmaxf(lmax[qa], __shfl_xor(lmax[qa], 16, 64));
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m_run[qa], tmax);
-        const float alpha = __builtin_amdgcn_exp2f(m_run[qa] - m_new);
+        // the row's maximum in score units is m_run + tmax - shift: the new running maximum, and what every exponent drops by
+        const float delta = fminf(0.0f, (BF ? 0.0f : kPShift) - tmax);  // m_run - m_new
+        const float alpha = __builtin_amdgcn_exp2f(delta);
         l_run[qa] *= alpha;
 #pragma unroll
         for (int dg = 0; dg < 4; ++dg) o[dg][qa] *= alpha;
-        m_run[qa] = m_new;
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sacc[kg][qa][r] += delta;
+        m_run[qa] -= delta;
       }
     }
 #pragma unroll
     for (int qa = 0; qa < 2; ++qa) {
-      const float shift = (BF ? 0.0f : kPShift) - m_run[qa];
       float psum = 0.0f;
 #pragma unroll
       for (int kg = 0; kg < 4; ++kg)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          sacc[kg][qa][r] = __builtin_amdgcn_exp2f(fmaf(sacc[kg][qa][r], s_inv, shift));
+          sacc[kg][qa][r] = __builtin_amdgcn_exp2f(sacc[kg][qa][r]);
           psum += sacc[kg][qa][r];
         }
       l_run[qa] += psum;  // this lane's keys only
