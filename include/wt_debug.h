@@ -89,6 +89,11 @@ int wt_dbg_self_attention(wt_engine* h, int batch, int heads, int cap, int pos, 
 int wt_dbg_gemm_bf16(wt_engine* h, int M, int N, int K, const float* A, const float* W, const float* bias,
                      const float* R, const float* pos, int pos_period, int epi, int bf16_out, int iters, float* C,
                      float* avg_ms);
+/* x = R + bias + A . W^T on bf16 operands with the LayerNorm of the finished rows fused into the epilogue (whole-row tiles:
+ * N 128 / 384 / 512): C = x (fp32), ln_out = LayerNorm(x) * ln_g + ln_b as the bf16 plane (returned as float), ln_y32 the
+ * same in fp32; *fused = 0 when N has no whole-row tile (then only C is written). */
+int wt_dbg_gemm_bf16_ln(wt_engine* h, int M, int N, int K, const float* A, const float* W, const float* bias, const float* R,
+                        const float* ln_g, const float* ln_b, float* C, float* ln_out, float* ln_y32, int* fused);
 int wt_dbg_encoder_attention_bf16(wt_engine* h, int batch, int T, int heads, const float* qkv, int iters, float* out,
                                   float* avg_ms);
 /* the decoder's kernels in the bf16 storage mode (k_decoder.hip instantiations with BF = true): weights as one bf16 plane in

@@ -482,6 +482,35 @@ def test_bf16_gemm_epilogues(eng, epi):
     assert rel_err(C, ref) < 3e-6
 
 
+@pytest.mark.parametrize("M,N,K", [(192, 128, 64), (500, 128, 512), (256, 384, 384), (1000, 384, 1536), (128, 512, 512), (777, 512, 2048), (1, 512, 64),
+                                   (300, 256, 128)])
+def test_bf16_gemm_layernorm_fused_in_the_epilogue(eng, M, N, K):
+    """Round 4: the bf16 mode's out-projection / fc2 / conv2 GEMMs write LayerNorm(finished row) as the next GEMM's bf16
+    operand (and, for ln_post, as fp32) from their epilogue — whole-row tiles for d_model 128 / 384 / 512, rows past M in
+    the last tile, one to four wavefront columns exchanging the row statistics.  Against fp64 on the bf16-rounded operands:
+    x at the GEMM's bar, the fp32 LayerNorm at 2e-5 absolute, the plane = that rounded to bf16 (half an ulp on top).  N = 256
+    has no whole-row tile: the launcher says so and the caller keeps the separate LayerNorm launch."""
+    rng = np.random.default_rng(M + 7 * N + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    R = (rng.standard_normal((M, N)) * 2).astype(np.float32)
+    g = (1.0 + 0.3 * rng.standard_normal(N)).astype(np.float32)
+    b = (0.2 * rng.standard_normal(N)).astype(np.float32)
+    x, ln, y32, fused = eng.dbg_gemm_bf16_ln(A, W, bias, R, g, b)
+    ref = R.astype(np.float64) + bias + bf16_round(A).astype(np.float64) @ bf16_round(W).astype(np.float64).T
+    assert rel_err(x, ref) < 3e-6
+    assert fused == (N in (128, 384, 512))
+    if not fused:
+        return
+    mu = ref.mean(axis=1, keepdims=True)
+    var = ((ref - mu) ** 2).mean(axis=1, keepdims=True)
+    want = (ref - mu) / np.sqrt(var + 1e-5) * g + b
+    assert np.abs(y32 - want).max() < 2e-5
+    assert np.array_equal(ln, bf16_round(ln))
+    assert (np.abs(ln - want) <= np.abs(want) * 2.0 ** -8 + 3e-5).all()
+
+
 def test_bf16_gemm_is_exact_on_integers(eng):
     """Small integers are exact in bf16: an asymmetric integer W against an identity-plus-pattern A catches a swapped
     fragment map or a wrong LDS swizzle of the 128-byte-row image."""

@@ -51,7 +51,7 @@ DEBUG_SYMBOLS = [
     "wt_dbg_cross_absorbed", "wt_dbg_cross_absorbed_bf16", "wt_dbg_gemm_planes_ln", "wt_dbg_gemm", "wt_dbg_gemm_bench", "wt_dbg_dec_gemm_bench", "wt_dbg_dec_gemm", "wt_dbg_dec_ln_gemm", "wt_dbg_layernorm", "wt_dbg_encoder_attention",
     "wt_dbg_cross_attention", "wt_dbg_self_attention", "wt_dbg_interference", "wt_dbg_concurrency",
     "wt_dbg_gemm_planes", "wt_dbg_set_plane_gemm_mode", "wt_dbg_set_forced_ids", "wt_dbg_dec_gemm_bf16", "wt_dbg_dec_ln_gemm_bf16",
-    "wt_dbg_self_attention_bf16", "wt_dbg_cross_attention_bf16", "wt_dbg_encoder_attention_planes", "wt_dbg_gemm_bf16", "wt_dbg_encoder_attention_bf16",
+    "wt_dbg_self_attention_bf16", "wt_dbg_cross_attention_bf16", "wt_dbg_encoder_attention_planes", "wt_dbg_gemm_bf16", "wt_dbg_gemm_bf16_ln", "wt_dbg_encoder_attention_bf16",
 ]
 
 
@@ -149,6 +149,7 @@ def lib() -> ctypes.CDLL:
         L.wt_dbg_gemm_bf16.argtypes = [c_void_p, c_int, c_int, c_int, fp, fp, fp, fp, fp, c_int, c_int, c_int, c_int, fp,
                                        POINTER(c_float)]
         L.wt_dbg_encoder_attention_bf16.argtypes = [c_void_p, c_int, c_int, c_int, fp, c_int, fp, POINTER(c_float)]
+        L.wt_dbg_gemm_bf16_ln.argtypes = [c_void_p, c_int, c_int, c_int, fp, fp, fp, fp, fp, fp, fp, fp, fp, POINTER(c_int)]
         L.wt_dbg_gemm_bench.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_float)]
         L.wt_dbg_dec_gemm_bench.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_float)]
         L.wt_dbg_dec_gemm.argtypes = [c_void_p, c_int, c_int, c_int, c_int, fp, fp, fp, fp, fp, ip64]
@@ -571,6 +572,19 @@ class Engine:
         a = np.ascontiguousarray(ids, dtype=np.int64)
         assert a.ndim == 2 and a.shape[1] == 32
         self._check(lib().wt_dbg_set_forced_ids(self._h, a.ctypes.data_as(POINTER(c_int64)), a.shape[0]))
+
+    def dbg_gemm_bf16_ln(self, A, W, bias, R, ln_g, ln_b):
+        """x = R + bias + A . W^T (bf16 operands) with the fused LayerNorm: returns (x, LayerNorm plane as float, fp32 LayerNorm, fused)"""
+        A, W, bias, R, ln_g, ln_b = (_f32(v) for v in (A, W, bias, R, ln_g, ln_b))
+        M, K = A.shape
+        N = W.shape[0]
+        C = np.zeros((M, N), np.float32)
+        ln = np.zeros((M, N), np.float32)
+        y32 = np.zeros((M, N), np.float32)
+        fused = c_int(0)
+        self._check(lib().wt_dbg_gemm_bf16_ln(self._h, M, N, K, _fp(A), _fp(W), _fp(bias), _fp(R), _fp(ln_g), _fp(ln_b), _fp(C), _fp(ln),
+                                              _fp(y32), byref(fused)))
+        return C, ln, y32, bool(fused.value)
 
     def dbg_dec_gemm_bench(self, kind, B, N, K, rows=None, iters=200) -> float:
         us = c_float(0)

@@ -1068,6 +1068,26 @@ int wt_dbg_gemm_bf16(wt_engine* h, int M, int N, int K, const float* A, const fl
   });
 }
 
+int wt_dbg_gemm_bf16_ln(wt_engine* h, int M, int N, int K, const float* A, const float* W, const float* bias, const float* R,
+                        const float* ln_g, const float* ln_b, float* C, float* ln_out, float* ln_y32, int* fused) {
+  if (!h || !A || !W || !bias || !R || !ln_g || !ln_b || !C || !ln_out || !ln_y32 || !fused || N % 128 || K % 64 || M < 1) return WT_ERR_INVALID_ARG;
+  return guarded(h, [&] {
+    const DevBf16 dA(A, size_t(M) * K), dW(W, size_t(N) * K);
+    DevBuf dB(bias, N), dC(R, size_t(M) * N), dG(ln_g, N), dS(ln_b, N), dY(size_t(M) * N);
+    const DevBf16 dL(nullptr, size_t(M) * N);
+    wt::PlaneGemmArgs g;  // x += A . W^T + bias, LayerNorm(x) as a bf16 plane and as fp32
+    g.A = dA.ptr(); g.lda = K; g.W = dW.ptr(); g.bias = dB.p; g.C = dC.p; g.R = dC.p; g.ldc = N;
+    g.M = M; g.N = N; g.K = K;
+    g.ln_g = dG.p; g.ln_b = dS.p; g.ln_P = dL.ptr(); g.ln_y32 = dY.p;
+    hipStream_t st = h->impl->stream();
+    *fused = wt::launch_gemm_bf16_planes(g, wt::kEpiBias | wt::kEpiResidual, st) ? 1 : 0;
+    h->impl->sync();
+    dC.to_host(C, size_t(M) * N);
+    dL.to_host(ln_out, size_t(M) * N);
+    dY.to_host(ln_y32, size_t(M) * N);
+  });
+}
+
 int wt_dbg_encoder_attention_bf16(wt_engine* h, int batch, int T, int heads, const float* qkv, int iters, float* out,
                                   float* avg_ms) {
   if (!h || !qkv || !out) return WT_ERR_INVALID_ARG;

@@ -1501,22 +1501,30 @@ void Engine::encode_enqueue_bf16(const float* d_mel, int batch) {
     launch_gemm_bf16_planes(g, kEpiBias | kEpiGelu, stream_);
     kt_end();
   }
+  bool have_ln = false;  // the LayerNorm plane of the coming layer is already in lnp (written by a GEMM epilogue)
   {
     PlaneGemmArgs g;  // conv2 (stride 2) + GELU + positional embedding
     g.A = ws_.h1pp; g.a_rpb = T; g.a_bs = long(T0 + 2) * d; g.lda = 2 * d;
     g.W = bf_.conv2; g.bias = conv2_b; g.pos = enc_pos; g.pos_period = T;
     g.C = ws_.x; g.ldc = d;
     g.M = M; g.N = d; g.K = 3 * d;
+    // (round 4) the LayerNorm in front of a layer's qkv / fc1 GEMM and ln_post are written by the epilogue of the GEMM
+    // that finishes the residual rows (k_gemm_bf16.hip, whole-row tiles): no separate launch re-reads the stream
+    if (c.n_audio_layer > 0) g.ln_g = enc_blocks_[0].attn_ln_g, g.ln_b = enc_blocks_[0].attn_ln_b, g.ln_P = lnp;
     kt_begin(kKcGemm, 2.0 * g.M * g.N * g.K, 0);
-    launch_gemm_bf16_planes(g, kEpiBias | kEpiGelu | kEpiPos, stream_);
+    have_ln = launch_gemm_bf16_planes(g, kEpiBias | kEpiGelu | kEpiPos, stream_);
     kt_end();
   }
+  const bool absorb = absorb_for(batch);  // the decoder streams the encoder output itself (one bf16 plane per slot): no cross-KV GEMM
+  bool have_post = false;
   for (int l = 0; l < c.n_audio_layer; ++l) {
     const BlockWeights& w = enc_blocks_[l];
     const Bf16Encoder::Layer& wb = bf_.layers[l];
-    kt_begin(kKcLayerNorm, 0, 1.5 * M * d * 4);
-    launch_layernorm_planes(ws_.x, lnp, 0, 1.0f, nullptr, w.attn_ln_g, w.attn_ln_b, M, d, stream_, nullptr, true);
-    kt_end();
+    if (!have_ln) {
+      kt_begin(kKcLayerNorm, 0, 1.5 * M * d * 4);
+      launch_layernorm_planes(ws_.x, lnp, 0, 1.0f, nullptr, w.attn_ln_g, w.attn_ln_b, M, d, stream_, nullptr, true);
+      kt_end();
+    }
     PlaneGemmArgs q;
     q.A = lnp; q.lda = d; q.W = wb.qkv; q.bias = w.attn.bqkv;
     q.P = qkvp; q.ldc = 3 * d; q.M = M; q.N = 3 * d; q.K = d;
@@ -1529,12 +1537,15 @@ void Engine::encode_enqueue_bf16(const float* d_mel, int batch) {
     PlaneGemmArgs o;
     o.A = attp; o.lda = d; o.W = wb.out; o.bias = w.attn.bo;
     o.C = ws_.x; o.R = ws_.x; o.ldc = d; o.M = M; o.N = d; o.K = d;
+    o.ln_g = w.mlp_ln_g; o.ln_b = w.mlp_ln_b; o.ln_P = lnp;
     kt_begin(kKcGemm, 2.0 * o.M * o.N * o.K, 0);
-    launch_gemm_bf16_planes(o, kEpiBias | kEpiResidual, stream_);
+    const bool have_mlp_ln = launch_gemm_bf16_planes(o, kEpiBias | kEpiResidual, stream_);
     kt_end();
-    kt_begin(kKcLayerNorm, 0, 1.5 * M * d * 4);
-    launch_layernorm_planes(ws_.x, lnp, 0, 1.0f, nullptr, w.mlp_ln_g, w.mlp_ln_b, M, d, stream_, nullptr, true);
-    kt_end();
+    if (!have_mlp_ln) {
+      kt_begin(kKcLayerNorm, 0, 1.5 * M * d * 4);
+      launch_layernorm_planes(ws_.x, lnp, 0, 1.0f, nullptr, w.mlp_ln_g, w.mlp_ln_b, M, d, stream_, nullptr, true);
+      kt_end();
+    }
     PlaneGemmArgs f1;
     f1.A = lnp; f1.lda = d; f1.W = wb.fc1; f1.bias = w.b1;
     f1.P = hidp; f1.ldc = 4 * d; f1.M = M; f1.N = 4 * d; f1.K = d;
@@ -1544,14 +1555,23 @@ void Engine::encode_enqueue_bf16(const float* d_mel, int batch) {
     PlaneGemmArgs f2;
     f2.A = hidp; f2.lda = 4 * d; f2.W = wb.fc2; f2.bias = w.b2;
     f2.C = ws_.x; f2.R = ws_.x; f2.ldc = d; f2.M = M; f2.N = d; f2.K = 4 * d;
+    const bool last = l + 1 == c.n_audio_layer;
+    if (!last) {
+      f2.ln_g = enc_blocks_[l + 1].attn_ln_g; f2.ln_b = enc_blocks_[l + 1].attn_ln_b; f2.ln_P = lnp;
+    } else {  // ln_post: the bf16 plane (the decoder's stream in the absorbed form), the fp32 enc_out and the non-finite flag
+      f2.ln_g = enc_ln_post_g; f2.ln_b = enc_ln_post_b; f2.ln_P = absorb ? slot.e_planes : lnp;
+      f2.ln_y32 = ws_.enc_out; f2.nonfinite = slot.d_flag;
+    }
     kt_begin(kKcGemm, 2.0 * f2.M * f2.N * f2.K, 0);
-    launch_gemm_bf16_planes(f2, kEpiBias | kEpiResidual, stream_);
+    const bool fused = launch_gemm_bf16_planes(f2, kEpiBias | kEpiResidual, stream_);
     kt_end();
+    (last ? have_post : have_ln) = fused;
   }
-  const bool absorb = absorb_for(batch);  // the decoder streams the encoder output itself (one bf16 plane per slot): no cross-KV GEMM
   kt_begin(kKcLayerNorm, 0, 2.5 * M * d * 4);
-  launch_layernorm_planes(ws_.x, absorb ? slot.e_planes : lnp, 0, 1.0f, ws_.enc_out, enc_ln_post_g, enc_ln_post_b, M, d, stream_,
-                          slot.d_flag, true);
+  if (!have_post) {
+    launch_layernorm_planes(ws_.x, absorb ? slot.e_planes : lnp, 0, 1.0f, ws_.enc_out, enc_ln_post_g, enc_ln_post_b, M, d, stream_,
+                            slot.d_flag, true);
+  }
   HIPCHK(hipMemcpyAsync(slot.h_flag, slot.d_flag, sizeof(int), hipMemcpyDeviceToHost, stream_));
   kt_end();
   HIPCHK(hipEventRecord(slot.enc_mid, stream_));

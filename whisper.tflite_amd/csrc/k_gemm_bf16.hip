@@ -24,8 +24,7 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
-constexpr int BM = 192, BK = 64;
-constexpr int MI = 3;
+constexpr int BK = 64;
 
 // diagnostic build (tools/gemm_bf16_probe.hip): WT_BF16_ABL 1 = no LDS-DMA after the first k-tile, 2 = no MFMAs,
 // 3 = no epilogue; s_memtime per phase of wave 0 into g_bf16_stamps.  The product build compiles none of it.
@@ -58,15 +57,27 @@ struct Bf16GemmDev {
   int ldc;
   int pos_period;
   int kv_batch, kv_heads, kv_dmodel;
+  // LN (round 4): LayerNorm of the finished rows (N == BN: a block owns whole rows), written as the bf16 plane the next
+  // GEMM reads, optionally also as fp32 (the encoder's enc_out) with the non-finite flag of the LayerNorm kernel
+  const float* ln_g;
+  const float* ln_b;
+  unsigned short* ln_P;
+  float* ln_y32;
+  int* nonfinite;
 };
 
 // Epilogue shared by the two tile kernels: each wavefront transposes one 32 x 32 MFMA tile at a time through a private
 // 4 KB LDS stage (conflict-free image of k_gemm_planes.hip) and moves 16 bytes per lane.  `smem` is the block's dynamic
 // LDS, dead as operand staging by the time this runs; (mw0, nw0) is the wave tile's origin.
-template <int EPI, bool BF_OUT, int MI_, int NI>
+template <int EPI, bool BF_OUT, int MI_, int NI, bool LN = false, int WN = 4>
 __device__ __forceinline__ void bf16_epilogue(const Bf16GemmDev& g, f32x4 (&acc)[2 * MI_][2 * NI], unsigned char* smem, int wid, int lane,
                                               int mw0, int nw0) {
+  static_assert(!LN || !BF_OUT, "LayerNorm fusion: fp32 output");
   const int lc = lane & 15, lq = lane >> 4;  // accumulator tile (16 x 16): column lc, rows 4 lq + r
+  // LN: the accumulator registers of a finished 32 x 32 block are dead and keep its row-major values: item i = 4 p + e
+  // (row p * 8 + prow, columns c0 + e) of block (mi, ni) lives in acc[2 mi + (i >> 3)][2 ni + ((i >> 2) & 1)][i & 3]
+  auto keep = [&](int mi, int ni, int i, float v) { acc[2 * mi + (i >> 3)][2 * ni + ((i >> 2) & 1)][i & 3] = v; };
+  auto kept = [&](int mi, int ni, int i) -> float { return acc[2 * mi + (i >> 3)][2 * ni + ((i >> 2) & 1)][i & 3]; };
   constexpr int SLD = 32;
   float* const stage = reinterpret_cast<float*>(smem) + wid * (32 * SLD);
   constexpr int CPL = BF_OUT ? 8 : 4;
@@ -141,9 +152,84 @@ __device__ __forceinline__ void bf16_epilogue(const Bf16GemmDev& g, f32x4 (&acc)
             f32x4 out = {v[0], v[1], v[2], v[3]};
             if (EPI & kEpiResidual) out += *reinterpret_cast<const f32x4*>(g.R + o);
             *reinterpret_cast<f32x4*>(g.C + o) = out;
+            if constexpr (LN) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) keep(mi, ni, 4 * p + e, out[e]);
+            }
           }
+        } else if constexpr (LN) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) keep(mi, ni, 4 * p + e, 0.0f);  // rows past M: no part in anything
         }
       }
+    }
+  }
+  if constexpr (LN) {
+    // LayerNorm of the rows this block has just finished (N == BN: whole rows), as in k_gemm_planes.hip: two-pass
+    // statistics, the WN wavefront columns of a block row exchange their partial sums through LDS (behind the stage
+    // area), first of the values, then of the squared deviations.  The separate LayerNorm launch re-read the fp32
+    // residual stream and wrote this plane: 295 MB per launch at 64 clips of whisper-base, 13 launches per pass.
+    constexpr int BN = WN * NI * 32, NW = 2 * WN, BMr = 64 * MI_;
+    float* const part = reinterpret_cast<float*>(smem) + NW * (32 * SLD);  // [BMr][4] partial sums, twice
+    const int wm = wid / WN, wn = wid % WN;
+    const int rbase = wm * (32 * MI_) + prow;
+    const int m0 = mw0 - wm * (32 * MI_), n0 = nw0 - wn * (NI * 32);
+    float mean[MI_][4], rstd[MI_][4];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+      for (int mi = 0; mi < MI_; ++mi)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          float t = 0.0f;
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float x = kept(mi, ni, 4 * p + e) - (pass ? mean[mi][p] : 0.0f);
+              t += pass ? x * x : x;
+            }
+          t += __shfl_xor(t, 1, 64);
+          t += __shfl_xor(t, 2, 64);
+          t += __shfl_xor(t, 4, 64);
+          if ((lane & 7) == 0) part[pass * (BMr * 4) + (rbase + mi * 32 + p * 8) * 4 + wn] = t;
+        }
+      __syncthreads();
+#pragma unroll
+      for (int mi = 0; mi < MI_; ++mi)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const f32x4 q = *reinterpret_cast<const f32x4*>(&part[pass * (BMr * 4) + (rbase + mi * 32 + p * 8) * 4]);
+          float tot = q[0];
+          if (WN > 1) tot += q[1];
+          if (WN > 2) tot += q[2] + q[3];
+          tot *= 1.0f / (float)BN;
+          if (pass == 0) {
+            mean[mi][p] = tot;
+          } else {
+            if (g.nonfinite != nullptr && (lane & 7) == 0 && wn == 0 && !(fabsf(mean[mi][p]) <= 3.0e38f && tot <= 3.0e38f)) atomicOr(g.nonfinite, 1);
+            rstd[mi][p] = rsqrtf(tot + 1e-5f);
+          }
+        }
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int n = n0 + (wn * NI + ni) * 32 + c0;
+      const f32x4 gg = *reinterpret_cast<const f32x4*>(g.ln_g + n), bb = *reinterpret_cast<const f32x4*>(g.ln_b + n);
+#pragma unroll
+      for (int mi = 0; mi < MI_; ++mi)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int m = m0 + rbase + mi * 32 + p * 8;
+          if (m >= g.M) continue;
+          f32x4 y;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) y[e] = (kept(mi, ni, 4 * p + e) - mean[mi][p]) * rstd[mi][p] * gg[e] + bb[e];
+          const long o = (long)m * BN + n;
+          if (g.ln_y32 != nullptr) __builtin_nontemporal_store(y, reinterpret_cast<f32x4*>(g.ln_y32 + o));
+          using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+          *reinterpret_cast<u32x2*>(g.ln_P + o) = u32x2{pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
+        }
     }
   }
 }
@@ -151,8 +237,11 @@ __device__ __forceinline__ void bf16_epilogue(const Bf16GemmDev& g, f32x4 (&acc)
 // Block tile 192 x BN, BN = WN * NI * 32, 2 x WN wavefronts of 3 x NI MFMA tiles:
 //   (2, 2) 192 x 128, 4 wavefronts, 40 KB per stage, two blocks per CU;  (4, 2) 192 x 256 and (4, 3) 192 x 384,
 //   8 wavefronts, 56 / 72 KB per stage, one block per CU.
-template <int EPI, bool BF_OUT, int WN, int NI>
+template <int EPI, bool BF_OUT, int WN, int NI, int MI_ = 3, bool LN = false>
 __global__ __launch_bounds__(128 * WN, 2) void gemm_bf16_planes(Bf16GemmDev g) {
+  // MI_ = 32-row blocks per wavefront (two wavefront rows): 3 -> 192 block rows; 2 -> 128 rows, for the 512-column
+  // LayerNorm-fused tile (N == BN: the block owns whole rows) whose accumulators would not fit at 3
+  constexpr int BM = 64 * MI_, MI = MI_;
   constexpr int BN = WN * NI * 32, NW = 2 * WN;
   constexpr int kABytes = BM * BK * 2, kWBytes = BN * BK * 2;
   constexpr int kStage = kABytes + kWBytes;
@@ -216,7 +305,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_bf16_planes(Bf16GemmDev g) {
 
   const int lc = lane & 15, lq = lane >> 4;
   const int swz = (lc >> 1) & 7;  // fragment bases are multiples of 16 rows: the swizzle term depends on the lane only
-  const int a_off = (wm * 96 + lc) * 128, b_off = kABytes + (wn * NI * 32 + lc) * 128;
+  const int a_off = (wm * (32 * MI) + lc) * 128, b_off = kABytes + (wn * NI * 32 + lc) * 128;
   auto compute = [&](int buf) {
     const unsigned char* base = smem + buf * kStage;
 #pragma unroll
@@ -249,23 +338,35 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_bf16_planes(Bf16GemmDev g) {
   BF_STAMP(2);
   if (WT_BF16_ABL == 3 && acc[0][0][0] != 12345.678f) return;
 
-  bf16_epilogue<EPI, BF_OUT, MI, NI>(g, acc, smem, wid, lane, m0 + wm * (MI * 32), n0 + wn * (NI * 32));
+  bf16_epilogue<EPI, BF_OUT, MI, NI, LN, WN>(g, acc, smem, wid, lane, m0 + wm * (MI * 32), n0 + wn * (NI * 32));
   BF_STAMP(3);
   BF_STAMP_RT(5);
 }
 
-template <int EPI, bool BF_OUT, int WN, int NI>
+template <int EPI, bool BF_OUT, int WN, int NI, int MI_ = 3, bool LN = false>
 void launch_shape(const Bf16GemmDev& g, hipStream_t s) {
-  constexpr int BN = WN * NI * 32;
-  const int blocks = ((g.M + BM - 1) / BM) * (g.N / BN);
-  constexpr size_t smem = 2 * (BM * BK * 2 + BN * BK * 2);
+  constexpr int BN = WN * NI * 32, BMs = 64 * MI_;
+  const int blocks = ((g.M + BMs - 1) / BMs) * (g.N / BN);
+  constexpr size_t smem = 2 * (BMs * BK * 2 + BN * BK * 2);
+  static_assert(!LN || smem >= (size_t)(2 * WN) * 4096 + (size_t)BMs * 4 * 2 * 4, "the LayerNorm partial sums sit behind the epilogue stages");
   static const bool raised = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_planes<EPI, BF_OUT, WN, NI>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_planes<EPI, BF_OUT, WN, NI, MI_, LN>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return true;
   }();
   (void)raised;
-  WT_LAUNCH_TIMED((gemm_bf16_planes<EPI, BF_OUT, WN, NI>), dim3(blocks), dim3(128 * WN), smem, s, g);
+  WT_LAUNCH_TIMED((gemm_bf16_planes<EPI, BF_OUT, WN, NI, MI_, LN>), dim3(blocks), dim3(128 * WN), smem, s, g);
+}
+
+// LayerNorm fusion: the tile whose columns are the whole row (d_model 512 / 384 / 128)
+template <int EPI>
+bool launch_bf16_ln(const Bf16GemmDev& g, hipStream_t s) {
+  switch (g.N) {
+    case 512: launch_shape<EPI, false, 4, 4, 2, true>(g, s); return true;
+    case 384: launch_shape<EPI, false, 4, 3, 3, true>(g, s); return true;
+    case 128: launch_shape<EPI, false, 2, 2, 3, true>(g, s); return true;
+    default: return false;
+  }
 }
 
 template <int EPI, bool BF_OUT>
@@ -287,7 +388,7 @@ void launch_bf16_planes(const Bf16GemmDev& g, hipStream_t s) {
 
 }  // namespace
 
-void launch_gemm_bf16_planes(const PlaneGemmArgs& a, int epi, hipStream_t s) {
+bool launch_gemm_bf16_planes(const PlaneGemmArgs& a, int epi, hipStream_t s) {
   Bf16GemmDev g{};
   g.A = a.A; g.W = a.W; g.C = a.C; g.P = a.P;
   g.bias = a.bias; g.R = a.R; g.pos = a.pos;
@@ -309,6 +410,18 @@ void launch_gemm_bf16_planes(const PlaneGemmArgs& a, int epi, hipStream_t s) {
       throw Error(kErrInvalidArg, "bf16 GEMM operand spans more than the 4 GiB its 32-bit offsets reach");
     }
   }
+  // LayerNorm fusion (ln_g set): fp32 output in contiguous [M][N] rows, N one of the whole-row tiles; WT_BF16_LN_FUSE=0
+  // keeps the separate LayerNorm launch (A/B runs).  Returns whether the LayerNorm was done here.
+  static const bool fuse = [] {
+    const char* v = getenv("WT_BF16_LN_FUSE");
+    return !v || atoi(v) != 0;
+  }();
+  if (a.ln_g != nullptr && fuse && !bf_out && a.ln_b != nullptr && a.ln_P != nullptr && a.ldc == a.N && a.c_rpb >= a.M &&
+      (a.N == 512 || a.N == 384 || a.N == 128)) {
+    g.ln_g = a.ln_g; g.ln_b = a.ln_b; g.ln_P = a.ln_P; g.ln_y32 = a.ln_y32; g.nonfinite = a.nonfinite;
+    if (epi == (kEpiBias | kEpiResidual)) return launch_bf16_ln<kEpiBias | kEpiResidual>(g, s);
+    if (epi == (kEpiBias | kEpiGelu | kEpiPos)) return launch_bf16_ln<kEpiBias | kEpiGelu | kEpiPos>(g, s);
+  }
   switch (epi | (bf_out ? 256 : 0)) {
     case kEpiBias: launch_bf16_planes<kEpiBias, false>(g, s); break;
     case kEpiBias | kEpiResidual: launch_bf16_planes<kEpiBias | kEpiResidual, false>(g, s); break;
@@ -318,6 +431,7 @@ void launch_gemm_bf16_planes(const PlaneGemmArgs& a, int epi, hipStream_t s) {
     case kEpiBias | kEpiKvLayout | 256: launch_bf16_planes<kEpiBias | kEpiKvLayout, true>(g, s); break;
     default: throw Error(kErrInvalidArg, "unsupported bf16 GEMM epilogue combination");
   }
+  return false;
 }
 
 }  // namespace wt

@@ -131,7 +131,8 @@ void set_plane_gemm_mode(int m);
 // bf16 storage mode (k_gemm_bf16.hip): A, W single bf16 matrices (the plane offsets and scales of the struct are
 // unused), K a multiple of 64; P set = bf16 output (row-major, or the cross-KV cache layout with kEpiKvLayout),
 // else fp32 output C
-void launch_gemm_bf16_planes(const PlaneGemmArgs& a, int epi, hipStream_t s);
+// returns true when the LayerNorm fusion (a.ln_g ...: as in launch_gemm_planes, ONE bf16 plane at ln_P, ln_scale unused) was done
+bool launch_gemm_bf16_planes(const PlaneGemmArgs& a, int epi, hipStream_t s);
 // W [N][K] fp32 -> bf16 [N][Kpad] (round to nearest even, zero filled)
 std::vector<unsigned short> round_weights_bf16(const float* W, int N, int K, int Kpad);
 // W [N][K] fp32 -> both fp16 planes, scaled by `scale`, as [N / 16][Kpad / 32][hi | lo][16 rows][32 k] with swizzled
