@@ -728,7 +728,10 @@ def main() -> None:
             "roofline": ({**roof, "isolated": {k: iso_det[dom][k] for k in ("achieved", "frac", "avg_launch_us")},
                           "note": "achieved/avg_launch_us: HIP events inside the timed (pipelined) region, where decoder "
                                   "chains share the chip; isolated: the same launches in two synchronous passes after it — "
-                                  "the figure a serialising profiler (rocprofv3 --kernel-trace, profiles/) reproduces"}
+                                  "the figure a serialising profiler (rocprofv3 --kernel-trace, profiles/) reproduces.  The "
+                                  "launch durations include the LayerNorms fused into the conv2 / out-projection / fc2 epilogues "
+                                  "(9 per pass at 4 layers, 13 at 6: statistics, normalisation and the next operand's planes — "
+                                  "work the flop count of the fraction does not credit)"}
                          if roof and iso_det and dom in iso_det else roof),
             "roofline_detail": detail,
             "roofline_isolated": iso_det,
