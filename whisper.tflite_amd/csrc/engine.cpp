@@ -949,7 +949,7 @@ void Engine::sync() {
 // The cross K/V cache (layers x 2 x clips x 1500 x d fp32: 590 MB per slot for tiny at 32 clips, 1.2 GB for base at 64)
 // belongs to the cached decoder form only — cross_absorb = 0, synchronous calls below 32 clips, a flagged cross
 // operand — so it is allocated per slot the first time a batch of that form is encoded into the slot, not for all
-// twelve slots up front (the default absorbed form never touches it).
+// every slot up front (the default absorbed form never touches it).
 void Engine::need_cross_kv(Slot& slot) {
   if (slot.cross_kv) return;
   const wtw::Dims& c = dims_;
