@@ -523,3 +523,38 @@ def test_bench_two_ranks_share_the_gpu_and_the_gather_cadence(tmp_path):
     assert a["ids_digest"] == b["ids_digest"] and a["ids_digest"] != 0
     assert a["value"] > 0 and b["value"] > 0
     assert len(b["hip_runtimes_mapped"]) == 1, b["hip_runtimes_mapped"]
+
+
+def test_device_buffers_of_the_c_abi(pkg, assets):
+    """wt_device_alloc / upload / download / free / synchronize (include/wt_capi.h, round 4): a host program without a HIP
+    runtime of its own keeps its inputs resident through the engine.  Round trip at an offset, the *_dev entry points take
+    the pointer (same ids as the host-buffer call), bad arguments are refused with a status, not a fault."""
+    from ctypes import byref, c_void_p
+    prefix, vocab = assets("micro")
+    e = pkg.Engine(prefix, vocab, True)
+    e.set_option("stop_at_eot", 0)
+    e.set_prompt([3, 5, 7, 11])
+    rng = np.random.default_rng(31)
+    mel = rng.uniform(-1.0, 1.5, size=(3,) + e.mel_shape).astype(np.float32)
+    d = e.device_array(mel)
+    assert np.array_equal(d.download(), mel)
+    L = pkg.lib()
+    patch = rng.standard_normal(64).astype(np.float32)
+    assert L.wt_device_upload(e._h, c_void_p(d.data_ptr()), 1024, patch.ctypes.data_as(c_void_p), patch.nbytes) == 0
+    back = np.empty(64, np.float32)
+    assert L.wt_device_download(e._h, back.ctypes.data_as(c_void_p), c_void_p(d.data_ptr()), 1024, back.nbytes) == 0
+    assert np.array_equal(back, patch)
+    assert L.wt_device_upload(e._h, c_void_p(d.data_ptr()), 0, mel.ctypes.data_as(c_void_p), mel.nbytes) == 0
+    e.device_synchronize()
+    want = e.encdec_tokens_batch(mel)
+    got = e.encdec_tokens_batch_dev(d.data_ptr(), 3)
+    assert np.array_equal(want[0], got[0]) and np.array_equal(want[1], got[1])
+    p = c_void_p()
+    assert L.wt_device_alloc(e._h, 0, byref(p)) == 0 and p.value  # an empty request still returns a buffer the caller frees
+    assert L.wt_device_free(e._h, p) == 0
+    assert L.wt_device_alloc(None, 16, byref(p)) != 0         # no engine
+    assert L.wt_device_upload(e._h, None, 0, mel.ctypes.data_as(c_void_p), 16) != 0
+    assert L.wt_device_download(e._h, None, c_void_p(d.data_ptr()), 0, 16) != 0
+    d.free()
+    d.free()  # idempotent on the Python side
+    e.close()

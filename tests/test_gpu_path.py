@@ -323,6 +323,35 @@ def test_pipeline_pairs_two_batches_per_decoder_chain(tiny):
         d.free()
 
 
+def test_pipeline_groups_at_full_rows(tiny):
+    """dec_group at the sizes the bench uses: 32-clip batches, three and four per decoder chain = 96 and 128 rows per decoder
+    pass (the decoder GEMMs' row limit), up to four encoder-plane sources per cross-attention launch.  Every batch comes
+    back with the ids of the synchronous call AT THE SAME KEY-CHUNK COUNT: the chunk count is the order in which the
+    absorbed cross-attention adds up its softmax, and one clip of this very input has two logits 2 ulp apart at one
+    position (1.5864166 / 1.5864170: tools/group_check.py) — a chain of four batches takes one chunk per clip by default,
+    the synchronous call eight, and they pick different ones of the two; at equal chunk counts the ids are bit-identical
+    whatever the rows per pass."""
+    from conftest import DevBuf
+    e, _ = tiny
+    rng = np.random.default_rng(96128)
+    mels = [rng.uniform(-1.0, 1.5, size=(32, 80, 3000)).astype(np.float32) for _ in range(3)]
+    e.set_option("abs_chunks", 2)
+    want = [e.encdec_tokens_batch(m) for m in mels]
+    dev = [DevBuf(m) for m in mels]
+    for group in (3, 4):
+        e.set_option("dec_group", group)
+        order = [0, 1, 2, 1, 0, 2, 2, 0, 1]
+        for k in order:
+            e.pipeline_submit_dev(dev[k].data_ptr(), 32)
+        for k in order:
+            ids_g, n_g = e.pipeline_collect()
+            assert np.array_equal(want[k][0], ids_g) and np.array_equal(want[k][1], n_g), (group, k)
+    e.set_option("dec_group", 2)
+    e.set_option("abs_chunks", 0)
+    for d in dev:
+        d.free()
+
+
 def test_pipeline_follower_ids_survive_reuse_of_the_leaders_slot(tiny):
     """A group's later batches keep their ids in their OWN slots: with all 24 slots in flight as twelve pairs (eight
     triples), the first collect frees the first leader's slot, and a batch that is decoded at once (announced last batch)
