@@ -20,6 +20,7 @@ pcm = np.clip(rng.normal(0, 0.1, 480000), -1, 1).astype(np.float32)
 eng.transcribe(pcm)
 for stop in (1, 0):
     eng.set_option("stop_at_eot", stop)
+    eng.transcribe(pcm)  # the first call of a configuration captures its decoder graphs (every pipeline slot at once)
     t0 = time.perf_counter()
     for _ in range(10):
         eng.transcribe(pcm)
